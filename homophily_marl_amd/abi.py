@@ -1,0 +1,142 @@
+"""ctypes mirror of include/ssd_hip.h and the loader of the in-tree HIP library.
+
+The native library is REQUIRED: there is no CPU fallback on the product path.  `load_library()` raises if
+`libssd_hip.so` is missing or does not export every symbol the header declares.
+"""
+import ctypes as C
+import os
+
+ABI_VERSION = 1
+MAX_AGENTS = 10
+MAX_CELLS = 1024
+MAX_SITES = 256
+
+ENV_CLEANUP, ENV_HARVEST = 0, 1
+RNG_TAPE, RNG_COUNTER = 0, 1
+OBS_F32, OBS_BF16, OBS_U8, OBS_CODE = 0, 1, 2, 3
+COLOR_SIMPLIFIED, COLOR_FULL = 0, 1
+STREAM_UNIFORM, STREAM_MOVE, STREAM_WASTE, STREAM_SPAWN_ROT = 0, 1, 2, 3
+
+SSD_OK, SSD_ERR_INVALID, SSD_ERR_DEVICE, SSD_ERR_NOMEM, SSD_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+
+
+class SsdConfig(C.Structure):
+    _fields_ = [
+        ("env_kind", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+        ("ascii_map", C.c_char_p),
+        ("n_agents", C.c_int32), ("n_env", C.c_int32), ("view_size", C.c_int32), ("episode_limit", C.c_int32),
+        ("random_spawn_point", C.c_int32), ("spawn_rotation", C.c_int32), ("obs_color", C.c_int32),
+        ("rng_mode", C.c_int32), ("device", C.c_int32), ("env_id_base", C.c_uint32), ("seed", C.c_uint64),
+        ("threshold_depletion", C.c_double), ("threshold_restoration", C.c_double),
+        ("waste_spawn_prob", C.c_double), ("apple_respawn_prob", C.c_double),
+        ("harvest_spawn_prob", C.c_double * 4),
+    ]
+
+
+class SsdTape(C.Structure):
+    _fields_ = [
+        ("move_order", C.c_void_p), ("uniforms", C.c_void_p), ("uniforms_stride", C.c_int32),
+        ("waste_order", C.c_void_p), ("spawn_rot", C.c_void_p),
+    ]
+
+
+class SsdStepOut(C.Structure):
+    _fields_ = [
+        ("reward", C.c_void_p), ("clean_num", C.c_void_p), ("apple_den", C.c_void_p), ("terminated", C.c_void_p),
+        ("collective_return", C.c_void_p), ("equality", C.c_void_p), ("n_draws", C.c_void_p),
+    ]
+
+
+class SsdObsOut(C.Structure):
+    _fields_ = [
+        ("obs", C.c_void_p), ("obs_format", C.c_int32), ("state", C.c_void_p), ("pos", C.c_void_p),
+        ("orient", C.c_void_p),
+    ]
+
+
+class SsdState(C.Structure):
+    _fields_ = [
+        ("grid", C.c_void_p), ("pos", C.c_void_p), ("orient", C.c_void_p), ("ep_reward", C.c_void_p),
+        ("ep_step", C.c_void_p), ("epoch", C.c_void_p),
+    ]
+
+
+class SsdInfo(C.Structure):
+    _fields_ = [
+        ("n_actions", C.c_int32), ("n_apple_sites", C.c_int32), ("n_waste_sites", C.c_int32),
+        ("n_spawn_points", C.c_int32), ("max_uniforms", C.c_int32), ("obs_edge", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); the single source the symbol test and both loaders use.
+def _sigs(prefix, with_stream):
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    st = [vp] if with_stream else []
+    P = C.POINTER
+    return {
+        prefix + "abi_version": (C.c_int, []),
+        prefix + "last_error": (C.c_char_p, []),
+        prefix + "create": (C.c_int, [P(SsdConfig), P(vp)]),
+        prefix + "destroy": (C.c_int, [vp]),
+        prefix + "reset": (C.c_int, [vp, vp, P(SsdTape), P(SsdStepOut)] + st),
+        prefix + "step": (C.c_int, [vp, vp, P(SsdTape), P(SsdStepOut)] + st),
+        prefix + "observe": (C.c_int, [vp, P(SsdObsOut)] + st),
+        prefix + "export_state": (C.c_int, [vp, P(SsdState)] + st),
+        prefix + "import_state": (C.c_int, [vp, P(SsdState)] + st),
+        prefix + "get_info": (C.c_int, [vp, P(SsdInfo)]),
+        prefix + "build_inputs": (C.c_int, [i32, i32, i32, i32, vp, vp, vp, vp, f32, vp, i32, i32] + st),
+        prefix + "incentive_transfer": (C.c_int, [i32, i32, i32, vp, vp, f32, f32, f32, f32,
+                                                  vp, vp, vp, vp, vp, vp] + st),
+    }
+
+
+HIP_SIGNATURES = _sigs("ssd_", True)
+HIP_SIGNATURES["ssd_step_observe"] = (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SsdTape), C.POINTER(SsdStepOut),
+                                                C.POINTER(SsdObsOut), C.c_void_p])
+CPU_SIGNATURES = _sigs("ssd_cpu_", False)
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_PKG_DIR, "libssd_hip.so")
+_lib = None
+
+
+def bind(lib, signatures):
+    missing = []
+    for name, (res, args) in signatures.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:
+        raise ImportError("native library is missing symbols: " + ", ".join(missing))
+    return lib
+
+
+def load_library():
+    """Load homophily_marl_amd/libssd_hip.so (built by __graft_entry__.build()).  Fails loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % HIP_LIB_PATH)
+        lib = C.CDLL(HIP_LIB_PATH)
+        bind(lib, HIP_SIGNATURES)
+        ver = lib.ssd_abi_version()
+        if ver != ABI_VERSION:
+            raise ImportError("libssd_hip.so ABI version %d != %d" % (ver, ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+class SsdError(RuntimeError):
+    pass
+
+
+def check(lib, rc, err_fn="ssd_last_error"):
+    if rc != 0:
+        msg = getattr(lib, err_fn)()
+        raise SsdError("ssd error %d: %s" % (rc, msg.decode() if msg else "?"))

@@ -1,0 +1,184 @@
+/*
+ * ssd_hip.h -- C ABI of the MI355X-native vectorised SSD (Cleanup / Harvest) grid world.
+ *
+ * This is the drop-in boundary for the hot path of drdh/Homophily-MARL.  The reference has no FFI at all:
+ * its env is reached through Python duck-typing (src/envs/__init__.py:6-11, src/envs/multiagentenv.py:8-75).
+ * Every entry point below therefore cites the reference *Python* interface it replaces; the host-side
+ * mirror of that interface lives in homophily_marl_amd/envs/ and calls these symbols through ctypes.
+ *
+ * Conventions
+ *   - return 0 on success, a negative ssd_status otherwise; the message is in ssd_last_error() (thread local).
+ *   - no C++ exception crosses this boundary, nothing aborts.
+ *   - the caller owns every in/out array (device pointers for ssd_*, host pointers for the oracle's
+ *     ssd_cpu_* mirror); the library owns only the opaque handle.
+ *   - all GPU entry points are asynchronous on the hipStream_t passed as `void* stream` (0 = null stream).
+ *   - one handle = one device; calls on one handle are not re-entrant.
+ *
+ * Cell alphabet of the world grid (u8 codes): 0 ' ', 1 '@', 2 'A', 3 'H', 4 'R', 5 'S'
+ * (src/envs/ssd/map_env.py:132,817-820; src/envs/ssd/cleanup.py:117-124).
+ * Orientation codes: 0 LEFT, 1 RIGHT, 2 UP, 3 DOWN = list(ORIENTATIONS) order (map_env.py:28-31,791-793).
+ * Positions are [row, col] (map_env.py:20-31).
+ */
+#ifndef SSD_HIP_H
+#define SSD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSD_ABI_VERSION 1
+
+#define SSD_MAX_AGENTS 10   /* maps hold at most 10 spawn points; agent ids >= 10 break the reference (map_env.py:370) */
+#define SSD_MAX_CELLS 1024  /* H*W upper bound (largest reference map is 48x18 = 864) */
+#define SSD_MAX_SITES 256   /* apple / waste site list upper bound (largest: 206 apple sites) */
+
+typedef enum ssd_status {
+    SSD_OK = 0,
+    SSD_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+    SSD_ERR_DEVICE = -2,      /* HIP runtime error */
+    SSD_ERR_NOMEM = -3,
+    SSD_ERR_UNSUPPORTED = -4
+} ssd_status;
+
+enum { SSD_ENV_CLEANUP = 0, SSD_ENV_HARVEST = 1 };
+enum { SSD_RNG_TAPE = 0, SSD_RNG_COUNTER = 1 };
+enum { SSD_OBS_F32 = 0, SSD_OBS_BF16 = 1, SSD_OBS_U8 = 2, SSD_OBS_CODE = 3 };
+enum { SSD_COLOR_SIMPLIFIED = 0, SSD_COLOR_FULL = 1 };
+
+/* Constructor arguments.  Replaces CleanupEnv.__init__ / HarvestEnv.__init__ kwargs
+ * (cleanup.py:29-61, harvest.py:18-29, config/envs/cleanup.yaml:3-15). */
+typedef struct ssd_config {
+    int32_t env_kind;            /* SSD_ENV_* */
+    int32_t height, width;       /* map rows, cols */
+    const char* ascii_map;       /* height*width chars, row-major, alphabet of constants.py:1-10 */
+    int32_t n_agents;            /* <= SSD_MAX_AGENTS */
+    int32_t n_env;               /* envs in this handle (this rank's shard) */
+    int32_t view_size;           /* v; window edge V = 2v+1 */
+    int32_t episode_limit;       /* terminated iff steps >= episode_limit (map_env.py:890-894) */
+    int32_t random_spawn_point;  /* extra_args.random_spawn_point; 1 is SSD_ERR_UNSUPPORTED in ABI v1 */
+    int32_t spawn_rotation;      /* extra_args.random_spawn_rotation: 0..3, or -1 = None = random */
+    int32_t obs_color;           /* SSD_COLOR_* (extra_args.obs_color) */
+    int32_t rng_mode;            /* SSD_RNG_* */
+    int32_t device;              /* HIP device ordinal (ignored by the ssd_cpu_* mirror) */
+    uint32_t env_id_base;        /* global id of env 0 of this shard (COUNTER streams are keyed by global id) */
+    uint64_t seed;               /* COUNTER mode key */
+    /* Cleanup thresholds (cleanup.py:31-54) */
+    double threshold_depletion, threshold_restoration, waste_spawn_prob, apple_respawn_prob;
+    /* Harvest SPAWN_PROB[min(k,3)] (harvest.py:20-22,118) */
+    double harvest_spawn_prob[4];
+} ssd_config;
+
+/* One call's worth of recorded random draws (TAPE mode; appendix A.6 of SURVEY.md).  All arrays are
+ * per env, row-major, and may be NULL in COUNTER mode.
+ *   move_order  : result of np.random.shuffle over the MOVE/STAY list (map_env.py:540-542): the agent ids in
+ *                 shuffled order, 0xFF padded.
+ *   uniforms    : every np.random.rand(1)[0] of the call in consumption order (cleanup.py:172,183, harvest.py:119).
+ *   waste_order : self.waste_points after random.shuffle (cleanup.py:178) as indices into the row-major waste
+ *                 site list; only read when the call shuffles.
+ *   spawn_rot   : np.random.randint(4) per agent at reset (map_env.py:789); only read when spawn_rotation = -1. */
+typedef struct ssd_tape {
+    const uint8_t* move_order;   /* [n_env, n_agents] */
+    const double* uniforms;      /* [n_env, uniforms_stride] */
+    int32_t uniforms_stride;
+    const uint8_t* waste_order;  /* [n_env, n_waste_sites] */
+    const uint8_t* spawn_rot;    /* [n_env, n_agents] */
+} ssd_tape;
+
+/* Outputs of one transition.  Replaces the return of MapEnv.step (map_env.py:874-915):
+ * reward f64[n] -> f32, terminated, info{clean_num, apple_den, collective_return, equality_metric}. */
+typedef struct ssd_step_out {
+    float* reward;              /* [n_env, n] */
+    float* clean_num;           /* [n_env, n] */
+    float* apple_den;           /* [n_env, n] (same value for every agent, map_env.py:291-292) */
+    uint8_t* terminated;        /* [n_env] */
+    float* collective_return;   /* [n_env], written at termination (map_env.py:901-912), nullable */
+    float* equality;            /* [n_env], written at termination, nullable */
+    int32_t* n_draws;           /* [n_env] uniforms consumed by the call (parity check of the draw count), nullable */
+} ssd_step_out;
+
+/* Outputs of an observation pass.  Replaces get_obs / get_state / get_agent_pos / get_agent_orientation
+ * (map_env.py:917-957).  Every pointer is nullable: only non-NULL outputs are produced.
+ *   obs   : [n_env, n, 3, V, V] as f32 / bf16 (values k/256) or u8 (values k), or with SSD_OBS_CODE
+ *           [n_env, n, V, V] u8 cell classes (0 nothing, 1 apple, 2 waste, 3 wall-or-agent; simplified colours only).
+ *   state : [n_env, 3, H, W] f32. */
+typedef struct ssd_obs_out {
+    void* obs;
+    int32_t obs_format;         /* SSD_OBS_* */
+    float* state;
+    float* pos;                 /* [n_env, n, 2] row, col as float */
+    float* orient;              /* [n_env, n, 2] ORIENTATIONS vector as float */
+} ssd_obs_out;
+
+/* Raw env state for parity tests and KATs (Agent.set_pos etc. in the reference). */
+typedef struct ssd_state {
+    uint8_t* grid;              /* [n_env, H*W] cell codes */
+    int16_t* pos;               /* [n_env, n, 2] */
+    uint8_t* orient;            /* [n_env, n] */
+    int32_t* ep_reward;         /* [n_env, n] cumulative episode reward (self.rewards, map_env.py:885-888) */
+    int32_t* ep_step;           /* [n_env] self._episode_steps */
+    uint32_t* epoch;            /* [n_env] COUNTER-mode call counter (reset/step calls completed) */
+} ssd_state;
+
+typedef struct ssd_env ssd_env; /* opaque */
+
+int ssd_abi_version(void);
+const char* ssd_last_error(void);
+
+/* REGISTRY[env](**env_args)  (envs/__init__.py:6-11, runners/episode_runner.py:15) */
+int ssd_create(const ssd_config* cfg, ssd_env** out);
+int ssd_destroy(ssd_env* env);
+
+/* MapEnv.reset (map_env.py:986-993 -> _reset :297-326).  env_mask: u8[n_env] device pointer, nullable = all. */
+int ssd_reset(ssd_env* env, const uint8_t* env_mask, const ssd_tape* tape, ssd_step_out* out, void* stream);
+/* MapEnv.step (map_env.py:874-915).  actions: int32[n_env, n] device pointer. */
+int ssd_step(ssd_env* env, const int32_t* actions, const ssd_tape* tape, ssd_step_out* out, void* stream);
+/* get_obs / get_state / get_agent_pos / get_agent_orientation (map_env.py:917-957) */
+int ssd_observe(ssd_env* env, ssd_obs_out* out, void* stream);
+/* step immediately followed by observe of the new state, in one launch (the rollout inner loop,
+ * runners/episode_runner.py:57-97: env.step then next iteration's get_obs). */
+int ssd_step_observe(ssd_env* env, const int32_t* actions, const ssd_tape* tape, ssd_step_out* out,
+                     ssd_obs_out* obs, void* stream);
+
+int ssd_export_state(ssd_env* env, ssd_state* dst, void* stream);
+int ssd_import_state(ssd_env* env, const ssd_state* src, void* stream);
+
+/* Static facts derived from the map (get_env_info, map_env.py:1008-1019 and the site lists of
+ * cleanup.py:72-90 / harvest.py:31-35). */
+typedef struct ssd_info {
+    int32_t n_actions;          /* 9 Cleanup, 8 Harvest (agent.py:153-154,207-209) */
+    int32_t n_apple_sites, n_waste_sites, n_spawn_points;
+    int32_t max_uniforms;       /* upper bound of uniforms consumed by one call = apple sites + waste sites */
+    int32_t obs_edge;           /* V */
+} ssd_info;
+int ssd_get_info(const ssd_env* env, ssd_info* out);
+
+/* HomophilyMAC._build_inputs tail (controllers/homophily_controller.py:137-184): everything except the conv
+ * encoder.  Writes [B*n, A + n + 1 + 1 + 2] = onehot(last action) | onehot(id) | sign(last reward) |
+ * sign(#recv+ - #recv-) | pos/||(H,W)||.  t0 != 0 selects the t == 0 branch (zeros for the three history terms). */
+int ssd_build_inputs(int32_t batch, int32_t n_agents, int32_t n_actions, int32_t t0,
+                     const int64_t* last_actions /*[B,n]*/, const float* last_reward /*[B,n]*/,
+                     const int64_t* last_actions_inc /*[B,n,n]*/, const float* pos /*[B,n,2]*/,
+                     float pos_scale, float* out, int32_t out_stride, int32_t out_offset, void* stream);
+
+/* Incentive reward transfer (learners/homophily_learner.py:94-115).  actions_inc int64[B,T,n,n] (giver dim 2,
+ * receiver dim 3), rewards f32[B,T-1,n].  Outputs f32: give[B,T-1,n], recv_pos/neg/zero[B,T,n],
+ * rewards_for_env/inc[B,T-1,n] = (r +/- ...) / seq_len with seq_len = batch.max_seq_length (true division). */
+int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int64_t* actions_inc,
+                           const float* rewards, float effect_ratio, float cost_ratio, float incentive,
+                           float seq_len, float* give, float* recv_pos, float* recv_neg, float* recv_zero,
+                           float* rewards_for_env, float* rewards_for_inc, void* stream);
+
+/* ---- COUNTER-mode generator (shared definition) ---------------------------------------------
+ * x = philox4x32_10(counter = {k, stream, env_global_id, epoch}, key = {seed_lo, seed_hi})[0]
+ *   epoch  = number of reset/step calls this env has completed before the current call
+ *   stream = SSD_STREAM_*
+ *   uniform: u = (x >> 8) * 2^-24 as double, compared `u < p` in fp64
+ *   shuffles: stable sort of the items by (x(item index), item index)                                         */
+enum { SSD_STREAM_UNIFORM = 0, SSD_STREAM_MOVE = 1, SSD_STREAM_WASTE = 2, SSD_STREAM_SPAWN_ROT = 3 };
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSD_HIP_H */
