@@ -1,0 +1,283 @@
+// ssd_abi.hip -- the extern "C" boundary of libssd_hip.so (declared in include/ssd_hip.h).
+// Host code only: argument checking, map parsing, device allocation, kernel launches.  No torch types, no
+// exceptions across the boundary, nothing aborts; all launches are asynchronous on the caller's stream.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ssd_device.h"
+
+using namespace ssd;
+
+struct ssd_env {
+    DevSpec hs;        // host copy
+    DevSpec* dspec;    // device copy
+    DevState st;
+    int device;
+    int n_spawn;
+};
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, const char* a = "") {
+    std::snprintf(g_err, sizeof g_err, fmt, a);
+    return code;
+}
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) return fail(SSD_ERR_DEVICE, #expr ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+static uint32_t magic(uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : (uint32_t)(0x100000000ull / d) + 1u; }
+
+extern "C" {
+
+int ssd_abi_version(void) { return SSD_ABI_VERSION; }
+const char* ssd_last_error(void) { return g_err; }
+
+int ssd_create(const ssd_config* cfg, ssd_env** out) {
+    if (!cfg || !out || !cfg->ascii_map) return fail(SSD_ERR_INVALID, "null argument");
+    if (cfg->n_agents < 1 || cfg->n_agents > SSD_MAX_AGENTS) return fail(SSD_ERR_INVALID, "n_agents out of range (1..10)");
+    if (cfg->height < 3 || cfg->width < 3 || cfg->height > 255 || cfg->width > 255 || cfg->height * cfg->width > SSD_MAX_CELLS)
+        return fail(SSD_ERR_INVALID, "map size out of range");
+    if (cfg->n_env < 1) return fail(SSD_ERR_INVALID, "n_env must be >= 1");
+    if (cfg->view_size < 0 || cfg->view_size > 31) return fail(SSD_ERR_INVALID, "view_size out of range (0..31)");
+    if (cfg->random_spawn_point) return fail(SSD_ERR_UNSUPPORTED, "random_spawn_point is not supported in ABI v1");
+    if (cfg->spawn_rotation > 3) return fail(SSD_ERR_INVALID, "spawn_rotation must be -1..3");
+    if (cfg->env_kind != SSD_ENV_CLEANUP && cfg->env_kind != SSD_ENV_HARVEST) return fail(SSD_ERR_INVALID, "env_kind");
+    if (cfg->rng_mode != SSD_RNG_TAPE && cfg->rng_mode != SSD_RNG_COUNTER) return fail(SSD_ERR_INVALID, "rng_mode");
+
+    ssd_env* E = new (std::nothrow) ssd_env();
+    if (!E) return fail(SSD_ERR_NOMEM, "host allocation failed");
+    std::memset(E, 0, sizeof *E);
+    DevSpec& S = E->hs;
+    S.kind = cfg->env_kind; S.H = cfg->height; S.W = cfg->width; S.HW = S.H * S.W; S.GS = (S.HW + 15) & ~15;
+    S.n = cfg->n_agents; S.N = cfg->n_env; S.v = cfg->view_size; S.V = 2 * S.v + 1; S.VV = S.V * S.V; S.VVp = (S.VV + 3) & ~3;
+    S.episode_limit = cfg->episode_limit; S.spawn_rotation = cfg->spawn_rotation < 0 ? -1 : cfg->spawn_rotation;
+    S.obs_color = cfg->obs_color == SSD_COLOR_FULL ? SSD_COLOR_FULL : SSD_COLOR_SIMPLIFIED;
+    S.rng_mode = cfg->rng_mode; S.n_actions = S.kind == SSD_ENV_CLEANUP ? 9 : 8;
+    S.env_id_base = cfg->env_id_base; S.seed_lo = (uint32_t)cfg->seed; S.seed_hi = (uint32_t)(cfg->seed >> 32);
+    S.magic_W = magic(S.W); S.magic_V = magic(S.V); S.magic_VV = magic(S.VV); S.magic_3VV = magic(3 * S.VV); S.magic_HW = magic(S.HW);
+    S.thr_dep = cfg->threshold_depletion; S.thr_res = cfg->threshold_restoration;
+    S.p_waste = cfg->waste_spawn_prob; S.p_apple = cfg->apple_respawn_prob;
+    for (int i = 0; i < 4; ++i) S.harvest_p[i] = cfg->harvest_spawn_prob[i];
+    if ((long)S.n * 3 * S.VV >= 65536) { delete E; return fail(SSD_ERR_INVALID, "n_agents * 3 * V * V must stay below 65536"); }
+
+    // Row-major scan of the layout (map_env.py:143-148, cleanup.py:77-90, harvest.py:31-35).
+    std::vector<int> spawn;
+    for (int i = 0; i < S.HW; ++i) {
+        const char ch = cfg->ascii_map[i];
+        uint8_t code = C_EMPTY;
+        bool overflow = false;
+        if (ch == '@') code = C_WALL;
+        else if (ch == 'P') spawn.push_back(i);
+        else if (S.kind == SSD_ENV_CLEANUP) {
+            if (ch == 'B') { if (S.n_apple < SSD_MAX_SITES) S.apple[S.n_apple++] = (uint16_t)i; else overflow = true; }
+            else if (ch == 'H') { code = C_WASTE; if (S.n_waste < SSD_MAX_SITES) S.waste[S.n_waste++] = (uint16_t)i; else overflow = true; }
+            else if (ch == 'R') code = C_RIVER;
+            else if (ch == 'S') code = C_STREAM;
+        } else if (ch == 'A') { code = C_APPLE; if (S.n_apple < SSD_MAX_SITES) S.apple[S.n_apple++] = (uint16_t)i; else overflow = true; }
+        if (overflow) { delete E; return fail(SSD_ERR_INVALID, "too many apple / waste sites (max 256)"); }
+        S.reset_grid[i] = code;
+    }
+    E->n_spawn = (int)spawn.size();
+    if ((int)spawn.size() < S.n) { delete E; return fail(SSD_ERR_INVALID, "There are not enough spawn points! Check your map?"); }
+    // spawn_point() returns the LAST free spawn point (map_env.py:779-784): agent a gets the a-th from the end.
+    for (int a = 0; a < S.n; ++a) S.spawn_cell[a] = (uint16_t)spawn[spawn.size() - 1 - a];
+    // agents must never stand on the border (the kernels index t = P +- W, P +- 1 without a bounds test on rows)
+    for (int a = 0; a < S.n; ++a) {
+        const int r = S.spawn_cell[a] / S.W, c = S.spawn_cell[a] % S.W;
+        if (r == 0 || c == 0 || r == S.H - 1 || c == S.W - 1) { delete E; return fail(SSD_ERR_INVALID, "spawn point on the map border"); }
+    }
+    for (int i = 0; i < S.HW; ++i) {
+        const int r = i / S.W, c = i % S.W;
+        if ((r == 0 || c == 0 || r == S.H - 1 || c == S.W - 1) && S.reset_grid[i] != C_WALL) {
+            delete E; return fail(SSD_ERR_INVALID, "the map border must be wall ('@')");
+        }
+    }
+    // Full-colour LUT (map_env.py:33-62 DEFAULT_COLOURS; cleanup.py:14-17 CLEANUP_COLORS), rows: cell codes 0..5, then 5 + agent char.
+    static const uint8_t agent_rgb[10][3] = {{0, 0, 0}, {159, 67, 255}, {2, 81, 154}, {204, 0, 204}, {216, 30, 54},
+                                             {254, 151, 0}, {205, 155, 155}, {99, 99, 255}, {250, 204, 255}, {238, 223, 16}};
+    uint8_t (*lut)[3] = (uint8_t (*)[3])S.lut;
+    lut[C_WALL][0] = lut[C_WALL][1] = lut[C_WALL][2] = 180;
+    lut[C_APPLE][1] = 255;
+    if (S.kind == SSD_ENV_CLEANUP) {
+        lut[C_WASTE][0] = 99; lut[C_WASTE][1] = 156; lut[C_WASTE][2] = 194;
+        lut[C_RIVER][0] = lut[C_STREAM][0] = 113; lut[C_RIVER][1] = lut[C_STREAM][1] = 75; lut[C_RIVER][2] = lut[C_STREAM][2] = 24;
+    }
+    for (int ch = 1; ch <= 9; ++ch) std::memcpy(lut[5 + ch], agent_rgb[ch], 3);
+
+    // ---- device side ----
+    int prev = 0;
+    E->device = cfg->device;
+    hipError_t e = hipGetDevice(&prev);
+    if (e == hipSuccess) e = hipSetDevice(cfg->device);
+    const size_t N = (size_t)S.N, n = (size_t)S.n;
+    if (e == hipSuccess) e = hipMalloc((void**)&E->dspec, sizeof(DevSpec));
+    if (e == hipSuccess) e = hipMalloc((void**)&E->st.grid, N * S.GS);
+    if (e == hipSuccess) e = hipMalloc((void**)&E->st.arec, N * n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&E->st.ep_reward, N * n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&E->st.ep_step, N * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&E->st.epoch, N * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&E->st.err, 4);
+    if (e == hipSuccess) e = hipMemcpy(E->dspec, &S, sizeof(DevSpec), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(E->st.grid, 0, N * S.GS);
+    if (e == hipSuccess) e = hipMemset(E->st.arec, 0, N * n * 4);
+    if (e == hipSuccess) e = hipMemset(E->st.ep_reward, 0, N * n * 4);
+    if (e == hipSuccess) e = hipMemset(E->st.ep_step, 0, N * 4);
+    if (e == hipSuccess) e = hipMemset(E->st.epoch, 0, N * 4);
+    if (e == hipSuccess) e = hipMemset(E->st.err, 0, 4);
+    if (e == hipSuccess) {
+        // a fresh handle holds the reset image with agents on their spawn cells (the reference constructor
+        // also builds agents before the first reset, map_env.py:149)
+        std::vector<uint8_t> g((size_t)S.GS, 0);
+        std::memcpy(g.data(), S.reset_grid, (size_t)S.HW);
+        std::vector<uint32_t> rec(n);
+        for (size_t a = 0; a < n; ++a) {
+            const uint32_t r = S.spawn_cell[a] / S.W, c = S.spawn_cell[a] % S.W;
+            rec[a] = r | (c << 8) | ((uint32_t)(S.spawn_rotation < 0 ? 0 : S.spawn_rotation) << 16);
+        }
+        std::vector<uint8_t> gall(N * S.GS);
+        std::vector<uint32_t> rall(N * n);
+        for (size_t i = 0; i < N; ++i) { std::memcpy(&gall[i * S.GS], g.data(), (size_t)S.GS); std::memcpy(&rall[i * n], rec.data(), n * 4); }
+        e = hipMemcpy(E->st.grid, gall.data(), gall.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(E->st.arec, rall.data(), rall.size() * 4, hipMemcpyHostToDevice);
+    }
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) {
+        fail(SSD_ERR_DEVICE, "device setup failed: %s", hipGetErrorString(e));
+        ssd_destroy(E);
+        return SSD_ERR_DEVICE;
+    }
+    *out = E;
+    return SSD_OK;
+}
+
+int ssd_destroy(ssd_env* E) {
+    if (!E) return SSD_OK;
+    (void)hipFree(E->dspec); (void)hipFree(E->st.grid); (void)hipFree(E->st.arec); (void)hipFree(E->st.ep_reward);
+    (void)hipFree(E->st.ep_step); (void)hipFree(E->st.epoch); (void)hipFree(E->st.err);
+    delete E;
+    return SSD_OK;
+}
+
+int ssd_get_info(const ssd_env* E, ssd_info* o) {
+    if (!E || !o) return fail(SSD_ERR_INVALID, "null argument");
+    o->n_actions = E->hs.n_actions; o->n_apple_sites = E->hs.n_apple; o->n_waste_sites = E->hs.n_waste;
+    o->n_spawn_points = E->n_spawn; o->max_uniforms = E->hs.n_apple + E->hs.n_waste; o->obs_edge = E->hs.V;
+    return SSD_OK;
+}
+
+static int make_tape(const ssd_env* E, const ssd_tape* t, DevTape* d) {
+    std::memset(d, 0, sizeof *d);
+    if (E->hs.rng_mode == SSD_RNG_TAPE) {
+        if (!t || !t->uniforms || !t->move_order) return fail(SSD_ERR_INVALID, "TAPE mode needs tape.uniforms and tape.move_order");
+        if (E->hs.kind == SSD_ENV_CLEANUP && E->hs.n_waste > 0 && !t->waste_order) return fail(SSD_ERR_INVALID, "TAPE mode needs tape.waste_order for Cleanup");
+        if (E->hs.spawn_rotation < 0 && !t->spawn_rot) return fail(SSD_ERR_INVALID, "TAPE mode with random rotation needs tape.spawn_rot");
+        if (t->uniforms_stride < 1) return fail(SSD_ERR_INVALID, "tape.uniforms_stride");
+    }
+    if (t) { d->move_order = t->move_order; d->uniforms = t->uniforms; d->ustride = t->uniforms_stride; d->waste_order = t->waste_order; d->spawn_rot = t->spawn_rot; }
+    return SSD_OK;
+}
+static DevStepOut make_so(const ssd_step_out* o) {
+    DevStepOut d; std::memset(&d, 0, sizeof d);
+    if (o) { d.reward = o->reward; d.clean_num = o->clean_num; d.apple_den = o->apple_den; d.terminated = o->terminated;
+             d.collective = o->collective_return; d.equality = o->equality; d.n_draws = o->n_draws; }
+    return d;
+}
+static int make_oo(const ssd_env* E, const ssd_obs_out* o, DevObsOut* d) {
+    std::memset(d, 0, sizeof *d);
+    if (!o) return fail(SSD_ERR_INVALID, "null ssd_obs_out");
+    if (o->obs) {
+        if (o->obs_format < SSD_OBS_F32 || o->obs_format > SSD_OBS_CODE) return fail(SSD_ERR_INVALID, "obs_format");
+        if (o->obs_format == SSD_OBS_CODE && E->hs.obs_color != SSD_COLOR_SIMPLIFIED) return fail(SSD_ERR_INVALID, "SSD_OBS_CODE needs simplified colours");
+        if (((uintptr_t)o->obs & 15) != 0) return fail(SSD_ERR_INVALID, "obs must be 16-byte aligned");
+    }
+    if (o->state && ((uintptr_t)o->state & 15) != 0) return fail(SSD_ERR_INVALID, "state must be 16-byte aligned");
+    d->obs = o->obs; d->fmt = o->obs_format; d->state = o->state; d->pos = o->pos; d->orient = o->orient;
+    return SSD_OK;
+}
+static int launched(void) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SSD_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    return SSD_OK;
+}
+
+int ssd_reset(ssd_env* E, const uint8_t* env_mask, const ssd_tape* tape, ssd_step_out* out, void* stream) {
+    if (!E) return fail(SSD_ERR_INVALID, "null env");
+    DevTape t; if (int rc = make_tape(E, tape, &t)) return rc;
+    DevObsOut oo; std::memset(&oo, 0, sizeof oo);
+    launch_env(MODE_RESET, E->dspec, E->hs, E->st, nullptr, env_mask, t, make_so(out), oo, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_step(ssd_env* E, const int32_t* actions, const ssd_tape* tape, ssd_step_out* out, void* stream) {
+    if (!E || !actions) return fail(SSD_ERR_INVALID, "null argument");
+    DevTape t; if (int rc = make_tape(E, tape, &t)) return rc;
+    DevObsOut oo; std::memset(&oo, 0, sizeof oo);
+    launch_env(MODE_STEP, E->dspec, E->hs, E->st, actions, nullptr, t, make_so(out), oo, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_observe(ssd_env* E, ssd_obs_out* out, void* stream) {
+    if (!E) return fail(SSD_ERR_INVALID, "null env");
+    DevObsOut oo; if (int rc = make_oo(E, out, &oo)) return rc;
+    DevTape t; std::memset(&t, 0, sizeof t);
+    launch_env(MODE_OBS, E->dspec, E->hs, E->st, nullptr, nullptr, t, make_so(nullptr), oo, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_step_observe(ssd_env* E, const int32_t* actions, const ssd_tape* tape, ssd_step_out* out, ssd_obs_out* obs, void* stream) {
+    if (!E || !actions) return fail(SSD_ERR_INVALID, "null argument");
+    DevTape t; if (int rc = make_tape(E, tape, &t)) return rc;
+    DevObsOut oo; if (int rc = make_oo(E, obs, &oo)) return rc;
+    launch_env(MODE_STEP_OBS, E->dspec, E->hs, E->st, actions, nullptr, t, make_so(out), oo, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_poll_error(ssd_env* E, int32_t* bits) {
+    if (!E || !bits) return fail(SSD_ERR_INVALID, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(bits, E->st.err, 4, hipMemcpyDeviceToHost));
+    if (*bits) HIP_TRY(hipMemset(E->st.err, 0, 4));
+    return SSD_OK;
+}
+
+int ssd_export_state(ssd_env* E, ssd_state* dst, void* stream) {
+    if (!E || !dst) return fail(SSD_ERR_INVALID, "null argument");
+    launch_export(E->dspec, E->hs, E->st, *dst, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_import_state(ssd_env* E, const ssd_state* src, void* stream) {
+    if (!E || !src) return fail(SSD_ERR_INVALID, "null argument");
+    launch_import(E->dspec, E->hs, E->st, *src, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_build_inputs(int32_t batch, int32_t n_agents, int32_t n_actions, int32_t t0, const int64_t* last_actions,
+                     const float* last_reward, const int64_t* last_actions_inc, const float* pos, float pos_scale,
+                     float* out, int32_t out_stride, int32_t out_offset, void* stream) {
+    if (batch < 1 || n_agents < 1 || n_actions < 1 || !out || !pos) return fail(SSD_ERR_INVALID, "bad argument");
+    if (!t0 && (!last_actions || !last_reward || !last_actions_inc)) return fail(SSD_ERR_INVALID, "t > 0 needs the t-1 tensors");
+    if (out_stride < out_offset + n_actions + n_agents + 4) return fail(SSD_ERR_INVALID, "out_stride too small");
+    launch_build_inputs(batch, n_agents, n_actions, t0, last_actions, last_reward, last_actions_inc, pos, pos_scale, out,
+                        out_stride, out_offset, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int64_t* actions_inc, const float* rewards,
+                           float effect_ratio, float cost_ratio, float incentive, float seq_len, float* give,
+                           float* recv_pos, float* recv_neg, float* recv_zero, float* rewards_for_env,
+                           float* rewards_for_inc, void* stream) {
+    if (batch < 1 || T < 2 || n_agents < 1 || !actions_inc || !rewards || !give || !recv_pos || !recv_neg || !recv_zero ||
+        !rewards_for_env || !rewards_for_inc)
+        return fail(SSD_ERR_INVALID, "bad argument");
+    launch_incentive_transfer(batch, T, n_agents, actions_inc, rewards, effect_ratio, cost_ratio, incentive, seq_len, give,
+                              recv_pos, recv_neg, recv_zero, rewards_for_env, rewards_for_inc, (hipStream_t)stream);
+    return launched();
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// ssd_device.h -- device-side structures shared by the kernels (ssd_env.hip) and the C ABI (ssd_abi.hip).
+// gfx950 only: one 64-lane wavefront owns one env; 4 waves (4 envs) per workgroup; no workgroup barriers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ssd_hip.h"
+
+namespace ssd {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+
+enum : int { C_EMPTY = 0, C_WALL = 1, C_APPLE = 2, C_WASTE = 3, C_RIVER = 4, C_STREAM = 5 };
+enum : int { O_LEFT = 0, O_RIGHT = 1, O_UP = 2, O_DOWN = 3 };
+enum : int { MODE_RESET = 0, MODE_STEP = 1, MODE_STEP_OBS = 2, MODE_OBS = 3 };
+
+// Static description of the world, one per handle, resident in HBM and read through the scalar cache.
+struct DevSpec {
+    int32_t kind, H, W, HW, GS;          // GS = grid row stride in bytes (HW rounded up to 16)
+    int32_t n, N, V, v, VV, VVp;         // VVp = V*V rounded up to 4 (LDS window stride)
+    int32_t episode_limit, spawn_rotation, obs_color, rng_mode, n_actions;
+    int32_t n_apple, n_waste;
+    uint32_t env_id_base, seed_lo, seed_hi;
+    uint32_t magic_W, magic_V, magic_VV, magic_3VV, magic_HW;  // floor(2^32/d)+1: q = umulhi(x, magic), exact for x < 2^16
+    double thr_dep, thr_res, p_waste, p_apple;
+    double harvest_p[4];
+    uint16_t apple[SSD_MAX_SITES];       // cell index of each apple site, row-major scan order
+    uint16_t waste[SSD_MAX_SITES];
+    uint16_t spawn_cell[SSD_MAX_AGENTS]; // spawn cell of agent a under random_spawn_point = False
+    alignas(16) uint8_t reset_grid[SSD_MAX_CELLS];   // world after reset_map + custom_reset
+    uint8_t lut[16 * 3];                 // full-colour LUT by class (0..5 cell codes, 5 + agent char)
+};
+
+// Mutable per-env state (device pointers).  arec packs one agent into 32 bits: row | col << 8 | orient << 16.
+struct DevState {
+    uint8_t* grid;       // [N, GS]
+    uint32_t* arec;      // [N, n]
+    int32_t* ep_reward;  // [N, n]
+    int32_t* ep_step;    // [N]
+    uint32_t* epoch;     // [N]
+    int32_t* err;        // [1] sticky error bits
+};
+
+struct DevTape {
+    const uint8_t* move_order;
+    const double* uniforms;
+    int32_t ustride;
+    const uint8_t* waste_order;
+    const uint8_t* spawn_rot;
+};
+
+struct DevStepOut {
+    float *reward, *clean_num, *apple_den;
+    uint8_t* terminated;
+    float *collective, *equality;
+    int32_t* n_draws;
+};
+
+struct DevObsOut {
+    void* obs;
+    int32_t fmt;
+    float *state, *pos, *orient;
+};
+
+enum : int { ERR_BAD_ACTION = 1, ERR_BAD_TAPE = 2, ERR_KEYERROR = 4, ERR_TAPE_OVERRUN = 8 };
+
+// LDS bytes one wave needs.
+inline int lds_per_wave(int GS, int n, int VVp) {
+    int scratch = n * VVp;            // window classes; doubles as scratch for the tape waste order (needs 2*256)
+    if (scratch < 512) scratch = 512;
+    int b = 2 * GS + scratch + 64;    // grid | occupancy overlay | window classes / scratch | colour lut
+    return (b + 15) & ~15;
+}
+
+void launch_env(int mode, const DevSpec* spec, const DevSpec& host_spec, DevState st, const int32_t* actions,
+                const uint8_t* env_mask, DevTape tape, DevStepOut so, DevObsOut oo, hipStream_t stream);
+
+void launch_export(const DevSpec* spec, const DevSpec& hs, DevState st, ssd_state dst, hipStream_t stream);
+void launch_import(const DevSpec* spec, const DevSpec& hs, DevState st, ssd_state src, hipStream_t stream);
+
+void launch_build_inputs(int32_t batch, int32_t n, int32_t A, int32_t t0, const int64_t* last_actions,
+                         const float* last_reward, const int64_t* last_actions_inc, const float* pos, float pos_scale,
+                         float* out, int32_t out_stride, int32_t out_offset, hipStream_t stream);
+void launch_incentive_transfer(int32_t B, int32_t T, int32_t n, const int64_t* a_inc, const float* rewards,
+                               float effect_ratio, float cost_ratio, float incentive, float seq_len, float* give,
+                               float* recv_pos, float* recv_neg, float* recv_zero, float* r_env, float* r_inc,
+                               hipStream_t stream);
+
+}  // namespace ssd

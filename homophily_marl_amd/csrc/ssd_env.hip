@@ -1,0 +1,706 @@
+// ssd_env.hip -- gfx950 kernels of the vectorised SSD grid world (Cleanup / Harvest).
+//
+// Execution model: ONE 64-lane wavefront owns ONE env for the whole transition.  Its grid lives in LDS, its agents
+// live one per lane (lanes 0..n-1) in registers, and every "dict lookup" of the reference's Python becomes a wave
+// ballot / readlane.  There are no workgroup barriers: the 4 waves of a workgroup are independent envs, so a wave
+// that needs the serial conflict resolution does not hold up its neighbours.
+//
+// Reference behaviour restated here (cited per function): src/envs/ssd/map_env.py, cleanup.py, harvest.py, agent.py,
+// src/utils/utility_funcs.py.  The CPU oracle under oracle/ is a separate, serial restatement used only by tests.
+#include "ssd_device.h"
+
+namespace ssd {
+
+// ---------------------------------------------------------------------------------------------------------------
+// wave primitives
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int rl(int v, int idx) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(idx)); }
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m) {  // set bits of m in lanes below mine
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ int popc64(uint64_t m) { return __builtin_popcountll(m); }
+__device__ __forceinline__ int first_lane(uint64_t m) { return __builtin_ctzll(m); }
+__device__ __forceinline__ int last_lane(uint64_t m) { return 63 - __builtin_clzll(m); }
+// order LDS traffic of the lanes of this wave (no other wave touches this wave's LDS slice)
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint32_t udiv(uint32_t x, uint32_t magic) { return __umulhi(x, magic); }
+
+// COUNTER-mode generator (include/ssd_hip.h): word 0 of Philox4x32-10
+__device__ __forceinline__ uint32_t philox_x0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+struct Rng {
+    bool tape;
+    const double* tape_u;  // this env's row
+    int ustride;
+    uint32_t gid, epoch, k0, k1;
+    int32_t* err;
+    __device__ __forceinline__ uint32_t u32(uint32_t stream, uint32_t k) const { return philox_x0(k, stream, gid, epoch, k0, k1); }
+    // np.random.rand(1)[0] number k of this call (cleanup.py:172,183; harvest.py:119)
+    __device__ __forceinline__ double uniform(int k) const {
+        if (tape) {
+            if (k >= ustride) { atomicOr(err, ERR_TAPE_OVERRUN); return 2.0; }
+            return tape_u[k];
+        }
+        return (double)(u32(SSD_STREAM_UNIFORM, (uint32_t)k) >> 8) * (1.0 / 16777216.0);
+    }
+};
+
+// Everything one wave knows about its env.
+struct Env {
+    const DevSpec* S;
+    uint8_t* g;     // LDS grid [GS]
+    uint8_t* occ;   // LDS agent overlay [GS]: 0 or the agent char (1..9) of the highest id standing there
+    uint8_t* win;   // LDS window classes [n * VVp] (observe) / scratch (step)
+    int lane, n, W, HW, GS;
+    bool ag;        // lane < n
+    int P;          // my agent's cell (r * W + c); unique negative for non-agent lanes
+    int O;          // orientation
+};
+
+__device__ __forceinline__ int agent_char(int a) { int v = (a % 10) + 1; return v >= 10 ? 1 : v; }  // '<U1' truncation, map_env.py:370,377
+
+// occ[] := overlay of get_map_with_agents (map_env.py:360-379): later ids overwrite earlier ones
+__device__ __forceinline__ void paint_agents(Env& E) {
+    bool higher = false;
+    for (int b = 0; b < E.n; ++b) { int pb = rl(E.P, b); higher |= (b > E.lane && pb == E.P); }
+    if (E.ag && !higher) E.occ[E.P] = (uint8_t)agent_char(E.lane);
+}
+__device__ __forceinline__ void clear_agents(Env& E) { if (E.ag) E.occ[E.P] = 0; }
+
+// count cells with g == code (and, if free_only, no agent on them)
+__device__ __forceinline__ int count_cells(const Env& E, uint32_t code, bool free_only) {
+    int cnt = 0;
+    const uint32_t pat = code * 0x01010101u;
+    for (int base = 0; base < E.GS; base += 4 * kWave) {
+        int i = base + 4 * E.lane;
+        uint32_t t = 0x7F7F7F7Fu;  // "no match" for lanes past the end
+        if (i < E.GS) {
+            t = *(const uint32_t*)(E.g + i) ^ pat;          // zero byte <=> match (padding bytes hold 0 = C_EMPTY)
+            if (free_only) t |= *(const uint32_t*)(E.occ + i);
+        }
+        uint32_t nz = (t + 0x7F7F7F7Fu) & 0x80808080u;      // bytes are < 0x80: bit 7 set <=> byte != 0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cnt += popc64(ballot(!((nz >> (8 * j + 7)) & 1u)));
+    }
+    return cnt;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// update_moves (map_env.py:477-661)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void resolve_moves(Env& E, int T, uint64_t mover_mask, const Rng& R, const DevTape& tape, int env) {
+    const int n = E.n, lane = E.lane;
+    const bool mover = (mover_mask >> lane) & 1;
+    const int nm = popc64(mover_mask);
+    // O = shuffled mover list (map_env.py:540-542); lane i holds O[i]
+    int Oi = 0xFF;
+    if (R.tape) {
+        if (lane < nm) Oi = tape.move_order[(size_t)env * n + lane];
+        bool bad = lane < nm && (Oi >= n || !((mover_mask >> (Oi & 63)) & 1));
+        if (ballot(bad)) { if (lane == 0) atomicOr(R.err, ERR_BAD_TAPE); Oi = 0; }
+    } else {
+        uint32_t key = R.u32(SSD_STREAM_MOVE, (uint32_t)lane);
+        int ork = 0;
+        for (int b = 0; b < n; ++b) {
+            uint32_t kb = (uint32_t)rl((int)key, b);
+            bool mb = (mover_mask >> b) & 1;
+            ork += mb && (kb < key || (kb == key && b < lane));
+        }
+        for (int b = 0; b < n; ++b) { int ob = rl(ork, b); if (((mover_mask >> b) & 1) && ob == lane) Oi = b; }
+    }
+    int M = T;  // agent_moves[a]
+    // contested cells in lexicographic (= cell index) order (np.unique, :543-544, :553-609)
+    int cntT = 0;
+    for (int b = 0; b < n; ++b) { int tb = rl(T, b); cntT += ((mover_mask >> b) & 1) && tb == T; }
+    int last = -1;
+    for (;;) {
+        uint64_t cand = ballot(mover && cntT > 1 && T > last);
+        if (!cand) break;
+        int u = 0x7FFFFFFF;
+        for (uint64_t m = cand; m; m &= m - 1) { int tb = rl(T, first_lane(m)); u = tb < u ? tb : u; }
+        last = u;
+        const uint64_t cont = ballot(mover && T == u);
+        const uint64_t live = ballot(E.ag && E.P == u);                      // move in self.agent_pos (:567)
+        bool cell_free = true;
+        if (live) {
+            const int occ = last_lane(live);                                  // agent_by_pos: highest id wins (:570)
+            const int Pocc = rl(E.P, occ), Mocc = rl(M, occ);
+            const bool hm_occ = (mover_mask >> occ) & 1;
+            const int cm = hm_occ ? Mocc : Pocc;                              // agent_moves.get(occ, pos) (:574)
+            const bool blocked = lane == occ || !hm_occ || Pocc == cm || (Mocc == E.P && u == Pocc);  // (:578-594)
+            cell_free = ballot(((cont >> lane) & 1) && blocked) == 0;
+        }
+        if (cell_free) {                                                      // :598-601 first contender in O order moves in
+            int winner = -1;
+            for (int i = 0; i < nm; ++i) { int c = rl(Oi, i); if (winner < 0 && ((cont >> (c & 63)) & 1)) winner = c; }
+            if (lane == winner) E.P = u;
+        }
+        if ((cont >> lane) & 1) M = E.P;                                      // :604-609
+    }
+    // settle loop (:612-661)
+    uint64_t hm = mover_mask;
+    while (hm) {
+        const int SN = E.P;                   // agent_by_pos snapshot of this pass (:613)
+        const uint64_t incopy = hm;           // moves_copy keys (:616)
+        uint64_t del = 0;
+        const int before = popc64(hm);
+        for (int a = 0; a < n; ++a) {
+            const uint64_t bit_a = 1ull << a;
+            if (!(incopy & bit_a) || (del & bit_a)) continue;
+            const int m = rl(M, a);
+            const uint64_t live = ballot(E.ag && E.P == m);                   // move in self.agent_pos (:621)
+            if (live) {
+                const uint64_t snap = ballot(E.ag && SN == m);
+                if (!snap) {                                                  // KeyError in the reference; unreachable
+                    if (lane == 0) atomicOr(R.err, ERR_KEYERROR);
+                    hm &= ~bit_a; del |= bit_a; continue;
+                }
+                const int occ = last_lane(snap);                              // :624
+                const uint64_t bit_o = 1ull << occ;
+                const int Pocc = rl(E.P, occ), Mocc = rl(M, occ), Pa = rl(E.P, a);
+                const int cm = (hm & bit_o) ? Mocc : Pocc;                    // live agent_moves (:627)
+                if (a == occ) { hm &= ~bit_a; del |= bit_a; }                 // :630
+                else if (!(incopy & bit_o) || Pocc == cm) { hm &= ~bit_a; del |= bit_a; }            // :636
+                else if (Mocc == Pa && m == Pocc) { hm &= ~(bit_a | bit_o); del |= bit_a | bit_o; }  // :642-648
+            } else {                                                          // :650-653
+                if (lane == a) E.P = m;
+                hm &= ~bit_a; del |= bit_a;
+            }
+        }
+        if (popc64(hm) == before) {                                           // :658-661 cycles: move them all
+            if ((hm >> lane) & 1) E.P = M;
+            break;
+        }
+    }
+}
+
+// returns the MOVE/STAY mask after applying turns and computing wall-checked targets (map_env.py:498-511)
+__device__ __forceinline__ void move_phase(Env& E, int act, const Rng& R, const DevTape& tape, int env) {
+    const DevSpec* S = E.S;
+    const int n = E.n, lane = E.lane;
+    const bool mover = E.ag && (unsigned)act <= 4u;
+    if (E.ag && act == 5) E.O = (0x0132 >> (4 * E.O)) & 3;   // TURN_CLOCKWISE: LEFT->UP->RIGHT->DOWN (map_env.py:853-861)
+    if (E.ag && act == 6) E.O = (0x1023 >> (4 * E.O)) & 3;   // TURN_COUNTERCLOCKWISE: LEFT->DOWN->RIGHT->UP (:844-852)
+    int T = E.P;
+    if (mover && act != 4) {
+        // ACTIONS vectors [row, col] (map_env.py:20-24) rotated by orientation (rotate_action :826-841)
+        int v0 = act == 0 ? -1 : act == 1 ? 1 : 0;
+        int v1 = act == 2 ? -1 : act == 3 ? 1 : 0;
+        int d0, d1;
+        if (E.O == O_UP) { d0 = v0; d1 = v1; }
+        else if (E.O == O_LEFT) { d0 = v1; d1 = -v0; }        // np.dot([[0,1],[-1,0]], v)
+        else if (E.O == O_RIGHT) { d0 = -v1; d1 = v0; }       // np.dot([[0,-1],[1,0]], v)
+        else { d0 = -v0; d1 = -v1; }
+        int t = E.P + d0 * E.W + d1;                          // the border is all wall, so t stays inside the map
+        if ((unsigned)t < (unsigned)E.HW && E.g[t] != C_WALL) T = t;   // return_valid_pos (agent.py:111-119)
+    }
+    const uint64_t mover_mask = ballot(mover);
+    if (!mover_mask) return;                                  // :534
+    // fast path: nobody targets another agent's cell and no two movers share a target => every move applies
+    bool clash = false;
+    for (int b = 0; b < n; ++b) {
+        int pb = rl(E.P, b), tb = rl(T, b);
+        bool mb = (mover_mask >> b) & 1;
+        if (mover && b != lane) clash |= (T == pb) | (mb && T == tb);
+    }
+    if (ballot(clash) == 0) { if (mover) E.P = T; return; }
+    resolve_moves(E, T, mover_mask, R, tape, env);
+    (void)S;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CLEAN beams (map_env.py:687-769 with cleanup.py:135-143).  FIRE beams change nothing but the shooter's reward
+// (hit() is a no-op, agent.py:184-186,246-248; blocking_cells='P' never occurs), so they are not traced.
+// Returns the number of cells cleaned by agent f; 15 lanes = 3 beams x 5 cells.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clean_beams(Env& E, int f) {
+    const int W = E.W, H = E.S->H;
+    const int pf = rl(E.P, f), of = rl(E.O, f);
+    const int pr = (int)udiv((uint32_t)pf, E.S->magic_W), pc = pf - pr * W;
+    const int dr = of == O_LEFT ? -1 : of == O_RIGHT ? 1 : 0;
+    const int dc = of == O_UP ? -1 : of == O_DOWN ? 1 : 0;
+    const int rr = -dc, rc = dr;                      // rotate_right(dir) = np.dot([[0,-1],[1,0]], dir)
+    const int b = E.lane / 5, k = E.lane - 5 * b;     // beam, step
+    const int sr = b == 0 ? pr : b == 1 ? pr + rr - dr : pr - rr - dr;
+    const int sc = b == 0 ? pc : b == 1 ? pc + rc - dc : pc - rc - dc;
+    const int r = sr + (k + 1) * dr, c = sc + (k + 1) * dc;
+    const bool act15 = E.lane < 15;
+    const bool inb = act15 && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W;
+    const int cell = inb ? r * W + c : 0;
+    const int gc = inb ? E.g[cell] : C_WALL;
+    const int oc = inb ? E.occ[cell] : 0;
+    const bool stop = act15 && (!inb || gc == C_WALL || oc != 0 || gc == C_WASTE);
+    const uint32_t m = (uint32_t)ballot(stop);
+    const uint32_t field = b < 3 ? (m >> (5 * b)) & 31u : 0u;
+    const bool first = stop && (field & ((1u << k) - 1u)) == 0;
+    const bool hit = first && inb && gc == C_WASTE;   // :745-754: 'H' -> 'R', with or without an agent on it
+    const int cnt = popc64(ballot(hit));
+    wsync();
+    if (hit) E.g[cell] = C_RIVER;
+    wsync();
+    return cnt;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// custom_map_update: Cleanup (cleanup.py:146-204) / Harvest (harvest.py:86-122).  Returns the uniforms consumed.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const DevTape& tape, int env) {
+    const DevSpec* S = E.S;
+    const int lane = E.lane;
+    // compute_probabilities (cleanup.py:189-204), fp64, reference operation order
+    double p_apple = 0, p_waste = 0, wd = 0;
+    const int potential = S->n_waste;
+    if (potential > 0) {
+        const int current = count_cells(E, C_WASTE, false);
+        const int free_area = potential - current;
+        wd = 1 - (double)free_area / (double)potential;
+    }
+    if (!(wd >= S->thr_dep)) {
+        p_waste = S->p_waste;
+        if (wd <= S->thr_res) p_apple = S->p_apple;
+        else p_apple = (1 - (wd - S->thr_res) / (S->thr_dep - S->thr_res)) * S->p_apple;
+    }
+    int k = 0;
+    // apples: one draw per site that holds neither an agent nor an apple, in site order (cleanup.py:168-174).
+    // Apple sites and waste sites are disjoint, so writing 'A' at once is equivalent to the deferred update_map.
+    for (int base = 0; base < S->n_apple; base += kWave) {
+        const int i = base + lane;
+        const bool in = i < S->n_apple;
+        const int cell = in ? S->apple[i] : 0;
+        const bool elig = in && E.occ[cell] == 0 && E.g[cell] != C_APPLE;
+        const uint64_t bal = ballot(elig);
+        if (elig && p_apple > 0) {
+            const double u = R.uniform(k + (int)lanes_below(bal));
+            if (u < p_apple) E.g[cell] = C_APPLE;
+        }
+        k += popc64(bal);
+    }
+    // waste: at most one spawn, first free site in shuffled order whose draw succeeds (cleanup.py:177-186)
+    if (!(fabs(p_waste) <= 1e-8)) {                           // np.isclose(p, 0)
+        const int nw = S->n_waste;
+        uint16_t* scratch = (uint16_t*)E.win;                 // tape mode: rank of each site in the shuffled list
+        if (R.tape) {
+            for (int base = 0; base < nw; base += kWave) {
+                const int p = base + lane;
+                if (p < nw) {
+                    int s = tape.waste_order[(size_t)env * nw + p];
+                    if (s >= nw) { atomicOr(R.err, ERR_BAD_TAPE); s = 0; }
+                    scratch[s] = (uint16_t)p;
+                }
+            }
+            wsync();
+        }
+        // free sites and their sort keys (<= 4 chunks of 64 sites)
+        int nfree = 0;
+        uint64_t best[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            best[ch] = ~0ull;
+            const int s = ch * kWave + lane;
+            if (ch * kWave < nw) {
+                const bool fr = s < nw && E.g[S->waste[s]] != C_WASTE;
+                nfree += popc64(ballot(fr));
+                if (fr) {
+                    const uint32_t key = R.tape ? (uint32_t)scratch[s] : R.u32(SSD_STREAM_WASTE, (uint32_t)s);
+                    best[ch] = ((uint64_t)key << 32) | (uint32_t)s;
+                }
+            }
+        }
+        // J = index (in shuffled free-site order) of the first successful draw
+        int J = -1;
+        for (int base = 0; base < nfree && J < 0; base += kWave) {
+            const int j = base + lane;
+            const bool ok = j < nfree && R.uniform(k + j) < p_waste;
+            const uint64_t b = ballot(ok);
+            if (b) J = base + first_lane(b);
+        }
+        k += J >= 0 ? J + 1 : nfree;
+        if (J >= 0) {
+            // the (J+1)-th smallest (key, site) among the free sites
+            uint64_t sel = ~0ull;
+            for (int it = 0; it <= J; ++it) {
+                uint64_t mn = best[0];
+#pragma unroll
+                for (int ch = 1; ch < 4; ++ch) mn = best[ch] < mn ? best[ch] : mn;
+#pragma unroll
+                for (int sh = 32; sh >= 1; sh >>= 1) { uint64_t o = shfl_xor64(mn, sh); mn = o < mn ? o : mn; }
+                sel = mn;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) if (best[ch] == sel) best[ch] = ~0ull;
+            }
+            const int s = (int)(uint32_t)sel;
+            if (lane == 0) E.g[S->waste[s]] = C_WASTE;
+        }
+    }
+    wsync();
+    return k;
+}
+
+__device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R) {
+    const DevSpec* S = E.S;
+    const int lane = E.lane, W = E.W, H = S->H;
+    int k = 0;
+    uint32_t spawn_bits = 0;  // decisions are applied after ALL sites were examined (synchronous update, harvest.py:86-90)
+    for (int base = 0, ch = 0; base < S->n_apple; base += kWave, ++ch) {
+        const int i = base + lane;
+        const bool in = i < S->n_apple;
+        const int cell = in ? S->apple[i] : 0;
+        const bool elig = in && E.occ[cell] == 0 && E.g[cell] != C_APPLE;
+        const uint64_t bal = ballot(elig);
+        if (elig) {
+            const int r = (int)udiv((uint32_t)cell, S->magic_W), c = cell - r * W;
+            int num = 0;  // offsets with j*j + k*k <= APPLE_RADIUS (= 2): the 3x3 block (harvest.py:108-116)
+#pragma unroll
+            for (int j = -1; j <= 1; ++j)
+#pragma unroll
+                for (int q = -1; q <= 1; ++q) {
+                    const int x = r + j, y = c + q;
+                    if ((unsigned)x < (unsigned)H && (unsigned)y < (unsigned)W) num += E.g[x * W + y] == C_APPLE;
+                }
+            const double p = S->harvest_p[num < 3 ? num : 3];
+            const double u = R.uniform(k + (int)lanes_below(bal));
+            if (u < p) spawn_bits |= 1u << ch;
+        }
+        k += popc64(bal);
+    }
+    wsync();
+    for (int base = 0, ch = 0; base < S->n_apple; base += kWave, ++ch)
+        if ((spawn_bits >> ch) & 1) E.g[S->apple[base + lane]] = C_APPLE;
+    wsync();
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// observation (map_env.py:360-379,418-446,795-815,923-957; utility_funcs.py:58-116)
+// ---------------------------------------------------------------------------------------------------------------
+// class of one map cell: simplified colours -> 0 nothing, 1 apple (G), 2 waste (R), 3 wall or agent (B);
+// full colours -> LUT row (cell code, or 5 + agent char)
+template <bool FULL>
+__device__ __forceinline__ int cell_class(const Env& E, int cell) {
+    const int gc = E.g[cell], oc = E.occ[cell];
+    if (FULL) return oc ? 5 + oc : gc;
+    if (oc || gc == C_WALL) return 3;
+    if (gc == C_APPLE) return 1;
+    return (gc == C_WASTE && E.S->kind == SSD_ENV_CLEANUP) ? 2 : 0;
+}
+template <bool FULL>
+__device__ __forceinline__ uint32_t class_value(const uint8_t* lut, int cls, int ch) {
+    if (FULL) return lut[cls * 3 + ch];
+    return cls == (ch == 0 ? 2 : ch == 1 ? 1 : 3) ? 255u : 0u;   // R <- waste, G <- apple, B <- wall/agent
+}
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> { static __device__ __forceinline__ float f(uint32_t v) { return (float)v * (1.0f / 256.0f); } };
+template <> struct Cvt<uint16_t> { static __device__ __forceinline__ uint16_t f(uint32_t v) { return (uint16_t)(__float_as_uint((float)v * (1.0f / 256.0f)) >> 16); } };
+template <> struct Cvt<uint8_t> { static __device__ __forceinline__ uint8_t f(uint32_t v) { return (uint8_t)v; } };
+
+// Write L elements val(0..L-1) to dst[0..L) with 16-byte stores wherever the address allows.
+// elem_off = index of dst[0] in the (16-byte aligned) output tensor.
+template <typename T, typename F>
+__device__ __forceinline__ void emit(T* dst, size_t elem_off, int L, int lane, F val) {
+    constexpr int EPV = 16 / (int)sizeof(T);
+    int head = (int)((EPV - (elem_off % EPV)) % EPV);
+    if (head > L) head = L;
+    for (int i = lane; i < head; i += kWave) dst[i] = Cvt<T>::f(val(i));
+    const int nvec = (L - head) / EPV;
+    for (int q = lane; q < nvec; q += kWave) {
+        const int f0 = head + q * EPV;
+        union { T e[EPV]; uint4 v; } u;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) u.e[j] = Cvt<T>::f(val(f0 + j));
+        *(uint4*)(dst + f0) = u.v;
+    }
+    const int t0 = head + nvec * EPV;
+    for (int i = t0 + lane; i < L; i += kWave) dst[i] = Cvt<T>::f(val(i));
+}
+
+template <bool FULL>
+__device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& oo) {
+    const DevSpec* S = E.S;
+    const int lane = E.lane, n = E.n, W = E.W, H = S->H, V = S->V, v = S->v, VV = S->VV, VVp = S->VVp;
+    uint8_t* lut = E.win + n * VVp;  // 48 bytes behind the windows
+    if (FULL) { if (lane < 48) lut[lane] = S->lut[lane]; wsync(); }
+    if (oo.obs) {
+        // pass 1: class of every window cell, window of agent a rotated by its orientation
+        for (int a = 0; a < n; ++a) {
+            const int pa = rl(E.P, a), oa = rl(E.O, a);
+            const int pr = (int)udiv((uint32_t)pa, S->magic_W), pc = pa - pr * W;
+            for (int ij = lane; ij < VV; ij += kWave) {
+                const int i = (int)udiv((uint32_t)ij, S->magic_V), j = ij - i * V;
+                // rotate_view = np.rot90(view, k): k = 0 UP, 1 LEFT, 2 DOWN, 3 RIGHT (map_env.py:795-815)
+                int x, y;
+                if (oa == O_UP) { x = i; y = j; }
+                else if (oa == O_LEFT) { x = j; y = V - 1 - i; }
+                else if (oa == O_DOWN) { x = V - 1 - i; y = V - 1 - j; }
+                else { x = V - 1 - j; y = i; }
+                const int r = pr - v + x, c = pc - v + y;   // return_view zero padding (utility_funcs.py:58-116)
+                int cls = 0;
+                if ((unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W) cls = cell_class<FULL>(E, r * W + c);
+                E.win[a * VVp + ij] = (uint8_t)cls;
+            }
+        }
+        wsync();
+        // pass 2: expand to [n, 3, V, V] (CHW, value / 256) with vector stores
+        if (oo.fmt == SSD_OBS_CODE) {
+            const int L = n * VV;
+            const size_t off = (size_t)env * L;
+            emit<uint8_t>((uint8_t*)oo.obs + off, off, L, lane, [&](int f) -> uint32_t {
+                const int a = (int)udiv((uint32_t)f, S->magic_VV);
+                return E.win[a * VVp + (f - a * VV)];
+            });
+        } else {
+            const int L = n * 3 * VV;
+            const size_t off = (size_t)env * L;
+            auto val = [&](int f) -> uint32_t {
+                const int a = (int)udiv((uint32_t)f, S->magic_3VV);
+                const int fr = f - a * 3 * VV;
+                const int ch = (fr >= VV) + (fr >= 2 * VV);
+                return class_value<FULL>(lut, E.win[a * VVp + (fr - ch * VV)], ch);
+            };
+            if (oo.fmt == SSD_OBS_F32) emit<float>((float*)oo.obs + off, off, L, lane, val);
+            else if (oo.fmt == SSD_OBS_BF16) emit<uint16_t>((uint16_t*)oo.obs + off, off, L, lane, val);
+            else emit<uint8_t>((uint8_t*)oo.obs + off, off, L, lane, val);
+        }
+    }
+    if (oo.state) {  // get_state (map_env.py:950-957): [3, H, W] / 256
+        const int L = 3 * E.HW;
+        const size_t off = (size_t)env * L;
+        emit<float>(oo.state + off, off, L, lane, [&](int f) -> uint32_t {
+            const int ch = (int)udiv((uint32_t)f, S->magic_HW);
+            return class_value<FULL>(lut, cell_class<FULL>(E, f - ch * E.HW), ch);
+        });
+    }
+    if (E.ag) {
+        const int pr = (int)udiv((uint32_t)E.P, S->magic_W), pc = E.P - pr * W;
+        const size_t o2 = ((size_t)env * n + lane) * 2;
+        if (oo.pos) { oo.pos[o2] = (float)pr; oo.pos[o2 + 1] = (float)pc; }                 // get_agent_pos (:917-918)
+        if (oo.orient) {                                                                    // ORIENTATIONS vector (:920-921)
+            oo.orient[o2] = E.O == O_LEFT ? -1.f : E.O == O_RIGHT ? 1.f : 0.f;
+            oo.orient[o2 + 1] = E.O == O_UP ? -1.f : E.O == O_DOWN ? 1.f : 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the kernel: MODE_RESET (_reset, map_env.py:297-326), MODE_STEP / MODE_STEP_OBS (_step + step, :227-295,:874-915),
+// MODE_OBS (get_obs & co, :917-957)
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, DevState st, const int32_t* __restrict__ actions,
+                                                 const uint8_t* __restrict__ env_mask, DevTape tape, DevStepOut so,
+                                                 DevObsOut oo, int lds_stride) {
+    extern __shared__ uint4 smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int env = blockIdx.x * kWavesPerBlock + wave;
+    if (env >= S->N) return;
+    if (MODE == MODE_RESET && env_mask && !env_mask[env]) return;
+
+    Env E;
+    E.S = S; E.lane = lane; E.n = S->n; E.W = S->W; E.HW = S->HW; E.GS = S->GS;
+    E.g = (uint8_t*)smem + (size_t)wave * lds_stride;
+    E.occ = E.g + E.GS;
+    E.win = E.occ + E.GS;
+    E.ag = lane < E.n;
+    const int n = E.n, GS = E.GS;
+
+    uint8_t* ggrid = st.grid + (size_t)env * GS;
+    // ---- load the grid (or the reset image) into LDS, clear the overlay ----
+    for (int i = lane * 16; i < GS; i += kWave * 16) {
+        *(uint4*)(E.g + i) = MODE == MODE_RESET ? *(const uint4*)(S->reset_grid + i) : *(const uint4*)(ggrid + i);
+        *(uint4*)(E.occ + i) = make_uint4(0, 0, 0, 0);
+    }
+    const uint32_t epoch = st.epoch[env];
+    Rng R;
+    R.tape = S->rng_mode == SSD_RNG_TAPE;
+    R.ustride = tape.ustride;
+    R.tape_u = R.tape ? tape.uniforms + (size_t)env * tape.ustride : nullptr;
+    R.gid = S->env_id_base + (uint32_t)env; R.epoch = epoch; R.k0 = S->seed_lo; R.k1 = S->seed_hi; R.err = st.err;
+
+    int act = 4, ep_r = 0;
+    if (E.ag) {
+        if (MODE == MODE_RESET) {
+            // setup_agents: agent a takes the last spawn point still free (map_env.py:771-784) = spawn_cell[a];
+            // spawn_rotation (:786-793)
+            E.P = S->spawn_cell[lane];
+            if (S->spawn_rotation >= 0) E.O = S->spawn_rotation;
+            else if (R.tape) E.O = tape.spawn_rot[(size_t)env * n + lane] & 3;
+            else E.O = (int)(R.u32(SSD_STREAM_SPAWN_ROT, (uint32_t)lane) >> 30);
+        } else {
+            const uint32_t rec = st.arec[(size_t)env * n + lane];
+            E.P = (int)(rec & 0xFF) * E.W + (int)((rec >> 8) & 0xFF);
+            E.O = (int)((rec >> 16) & 3);
+            ep_r = st.ep_reward[(size_t)env * n + lane];
+        }
+        if (MODE == MODE_STEP || MODE == MODE_STEP_OBS) {
+            act = actions[(size_t)env * n + lane];
+            if ((unsigned)act >= (unsigned)S->n_actions) { atomicOr(st.err, ERR_BAD_ACTION); act = 4; }  // KeyError in action_map
+        }
+    } else {
+        E.P = -1 - lane; E.O = 0;
+    }
+    wsync();
+
+    int n_draws = 0;
+    if (MODE == MODE_RESET) {
+        paint_agents(E);
+        wsync();
+        n_draws = S->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape, env) : spawn_harvest(E, R);   // map_env.py:313
+        ep_r = 0;
+        if (lane == 0) { st.ep_step[env] = 0; st.epoch[env] = epoch + 1; if (so.n_draws) so.n_draws[env] = n_draws; }
+    }
+    if (MODE == MODE_STEP || MODE == MODE_STEP_OBS) {
+        int reward = 0, cleaned = 0;
+        move_phase(E, act, R, tape, env);                                        // map_env.py:251
+        // consume (map_env.py:253-256, agent.py:195-201,250-256): in id order, so only the lowest id on a cell eats
+        {
+            bool lower = false;
+            for (int b = 0; b < n; ++b) { int pb = rl(E.P, b); lower |= (b < lane && pb == E.P); }
+            if (E.ag && !lower && E.g[E.P] == C_APPLE) { reward += 1; E.g[E.P] = C_EMPTY; }
+        }
+        paint_agents(E);
+        wsync();
+        // update_custom_moves (map_env.py:663-673): sequential over agents, the map is updated after each one
+        {
+            const uint64_t fire = ballot(E.ag && act >= 7);
+            for (uint64_t m = fire; m; m &= m - 1) {
+                const int f = first_lane(m);
+                const int af = rl(act, f);
+                if (S->kind == SSD_ENV_CLEANUP && af == 8) {                      // CLEAN (cleanup.py:135-143)
+                    const int c = clean_beams(E, f);
+                    if (lane == f) cleaned = c;
+                } else if (lane == f) reward -= 1;                                // fire_beam('F') (agent.py:188-190,239-241)
+            }
+        }
+        n_draws = S->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape, env) : spawn_harvest(E, R);   // map_env.py:263
+        // scalars (map_env.py:291-292, 883-914)
+        const int apples = count_cells(E, C_APPLE, true);
+        const float den = (float)((double)apples / (double)E.HW);
+        ep_r += reward;
+        const int step = st.ep_step[env] + 1;
+        const bool term = step >= S->episode_limit;
+        if (E.ag) {
+            const size_t o = (size_t)env * n + lane;
+            if (so.reward) so.reward[o] = (float)reward;
+            if (so.clean_num) so.clean_num[o] = (float)cleaned;
+            if (so.apple_den) so.apple_den[o] = den;
+        }
+        if (term && (so.collective || so.equality)) {
+            double sum = 0, asum = 0, diff = 0;
+            for (int b = 0; b < n; ++b) {
+                const double rb = (double)rl(ep_r, b);
+                sum += rb; asum += fabs(rb);
+                for (int c = 0; c < n; ++c) diff += fabs(rb - (double)rl(ep_r, c));
+            }
+            const double eq = sum != 0 ? 1 - diff / (2 * n * asum) : 1.0;
+            if (lane == 0) { if (so.collective) so.collective[env] = (float)sum; if (so.equality) so.equality[env] = (float)eq; }
+        }
+        if (lane == 0) {
+            st.ep_step[env] = step; st.epoch[env] = epoch + 1;
+            if (so.terminated) so.terminated[env] = term ? 1 : 0;
+            if (so.n_draws) so.n_draws[env] = n_draws;
+        }
+    }
+    if (MODE == MODE_OBS) { paint_agents(E); wsync(); }
+
+    if (MODE != MODE_OBS) {
+        // ---- write the state back ----
+        for (int i = lane * 16; i < GS; i += kWave * 16) *(uint4*)(ggrid + i) = *(const uint4*)(E.g + i);
+        if (E.ag) {
+            const int pr = (int)udiv((uint32_t)E.P, S->magic_W), pc = E.P - pr * E.W;
+            st.arec[(size_t)env * n + lane] = (uint32_t)pr | ((uint32_t)pc << 8) | ((uint32_t)E.O << 16);
+            st.ep_reward[(size_t)env * n + lane] = ep_r;
+        }
+    }
+    if (MODE == MODE_STEP_OBS || MODE == MODE_OBS) {
+        if (S->obs_color == SSD_COLOR_FULL) observe_phase<true>(E, env, oo);
+        else observe_phase<false>(E, env, oo);
+    }
+}
+
+void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, const int32_t* actions,
+                const uint8_t* env_mask, DevTape tape, DevStepOut so, DevObsOut oo, hipStream_t stream) {
+    const int blocks = (hs.N + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int stride = lds_per_wave(hs.GS, hs.n, hs.VVp);
+    const size_t lds = (size_t)stride * kWavesPerBlock;
+    switch (mode) {
+        case MODE_RESET: hipLaunchKernelGGL(k_env<MODE_RESET>, dim3(blocks), dim3(kBlock), lds, stream, spec, st, actions, env_mask, tape, so, oo, stride); break;
+        case MODE_STEP: hipLaunchKernelGGL(k_env<MODE_STEP>, dim3(blocks), dim3(kBlock), lds, stream, spec, st, actions, env_mask, tape, so, oo, stride); break;
+        case MODE_STEP_OBS: hipLaunchKernelGGL(k_env<MODE_STEP_OBS>, dim3(blocks), dim3(kBlock), lds, stream, spec, st, actions, env_mask, tape, so, oo, stride); break;
+        default: hipLaunchKernelGGL(k_env<MODE_OBS>, dim3(blocks), dim3(kBlock), lds, stream, spec, st, actions, env_mask, tape, so, oo, stride); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// state export / import (parity tests, KATs, warm starts)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_export(DevSpec const* S, DevState st, ssd_state d) {
+    const int N = S->N, n = S->n, HW = S->HW, GS = S->GS;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    if (d.grid) for (size_t i = tid; i < (size_t)N * HW; i += nt) { size_t e = i / HW; d.grid[i] = st.grid[e * GS + (i - e * HW)]; }
+    for (size_t i = tid; i < (size_t)N * n; i += nt) {
+        const uint32_t rec = st.arec[i];
+        if (d.pos) { d.pos[2 * i] = (int16_t)(rec & 0xFF); d.pos[2 * i + 1] = (int16_t)((rec >> 8) & 0xFF); }
+        if (d.orient) d.orient[i] = (uint8_t)((rec >> 16) & 3);
+        if (d.ep_reward) d.ep_reward[i] = st.ep_reward[i];
+    }
+    for (size_t i = tid; i < (size_t)N; i += nt) {
+        if (d.ep_step) d.ep_step[i] = st.ep_step[i];
+        if (d.epoch) d.epoch[i] = st.epoch[i];
+    }
+}
+
+__global__ void k_import(DevSpec const* S, DevState st, ssd_state s) {
+    const int N = S->N, n = S->n, HW = S->HW, GS = S->GS;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    if (s.grid) for (size_t i = tid; i < (size_t)N * HW; i += nt) {
+        size_t e = i / HW;
+        uint8_t c = s.grid[i];
+        st.grid[e * GS + (i - e * HW)] = c <= C_STREAM ? c : (uint8_t)C_EMPTY;
+    }
+    for (size_t i = tid; i < (size_t)N * n; i += nt) {
+        uint32_t rec = st.arec[i];
+        if (s.pos) {
+            int r = s.pos[2 * i], c = s.pos[2 * i + 1];
+            r = r < 0 ? 0 : r >= S->H ? S->H - 1 : r; c = c < 0 ? 0 : c >= S->W ? S->W - 1 : c;
+            rec = (rec & ~0xFFFFu) | (uint32_t)r | ((uint32_t)c << 8);
+        }
+        if (s.orient) rec = (rec & ~0x30000u) | ((uint32_t)(s.orient[i] & 3) << 16);
+        st.arec[i] = rec;
+        if (s.ep_reward) st.ep_reward[i] = s.ep_reward[i];
+    }
+    for (size_t i = tid; i < (size_t)N; i += nt) {
+        if (s.ep_step) st.ep_step[i] = s.ep_step[i];
+        if (s.epoch) st.epoch[i] = s.epoch[i];
+    }
+}
+
+void launch_export(const DevSpec* spec, const DevSpec& hs, DevState st, ssd_state dst, hipStream_t stream) {
+    size_t work = (size_t)hs.N * hs.HW;
+    int blocks = (int)((work + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_export, dim3(blocks), dim3(256), 0, stream, spec, st, dst);
+}
+void launch_import(const DevSpec* spec, const DevSpec& hs, DevState st, ssd_state src, hipStream_t stream) {
+    size_t work = (size_t)hs.N * hs.HW;
+    int blocks = (int)((work + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_import, dim3(blocks), dim3(256), 0, stream, spec, st, src);
+}
+
+}  // namespace ssd

@@ -141,6 +141,10 @@ int ssd_observe(ssd_env* env, ssd_obs_out* out, void* stream);
 int ssd_step_observe(ssd_env* env, const int32_t* actions, const ssd_tape* tape, ssd_step_out* out,
                      ssd_obs_out* obs, void* stream);
 
+/* Sticky device-side error bits (1 action out of range = KeyError in action_map, agent.py:174-176,235-237;
+ * 2 malformed tape; 4 agent_by_pos KeyError; 8 tape overrun).  Synchronises the device; clears the bits. */
+int ssd_poll_error(ssd_env* env, int32_t* bits);
+
 int ssd_export_state(ssd_env* env, ssd_state* dst, void* stream);
 int ssd_import_state(ssd_env* env, const ssd_state* src, void* stream);
 

@@ -1,0 +1,191 @@
+"""GPU suite: the HIP kernels (through the C ABI) against the golden vectors and against the CPU oracle."""
+import numpy as np
+import pytest
+
+from homophily_marl_amd import abi
+from tests import golden_util as GU
+
+pytestmark = pytest.mark.gpu
+
+ALL = dict(disable_rotation_action=False, disable_fire_action=False)
+CONFIGS = {
+    "cleanup3": dict(env="cleanup", map="default3", num_agents=3, view_size=7),
+    "cleanup5": dict(env="cleanup", map="default5", num_agents=5, view_size=7),
+    "cleanup10": dict(env="cleanup", map="default10", num_agents=10, view_size=7),
+    "harvest5": dict(env="harvest", map="default10", num_agents=5, view_size=15),
+    "harvest10": dict(env="harvest", map="default10", num_agents=10, view_size=7),
+}
+
+
+def _hip():
+    from tests.hip_adapter import HipEnv, hip_tape
+    return HipEnv, hip_tape
+
+
+@pytest.mark.parametrize("path", GU.traj_files(), ids=lambda p: p.split("traj_")[-1][:-4])
+def test_golden_trajectory(path):
+    HipEnv, hip_tape = _hip()
+    assert GU.replay(HipEnv, hip_tape, path, n_env=1) > 50
+
+
+def test_golden_trajectory_batched():
+    HipEnv, hip_tape = _hip()
+    for key in ("cleanup5_cluster", "harvest5_allact"):
+        path = [p for p in GU.traj_files() if key in p][0]
+        GU.replay(HipEnv, hip_tape, path, n_env=7)      # 7: a partially filled workgroup (4 envs per workgroup)
+
+
+def test_move_kats():
+    HipEnv, hip_tape = _hip()
+    assert GU.replay_kats(HipEnv, hip_tape) > 2000
+
+
+def _cluster(rng, grid, N, n, HW_shape):
+    H, W = HW_shape
+    free = np.argwhere(grid.reshape(H, W) != 1)
+    pos = np.zeros((N, n, 2), np.int16)
+    for e in range(N):
+        c = free[rng.integers(len(free))]
+        k = 0
+        while k < n:
+            p = c + rng.integers(-2, 3, 2)
+            if 0 < p[0] < H - 1 and 0 < p[1] < W - 1 and grid.reshape(H, W)[p[0], p[1]] != 1:
+                pos[e, k] = p; k += 1
+    return pos
+
+
+def _compare_step(tag, a, b, keys=("reward", "clean_num", "apple_den", "terminated", "n_draws")):
+    for k in keys:
+        assert (a[k] == b[k]).all(), (tag, k, np.argwhere(a[k] != b[k])[:4].tolist())
+
+
+def _compare_state(tag, dev, orc):
+    sa, sb = dev.export_state(), orc.export_state()
+    for k in ("grid", "pos", "orient", "ep_reward", "ep_step", "epoch"):
+        assert (sa[k] == sb[k]).all(), (tag, k, np.argwhere(sa[k] != sb[k])[:4].tolist())
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("opts", [None, dict(ALL, random_spawn_rotation=None, obs_color="full")], ids=["default", "allact_full"])
+def test_counter_mode_vs_oracle(name, opts):
+    """Random actions, COUNTER RNG, 258 envs, 2 episodes of 40 steps; everything compared every step."""
+    from oracle.oracle_py import OracleEnv
+    HipEnv, _ = _hip()
+    cfg = CONFIGS[name]
+    N, T = 258, 40
+    kw = dict(map=cfg["map"], num_agents=cfg["num_agents"], n_env=N, view_size=cfg["view_size"], episode_limit=T,
+              extra_args=opts, rng_mode=abi.RNG_COUNTER, seed=0xC0FFEE + len(name), env_id_base=1000)
+    dev, orc = HipEnv(cfg["env"], **kw), OracleEnv(cfg["env"], **kw)
+    n = cfg["num_agents"]
+    rng = np.random.default_rng(len(name))
+    avail = list(range(dev.n_actions)) if opts else [a for a in range(dev.n_actions) if a not in (5, 6, 7)]
+    simplified = not opts
+    for ep in range(2):
+        _compare_step(("reset", ep), dev.reset(), orc.reset(), keys=("n_draws",))
+        _compare_state(("reset", ep), dev, orc)
+        for t in range(T):
+            if t % 9 == 4:   # teleport half of the envs into tight clusters: dense move conflicts
+                g = orc.export_state()["grid"][0]
+                pos = orc.export_state()["pos"]
+                cl = _cluster(rng, g, N, n, (dev.H, dev.W))
+                pos[::2] = cl[::2]
+                dev.import_state(pos=pos); orc.import_state(pos=pos)
+            acts = rng.choice(avail, size=(N, n)).astype(np.int32)
+            if t % 3 == 0:
+                a = dev.step_observe(acts)
+                b = orc.step(acts)
+                _compare_step((ep, t), a, b)
+                ob = orc.observe(abi.OBS_F32)
+                for k in ("obs", "pos", "orient"):
+                    assert (a[k] == ob[k]).all(), (ep, t, k)
+            else:
+                _compare_step((ep, t), dev.step(acts), orc.step(acts))
+            _compare_state((ep, t), dev, orc)
+            if t % 10 == 5:
+                fmts = [abi.OBS_F32, abi.OBS_U8, abi.OBS_BF16] + ([abi.OBS_CODE] if simplified else [])
+                for fmt in fmts:
+                    a, b = dev.observe(fmt, want_state=True), orc.observe(fmt, want_state=True)
+                    for k in ("obs", "state", "pos", "orient"):
+                        assert (a[k] == b[k]).all(), (ep, t, fmt, k)
+    dev.close(); orc.close()
+
+
+def test_full_size_cleanup5_4096_envs_vs_oracle():
+    """BASELINE.json configs[1] size: 4096 envs x 5 agents, one full 100-step episode, every step compared."""
+    from oracle.oracle_py import OracleEnv
+    HipEnv, _ = _hip()
+    N, n, T = 4096, 5, 100
+    kw = dict(map="default5", num_agents=n, n_env=N, view_size=7, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=1)
+    dev, orc = HipEnv("cleanup", **kw), OracleEnv("cleanup", **kw)
+    rng = np.random.default_rng(0x5D5D)
+    avail = np.array([0, 1, 2, 3, 4, 8])
+    dev.reset(); orc.reset()
+    for t in range(T):
+        acts = avail[rng.integers(0, 6, (N, n))].astype(np.int32)
+        a, b = dev.step_observe(acts), orc.step(acts)
+        _compare_step(t, a, b)
+        if t % 25 == 24:
+            assert (a["obs"] == orc.observe()["obs"]).all(), t
+            _compare_state(t, dev, orc)
+    assert a["terminated"].all()
+    assert (a["collective_return"] == b["collective_return"]).all() and (a["equality"] == b["equality"]).all()
+    # domain invariants that hold for any size (checked on the full batch)
+    st = dev.export_state()
+    grid = st["grid"].reshape(N, 25, 18)
+    base = np.frombuffer(dev.e.spec.ascii, np.uint8).reshape(25, 18)
+    assert np.isin(grid[:, base == ord("B")], (0, 2)).all()          # apple sites hold ' ' or 'A'
+    assert np.isin(grid[:, base == ord("H")], (3, 4)).all()          # waste sites hold 'H' or 'R'
+    assert (grid[:, base == ord("R")] == 4).all() and (grid[:, base == ord("S")] == 5).all() and (grid[:, base == ord("@")] == 1).all()
+    assert (grid[:, (base == ord(" ")) | (base == ord("P"))] == 0).all()
+    r, c = st["pos"][..., 0].astype(int), st["pos"][..., 1].astype(int)
+    assert (base[r, c] != ord("@")).all()                            # nobody stands in a wall
+    assert (st["ep_step"] == T).all()
+    dev.close(); orc.close()
+
+
+def test_sharding_reproduces_the_unsharded_job():
+    """Env streams are keyed by global env id: 2 shards of 64 == one job of 128 (the multi-GPU decomposition)."""
+    HipEnv, _ = _hip()
+    kw = dict(map="default5", num_agents=5, view_size=7, episode_limit=30, rng_mode=abi.RNG_COUNTER, seed=5)
+    full = HipEnv("cleanup", n_env=128, **kw)
+    sh = [HipEnv("cleanup", n_env=64, env_id_base=64 * i, **kw) for i in range(2)]
+    rng = np.random.default_rng(3)
+    full.reset(); [s.reset() for s in sh]
+    for t in range(30):
+        acts = rng.integers(0, 9, (128, 5)).astype(np.int32)
+        a = full.step_observe(acts)
+        for i, s in enumerate(sh):
+            b = s.step_observe(acts[64 * i:64 * (i + 1)])
+            for k in ("reward", "clean_num", "apple_den", "obs", "terminated"):
+                assert (a[k][64 * i:64 * (i + 1)] == b[k]).all(), (t, i, k)
+    full.close(); [s.close() for s in sh]
+
+
+def test_partial_reset_and_error_paths():
+    import torch
+    HipEnv, _ = _hip()
+    e = HipEnv("cleanup", map="default5", num_agents=5, n_env=6, rng_mode=abi.RNG_COUNTER, seed=2)
+    e.reset()
+    for _ in range(5):
+        e.step(np.full((6, 5), 1))
+    before = e.export_state()
+    mask = np.array([1, 0, 0, 1, 0, 0], np.uint8)
+    e.reset(env_mask=mask)
+    after = e.export_state()
+    assert (after["ep_step"] == np.where(mask, 0, 5)).all()
+    assert (after["pos"][1] == before["pos"][1]).all() and (after["pos"][0] != before["pos"][0]).any()
+    # invalid action: sticky device-side flag (KeyError in the reference's action_map)
+    e.step(np.full((6, 5), 9))
+    assert e.e.poll_error() & 1
+    assert e.e.poll_error() == 0
+    # misaligned obs buffer is rejected on the host
+    buf = torch.empty(6 * 5 * 3 * 15 * 15 + 1, dtype=torch.float32, device="cuda")[1:]
+    with pytest.raises(abi.SsdError):
+        e.e.observe(abi.OBS_F32, out=dict(obs=buf))
+    # TAPE mode without a tape
+    t = HipEnv("cleanup", map="default5", num_agents=5, n_env=2, rng_mode=abi.RNG_TAPE)
+    with pytest.raises(abi.SsdError):
+        t.reset()
+    with pytest.raises(abi.SsdError):
+        HipEnv("cleanup", map="default3", num_agents=5, n_env=2)
+    e.close(); t.close()
