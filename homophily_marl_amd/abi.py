@@ -120,6 +120,11 @@ def load_library():
     """Load homophily_marl_amd/libssd_hip.so (built by __graft_entry__.build()).  Fails loudly when absent."""
     global _lib
     if _lib is None:
+        # torch first: the PyTorch-ROCm wheel bundles its own libamdhip64.so (soname libamdhip64.so.7).  Loaded
+        # first, it satisfies this library's NEEDED entry, so both share ONE HIP runtime (device pointers and
+        # streams are only meaningful within one runtime).  Loaded second, /opt/rocm's copy would already be in
+        # the process and torch would bring a second runtime.
+        import torch  # noqa: F401
         if not os.path.exists(HIP_LIB_PATH):
             raise ImportError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -50,10 +50,7 @@ struct Rng {
     __device__ __forceinline__ uint32_t u32(uint32_t stream, uint32_t k) const { return philox_x0(k, stream, gid, epoch, k0, k1); }
     // np.random.rand(1)[0] number k of this call (cleanup.py:172,183; harvest.py:119)
     __device__ __forceinline__ double uniform(int k) const {
-        if (tape) {
-            if (k >= ustride) { atomicOr(err, ERR_TAPE_OVERRUN); return 2.0; }
-            return tape_u[k];
-        }
+        if (tape) return k < ustride ? tape_u[k] : 2.0;   // lanes past the first success read speculatively
         return (double)(u32(SSD_STREAM_UNIFORM, (uint32_t)k) >> 8) * (1.0 / 16777216.0);
     }
 };
@@ -564,7 +561,11 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
         wsync();
         n_draws = S->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape, env) : spawn_harvest(E, R);   // map_env.py:313
         ep_r = 0;
-        if (lane == 0) { st.ep_step[env] = 0; st.epoch[env] = epoch + 1; if (so.n_draws) so.n_draws[env] = n_draws; }
+        if (lane == 0) {
+            st.ep_step[env] = 0; st.epoch[env] = epoch + 1;
+            if (so.n_draws) so.n_draws[env] = n_draws;
+            if (R.tape && n_draws > R.ustride) atomicOr(st.err, ERR_TAPE_OVERRUN);
+        }
     }
     if (MODE == MODE_STEP || MODE == MODE_STEP_OBS) {
         int reward = 0, cleaned = 0;
@@ -616,6 +617,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
             st.ep_step[env] = step; st.epoch[env] = epoch + 1;
             if (so.terminated) so.terminated[env] = term ? 1 : 0;
             if (so.n_draws) so.n_draws[env] = n_draws;
+            if (R.tape && n_draws > R.ustride) atomicOr(st.err, ERR_TAPE_OVERRUN);
         }
     }
     if (MODE == MODE_OBS) { paint_agents(E); wsync(); }
