@@ -97,7 +97,8 @@ HIP_SIGNATURES["ssd_poll_error"] = (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)])
 CPU_SIGNATURES = _sigs("ssd_cpu_", False)
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_PKG_DIR, "libssd_hip.so")
+# SSD_HIP_LIB_PATH: diagnostics only (tools/stamps.py loads a -DSSD_STAMPS build of the same sources)
+HIP_LIB_PATH = os.environ.get("SSD_HIP_LIB_PATH", os.path.join(_PKG_DIR, "libssd_hip.so"))
 _lib = None
 
 

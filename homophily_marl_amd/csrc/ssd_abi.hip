@@ -44,6 +44,11 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
         return fail(SSD_ERR_INVALID, "map size out of range");
     if (cfg->n_env < 1) return fail(SSD_ERR_INVALID, "n_env must be >= 1");
     if (cfg->view_size < 0 || cfg->view_size > 31) return fail(SSD_ERR_INVALID, "view_size out of range (0..31)");
+    {   // LDS budget: 4 waves (envs) per workgroup must fit the 160 KiB of a CU
+        const long V = 2L * cfg->view_size + 1, pm = (cfg->height + 2L * cfg->view_size) * (cfg->width + 2L * cfg->view_size);
+        const long per_wave = 2L * ((cfg->height * cfg->width + 15) & ~15) + pm + 16 + cfg->n_agents * 3L * V * V + 32 + 64;
+        if (per_wave * 4 > 160 * 1024) return fail(SSD_ERR_INVALID, "map / view_size / n_agents exceed the LDS budget of one workgroup");
+    }
     if (cfg->random_spawn_point) return fail(SSD_ERR_UNSUPPORTED, "random_spawn_point is not supported in ABI v1");
     if (cfg->spawn_rotation > 3) return fail(SSD_ERR_INVALID, "spawn_rotation must be -1..3");
     if (cfg->env_kind != SSD_ENV_CLEANUP && cfg->env_kind != SSD_ENV_HARVEST) return fail(SSD_ERR_INVALID, "env_kind");
@@ -55,6 +60,8 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
     DevSpec& S = E->hs;
     S.kind = cfg->env_kind; S.H = cfg->height; S.W = cfg->width; S.HW = S.H * S.W; S.GS = (S.HW + 15) & ~15;
     S.n = cfg->n_agents; S.N = cfg->n_env; S.v = cfg->view_size; S.V = 2 * S.v + 1; S.VV = S.V * S.V; S.VVp = (S.VV + 3) & ~3;
+    S.Wp = S.W + 2 * S.v; S.PMS = ((S.H + 2 * S.v) * S.Wp + 15) & ~15;
+    S.vshift = 0; while ((1 << S.vshift) < S.V) ++S.vshift;
     S.episode_limit = cfg->episode_limit; S.spawn_rotation = cfg->spawn_rotation < 0 ? -1 : cfg->spawn_rotation;
     S.obs_color = cfg->obs_color == SSD_COLOR_FULL ? SSD_COLOR_FULL : SSD_COLOR_SIMPLIFIED;
     S.rng_mode = cfg->rng_mode; S.n_actions = S.kind == SSD_ENV_CLEANUP ? 9 : 8;
@@ -197,6 +204,7 @@ static int make_oo(const ssd_env* E, const ssd_obs_out* o, DevObsOut* d) {
     }
     if (o->state && ((uintptr_t)o->state & 15) != 0) return fail(SSD_ERR_INVALID, "state must be 16-byte aligned");
     d->obs = o->obs; d->fmt = o->obs_format; d->state = o->state; d->pos = o->pos; d->orient = o->orient;
+    d->stamps = E->st.stamps;
     return SSD_OK;
 }
 static int launched(void) {
@@ -236,6 +244,11 @@ int ssd_step_observe(ssd_env* E, const int32_t* actions, const ssd_tape* tape, s
     launch_env(MODE_STEP_OBS, E->dspec, E->hs, E->st, actions, nullptr, t, make_so(out), oo, (hipStream_t)stream);
     return launched();
 }
+
+#ifdef SSD_STAMPS
+// diagnostic build only: device buffer [n_env, 16] of u64 receiving the phase stamps
+int ssd_debug_set_stamps(ssd_env* E, unsigned long long* buf) { E->st.stamps = buf; return SSD_OK; }
+#endif
 
 int ssd_poll_error(ssd_env* E, int32_t* bits) {
     if (!E || !bits) return fail(SSD_ERR_INVALID, "null argument");

@@ -19,7 +19,9 @@ enum : int { MODE_RESET = 0, MODE_STEP = 1, MODE_STEP_OBS = 2, MODE_OBS = 3 };
 // Static description of the world, one per handle, resident in HBM and read through the scalar cache.
 struct DevSpec {
     int32_t kind, H, W, HW, GS;          // GS = grid row stride in bytes (HW rounded up to 16)
-    int32_t n, N, V, v, VV, VVp;         // VVp = V*V rounded up to 4 (LDS window stride)
+    int32_t n, N, V, v, VV, VVp;         // VVp = V*V rounded up to 4
+    int32_t Wp, PMS;                     // padded class map: row stride W + 2v, bytes (H + 2v) * Wp rounded up to 16
+    int32_t vshift;                      // log2 of the power of two >= V: window rows are dealt to lanes 2^vshift at a time
     int32_t episode_limit, spawn_rotation, obs_color, rng_mode, n_actions;
     int32_t n_apple, n_waste;
     uint32_t env_id_base, seed_lo, seed_hi;
@@ -41,6 +43,7 @@ struct DevState {
     int32_t* ep_step;    // [N]
     uint32_t* epoch;     // [N]
     int32_t* err;        // [1] sticky error bits
+    unsigned long long* stamps;  // diagnostic builds only (-DSSD_STAMPS): [N, 16] s_memtime per phase; else null
 };
 
 struct DevTape {
@@ -62,16 +65,18 @@ struct DevObsOut {
     void* obs;
     int32_t fmt;
     float *state, *pos, *orient;
+    unsigned long long* stamps;  // diagnostic builds only
 };
 
 enum : int { ERR_BAD_ACTION = 1, ERR_BAD_TAPE = 2, ERR_KEYERROR = 4, ERR_TAPE_OVERRUN = 8 };
 
-// LDS bytes one wave needs.
-inline int lds_per_wave(int GS, int n, int VVp) {
-    int scratch = n * VVp;            // window classes; doubles as scratch for the tape waste order (needs 2*256)
-    if (scratch < 512) scratch = 512;
-    int b = 2 * GS + scratch + 64;    // grid | occupancy overlay | window classes / scratch | colour lut
-    return (b + 15) & ~15;
+// LDS bytes one wave needs: grid | agent overlay | padded class map | output planes (+16 alignment slack) | colour lut.
+// The class map + planes region doubles as scratch for the tape-mode waste ranks (2 * 256 bytes) during the step.
+__host__ __device__ inline int lds_planes_bytes(const DevSpec& s) { return ((s.n * 3 * s.VV + 16) + 15) & ~15; }
+__host__ __device__ inline int lds_per_wave(const DevSpec& s) {
+    int obs = s.PMS + lds_planes_bytes(s);
+    if (obs < 512) obs = 512;
+    return 2 * s.GS + obs + 64;
 }
 
 void launch_env(int mode, const DevSpec* spec, const DevSpec& host_spec, DevState st, const int32_t* actions,

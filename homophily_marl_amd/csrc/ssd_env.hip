@@ -5,11 +5,34 @@
 // ballot / readlane.  There are no workgroup barriers: the 4 waves of a workgroup are independent envs, so a wave
 // that needs the serial conflict resolution does not hold up its neighbours.
 //
+// The kernel is VALU-issue bound, not HBM bound (profiles/): the design below minimises instructions per env:
+//   - the wave index is forced scalar, so every per-env address and the Philox base are computed on the scalar unit;
+//   - the observation is produced in three linear passes through LDS: a zero-padded class map (no bounds tests in the
+//     window gather), the windows gathered into LDS in exactly the output order [n][3][V][V], and a byte -> float
+//     expansion with aligned ds_read + 16-byte global stores (no per-element index decode).
+//
 // Reference behaviour restated here (cited per function): src/envs/ssd/map_env.py, cleanup.py, harvest.py, agent.py,
 // src/utils/utility_funcs.py.  The CPU oracle under oracle/ is a separate, serial restatement used only by tests.
+#include <type_traits>
+
 #include "ssd_device.h"
 
 namespace ssd {
+
+// Diagnostic build (tools/stamps.py, -DSSD_STAMPS): lane 0 records s_memtime at phase boundaries after draining
+// the wave's outstanding memory operations.  In the product build the macros are empty and no stamp executes.
+#ifdef SSD_STAMPS
+#define STAMP_TO(buf, i)                                                                               \
+    do {                                                                                               \
+        __builtin_amdgcn_s_waitcnt(0);                                                                 \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
+        if ((buf) && lane == 0) (buf)[(size_t)env * 16 + (i)] = t_;                                    \
+    } while (0)
+#else
+#define STAMP_TO(buf, i) do {} while (0)
+#endif
+#define STAMP(i) STAMP_TO(st.stamps, i)
+#define STAMP_OBS(i) STAMP_TO(oo.stamps, i)
 
 // ---------------------------------------------------------------------------------------------------------------
 // wave primitives
@@ -22,15 +45,17 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t m) {  // set bits of m 
 __device__ __forceinline__ int popc64(uint64_t m) { return __builtin_popcountll(m); }
 __device__ __forceinline__ int first_lane(uint64_t m) { return __builtin_ctzll(m); }
 __device__ __forceinline__ int last_lane(uint64_t m) { return 63 - __builtin_clzll(m); }
-// order LDS traffic of the lanes of this wave (no other wave touches this wave's LDS slice)
+// Order the LDS traffic of the lanes of this wave.  LDS executes one wave's instructions in issue order and no other
+// wave touches this wave's slice, so a wavefront-scope fence (a compiler ordering constraint, no s_waitcnt) suffices.
 __device__ __forceinline__ void wsync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ uint32_t udiv(uint32_t x, uint32_t magic) { return __umulhi(x, magic); }
 
-// COUNTER-mode generator (include/ssd_hip.h): word 0 of Philox4x32-10
-__device__ __forceinline__ uint32_t philox_x0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+// COUNTER-mode generator (include/ssd_hip.h): b = Philox4x32-10({0, 0, env, epoch}, seed) once per call (wave-uniform,
+// scalar unit), then x(stream, k) = mix32(b[stream] ^ k) per draw.
+__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* o) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
@@ -38,16 +63,20 @@ __device__ __forceinline__ uint32_t philox_x0(uint32_t c0, uint32_t c1, uint32_t
         c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return c0;
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {  // triple32
+    x ^= x >> 17; x *= 0xed5ad4bbu; x ^= x >> 11; x *= 0xac4c1b51u; x ^= x >> 15; x *= 0x31848babu; x ^= x >> 14;
+    return x;
 }
 
 struct Rng {
     bool tape;
     const double* tape_u;  // this env's row
     int ustride;
-    uint32_t gid, epoch, k0, k1;
+    uint32_t b[4];         // Philox base words, one per stream (wave-uniform)
     int32_t* err;
-    __device__ __forceinline__ uint32_t u32(uint32_t stream, uint32_t k) const { return philox_x0(k, stream, gid, epoch, k0, k1); }
+    __device__ __forceinline__ uint32_t u32(int stream, uint32_t k) const { return mix32(b[stream] ^ k); }
     // np.random.rand(1)[0] number k of this call (cleanup.py:172,183; harvest.py:119)
     __device__ __forceinline__ double uniform(int k) const {
         if (tape) return k < ustride ? tape_u[k] : 2.0;   // lanes past the first success read speculatively
@@ -60,22 +89,16 @@ struct Env {
     const DevSpec* S;
     uint8_t* g;     // LDS grid [GS]
     uint8_t* occ;   // LDS agent overlay [GS]: 0 or the agent char (1..9) of the highest id standing there
-    uint8_t* win;   // LDS window classes [n * VVp] (observe) / scratch (step)
+    uint8_t* pm;    // LDS padded class map [PMS] (observe) / scratch (step)
+    uint8_t* pl;    // LDS output planes
     int lane, n, W, HW, GS;
     bool ag;        // lane < n
     int P;          // my agent's cell (r * W + c); unique negative for non-agent lanes
     int O;          // orientation
+    int ap[4], ws[4];  // my lanes' apple / waste site cells (site index = chunk * 64 + lane), preloaded
 };
 
 __device__ __forceinline__ int agent_char(int a) { int v = (a % 10) + 1; return v >= 10 ? 1 : v; }  // '<U1' truncation, map_env.py:370,377
-
-// occ[] := overlay of get_map_with_agents (map_env.py:360-379): later ids overwrite earlier ones
-__device__ __forceinline__ void paint_agents(Env& E) {
-    bool higher = false;
-    for (int b = 0; b < E.n; ++b) { int pb = rl(E.P, b); higher |= (b > E.lane && pb == E.P); }
-    if (E.ag && !higher) E.occ[E.P] = (uint8_t)agent_char(E.lane);
-}
-__device__ __forceinline__ void clear_agents(Env& E) { if (E.ag) E.occ[E.P] = 0; }
 
 // count cells with g == code (and, if free_only, no agent on them)
 __device__ __forceinline__ int count_cells(const Env& E, uint32_t code, bool free_only) {
@@ -98,14 +121,14 @@ __device__ __forceinline__ int count_cells(const Env& E, uint32_t code, bool fre
 // ---------------------------------------------------------------------------------------------------------------
 // update_moves (map_env.py:477-661)
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void resolve_moves(Env& E, int T, uint64_t mover_mask, const Rng& R, const DevTape& tape, int env) {
+__device__ __forceinline__ void resolve_moves(Env& E, int T, uint64_t mover_mask, const Rng& R, const uint8_t* tape_order) {
     const int n = E.n, lane = E.lane;
     const bool mover = (mover_mask >> lane) & 1;
     const int nm = popc64(mover_mask);
     // O = shuffled mover list (map_env.py:540-542); lane i holds O[i]
     int Oi = 0xFF;
     if (R.tape) {
-        if (lane < nm) Oi = tape.move_order[(size_t)env * n + lane];
+        if (lane < nm) Oi = tape_order[lane];
         bool bad = lane < nm && (Oi >= n || !((mover_mask >> (Oi & 63)) & 1));
         if (ballot(bad)) { if (lane == 0) atomicOr(R.err, ERR_BAD_TAPE); Oi = 0; }
     } else {
@@ -184,9 +207,8 @@ __device__ __forceinline__ void resolve_moves(Env& E, int T, uint64_t mover_mask
     }
 }
 
-// returns the MOVE/STAY mask after applying turns and computing wall-checked targets (map_env.py:498-511)
-__device__ __forceinline__ void move_phase(Env& E, int act, const Rng& R, const DevTape& tape, int env) {
-    const DevSpec* S = E.S;
+// turns, wall-checked targets (map_env.py:498-511), then conflict resolution
+__device__ __forceinline__ void move_phase(Env& E, int act, const Rng& R, const uint8_t* tape_order) {
     const int n = E.n, lane = E.lane;
     const bool mover = E.ag && (unsigned)act <= 4u;
     if (E.ag && act == 5) E.O = (0x0132 >> (4 * E.O)) & 3;   // TURN_CLOCKWISE: LEFT->UP->RIGHT->DOWN (map_env.py:853-861)
@@ -214,8 +236,7 @@ __device__ __forceinline__ void move_phase(Env& E, int act, const Rng& R, const 
         if (mover && b != lane) clash |= (T == pb) | (mb && T == tb);
     }
     if (ballot(clash) == 0) { if (mover) E.P = T; return; }
-    resolve_moves(E, T, mover_mask, R, tape, env);
-    (void)S;
+    resolve_moves(E, T, mover_mask, R, tape_order);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -259,7 +280,7 @@ __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-__device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const DevTape& tape, int env) {
+__device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t* tape_waste) {
     const DevSpec* S = E.S;
     const int lane = E.lane;
     // compute_probabilities (cleanup.py:189-204), fp64, reference operation order
@@ -278,27 +299,29 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const DevTape
     int k = 0;
     // apples: one draw per site that holds neither an agent nor an apple, in site order (cleanup.py:168-174).
     // Apple sites and waste sites are disjoint, so writing 'A' at once is equivalent to the deferred update_map.
-    for (int base = 0; base < S->n_apple; base += kWave) {
-        const int i = base + lane;
-        const bool in = i < S->n_apple;
-        const int cell = in ? S->apple[i] : 0;
-        const bool elig = in && E.occ[cell] == 0 && E.g[cell] != C_APPLE;
-        const uint64_t bal = ballot(elig);
-        if (elig && p_apple > 0) {
-            const double u = R.uniform(k + (int)lanes_below(bal));
-            if (u < p_apple) E.g[cell] = C_APPLE;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        if (ch * kWave < S->n_apple) {
+            const bool in = ch * kWave + lane < S->n_apple;
+            const int cell = E.ap[ch];
+            const bool elig = in && E.occ[cell] == 0 && E.g[cell] != C_APPLE;
+            const uint64_t bal = ballot(elig);
+            if (elig && p_apple > 0) {
+                const double u = R.uniform(k + (int)lanes_below(bal));
+                if (u < p_apple) E.g[cell] = C_APPLE;
+            }
+            k += popc64(bal);
         }
-        k += popc64(bal);
     }
     // waste: at most one spawn, first free site in shuffled order whose draw succeeds (cleanup.py:177-186)
     if (!(fabs(p_waste) <= 1e-8)) {                           // np.isclose(p, 0)
         const int nw = S->n_waste;
-        uint16_t* scratch = (uint16_t*)E.win;                 // tape mode: rank of each site in the shuffled list
+        uint16_t* scratch = (uint16_t*)E.pm;                  // tape mode: rank of each site in the shuffled list
         if (R.tape) {
             for (int base = 0; base < nw; base += kWave) {
                 const int p = base + lane;
                 if (p < nw) {
-                    int s = tape.waste_order[(size_t)env * nw + p];
+                    int s = tape_waste[p];
                     if (s >= nw) { atomicOr(R.err, ERR_BAD_TAPE); s = 0; }
                     scratch[s] = (uint16_t)p;
                 }
@@ -313,7 +336,7 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const DevTape
             best[ch] = ~0ull;
             const int s = ch * kWave + lane;
             if (ch * kWave < nw) {
-                const bool fr = s < nw && E.g[S->waste[s]] != C_WASTE;
+                const bool fr = s < nw && E.g[E.ws[ch]] != C_WASTE;
                 nfree += popc64(ballot(fr));
                 if (fr) {
                     const uint32_t key = R.tape ? (uint32_t)scratch[s] : R.u32(SSD_STREAM_WASTE, (uint32_t)s);
@@ -356,31 +379,34 @@ __device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R) {
     const int lane = E.lane, W = E.W, H = S->H;
     int k = 0;
     uint32_t spawn_bits = 0;  // decisions are applied after ALL sites were examined (synchronous update, harvest.py:86-90)
-    for (int base = 0, ch = 0; base < S->n_apple; base += kWave, ++ch) {
-        const int i = base + lane;
-        const bool in = i < S->n_apple;
-        const int cell = in ? S->apple[i] : 0;
-        const bool elig = in && E.occ[cell] == 0 && E.g[cell] != C_APPLE;
-        const uint64_t bal = ballot(elig);
-        if (elig) {
-            const int r = (int)udiv((uint32_t)cell, S->magic_W), c = cell - r * W;
-            int num = 0;  // offsets with j*j + k*k <= APPLE_RADIUS (= 2): the 3x3 block (harvest.py:108-116)
 #pragma unroll
-            for (int j = -1; j <= 1; ++j)
+    for (int ch = 0; ch < 4; ++ch) {
+        if (ch * kWave < S->n_apple) {
+            const bool in = ch * kWave + lane < S->n_apple;
+            const int cell = E.ap[ch];
+            const bool elig = in && E.occ[cell] == 0 && E.g[cell] != C_APPLE;
+            const uint64_t bal = ballot(elig);
+            if (elig) {
+                const int r = (int)udiv((uint32_t)cell, S->magic_W), c = cell - r * W;
+                int num = 0;  // offsets with j*j + k*k <= APPLE_RADIUS (= 2): the 3x3 block (harvest.py:108-116)
 #pragma unroll
-                for (int q = -1; q <= 1; ++q) {
-                    const int x = r + j, y = c + q;
-                    if ((unsigned)x < (unsigned)H && (unsigned)y < (unsigned)W) num += E.g[x * W + y] == C_APPLE;
-                }
-            const double p = S->harvest_p[num < 3 ? num : 3];
-            const double u = R.uniform(k + (int)lanes_below(bal));
-            if (u < p) spawn_bits |= 1u << ch;
+                for (int j = -1; j <= 1; ++j)
+#pragma unroll
+                    for (int q = -1; q <= 1; ++q) {
+                        const int x = r + j, y = c + q;
+                        if ((unsigned)x < (unsigned)H && (unsigned)y < (unsigned)W) num += E.g[x * W + y] == C_APPLE;
+                    }
+                const double p = S->harvest_p[num < 3 ? num : 3];
+                const double u = R.uniform(k + (int)lanes_below(bal));
+                if (u < p) spawn_bits |= 1u << ch;
+            }
+            k += popc64(bal);
         }
-        k += popc64(bal);
     }
     wsync();
-    for (int base = 0, ch = 0; base < S->n_apple; base += kWave, ++ch)
-        if ((spawn_bits >> ch) & 1) E.g[S->apple[base + lane]] = C_APPLE;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+        if ((spawn_bits >> ch) & 1) E.g[E.ap[ch]] = C_APPLE;
     wsync();
     return k;
 }
@@ -388,20 +414,20 @@ __device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R) {
 // ---------------------------------------------------------------------------------------------------------------
 // observation (map_env.py:360-379,418-446,795-815,923-957; utility_funcs.py:58-116)
 // ---------------------------------------------------------------------------------------------------------------
-// class of one map cell: simplified colours -> 0 nothing, 1 apple (G), 2 waste (R), 3 wall or agent (B);
-// full colours -> LUT row (cell code, or 5 + agent char)
+// class of one map cell.  Simplified colours: a channel bit mask, 1 = R (waste), 2 = G (apple), 4 = B (wall or agent).
+// Full colours: LUT row (cell code, or 5 + agent char).
 template <bool FULL>
-__device__ __forceinline__ int cell_class(const Env& E, int cell) {
-    const int gc = E.g[cell], oc = E.occ[cell];
+__device__ __forceinline__ int class_of(int gc, int oc, int kind) {
     if (FULL) return oc ? 5 + oc : gc;
-    if (oc || gc == C_WALL) return 3;
-    if (gc == C_APPLE) return 1;
-    return (gc == C_WASTE && E.S->kind == SSD_ENV_CLEANUP) ? 2 : 0;
+    if (oc || gc == C_WALL) return 4;
+    if (gc == C_APPLE) return 2;
+    return (gc == C_WASTE && kind == SSD_ENV_CLEANUP) ? 1 : 0;
 }
+// byte value (0..255) of channel ch for a class
 template <bool FULL>
 __device__ __forceinline__ uint32_t class_value(const uint8_t* lut, int cls, int ch) {
     if (FULL) return lut[cls * 3 + ch];
-    return cls == (ch == 0 ? 2 : ch == 1 ? 1 : 3) ? 255u : 0u;   // R <- waste, G <- apple, B <- wall/agent
+    return ((cls >> ch) & 1) ? 255u : 0u;
 }
 
 template <typename T> struct Cvt;
@@ -409,8 +435,8 @@ template <> struct Cvt<float> { static __device__ __forceinline__ float f(uint32
 template <> struct Cvt<uint16_t> { static __device__ __forceinline__ uint16_t f(uint32_t v) { return (uint16_t)(__float_as_uint((float)v * (1.0f / 256.0f)) >> 16); } };
 template <> struct Cvt<uint8_t> { static __device__ __forceinline__ uint8_t f(uint32_t v) { return (uint8_t)v; } };
 
-// Write L elements val(0..L-1) to dst[0..L) with 16-byte stores wherever the address allows.
-// elem_off = index of dst[0] in the (16-byte aligned) output tensor.
+// Generic element-wise emitter (used for the rarely requested `state` output): L elements val(0..L-1) to dst[0..L)
+// with 16-byte stores wherever the address allows.  elem_off = index of dst[0] in the 16-byte aligned tensor.
 template <typename T, typename F>
 __device__ __forceinline__ void emit(T* dst, size_t elem_off, int L, int lane, F val) {
     constexpr int EPV = 16 / (int)sizeof(T);
@@ -429,60 +455,160 @@ __device__ __forceinline__ void emit(T* dst, size_t elem_off, int L, int lane, F
     for (int i = t0 + lane; i < L; i += kWave) dst[i] = Cvt<T>::f(val(i));
 }
 
-template <bool FULL>
-__device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& oo) {
+// Expansion of LDS bytes to the output dtype (value / 256), 16 bytes per lane per store, packed explicitly so the
+// compiler cannot split the store.  Byte f of the env's block sits at pl[f + delta]; delta makes every vector's source
+// ONE naturally aligned LDS word.
+__device__ __forceinline__ float b2f(uint32_t w, int j) { return (float)((w >> (8 * j)) & 0xFFu) * (1.0f / 256.0f); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {   // k/256 is exact in bf16: truncation == rounding
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+template <typename T> struct Expand;
+template <> struct Expand<float> {
+    static __device__ __forceinline__ uint4 vec(const uint8_t* src, int q) {
+        const uint32_t w = *(const uint32_t*)(src + 4 * q);
+        return make_uint4(__float_as_uint(b2f(w, 0)), __float_as_uint(b2f(w, 1)), __float_as_uint(b2f(w, 2)), __float_as_uint(b2f(w, 3)));
+    }
+};
+template <> struct Expand<uint16_t> {
+    static __device__ __forceinline__ uint4 vec(const uint8_t* src, int q) {
+        const uint2 w = *(const uint2*)(src + 8 * q);
+        return make_uint4(pack_bf16(b2f(w.x, 0), b2f(w.x, 1)), pack_bf16(b2f(w.x, 2), b2f(w.x, 3)),
+                          pack_bf16(b2f(w.y, 0), b2f(w.y, 1)), pack_bf16(b2f(w.y, 2), b2f(w.y, 3)));
+    }
+};
+template <> struct Expand<uint8_t> {
+    static __device__ __forceinline__ uint4 vec(const uint8_t* src, int q) { return *(const uint4*)(src + 16 * q); }
+};
+
+// vectors [q0, q1) of the env's block: out = dst + head, src = pl + head + delta.  4 vectors per lane per batch so that
+// 4 LDS reads are in flight before the first store issues.
+template <typename T>
+__device__ __forceinline__ void expand_range(const uint8_t* src, T* out, int q0, int q1, int lane) {
+    constexpr int EPV = 16 / (int)sizeof(T);
+    for (int q = q0 + lane; q < q1; q += 4 * kWave) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (q + u * kWave < q1) ? Expand<T>::vec(src, q + u * kWave) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#ifdef SSD_NOSTORE   // diagnostic only: keep the compute, drop (almost) every store
+            if (v[u].x == 0x12345678u)
+#endif
+            if (q + u * kWave < q1) *(uint4*)(out + (size_t)(q + u * kWave) * EPV) = v[u];
+        }
+    }
+}
+
+// FMT: SSD_OBS_F32 / BF16 / U8 (three byte planes per agent) or SSD_OBS_CODE (one class plane per agent)
+template <bool FULL, int FMT>
+__device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut& oo, const uint8_t* lut) {
+    typedef typename std::conditional<FMT == SSD_OBS_F32, float, typename std::conditional<FMT == SSD_OBS_BF16, uint16_t, uint8_t>::type>::type T;
+    constexpr bool CODE = FMT == SSD_OBS_CODE;
+    constexpr int EPV = 16 / (int)sizeof(T);
     const DevSpec* S = E.S;
-    const int lane = E.lane, n = E.n, W = E.W, H = S->H, V = S->V, v = S->v, VV = S->VV, VVp = S->VVp;
-    uint8_t* lut = E.win + n * VVp;  // 48 bytes behind the windows
-    if (FULL) { if (lane < 48) lut[lane] = S->lut[lane]; wsync(); }
-    if (oo.obs) {
-        // pass 1: class of every window cell, window of agent a rotated by its orientation
-        for (int a = 0; a < n; ++a) {
-            const int pa = rl(E.P, a), oa = rl(E.O, a);
-            const int pr = (int)udiv((uint32_t)pa, S->magic_W), pc = pa - pr * W;
-            for (int ij = lane; ij < VV; ij += kWave) {
-                const int i = (int)udiv((uint32_t)ij, S->magic_V), j = ij - i * V;
-                // rotate_view = np.rot90(view, k): k = 0 UP, 1 LEFT, 2 DOWN, 3 RIGHT (map_env.py:795-815)
-                int x, y;
-                if (oa == O_UP) { x = i; y = j; }
-                else if (oa == O_LEFT) { x = j; y = V - 1 - i; }
-                else if (oa == O_DOWN) { x = V - 1 - i; y = V - 1 - j; }
-                else { x = V - 1 - j; y = i; }
-                const int r = pr - v + x, c = pc - v + y;   // return_view zero padding (utility_funcs.py:58-116)
-                int cls = 0;
-                if ((unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W) cls = cell_class<FULL>(E, r * W + c);
-                E.win[a * VVp + ij] = (uint8_t)cls;
+    const int lane = E.lane, n = E.n, W = E.W, V = S->V, VV = S->VV, Wp = S->Wp;
+    const int A = CODE ? VV : 3 * VV;                             // elements per agent
+    const int L = n * A;
+    const size_t off = (size_t)env * L;                           // element offset of this env's block
+    int head = (int)((EPV - (off % EPV)) % EPV);
+    if (head > L) head = L;
+    const int delta = (EPV - head % EPV) % EPV;
+    T* dst = (T*)oo.obs + off;
+    const uint8_t* src = E.pl + head + delta;                     // EPV-byte aligned
+    const int nvec = (L - head) / EPV;
+    // Rows of a window are dealt to lanes 2^vshift at a time: lane = (row in group, column).
+    const int sh = S->vshift, j = lane & ((1 << sh) - 1), il = lane >> sh, rpi = kWave >> sh;
+    const bool jv = j < V;
+    int q_done = 0;
+    for (int a = 0; a < n; ++a) {
+        const int pa = rl(E.P, a), oa = rl(E.O, a);
+        const int pr = (int)udiv((uint32_t)pa, S->magic_W), pc = pa - pr * W;
+        // rotate_view = np.rot90(view, k), k = 0 UP, 1 LEFT, 2 DOWN, 3 RIGHT (map_env.py:795-815): output (i, j) reads
+        // view (x, y) = UP (i, j); LEFT (j, V-1-i); DOWN (V-1-i, V-1-j); RIGHT (V-1-j, i).  In the padded class map the
+        // window's top-left is (pr, pc), so the source index is the affine form base + i * ci + j * cj.
+        int ci, cj, c0;
+        if (oa == O_UP) { ci = Wp; cj = 1; c0 = 0; }
+        else if (oa == O_LEFT) { ci = -1; cj = Wp; c0 = V - 1; }
+        else if (oa == O_DOWN) { ci = -Wp; cj = -1; c0 = (V - 1) * Wp + (V - 1); }
+        else { ci = 1; cj = -Wp; c0 = (V - 1) * Wp; }
+        const int sstep = rpi * ci, dstep = rpi * V;
+        int sidx = pr * Wp + pc + c0 + il * ci + j * cj;
+        int d = a * A + delta + il * V + j;
+        // 4 row groups per batch: the 4 class reads are in flight together, then the plane bytes are written
+        for (int i = il; i < V; i += 4 * rpi, sidx += 4 * sstep, d += 4 * dstep) {
+            int cls[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cls[u] = (jv && i + u * rpi < V) ? E.pm[sidx + u * sstep] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (jv && i + u * rpi < V) {
+                    const int du = d + u * dstep, c = cls[u];
+                    if (CODE) {
+                        E.pl[du] = (uint8_t)(c == 2 ? 1 : c == 1 ? 2 : c == 4 ? 3 : 0);
+                    } else if (FULL) {
+                        E.pl[du] = lut[c * 3]; E.pl[du + VV] = lut[c * 3 + 1]; E.pl[du + 2 * VV] = lut[c * 3 + 2];
+                    } else {
+                        E.pl[du] = (uint8_t)(0 - (c & 1)); E.pl[du + VV] = (uint8_t)(0 - ((c >> 1) & 1));
+                        E.pl[du + 2 * VV] = (uint8_t)(0 - ((c >> 2) & 1));
+                    }
+                }
             }
         }
         wsync();
-        // pass 2: expand to [n, 3, V, V] (CHW, value / 256) with vector stores
-        if (oo.fmt == SSD_OBS_CODE) {
-            const int L = n * VV;
-            const size_t off = (size_t)env * L;
-            emit<uint8_t>((uint8_t*)oo.obs + off, off, L, lane, [&](int f) -> uint32_t {
-                const int a = (int)udiv((uint32_t)f, S->magic_VV);
-                return E.win[a * VVp + (f - a * VV)];
-            });
-        } else {
-            const int L = n * 3 * VV;
-            const size_t off = (size_t)env * L;
-            auto val = [&](int f) -> uint32_t {
-                const int a = (int)udiv((uint32_t)f, S->magic_3VV);
-                const int fr = f - a * 3 * VV;
-                const int ch = (fr >= VV) + (fr >= 2 * VV);
-                return class_value<FULL>(lut, E.win[a * VVp + (fr - ch * VV)], ch);
-            };
-            if (oo.fmt == SSD_OBS_F32) emit<float>((float*)oo.obs + off, off, L, lane, val);
-            else if (oo.fmt == SSD_OBS_BF16) emit<uint16_t>((uint16_t*)oo.obs + off, off, L, lane, val);
-            else emit<uint8_t>((uint8_t*)oo.obs + off, off, L, lane, val);
+        // expand and store every vector that is complete by now, so the store stream overlaps the next agent's gather
+        const int q_end = a == n - 1 ? nvec : ((a + 1) * A - head) / EPV;
+        if (q_end > q_done) { expand_range<T>(src, dst + head, q_done, q_end, lane); q_done = q_end; }
+    }
+    // ragged ends (fewer than EPV elements each)
+    if (lane < head) dst[lane] = Cvt<T>::f(E.pl[lane + delta]);
+    const int t0 = head + nvec * EPV;
+    if (t0 + lane < L) dst[t0 + lane] = Cvt<T>::f(E.pl[t0 + lane + delta]);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& oo) {
+    const DevSpec* S = E.S;
+    const int lane = E.lane, n = E.n, W = E.W, v = S->v, Wp = S->Wp;
+    uint8_t* lut = E.pl + lds_planes_bytes(*S);  // 48 bytes behind the planes
+    if (FULL) { if (lane < 48) lut[lane] = S->lut[lane]; }
+    // pass 0: zero-padded class map, pm[(r + v) * Wp + (c + v)] = class of map cell (r, c); the padding IS
+    // return_view's zero padding (utility_funcs.py:93-116), so the window gather needs no bounds test
+    for (int i = lane * 16; i < S->PMS; i += kWave * 16) *(uint4*)(E.pm + i) = make_uint4(0, 0, 0, 0);
+    wsync();
+    for (int cell0 = lane; cell0 < E.HW; cell0 += 4 * kWave) {
+        int gc[4], oc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cell = cell0 + u * kWave;
+            gc[u] = cell < E.HW ? E.g[cell] : 0; oc[u] = cell < E.HW ? E.occ[cell] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cell = cell0 + u * kWave;
+            if (cell < E.HW) {
+                const int r = (int)udiv((uint32_t)cell, S->magic_W), c = cell - r * W;
+                E.pm[(r + v) * Wp + c + v] = (uint8_t)class_of<FULL>(gc[u], oc[u], S->kind);
+            }
         }
     }
+    wsync();
+    STAMP_OBS(8);
+    if (oo.obs) {
+        // gather windows into LDS in output order, expand to the output dtype (value / 256, CHW; map_env.py:945)
+        if (oo.fmt == SSD_OBS_F32) observe_windows<FULL, SSD_OBS_F32>(E, env, oo, lut);
+        else if (oo.fmt == SSD_OBS_BF16) observe_windows<FULL, SSD_OBS_BF16>(E, env, oo, lut);
+        else if (oo.fmt == SSD_OBS_U8) observe_windows<FULL, SSD_OBS_U8>(E, env, oo, lut);
+        else observe_windows<false, SSD_OBS_CODE>(E, env, oo, lut);
+    }
+    STAMP_OBS(9);
     if (oo.state) {  // get_state (map_env.py:950-957): [3, H, W] / 256
         const int L = 3 * E.HW;
         const size_t off = (size_t)env * L;
         emit<float>(oo.state + off, off, L, lane, [&](int f) -> uint32_t {
             const int ch = (int)udiv((uint32_t)f, S->magic_HW);
-            return class_value<FULL>(lut, cell_class<FULL>(E, f - ch * E.HW), ch);
+            const int cell = f - ch * E.HW;
+            const int r = (int)udiv((uint32_t)cell, S->magic_W), c = cell - r * W;
+            return class_value<FULL>(lut, E.pm[(r + v) * Wp + c + v], ch);
         });
     }
     if (E.ag) {
@@ -505,31 +631,54 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
                                                  const uint8_t* __restrict__ env_mask, DevTape tape, DevStepOut so,
                                                  DevObsOut oo, int lds_stride) {
     extern __shared__ uint4 smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: per-env addresses live in SGPRs
     const int env = blockIdx.x * kWavesPerBlock + wave;
     if (env >= S->N) return;
     if (MODE == MODE_RESET && env_mask && !env_mask[env]) return;
+
+    // Speed only (never correctness): the 4 waves that share a SIMD get distinct static priorities from their hardware
+    // wave slot, so they drift apart and their 16-byte store bursts are spread over the kernel instead of hitting the
+    // per-CU store path all at once at the end (profiles/: stores and compute otherwise do not overlap at all).
+    if (MODE == MODE_STEP_OBS || MODE == MODE_OBS) {
+        const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 3u;   // HW_REG_HW_ID.WAVE_ID[1:0]
+        if (slot == 0) __builtin_amdgcn_s_setprio(3);
+        else if (slot == 1) __builtin_amdgcn_s_setprio(2);
+        else if (slot == 2) __builtin_amdgcn_s_setprio(1);
+    }
 
     Env E;
     E.S = S; E.lane = lane; E.n = S->n; E.W = S->W; E.HW = S->HW; E.GS = S->GS;
     E.g = (uint8_t*)smem + (size_t)wave * lds_stride;
     E.occ = E.g + E.GS;
-    E.win = E.occ + E.GS;
+    E.pm = E.occ + E.GS;
+    E.pl = E.pm + S->PMS;
     E.ag = lane < E.n;
     const int n = E.n, GS = E.GS;
+    STAMP(0);
 
     uint8_t* ggrid = st.grid + (size_t)env * GS;
-    // ---- load the grid (or the reset image) into LDS, clear the overlay ----
+    // ---- issue every global load up front: grid (or reset image), agents, actions, counters, site lists ----
     for (int i = lane * 16; i < GS; i += kWave * 16) {
         *(uint4*)(E.g + i) = MODE == MODE_RESET ? *(const uint4*)(S->reset_grid + i) : *(const uint4*)(ggrid + i);
         *(uint4*)(E.occ + i) = make_uint4(0, 0, 0, 0);
     }
     const uint32_t epoch = st.epoch[env];
+    const int ep_step0 = MODE == MODE_RESET ? 0 : st.ep_step[env];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        E.ap[ch] = (MODE != MODE_OBS && ch * kWave + lane < S->n_apple) ? S->apple[ch * kWave + lane] : 0;
+        E.ws[ch] = (MODE != MODE_OBS && ch * kWave + lane < S->n_waste) ? S->waste[ch * kWave + lane] : 0;
+    }
     Rng R;
     R.tape = S->rng_mode == SSD_RNG_TAPE;
     R.ustride = tape.ustride;
     R.tape_u = R.tape ? tape.uniforms + (size_t)env * tape.ustride : nullptr;
-    R.gid = S->env_id_base + (uint32_t)env; R.epoch = epoch; R.k0 = S->seed_lo; R.k1 = S->seed_hi; R.err = st.err;
+    R.err = st.err;
+    R.b[0] = R.b[1] = R.b[2] = R.b[3] = 0;
+    if (MODE != MODE_OBS && !R.tape) philox4(0u, 0u, S->env_id_base + (uint32_t)env, epoch, S->seed_lo, S->seed_hi, R.b);
+    const uint8_t* tape_order = tape.move_order ? tape.move_order + (size_t)env * n : nullptr;
+    const uint8_t* tape_waste = tape.waste_order ? tape.waste_order + (size_t)env * S->n_waste : nullptr;
 
     int act = 4, ep_r = 0;
     if (E.ag) {
@@ -554,12 +703,13 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
         E.P = -1 - lane; E.O = 0;
     }
     wsync();
+    STAMP(1);
 
     int n_draws = 0;
     if (MODE == MODE_RESET) {
-        paint_agents(E);
+        if (E.ag) E.occ[E.P] = (uint8_t)agent_char(lane);   // spawn cells are distinct
         wsync();
-        n_draws = S->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape, env) : spawn_harvest(E, R);   // map_env.py:313
+        n_draws = S->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste) : spawn_harvest(E, R);   // map_env.py:313
         ep_r = 0;
         if (lane == 0) {
             st.ep_step[env] = 0; st.epoch[env] = epoch + 1;
@@ -569,15 +719,18 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
     }
     if (MODE == MODE_STEP || MODE == MODE_STEP_OBS) {
         int reward = 0, cleaned = 0;
-        move_phase(E, act, R, tape, env);                                        // map_env.py:251
-        // consume (map_env.py:253-256, agent.py:195-201,250-256): in id order, so only the lowest id on a cell eats
+        move_phase(E, act, R, tape_order);                                       // map_env.py:251
+        STAMP(2);
+        // consume (map_env.py:253-256, agent.py:195-201,250-256) runs in id order, so only the lowest id on a cell eats;
+        // the overlay of get_map_with_agents (map_env.py:360-379) keeps the highest id on a cell
         {
-            bool lower = false;
-            for (int b = 0; b < n; ++b) { int pb = rl(E.P, b); lower |= (b < lane && pb == E.P); }
+            bool lower = false, higher = false;
+            for (int b = 0; b < n; ++b) { const int pb = rl(E.P, b); lower |= (b < lane && pb == E.P); higher |= (b > lane && pb == E.P); }
             if (E.ag && !lower && E.g[E.P] == C_APPLE) { reward += 1; E.g[E.P] = C_EMPTY; }
+            if (E.ag && !higher) E.occ[E.P] = (uint8_t)agent_char(lane);
         }
-        paint_agents(E);
         wsync();
+        STAMP(3);
         // update_custom_moves (map_env.py:663-673): sequential over agents, the map is updated after each one
         {
             const uint64_t fire = ballot(E.ag && act >= 7);
@@ -590,12 +743,14 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
                 } else if (lane == f) reward -= 1;                                // fire_beam('F') (agent.py:188-190,239-241)
             }
         }
-        n_draws = S->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape, env) : spawn_harvest(E, R);   // map_env.py:263
+        STAMP(4);
+        n_draws = S->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste) : spawn_harvest(E, R);   // map_env.py:263
+        STAMP(5);
         // scalars (map_env.py:291-292, 883-914)
         const int apples = count_cells(E, C_APPLE, true);
         const float den = (float)((double)apples / (double)E.HW);
         ep_r += reward;
-        const int step = st.ep_step[env] + 1;
+        const int step = ep_step0 + 1;
         const bool term = step >= S->episode_limit;
         if (E.ag) {
             const size_t o = (size_t)env * n + lane;
@@ -620,7 +775,13 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
             if (R.tape && n_draws > R.ustride) atomicOr(st.err, ERR_TAPE_OVERRUN);
         }
     }
-    if (MODE == MODE_OBS) { paint_agents(E); wsync(); }
+    if (MODE == MODE_OBS) {
+        bool higher = false;
+        for (int b = 0; b < n; ++b) { const int pb = rl(E.P, b); higher |= (b > lane && pb == E.P); }
+        if (E.ag && !higher) E.occ[E.P] = (uint8_t)agent_char(lane);
+        wsync();
+    }
+    STAMP(6);
 
     if (MODE != MODE_OBS) {
         // ---- write the state back ----
@@ -631,16 +792,18 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
             st.ep_reward[(size_t)env * n + lane] = ep_r;
         }
     }
+    STAMP(7);
     if (MODE == MODE_STEP_OBS || MODE == MODE_OBS) {
         if (S->obs_color == SSD_COLOR_FULL) observe_phase<true>(E, env, oo);
         else observe_phase<false>(E, env, oo);
     }
+    STAMP(10);
 }
 
 void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, const int32_t* actions,
                 const uint8_t* env_mask, DevTape tape, DevStepOut so, DevObsOut oo, hipStream_t stream) {
     const int blocks = (hs.N + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int stride = lds_per_wave(hs.GS, hs.n, hs.VVp);
+    const int stride = lds_per_wave(hs);
     const size_t lds = (size_t)stride * kWavesPerBlock;
     switch (mode) {
         case MODE_RESET: hipLaunchKernelGGL(k_env<MODE_RESET>, dim3(blocks), dim3(kBlock), lds, stream, spec, st, actions, env_mask, tape, so, oo, stride); break;

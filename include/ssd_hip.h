@@ -175,11 +175,15 @@ int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int
                            float* rewards_for_env, float* rewards_for_inc, void* stream);
 
 /* ---- COUNTER-mode generator (shared definition) ---------------------------------------------
- * x = philox4x32_10(counter = {k, stream, env_global_id, epoch}, key = {seed_lo, seed_hi})[0]
- *   epoch  = number of reset/step calls this env has completed before the current call
- *   stream = SSD_STREAM_*
- *   uniform: u = (x >> 8) * 2^-24 as double, compared `u < p` in fp64
- *   shuffles: stable sort of the items by (x(item index), item index)                                         */
+ * Two levels, so that the expensive part is computed once per env and call (wave-uniform on the GPU):
+ *   b[0..3] = philox4x32_10(counter = {0, 0, env_global_id, epoch}, key = {seed_lo, seed_hi})
+ *             epoch = number of reset/step calls this env has completed before the current call
+ *   x(stream, k) = mix32(b[stream] ^ k),  stream = SSD_STREAM_*  (one Philox word per stream)
+ *   mix32(x): x ^= x >> 17; x *= 0xed5ad4bb; x ^= x >> 11; x *= 0xac4c1b51; x ^= x >> 15; x *= 0x31848bab; x ^= x >> 14
+ *             (the "triple32" integer hash, a bijection on 32 bits)
+ *   uniform number k of the call: u = (x(UNIFORM, k) >> 8) * 2^-24 as double, compared `u < p` in fp64
+ *   shuffles: stable sort of the items by (x(stream, item index), item index)
+ *   spawn rotation of agent a: x(SPAWN_ROT, a) >> 30                                                            */
 enum { SSD_STREAM_UNIFORM = 0, SSD_STREAM_MOVE = 1, SSD_STREAM_WASTE = 2, SSD_STREAM_SPAWN_ROT = 3 };
 
 #ifdef __cplusplus

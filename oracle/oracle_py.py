@@ -32,7 +32,9 @@ def lib():
             build()
         _LIB = abi.bind(C.CDLL(so), abi.CPU_SIGNATURES)
         _LIB.ssd_cpu_philox.restype = C.c_uint32
-        _LIB.ssd_cpu_philox.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]
+        _LIB.ssd_cpu_philox.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int]
+        _LIB.ssd_cpu_counter_u32.restype = C.c_uint32
+        _LIB.ssd_cpu_counter_u32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     return _LIB
 
 
@@ -140,5 +142,9 @@ class OracleEnv:
         abi.check(self.lib, self.lib.ssd_cpu_import_state(self.h, C.byref(s)), "ssd_cpu_last_error")
 
 
-def philox(k, stream, env, epoch, seed):
-    return lib().ssd_cpu_philox(k, stream, env, epoch, seed)
+def philox(c0, c1, c2, c3, seed, word=0):
+    return lib().ssd_cpu_philox(c0, c1, c2, c3, seed, word)
+
+
+def counter_u32(seed, env, epoch, stream, k):
+    return lib().ssd_cpu_counter_u32(seed, env, epoch, stream, k)

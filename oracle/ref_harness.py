@@ -41,8 +41,26 @@ def philox4x32_10(ctr, key):
     return c0, c1, c2, c3
 
 
+def mix32(x):
+    """triple32 integer hash (include/ssd_hip.h)."""
+    x ^= x >> 17; x = (x * 0xED5AD4BB) & M32
+    x ^= x >> 11; x = (x * 0xAC4C1B51) & M32
+    x ^= x >> 15; x = (x * 0x31848BAB) & M32
+    x ^= x >> 14
+    return x
+
+
+_BASE_CACHE = {}
+
+
 def ctr_u32(seed, env, epoch, stream, k):
-    return philox4x32_10((k & M32, stream, env & M32, epoch & M32), (seed & M32, (seed >> 32) & M32))[0]
+    """x(stream, k) of the COUNTER-mode generator (include/ssd_hip.h), independent pure-Python statement."""
+    key = (seed, env, epoch)
+    if key not in _BASE_CACHE:
+        if len(_BASE_CACHE) > 4096:
+            _BASE_CACHE.clear()
+        _BASE_CACHE[key] = philox4x32_10((0, 0, env & M32, epoch & M32), (seed & M32, (seed >> 32) & M32))
+    return mix32(_BASE_CACHE[key][stream] ^ (k & M32))
 
 
 def import_reference():

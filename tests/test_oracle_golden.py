@@ -29,7 +29,18 @@ def test_philox_known_answers(oracle_lib):
     # Random123 kat_vectors for philox4x32-10: x0 of (ctr, key)
     assert philox(0, 0, 0, 0, 0) == 0x6627E8D5
     assert philox(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF) == 0x408F276D
-    assert philox(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822 | (0x299F31D0 << 32)) == 0xD16CFE09
+    pi = (0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822 | (0x299F31D0 << 32))
+    assert [philox(*pi, word=w) for w in range(4)] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_counter_generator_matches_its_python_statement(oracle_lib):
+    # the two-level generator of include/ssd_hip.h: C oracle == independent pure-Python statement
+    from oracle.oracle_py import counter_u32
+    from oracle.ref_harness import ctr_u32
+    for seed, env, epoch in ((0, 0, 0), (0xDEADBEEFCAFE, 4097, 12345), (2 ** 64 - 1, 2 ** 32 - 1, 7)):
+        for stream in range(4):
+            for k in (0, 1, 2, 63, 64, 1000, 2 ** 31):
+                assert counter_u32(seed, env, epoch, stream, k) == ctr_u32(seed, env, epoch, stream, k)
 
 
 def test_reset_spawn_points(oracle_lib):

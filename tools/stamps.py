@@ -1,0 +1,52 @@
+"""Diagnostic: where does one wave spend its cycles?  Builds the kernels with -DSSD_STAMPS into
+gpurun_out/libssd_hip_stamps.so, runs a few fused step+observe launches and prints the median cycles per phase.
+(Stamps drain the wave's memory queue, so read SHARES, not totals.)  Usage: python tools/stamps.py [--n-env 4096]"""
+import argparse
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n-env", type=int, default=4096)
+ap.add_argument("--mode", default="step_observe")
+a = ap.parse_args()
+out = os.path.join(ROOT, "gpurun_out", "libssd_hip_stamps.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+srcs = [os.path.join(G.CSRC, s) for s in G.HIP_SOURCES]
+subprocess.check_call(["/opt/rocm/bin/hipcc"] + G.HIPCC_FLAGS + ["-DSSD_STAMPS", "-o", out] + srcs)
+os.environ["SSD_HIP_LIB_PATH"] = out
+import torch  # noqa: E402
+from homophily_marl_amd import abi  # noqa: E402
+from homophily_marl_amd.envs.native import NativeEnv  # noqa: E402
+
+N, n = a.n_env, 5
+env = NativeEnv("cleanup", device=0, map="default5", num_agents=n, n_env=N, view_size=7, episode_limit=100, rng_mode=abi.RNG_COUNTER, seed=1)
+stamps = torch.zeros(N, 16, dtype=torch.int64, device="cuda")
+env.lib.ssd_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
+env.lib.ssd_debug_set_stamps(env.h, stamps.data_ptr())
+avail = torch.tensor([0, 1, 2, 3, 4, 8], dtype=torch.int32, device="cuda")
+env.reset()
+names = ["load", "moves", "consume+paint", "beams", "spawn", "scalars", "writeback", "obs pass0", "obs pass1", "obs pass2"]
+acc = []
+for t in range(40):
+    acts = avail[torch.randint(0, 6, (N, n), device="cuda")].contiguous()
+    if a.mode == "step_observe":
+        env.step_observe(acts)
+    else:
+        env.step(acts)
+    torch.cuda.synchronize()
+    if t >= 20:
+        acc.append(stamps.clone())
+s = torch.stack(acc).double()            # [iters, N, 16]
+d = s[..., 1:11] - s[..., 0:10]
+tot = s[..., 10] - s[..., 0]
+print("per-wave cycles (s_memtime ticks = shader cycles), median / p90 over waves and launches:")
+for i, nm in enumerate(names):
+    x = d[..., i].flatten()
+    print("  %-14s %8.0f %8.0f" % (nm, x.median().item(), x.quantile(0.9).item()))
+print("  %-14s %8.0f %8.0f" % ("total", tot.flatten().median().item(), tot.flatten().quantile(0.9).item()))
