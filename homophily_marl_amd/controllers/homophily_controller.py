@@ -1,0 +1,135 @@
+"""HomophilyMAC: multi-agent controller with an env head and an incentive head per agent.
+
+Surface of the reference src/controllers/homophily_controller.py:11-206 (select_actions_env / select_actions_inc /
+forward / init_hidden / parameters* / load_state / save_models / load_models / cuda).  The agent-input assembly of
+`_build_inputs` (:127-184) writes straight into one preallocated [B*n, input_shape] buffer: the conv encoder output
+goes into its first columns and the HIP kernel ssd_build_inputs fills the rest (one launch instead of ~15 torch ops).
+"""
+import numpy as np
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..components.action_selectors import REGISTRY as action_REGISTRY
+from ..modules.agents import REGISTRY as agent_REGISTRY
+from .. import ops
+
+
+class HomophilyMAC(nn.Module):
+    def __init__(self, scheme, groups, args):
+        super().__init__()
+        self.n_agents = args.n_agents
+        self.args = args
+        for flag in ("obs_others_last_action", "obs_distance"):
+            if getattr(args, flag, False):
+                raise NotImplementedError("%s is off in every shipped config (config/default.yaml:45-51)" % flag)
+        self.input_shape = self._get_input_shape(scheme)
+        self.agent = agent_REGISTRY[args.agent](self.input_shape, args)
+        self.agent_output_type = args.agent_output_type
+        self.action_selector = action_REGISTRY[args.action_selector](args)
+        self.h_env = self.h_inc = None
+        self.extra_return_env = self.extra_return_inc = None
+        self.pos_scale = float(np.linalg.norm(args.state_dims))
+        self.register_buffer("inc_mask_actions", (1 - th.eye(self.n_agents)).reshape(1, self.n_agents, self.n_agents, 1), persistent=False)
+
+    # ---- acting ---------------------------------------------------------------------------------------------
+    def select_actions_env(self, ep_batch, t_ep, t_env, bs=slice(None), test_mode=False):
+        avail = ep_batch["avail_actions"][:, t_ep]
+        q_env = self.forward_env(ep_batch, t_ep, test_mode=test_mode)
+        chosen = self.action_selector.select_action(q_env[bs], avail[bs], t_env, test_mode=test_mode)
+        return chosen.unsqueeze(-1)                                                   # [bs, n, 1]
+
+    def select_actions_inc(self, chosen_actions, ep_batch, t_ep, t_env, bs=slice(None), test_mode=False, agent_pos_replay=None):
+        q_inc = self.forward_inc(ep_batch, t_ep, chosen_actions, test_mode=test_mode)
+        chosen = self.action_selector.select_action(q_inc[bs], th.ones_like(q_inc[bs]), t_env, test_mode=test_mode)
+        return chosen.unsqueeze(-1) * self.inc_mask_actions.to(chosen.dtype)          # no self-incentive; [bs, n, n, 1]
+
+    # ---- network evaluation ---------------------------------------------------------------------------------
+    def forward_env(self, ep_batch, t, test_mode=False, learning_mode=False):
+        self.agent_inputs = self._build_inputs(ep_batch, t)
+        q_env, self.h_env, self.extra_return_env = self.agent.forward_env(self.agent_inputs, self.h_env, learning_mode)
+        return q_env.reshape(ep_batch.batch_size, self.n_agents, -1)
+
+    def forward_inc(self, ep_batch, t, chosen_actions, test_mode=False, learning_mode=False):
+        actions_env = F.one_hot(chosen_actions.squeeze(-1), num_classes=self.args.n_actions)
+        q_inc, self.h_inc, self.extra_return_inc = self.agent.forward_inc(
+            self.agent_inputs, self.h_inc, actions_env,
+            ep_batch["agent_pos"][:, t] / self.pos_scale, ep_batch["agent_orientation"][:, t],
+            ep_batch["reward"][:, t].unsqueeze(-1), ep_batch["clean_num"][:, t].unsqueeze(-1),
+            ep_batch["apple_den"][:, t].unsqueeze(-1), learning_mode=learning_mode)
+        return q_inc.reshape(ep_batch.batch_size, self.n_agents, self.n_agents, -1)
+
+    def forward(self, ep_batch, t, test_mode=False):
+        """Learning-time evaluation: env head on the stored inputs, inc head on the stored env actions."""
+        q_env = self.forward_env(ep_batch, t, test_mode=test_mode, learning_mode=True)
+        q_inc = self.forward_inc(ep_batch, t, ep_batch["actions"][:, t, :], test_mode=test_mode, learning_mode=True)
+        return q_env, q_inc, self.extra_return_inc
+
+    def init_hidden(self, batch_size):
+        h_env, h_inc = self.agent.init_hidden()
+        self.h_env = h_env.repeat(batch_size, 1, 1, 1)
+        self.h_inc = h_inc.repeat(batch_size, 1, 1, 1)
+
+    # ---- parameters / persistence ---------------------------------------------------------------------------
+    def parameters(self, recurse=True):
+        return self.agent.parameters()
+
+    def parameters_env(self):
+        return self.agent.parameters_env()
+
+    def parameters_inc(self):
+        return self.agent.parameters_inc()
+
+    def load_state(self, other_mac):
+        self.agent.load_state_dict(other_mac.agent.state_dict())
+
+    def cuda(self, device=None):
+        self.agent.cuda(device)
+        self.inc_mask_actions = self.inc_mask_actions.cuda(device)
+        return self
+
+    def save_models(self, path):
+        th.save(self.agent.state_dict(), "{}/agent.th".format(path))
+
+    def load_models(self, path):
+        self.agent.load_state_dict(th.load("{}/agent.th".format(path), map_location=lambda storage, loc: storage, weights_only=True))
+
+    # ---- inputs ---------------------------------------------------------------------------------------------
+    def encode_obs(self, obs):
+        """obs [B, n, 3, V, V] (any float dtype) -> conv features [B * n, obs_dim_net]."""
+        B = obs.shape[0]
+        return self.agent.rgb_preprocess(obs.reshape(B * self.n_agents, 3, self.args.obs_dims[0], self.args.obs_dims[1]).float())
+
+    def assemble_inputs(self, feat, last_actions, last_reward, last_actions_inc, pos, t0):
+        """[feat | onehot(last action) | onehot(id) | sign(r) | sign(received incentives) | pos / ||(H,W)||]."""
+        a = self.args
+        B = pos.shape[0]
+        F0 = feat.shape[1]
+        tail = th.empty(B * self.n_agents, self.input_shape - F0, dtype=th.float32, device=feat.device)
+        # the tail layout below assumes the shipped flag set; flags that are off drop their columns
+        assert a.obs_last_action and a.obs_agent_id and a.obs_reward and a.obs_inc_reward and a.obs_agent_pos, \
+            "assemble_inputs implements the shipped flag set (config/default.yaml:45-51)"
+        ops.build_inputs_tail(tail, 0, last_actions, last_reward, last_actions_inc, pos, self.pos_scale, a.n_actions, t0)
+        return th.cat([feat, tail], dim=1)
+
+    def _build_inputs(self, batch, t):
+        if self.args.rgb_input:
+            feat = self.encode_obs(batch["obs"][:, t])
+        else:
+            feat = batch["obs"][:, t].reshape(batch.batch_size * self.n_agents, -1)
+        if t == 0:
+            return self.assemble_inputs(feat, None, None, None, batch["agent_pos"][:, t], True)
+        return self.assemble_inputs(feat, batch["actions"][:, t - 1].squeeze(-1), batch["reward"][:, t - 1],
+                                    batch["actions_inc"][:, t - 1].squeeze(-1), batch["agent_pos"][:, t], False)
+
+    def _get_input_shape(self, scheme):
+        a = self.args
+        shape = a.obs_dim_net if a.rgb_input else scheme["obs"]["vshape"]
+        if a.obs_last_action:
+            shape += scheme["actions_onehot"]["vshape"][0]
+        if a.obs_agent_id:
+            shape += self.n_agents
+        shape += int(bool(a.obs_reward)) + int(bool(a.obs_inc_reward))
+        if a.obs_agent_pos:
+            shape += 2
+        return shape

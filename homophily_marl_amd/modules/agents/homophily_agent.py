@@ -1,0 +1,125 @@
+"""Q-network of the homophily algorithm: a shared conv encoder and, PER AGENT (unshared weights), an env head and an
+incentive head, each fc1 -> GRU cell -> dueling Q.  Behaviour and parameter names follow the reference
+src/modules/agents/homophily_agent.py:7-214 so checkpoints (`agent.th`) interchange; the evaluation is re-organised
+for the GPU: the per-agent weights [1, n, in, out] are applied as ONE batched GEMM over the agent dimension
+([n, B, in] x [n, in, out], hipBLASLt / MFMA) and the six GRU projections run as two GEMMs on concatenated weights.
+"""
+import math
+
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class HomophilyAgent(nn.Module):
+    def __init__(self, input_shape, args):
+        super().__init__()
+        self.args = args
+        self.n_agents = n = args.n_agents
+        self.n_actions = args.n_actions
+        self.n_inc_actions = args.n_inc_actions
+        self.input_shape = input_shape
+        self.hidden = H = args.rnn_hidden_dim
+        self.extra_input_shape = args.n_actions + 2 + 2 + 3   # action one-hot, pos, orientation, reward/clean_num/apple_den
+        if args.rgb_input:
+            k = args.conv_kernel
+            flat = args.conv_out * (args.obs_dims[0] - k + 1) * (args.obs_dims[1] - k + 1)
+            self.conv_to_fc = nn.Sequential(nn.Conv2d(3, args.conv_out, k, args.conv_stride), nn.LeakyReLU(), nn.Flatten(),
+                                            nn.Linear(flat, args.obs_dim_net), nn.LeakyReLU())
+
+        def weight(fan_in, fan_out, kaiming=False):
+            t = th.empty(1, n, fan_in, fan_out)
+            if kaiming:     # reference: kaiming_uniform_(a=sqrt(5)) on the 4-D tensor (homophily_agent.py:29-30)
+                nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+            else:
+                nn.init.uniform_(t, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+            return nn.Parameter(t)
+
+        def bias(fan_in, fan_out):
+            return nn.Parameter(nn.init.uniform_(th.empty(1, n, 1, fan_out), -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in)))
+
+        # registration order = reference order (homophily_agent.py:37-125); optimiser state interchange depends on it
+        for head, fc1_in, fc2_in, fc2_out in (("env", input_shape, H, self.n_actions),
+                                              ("inc", input_shape + self.n_actions, H + self.extra_input_shape, self.n_inc_actions)):
+            setattr(self, "fc1_%s_w" % head, weight(fc1_in, H, kaiming=True))
+            setattr(self, "fc1_%s_b" % head, bias(fc1_in, H))
+            for gate in ("ir", "hr", "iz", "hz", "in", "hn"):
+                setattr(self, "rnn_%s_%s_w" % (head, gate), weight(H, H))
+                setattr(self, "rnn_%s_%s_b" % (head, gate), bias(H, H))
+            setattr(self, "fc2_%s_w" % head, weight(fc2_in, fc2_out, kaiming=True))
+            setattr(self, "fc2_%s_b" % head, bias(fc2_in, fc2_out))
+            setattr(self, "fc2_%s_v_w" % head, weight(fc2_in, 1, kaiming=True))
+            setattr(self, "fc2_%s_v_b" % head, bias(fc2_in, 1))
+
+    # ---- parameter groups (homophily_agent.py:127-146): the encoder belongs to BOTH groups -----------------------
+    def _group(self, tag):
+        params = list(self.conv_to_fc.parameters()) if self.args.rgb_input else []
+        return params + [p for name, p in self.named_parameters() if tag in name]
+
+    def parameters_env(self):
+        return self._group("env")
+
+    def parameters_inc(self):
+        return self._group("inc")
+
+    def init_hidden(self):
+        z = self.fc1_env_w.new_zeros(1, self.n_agents, 1, self.hidden)
+        return z.detach(), z.clone().detach()
+
+    def rgb_preprocess(self, x):
+        return self.conv_to_fc(x)
+
+    # ---- building blocks ----------------------------------------------------------------------------------------
+    def _w(self, name):
+        return getattr(self, name)[0]            # [n, in, out]
+
+    def _b(self, name):
+        return getattr(self, name)[0]            # [n, 1, out]
+
+    def _gru(self, head, x, h):
+        """x, h: [n, B, H].  r, z, n gates exactly as homophily_agent.py:162-165 / 188-191."""
+        p = "rnn_%s_" % head
+        wi = th.cat([self._w(p + "ir_w"), self._w(p + "iz_w"), self._w(p + "in_w")], dim=2)
+        wh = th.cat([self._w(p + "hr_w"), self._w(p + "hz_w"), self._w(p + "hn_w")], dim=2)
+        bi = th.cat([self._b(p + "ir_b"), self._b(p + "iz_b"), self._b(p + "in_b")], dim=2)
+        bh = th.cat([self._b(p + "hr_b"), self._b(p + "hz_b"), self._b(p + "hn_b")], dim=2)
+        gi = th.baddbmm(bi, x, wi)
+        gh = th.baddbmm(bh, h, wh)
+        H = self.hidden
+        r = th.sigmoid(gi[..., :H] + gh[..., :H])
+        z = th.sigmoid(gi[..., H:2 * H] + gh[..., H:2 * H])
+        cand = th.tanh(gi[..., 2 * H:] + r * gh[..., 2 * H:])
+        return (1 - z) * cand + z * h
+
+    # ---- heads --------------------------------------------------------------------------------------------------
+    def forward_env(self, inputs, h_in, learning_mode=False):
+        n, H = self.n_agents, self.hidden
+        x = inputs.reshape(-1, n, self.input_shape).transpose(0, 1)                 # [n, B, in]
+        h = h_in.reshape(-1, n, H).transpose(0, 1)
+        x = F.leaky_relu(th.baddbmm(self._b("fc1_env_b"), x, self._w("fc1_env_w")))
+        h_out = self._gru("env", x, h)
+        a = th.baddbmm(self._b("fc2_env_b"), h_out, self._w("fc2_env_w"))          # [n, B, A]
+        v = th.baddbmm(self._b("fc2_env_v_b"), h_out, self._w("fc2_env_v_w"))      # [n, B, 1]
+        q = v + a - a.mean(dim=-1, keepdim=True)                                    # dueling (homophily_agent.py:168-170)
+        return q.transpose(0, 1), h_out.transpose(0, 1).unsqueeze(2), {}
+        # [B, n, A], [B, n, 1, H]
+
+    def forward_inc(self, inputs, h_in, actions_env, agent_pos, agent_orientation, reward, clean_num, apple_den,
+                    learning_mode=False):
+        n, H = self.n_agents, self.hidden
+        act = actions_env.reshape(-1, n, self.n_actions).to(inputs.dtype)
+        B = act.shape[0]
+        x = th.cat([inputs.reshape(B, n, self.input_shape), act], dim=-1).transpose(0, 1)   # [n, B, in + A]
+        h = h_in.reshape(B, n, H).transpose(0, 1)
+        x = F.leaky_relu(th.baddbmm(self._b("fc1_inc_b"), x, self._w("fc1_inc_w")))
+        h_out = self._gru("inc", x, h)                                               # [n, B, H]
+        # per ordered pair (i -> j): [h_i | onehot(a_j), pos_j, orient_j, r_j, clean_j, apple_den_j] (homophily_agent.py:194-201)
+        other = th.cat([act, agent_pos.reshape(B, n, 2), agent_orientation.reshape(B, n, 2), reward.reshape(B, n, 1),
+                        clean_num.reshape(B, n, 1), apple_den.reshape(B, n, 1)], dim=-1)     # [B, n(j), E]
+        E = other.shape[-1]
+        cat = th.cat([h_out.unsqueeze(2).expand(n, B, n, H), other.unsqueeze(0).expand(n, B, n, E)], dim=-1)   # [n(i), B, n(j), H+E]
+        cat = cat.reshape(n, B * n, H + E)
+        a = th.baddbmm(self._b("fc2_inc_b"), cat, self._w("fc2_inc_w"))             # [n, B*n, 3]
+        v = th.baddbmm(self._b("fc2_inc_v_b"), cat, self._w("fc2_inc_v_w"))
+        q = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, B, n, -1).transpose(0, 1)   # [B, n(i), n(j), 3]
+        return q, h_out.transpose(0, 1).unsqueeze(2), {}

@@ -1,0 +1,74 @@
+"""Torch-facing wrappers of the two learner-side HIP kernels (csrc/ssd_learner.hip) through the C ABI.
+
+Device tensors always go through libssd_hip.so (load_library() raises if it is missing: no silent fallback on a GPU
+box).  For CPU tensors -- the CPU test-suite and the gloo rehearsal of the data-parallel path, where no HIP device
+exists -- the same arithmetic is evaluated with torch expressions; that branch is never taken by a GPU run.
+"""
+import torch as th
+
+from . import abi
+
+
+def _stream(t):
+    return th.cuda.current_stream(t.device).cuda_stream
+
+
+def build_inputs_tail(out, offset, last_actions, last_reward, last_actions_inc, pos, pos_scale, n_actions, t0):
+    """Fill out[:, offset : offset + A + n + 4] with the non-visual agent-input features of
+    HomophilyMAC._build_inputs (controllers/homophily_controller.py:137-184):
+    onehot(last action) | onehot(agent id) | sign(last reward) | sign(#recv+ - #recv-) | pos / ||(H, W)||.
+    out: f32 [B * n, stride]; last_actions i64 [B, n]; last_reward f32 [B, n]; last_actions_inc i64 [B, n, n];
+    pos f32 [B, n, 2].  t0: the t == 0 branch (the three history terms are zero, their tensors may be None)."""
+    B, n = pos.shape[0], pos.shape[1]
+    A = n_actions
+    if out.is_cuda:
+        lib = abi.load_library()
+        cont = lambda x: None if x is None else x.contiguous()
+        la, lr, li, p = cont(last_actions), cont(last_reward), cont(last_actions_inc), pos.contiguous()
+        assert out.is_contiguous() and out.dtype == th.float32
+        ptr = lambda x: None if x is None else x.data_ptr()
+        abi.check(lib, lib.ssd_build_inputs(B, n, A, 1 if t0 else 0, ptr(la), ptr(lr), ptr(li), p.data_ptr(), float(pos_scale),
+                                            out.data_ptr(), out.shape[1], offset, _stream(out)))
+        return out
+    o = out.view(B, n, -1)
+    if t0:
+        o[..., offset:offset + A] = 0
+        o[..., offset + A + n] = 0
+        o[..., offset + A + n + 1] = 0
+    else:
+        o[..., offset:offset + A] = th.nn.functional.one_hot(last_actions, A).to(o.dtype)
+        o[..., offset + A + n] = th.sign(last_reward)
+        m = last_actions_inc * (1 - th.eye(n, dtype=last_actions_inc.dtype, device=o.device))
+        recv = (m == 1).sum(dim=1) - (m == 2).sum(dim=1)                 # giver dim summed -> per receiver
+        o[..., offset + A + n + 1] = th.sign(recv.to(o.dtype))
+    o[..., offset + A:offset + A + n] = th.eye(n, dtype=o.dtype, device=o.device)
+    o[..., offset + A + n + 2:offset + A + n + 4] = pos / pos_scale
+    return out
+
+
+def incentive_transfer(actions_inc, rewards, effect_ratio, cost_ratio, incentive, seq_len):
+    """Incentive reward transfer (learners/homophily_learner.py:94-115).
+    actions_inc i64 [B, T, n, n] (giver dim 2, receiver dim 3), rewards f32 [B, T-1, n].
+    Returns give [B,T-1,n], recv_pos / recv_neg / recv_zero [B,T,n], rewards_for_env, rewards_for_inc [B,T-1,n] (f32)."""
+    B, T, n = actions_inc.shape[0], actions_inc.shape[1], actions_inc.shape[2]
+    dev = actions_inc.device
+    if actions_inc.is_cuda:
+        lib = abi.load_library()
+        a = actions_inc.contiguous()
+        r = rewards.contiguous().float()
+        mk = lambda t: th.empty(B, t, n, dtype=th.float32, device=dev)
+        give, rp, rn, rz, re, ri = mk(T - 1), mk(T), mk(T), mk(T), mk(T - 1), mk(T - 1)
+        abi.check(lib, lib.ssd_incentive_transfer(B, T, n, a.data_ptr(), r.data_ptr(), float(effect_ratio), float(cost_ratio),
+                                                  float(incentive), float(seq_len), give.data_ptr(), rp.data_ptr(), rn.data_ptr(),
+                                                  rz.data_ptr(), re.data_ptr(), ri.data_ptr(), _stream(a)))
+        return give, rp, rn, rz, re, ri
+    mask = (1 - th.eye(n, dtype=actions_inc.dtype, device=dev)).view(1, 1, n, n)
+    m = actions_inc * mask
+    give = (m[:, :-1] != 0).sum(dim=3).float()
+    rp = (m == 1).sum(dim=2).float()
+    rn = (m == 2).sum(dim=2).float()
+    rz = (n - 1) - rp - rn
+    rv = rp[:, :-1] - rn[:, :-1]
+    re = (rewards + rv * effect_ratio * incentive) / seq_len
+    ri = (rewards - give * cost_ratio * incentive) / seq_len
+    return give, rp, rn, rz, re, ri

@@ -1,0 +1,129 @@
+"""HipVecRunner: episode rollouts of N vectorised envs resident on the GPU, behind the reference's runner surface
+(src/runners/episode_runner.py:7-152: __init__(args, logger), setup, get_env_info, run(test_mode) -> EpisodeBatch,
+reset, close_env, save_replay, attrs t_env / batch_size).
+
+Per timestep (episode_runner.py:57-97): store obs -> env-head action selection -> env.step -> store rewards ->
+incentive-head action selection -> store.  Here the env transition and the observation of the NEXT state come from one
+fused kernel launch (ssd_step_observe) and nothing leaves the device.  `runner: "episode"` is the same loop with the
+reference's restriction batch_size_run == 1.
+"""
+from functools import partial
+
+import torch as th
+
+from .. import abi
+from ..components.episode_buffer import EpisodeBatch
+from ..envs import REGISTRY as env_REGISTRY
+
+
+class HipVecRunner:
+    single_env_only = False
+
+    def __init__(self, args, logger):
+        self.args, self.logger = args, logger
+        self.batch_size = args.batch_size_run
+        if self.single_env_only:
+            assert self.batch_size == 1                                   # episode_runner.py:13
+        env_args = dict(args.env_args)
+        env_args.setdefault("n_env", self.batch_size)
+        env_args.setdefault("device", getattr(args, "device_index", 0))
+        env_args.setdefault("env_id_base", getattr(args, "env_id_base", 0))
+        self.env = env_REGISTRY[args.env](**env_args)
+        self.episode_limit = self.env.episode_limit
+        self.t = 0
+        self.t_env = 0
+        self.train_returns, self.test_returns = [], []
+        self.train_stats, self.test_stats = {}, {}
+        self.log_train_stats_t = -1000000
+        self.obs_fmt = abi.OBS_F32
+
+    def setup(self, scheme, groups, preprocess, mac):
+        self.new_batch = partial(EpisodeBatch, scheme, groups, self.batch_size, self.episode_limit + 1, preprocess=preprocess,
+                                 device=self.args.device)
+        self.mac = mac
+        self.store_state = "state" in scheme and getattr(self.args, "store_state", True)
+
+    def get_env_info(self):
+        return self.env.get_env_info()
+
+    def save_replay(self):
+        self.env.save_replay()
+
+    def close_env(self):
+        self.env.close()
+
+    def reset(self):
+        self.batch = self.new_batch()
+        self.env.reset_batch()
+        self.t = 0
+
+    def _store_observation(self, o, t):
+        data = {"avail_actions": self.env.avail_actions_batch, "obs": o["obs"], "agent_pos": o["pos"], "agent_orientation": o["orient"]}
+        if self.store_state:
+            data["state"] = self.env.observe_batch(self.obs_fmt, want_state=True)["state"]
+        self.batch.update(data, ts=t)
+
+    def run(self, test_mode=False):
+        self.reset()
+        n_actions = self.args.n_actions
+        ep_return = th.zeros(self.batch_size, self.args.n_agents, device=self.env.device)
+        self.mac.init_hidden(batch_size=self.batch_size)
+        o = self.env.observe_batch(self.obs_fmt)
+        out = None
+        with th.no_grad():
+            for t in range(self.episode_limit):
+                self._store_observation(o, t)
+                actions = self.mac.select_actions_env(self.batch, t_ep=t, t_env=self.t_env, test_mode=test_mode)
+                out = self.env.step_batch((actions.squeeze(-1) % n_actions).to(th.int32), observe=True, fmt=self.obs_fmt)
+                ep_return += out["reward"]
+                # `terminated` is stored as the env flag: episode_limit never appears in info (episode_runner.py:83)
+                self.batch.update({"actions": actions, "reward": out["reward"], "terminated": out["terminated"].unsqueeze(-1),
+                                   "clean_num": out["clean_num"], "apple_den": out["apple_den"]}, ts=t)
+                actions_inc = self.mac.select_actions_inc(actions, self.batch, t_ep=t, t_env=self.t_env, test_mode=test_mode)
+                self.batch.update({"actions_inc": actions_inc}, ts=t)
+                o = out
+                self.t += 1
+            # slot T: last observation and the bootstrapping actions (episode_runner.py:99-119)
+            self._store_observation(o, self.t)
+            actions = self.mac.select_actions_env(self.batch, t_ep=self.t, t_env=self.t_env, test_mode=test_mode)
+            actions_inc = self.mac.select_actions_inc(actions, self.batch, t_ep=self.t, t_env=self.t_env, test_mode=test_mode)
+            self.batch.update({"actions_inc": actions_inc}, ts=self.t)
+            self.batch.update({"actions": actions}, ts=self.t)
+
+        stats = self.test_stats if test_mode else self.train_stats
+        returns = self.test_returns if test_mode else self.train_returns
+        prefix = "test_" if test_mode else ""
+        if getattr(self.args, "runner_stats", True):
+            env_info = {"collective_return": float(out["collective_return"].sum().item()),
+                        "equality_metric": float(out["equality"].sum().item())}
+            for k, v in env_info.items():
+                stats[k] = stats.get(k, 0) + v
+            stats["n_episodes"] = self.batch_size + stats.get("n_episodes", 0)
+            stats["ep_length"] = self.t * self.batch_size + stats.get("ep_length", 0)
+            returns.extend(ep_return.cpu().numpy())
+        if not test_mode:
+            self.t_env += self.t * self.batch_size
+        if getattr(self.args, "runner_stats", True):
+            if test_mode and len(self.test_returns) >= self.args.test_nepisode:
+                self._log(returns, stats, prefix)
+            elif not test_mode and self.t_env - self.log_train_stats_t >= self.args.runner_log_interval:
+                self._log(returns, stats, prefix)
+                if hasattr(self.mac.action_selector, "epsilon"):
+                    self.logger.log_stat("epsilon", self.mac.action_selector.epsilon, self.t_env)
+                self.log_train_stats_t = self.t_env
+        return self.batch
+
+    def _log(self, returns, stats, prefix):
+        import numpy as np
+        self.logger.log_stat(prefix + "return_mean", float(np.mean(returns)), self.t_env)
+        self.logger.log_stat(prefix + "return_std", float(np.std(returns)), self.t_env)
+        returns.clear()
+        for k, v in stats.items():
+            if k != "n_episodes":
+                self.logger.log_stat(prefix + k + "_mean", v / stats["n_episodes"], self.t_env)
+        stats.clear()
+
+
+class EpisodeRunner(HipVecRunner):
+    """`runner: "episode"`: one env, as the reference asserts (episode_runner.py:13)."""
+    single_env_only = True

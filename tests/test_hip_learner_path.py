@@ -1,0 +1,142 @@
+"""GPU suite: the learner-side HIP kernels (through the C ABI), the controller / learner on the device, the drop-in env
+surface and the vectorised runner."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch as th
+
+from homophily_marl_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_build_inputs_kernel_vs_oracle_and_torch():
+    from homophily_marl_amd import ops
+    from oracle.oracle_py import lib as oracle_lib
+    g = th.Generator().manual_seed(1)
+    for (B, n, A) in ((1, 3, 9), (257, 5, 9), (64, 10, 8)):
+        la = th.randint(0, A, (B, n), generator=g)
+        lr = th.randint(-2, 3, (B, n), generator=g).float()
+        li = th.randint(0, 3, (B, n, n), generator=g)
+        pos = th.randint(1, 40, (B, n, 2), generator=g).float()
+        width = A + n + 4
+        for t0 in (True, False):
+            ref = np.full((B * n, width + 3), -7, np.float32)
+            o = oracle_lib()
+            o.ssd_cpu_build_inputs(B, n, A, int(t0), la.numpy().ctypes.data, lr.numpy().ctypes.data, li.numpy().ctypes.data,
+                                   pos.numpy().ctypes.data, C.c_float(30.8), ref.ctypes.data, width + 3, 2)
+            dev = th.full((B * n, width + 3), -7.0, device="cuda")
+            ops.build_inputs_tail(dev, 2, la.cuda(), lr.cuda(), li.cuda(), pos.cuda(), 30.8, A, t0)
+            cpu = th.full((B * n, width + 3), -7.0)
+            ops.build_inputs_tail(cpu, 2, la, lr, li, pos, 30.8, A, t0)
+            assert (dev.cpu().numpy() == ref).all(), (B, n, A, t0)
+            assert (cpu.numpy() == ref).all(), (B, n, A, t0)
+
+
+def test_incentive_transfer_kernel_vs_oracle_and_torch():
+    from homophily_marl_amd import ops
+    from oracle.oracle_py import lib as oracle_lib
+    g = th.Generator().manual_seed(2)
+    for (B, T, n) in ((1, 2, 3), (16, 101, 5), (7, 13, 10)):
+        a = th.randint(0, 3, (B, T, n, n), generator=g)
+        r = th.randint(-3, 4, (B, T - 1, n), generator=g).float()
+        outs = [np.zeros((B, t, n), np.float32) for t in (T - 1, T, T, T, T - 1, T - 1)]
+        oracle_lib().ssd_cpu_incentive_transfer(B, T, n, a.numpy().ctypes.data, r.numpy().ctypes.data, C.c_float(1.0), C.c_float(0.1),
+                                                C.c_float(1.0), C.c_float(float(T)), *[x.ctypes.data for x in outs])
+        dev = ops.incentive_transfer(a.cuda(), r.cuda(), 1.0, 0.1, 1.0, float(T))
+        cpu = ops.incentive_transfer(a, r, 1.0, 0.1, 1.0, float(T))
+        for i in range(6):
+            assert (dev[i].cpu().numpy() == outs[i]).all(), (B, T, n, i)
+            assert (cpu[i].numpy() == outs[i]).all(), (B, T, n, i)
+
+
+@pytest.mark.parametrize("name", ["learner_cleanup5.npz", "learner_harvest5.npz"])
+def test_learner_on_device_matches_reference_fixture(name):
+    """Same fixtures as the CPU suite, network + HIP kernels on the GPU: Q-loss within 1e-5 (fp32)."""
+    from tests.learner_util import build, load_fixture
+    th.backends.cuda.matmul.allow_tf32 = False
+    z, meta = load_fixture(name)
+    args, batch, mac, learner = build(z, meta, device="cuda:0")
+    with th.no_grad():
+        got = mac._build_inputs(batch, 3).cpu().numpy()
+        nf = args.obs_dim_net
+        assert (got[:, nf:] == z["inputs_t3"][:, nf:]).all()
+        q_env, q_inc = learner.unroll(mac, batch)
+        assert np.abs(q_env.cpu().numpy() - z["q_env"]).max() < 1e-5
+        assert np.abs(q_inc.cpu().numpy() - z["q_inc"]).max() < 1e-5
+    for step in range(2):
+        logs = learner.cal_loss_and_step(batch)
+        for k in ("loss_value_env", "loss_value_inc", "loss_sim"):
+            assert abs(float(logs[k]) - float(z["step%d_%s" % (step, k)])) < 1e-5, (step, k, float(logs[k]))
+
+
+def test_env_class_drop_in_surface_single_env():
+    """REGISTRY['cleanup'](**env_args) with the reference's kwargs behaves like the reference env object (n_env = 1):
+    compared call by call with the CPU oracle on the same counter seed."""
+    from homophily_marl_amd.envs import REGISTRY
+    from oracle.oracle_py import OracleEnv
+    env_args = dict(num_agents=5, render=False, episode_limit=30, is_replay=False, view_size=7, map="default5",
+                    extra_args=dict(random_spawn_point=False, random_spawn_rotation=0, disable_rotation_action=True,
+                                    disable_fire_action=True, obs_color="simplified"), seed=11)
+    env = REGISTRY["cleanup"](**env_args)
+    orc = OracleEnv("cleanup", map="default5", num_agents=5, n_env=1, view_size=7, episode_limit=30, rng_mode=abi.RNG_COUNTER, seed=11)
+    info = env.get_env_info()
+    assert info["state_shape"] == (3, 25, 18) and info["obs_shape"] == (3, 15, 15) and info["n_actions"] == 9
+    assert info["n_agents"] == 5 and info["episode_limit"] == 30 and info["state_dims"] == (25, 18) and info["obs_dims"] == (15, 15)
+    assert env.get_avail_actions() == [[1, 1, 1, 1, 1, 0, 0, 0, 1]] * 5
+    env.reset(); orc.reset()
+    rng = np.random.default_rng(0)
+    term = False
+    t = 0
+    while not term:
+        obs = env.get_obs()
+        ref = orc.observe(want_state=True)
+        assert len(obs) == 5 and obs[0].dtype == np.float64 and (np.stack(obs) == ref["obs"][0]).all()
+        assert (env.get_state() == ref["state"][0]).all()
+        assert (env.get_agent_pos() == ref["pos"][0]).all() and (env.get_agent_orientation() == ref["orient"][0]).all()
+        acts = rng.choice([0, 1, 2, 3, 4, 8], 5)
+        reward, term, einfo = env.step(acts)
+        o = orc.step(acts[None])
+        assert reward.dtype == np.float64 and (reward == o["reward"][0]).all()
+        assert (einfo["clean_num"] == o["clean_num"][0]).all() and (einfo["apple_den"] == o["apple_den"][0]).all()
+        assert term == bool(o["terminated"][0])
+        t += 1
+    assert t == 30 and "collective_return" in einfo and "equality_metric" in einfo
+    with pytest.raises(KeyError):
+        env.step([9, 0, 0, 0, 0])
+    env.close()
+
+
+def test_vectorised_runner_and_one_training_iteration():
+    """hip_vec runner, 64 envs: batch contents are consistent (stored obs == observation of the stored state
+    trajectory re-played on the oracle with the stored actions) and one learner.train runs end to end."""
+    from homophily_marl_amd.run import load_config, setup, train_iteration
+    from oracle.oracle_py import OracleEnv
+    N, T = 64, 12
+    cfg = load_config("cleanup", overrides=dict(
+        runner="hip_vec", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False, store_state=False,
+        env_args=dict(num_agents=5, map="default5", episode_limit=T, seed=5), use_cuda=True, save_model=False))
+    ctx = setup(cfg)
+    batch = ctx.runner.run(test_mode=False)
+    assert batch.batch_size == N and batch.max_seq_length == T + 1
+    assert int(batch["filled"].sum().item()) == N * (T + 1)
+    assert ctx.runner.t_env == N * T
+    orc = OracleEnv("cleanup", map="default5", num_agents=5, n_env=N, view_size=7, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=5)
+    orc.reset()
+    acts = batch["actions"].squeeze(-1).cpu().numpy()
+    for t in range(T):
+        ob = orc.observe()
+        assert (batch["obs"][:, t].cpu().numpy() == ob["obs"]).all(), t
+        assert (batch["agent_pos"][:, t].cpu().numpy() == ob["pos"]).all()
+        o = orc.step(acts[:, t] % 9)
+        assert (batch["reward"][:, t].cpu().numpy() == o["reward"]).all()
+        assert (batch["clean_num"][:, t].cpu().numpy() == o["clean_num"]).all()
+        assert (batch["terminated"][:, t, 0].cpu().numpy() == o["terminated"]).all()
+    assert (batch["obs"][:, T].cpu().numpy() == orc.observe()["obs"]).all()
+    ai = batch["actions_inc"].squeeze(-1)
+    assert (ai.diagonal(dim1=2, dim2=3) == 0).all() and int(ai.max()) <= 2       # no self-incentive
+    assert (batch["actions_onehot"].argmax(-1) == batch["actions"].squeeze(-1)).all()
+    ep = train_iteration(ctx, 0)
+    assert ep == N and ctx.buffer.episodes_in_buffer == N
+    ctx.runner.close_env()

@@ -1,0 +1,78 @@
+"""CPU suite: controller inputs, Q-network, incentive transfer and the homophily learner of this package against the
+fixtures generated from the reference (oracle/gen_learner_golden.py).  Tolerance: the Q-loss must match within 1e-5
+in fp32 (BASELINE.json north_star); measured differences are ~1e-8 and come from GEMM summation order only."""
+import numpy as np
+import pytest
+import torch as th
+
+from tests.learner_util import build, load_fixture, param_checksums
+
+FIXTURES = ["learner_cleanup5.npz", "learner_harvest5.npz"]
+LOSS_TOL = 1e-5
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_build_inputs_matches_reference(name):
+    z, meta = load_fixture(name)
+    args, batch, mac, learner = build(z, meta)
+    with th.no_grad():
+        for t, key in ((0, "inputs_t0"), (3, "inputs_t3")):
+            got = mac._build_inputs(batch, t).numpy()
+            ref = z[key]
+            # the non-visual tail is integer / exact arithmetic: bit-exact; the conv features differ by GEMM rounding only
+            nf = args.obs_dim_net
+            assert (got[:, nf:] == ref[:, nf:]).all(), key
+            assert np.abs(got[:, :nf] - ref[:, :nf]).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_q_values_match_reference(name):
+    z, meta = load_fixture(name)
+    args, batch, mac, learner = build(z, meta)
+    with th.no_grad():
+        q_env, q_inc = learner.unroll(mac, batch)
+    assert np.abs(q_env.numpy() - z["q_env"]).max() < 2e-6
+    assert np.abs(q_inc.numpy() - z["q_inc"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_two_learner_steps_match_reference(name):
+    """Losses of two consecutive steps and every parameter after each step (pins the two-Adam / double-clip order and
+    the shared encoder being stepped by both optimisers, homophily_learner.py:43-44,220-226)."""
+    z, meta = load_fixture(name)
+    args, batch, mac, learner = build(z, meta)
+    for step in range(2):
+        logs = learner.cal_loss_and_step(batch)
+        for k in ("loss_value_env", "loss_value_inc", "loss_sim", "value_give_mean", "value_receive_mean", "q_env_taken_mean",
+                  "q_inc_taken_mean", "incentives_to_cleanup_per", "incentives_to_harvest_per"):
+            ref = float(z["step%d_%s" % (step, k)])
+            assert abs(float(logs[k]) - ref) < LOSS_TOL, (step, k, float(logs[k]), ref)
+        sums, sqs, heads = param_checksums(mac)
+        assert [str(x) for x in z["param_names"]] == list(mac.agent.state_dict().keys())
+        assert np.abs(heads - z["step%d_param_head" % step]).max() < 2e-5, step
+        assert np.abs(sqs - z["step%d_param_sq" % step]).max() / np.abs(z["step%d_param_sq" % step]).max() < 1e-5, step
+
+
+def test_state_dict_is_interchangeable_with_the_reference():
+    z, meta = load_fixture(FIXTURES[0])
+    args, batch, mac, learner = build(z, meta)
+    ours = {k: tuple(v.shape) for k, v in mac.agent.state_dict().items()}
+    ref = {k[2:]: z[k].shape for k in z.files if k.startswith("w_")}
+    assert ours == ref
+    assert sum(int(np.prod(s)) for s in ours.values()) == 322638          # SURVEY.md appendix B, Cleanup-5
+    assert len(learner.params_env) == 22 and len(learner.params_inc) == 22
+    shared = {id(p) for p in learner.params_env} & {id(p) for p in learner.params_inc}
+    assert len(shared) == 4                                                # the conv encoder is in both groups
+
+
+def test_incentive_transfer_closed_form():
+    from homophily_marl_amd import ops
+    g = th.Generator().manual_seed(0)
+    a = th.randint(0, 3, (3, 6, 4, 4), generator=g)
+    r = th.randn(3, 5, 4, generator=g)
+    give, rp, rn, rz, re, ri = ops.incentive_transfer(a, r, 1.0, 0.1, 1.0, 6.0)
+    m = a * (1 - th.eye(4, dtype=a.dtype))
+    assert (give == (m[:, :-1] != 0).sum(3)).all()
+    assert (rp == (m == 1).sum(2)).all() and (rn == (m == 2).sum(2)).all() and (rz == 3 - rp - rn).all()
+    assert th.equal(re, (r + (rp - rn)[:, :-1] * 1.0 * 1.0) / 6.0)
+    assert th.equal(ri, (r - give * 0.1 * 1.0) / 6.0)
