@@ -57,10 +57,10 @@ def cpu_baseline(n_env, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--n-env", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--workload", default=os.environ.get("SSD_BENCH_WORKLOAD", "env"), choices=["env", "e2e"])
+    ap.add_argument("--workload", default=os.environ.get("SSD_BENCH_WORKLOAD", "e2e"), choices=["env", "e2e"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=200)
     args = ap.parse_args()

@@ -1,0 +1,78 @@
+"""End-to-end workload of bench.py: the full homophily training loop on vectorised envs.
+
+One "step" = one transition of all N envs of this rank inside the real loop: observation storage, env-head and
+incentive-head action selection (Q-net forward), the fused ssd_step_observe launch, and -- at every episode end --
+slot-T bootstrapping, replay insertion, sampling and ONE learner.train (run.py:184-210 cadence, batch_size 16).
+Nothing is skipped inside the timed region.
+"""
+import time
+
+import torch as th
+import torch.distributed as dist
+
+from . import abi
+from .run import load_config, setup
+
+
+def run_e2e(args, rank, world, local_rank):
+    N, n, T = args.n_env, 5, 100
+    cfg = load_config("cleanup", overrides=dict(
+        runner="hip_vec", batch_size_run=N, batch_size=16, buffer_size=max(5000, N), buffer_cpu_only=False, store_state=False,
+        env_args=dict(num_agents=n, map="default5", episode_limit=T, view_size=7, seed=1), use_cuda=True, save_model=False,
+        device_index=local_rank, env_id_base=rank * N, runner_stats=False, learner_log_interval=10 ** 12))
+    th.manual_seed(0)                     # fixed-seed random-init weights, identical on every rank
+    ctx = setup(cfg)
+    runner, learner, buf = ctx.runner, ctx.learner, ctx.buffer
+    a = ctx.args
+    state = dict(episode=0, in_episode=False)
+
+    def one_step():
+        if not state["in_episode"]:
+            runner.begin_episode(False)
+            state["in_episode"] = True
+        if runner.step_once():
+            batch = runner.finish_episode()
+            buf.insert_episode_batch(batch)
+            if buf.can_sample(a.batch_size):
+                sample = buf.sample(a.batch_size)
+                sample = sample[:, :T + 1]
+                learner.train(sample, runner.t_env, state["episode"])
+            state["episode"] += a.batch_size_run
+            state["in_episode"] = False
+
+    # kernel timing: HIP events around the fused env launch of every step (on torch's current stream)
+    ev = []
+    orig = runner.env.step_batch
+
+    def timed_step_batch(*x, **k):
+        s, e = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        s.record()
+        r = orig(*x, **k)
+        e.record()
+        ev.append((s, e))
+        return r
+
+    for _ in range(args.warmup):
+        one_step()
+    runner.env.step_batch = timed_step_batch
+    th.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    th.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    th.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert runner.env.native.poll_error() == 0
+    ms = sorted(s.elapsed_time(e) for s, e in ev)
+    from bench import algorithmic_bytes_per_env_step
+    return dict(elapsed=elapsed, kern_avg_us=1e3 * sum(ms) / len(ms), kern_med_us=1e3 * ms[len(ms) // 2],
+                bytes_per_launch=algorithmic_bytes_per_env_step(25, 18, n, 15) * N, dtype="fp32",
+                workload="cleanup_default5_rollout_plus_homophily_train",
+                extra=dict(obs_format="f32[n_env,n,3,15,15]", kernel="ssd::k_env<MODE_STEP_OBS>", qnet_dtype="fp32",
+                           train="1 learner.train(batch_size 16 x T 101) per 100-step rollout, double-Q + sim loss, 2x Adam",
+                           buffer="device-resident ReplayBuffer, %d episodes" % buf.buffer_size))

@@ -63,33 +63,42 @@ class HipVecRunner:
             data["state"] = self.env.observe_batch(self.obs_fmt, want_state=True)["state"]
         self.batch.update(data, ts=t)
 
-    def run(self, test_mode=False):
+    # The rollout is exposed timestep by timestep (begin_episode / step_once / finish_episode) so that a caller such as
+    # bench.py can time an exact number of transitions; run() is the reference-shaped whole-episode call.
+    def begin_episode(self, test_mode=False):
         self.reset()
-        n_actions = self.args.n_actions
-        ep_return = th.zeros(self.batch_size, self.args.n_agents, device=self.env.device)
+        self._test_mode = test_mode
+        self._ep_return = th.zeros(self.batch_size, self.args.n_agents, device=self.env.device)
         self.mac.init_hidden(batch_size=self.batch_size)
-        o = self.env.observe_batch(self.obs_fmt)
-        out = None
-        with th.no_grad():
-            for t in range(self.episode_limit):
-                self._store_observation(o, t)
-                actions = self.mac.select_actions_env(self.batch, t_ep=t, t_env=self.t_env, test_mode=test_mode)
-                out = self.env.step_batch((actions.squeeze(-1) % n_actions).to(th.int32), observe=True, fmt=self.obs_fmt)
-                ep_return += out["reward"]
-                # `terminated` is stored as the env flag: episode_limit never appears in info (episode_runner.py:83)
-                self.batch.update({"actions": actions, "reward": out["reward"], "terminated": out["terminated"].unsqueeze(-1),
-                                   "clean_num": out["clean_num"], "apple_den": out["apple_den"]}, ts=t)
-                actions_inc = self.mac.select_actions_inc(actions, self.batch, t_ep=t, t_env=self.t_env, test_mode=test_mode)
-                self.batch.update({"actions_inc": actions_inc}, ts=t)
-                o = out
-                self.t += 1
-            # slot T: last observation and the bootstrapping actions (episode_runner.py:99-119)
-            self._store_observation(o, self.t)
-            actions = self.mac.select_actions_env(self.batch, t_ep=self.t, t_env=self.t_env, test_mode=test_mode)
-            actions_inc = self.mac.select_actions_inc(actions, self.batch, t_ep=self.t, t_env=self.t_env, test_mode=test_mode)
-            self.batch.update({"actions_inc": actions_inc}, ts=self.t)
-            self.batch.update({"actions": actions}, ts=self.t)
+        self._o = self.env.observe_batch(self.obs_fmt)
+        self._out = None
 
+    @th.no_grad()
+    def step_once(self):
+        t, test_mode = self.t, self._test_mode
+        self._store_observation(self._o, t)
+        actions = self.mac.select_actions_env(self.batch, t_ep=t, t_env=self.t_env, test_mode=test_mode)
+        out = self.env.step_batch((actions.squeeze(-1) % self.args.n_actions).to(th.int32), observe=True, fmt=self.obs_fmt)
+        self._ep_return += out["reward"]
+        # `terminated` is stored as the env flag: episode_limit never appears in info (episode_runner.py:83)
+        self.batch.update({"actions": actions, "reward": out["reward"], "terminated": out["terminated"].unsqueeze(-1),
+                           "clean_num": out["clean_num"], "apple_den": out["apple_den"]}, ts=t)
+        actions_inc = self.mac.select_actions_inc(actions, self.batch, t_ep=t, t_env=self.t_env, test_mode=test_mode)
+        self.batch.update({"actions_inc": actions_inc}, ts=t)
+        self._o = self._out = out
+        self.t += 1
+        return self.t >= self.episode_limit
+
+    @th.no_grad()
+    def finish_episode(self):
+        """slot T: last observation and the bootstrapping actions (episode_runner.py:99-119), then stats."""
+        test_mode = self._test_mode
+        self._store_observation(self._o, self.t)
+        actions = self.mac.select_actions_env(self.batch, t_ep=self.t, t_env=self.t_env, test_mode=test_mode)
+        actions_inc = self.mac.select_actions_inc(actions, self.batch, t_ep=self.t, t_env=self.t_env, test_mode=test_mode)
+        self.batch.update({"actions_inc": actions_inc}, ts=self.t)
+        self.batch.update({"actions": actions}, ts=self.t)
+        out, ep_return = self._out, self._ep_return
         stats = self.test_stats if test_mode else self.train_stats
         returns = self.test_returns if test_mode else self.train_returns
         prefix = "test_" if test_mode else ""
@@ -112,6 +121,12 @@ class HipVecRunner:
                     self.logger.log_stat("epsilon", self.mac.action_selector.epsilon, self.t_env)
                 self.log_train_stats_t = self.t_env
         return self.batch
+
+    def run(self, test_mode=False):
+        self.begin_episode(test_mode)
+        while not self.step_once():
+            pass
+        return self.finish_episode()
 
     def _log(self, returns, stats, prefix):
         import numpy as np
