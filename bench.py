@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--n-env", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--workload", default=os.environ.get("SSD_BENCH_WORKLOAD", "e2e"), choices=["env", "e2e"])
+    ap.add_argument("--runner", default="hip_graph", choices=["hip_vec", "hip_graph"], help="e2e: rollout runner")
+    ap.add_argument("--train-graph", type=int, default=1, help="e2e: capture the train step as hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=200)
     args = ap.parse_args()
@@ -139,7 +141,7 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             tr = json.load(open(tj))
-            if tr.get("workload") == result["workload"] and tr.get("n_env") == N:
+            if tr.get("kernel") == result["extra"]["kernel"] and tr.get("n_env") == N:
                 traffic = tr.get("hbm_bytes_per_launch")
         line = {
             "metric": "agent_steps_per_sec", "value": total_agent_steps / elapsed, "unit": "agent-steps/s",

@@ -17,7 +17,7 @@ from .run import load_config, setup
 def run_e2e(args, rank, world, local_rank):
     N, n, T = args.n_env, 5, 100
     cfg = load_config("cleanup", overrides=dict(
-        runner="hip_vec", batch_size_run=N, batch_size=16, buffer_size=max(5000, N), buffer_cpu_only=False, store_state=False,
+        runner=args.runner, train_graph=args.train_graph, batch_size_run=N, batch_size=16, buffer_size=max(5000, N), buffer_cpu_only=False, store_state=False,
         env_args=dict(num_agents=n, map="default5", episode_limit=T, view_size=7, seed=1), use_cuda=True, save_model=False,
         device_index=local_rank, env_id_base=rank * N, runner_stats=False, learner_log_interval=10 ** 12))
     th.manual_seed(0)                     # fixed-seed random-init weights, identical on every rank
@@ -40,21 +40,8 @@ def run_e2e(args, rank, world, local_rank):
             state["episode"] += a.batch_size_run
             state["in_episode"] = False
 
-    # kernel timing: HIP events around the fused env launch of every step (on torch's current stream)
-    ev = []
-    orig = runner.env.step_batch
-
-    def timed_step_batch(*x, **k):
-        s, e = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
-        s.record()
-        r = orig(*x, **k)
-        e.record()
-        ev.append((s, e))
-        return r
-
     for _ in range(args.warmup):
         one_step()
-    runner.env.step_batch = timed_step_batch
     th.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -68,6 +55,23 @@ def run_e2e(args, rank, world, local_rank):
     th.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert runner.env.native.poll_error() == 0
+    # Kernel timing for the roofline: inside a hipGraph replay there is no host call to bracket, so the SAME kernel on the
+    # SAME live env state is timed with HIP-event pairs (torch's current stream = the launch stream) right after the
+    # timed region, with actions drawn like the policy's epsilon-random ones.
+    env = runner.env
+    avail = th.nonzero(env.avail_actions_batch[0, 0]).squeeze(-1).to(th.int32)
+    acts = [avail[th.randint(0, avail.numel(), (N, n), device=env.device)].contiguous() for _ in range(8)]
+    ev = []
+    for i in range(220):
+        if i % T == 0:
+            env.reset_batch()
+        s, e = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        s.record()
+        env.step_batch(acts[i % 8], observe=True, fmt=abi.OBS_F32)
+        e.record()
+        if i >= 20:
+            ev.append((s, e))
+    th.cuda.synchronize()
     ms = sorted(s.elapsed_time(e) for s, e in ev)
     from bench import algorithmic_bytes_per_env_step
     return dict(elapsed=elapsed, kern_avg_us=1e3 * sum(ms) / len(ms), kern_med_us=1e3 * ms[len(ms) // 2],
@@ -75,4 +79,5 @@ def run_e2e(args, rank, world, local_rank):
                 workload="cleanup_default5_rollout_plus_homophily_train",
                 extra=dict(obs_format="f32[n_env,n,3,15,15]", kernel="ssd::k_env<MODE_STEP_OBS>", qnet_dtype="fp32",
                            train="1 learner.train(batch_size 16 x T 101) per 100-step rollout, double-Q + sim loss, 2x Adam",
-                           buffer="device-resident ReplayBuffer, %d episodes" % buf.buffer_size))
+                           buffer="device-resident ReplayBuffer, %d episodes" % buf.buffer_size,
+                           runner=args.runner, train_graph=bool(args.train_graph)))

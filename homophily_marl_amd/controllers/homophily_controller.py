@@ -112,6 +112,27 @@ class HomophilyMAC(nn.Module):
         ops.build_inputs_tail(tail, 0, last_actions, last_reward, last_actions_inc, pos, self.pos_scale, a.n_actions, t0)
         return th.cat([feat, tail], dim=1)
 
+    def unroll(self, batch):
+        """q_env [B, T, n, A], q_inc [B, T, n, n, 3] for every timestep of `batch` -- what calling forward(batch, t) for
+        t = 0..T-1 from fresh hidden states returns (the learner's loops, homophily_learner.py:68-91) -- with the encoder,
+        the input assembly and all non-recurrent layers evaluated once over all T."""
+        a = self.args
+        B, T, n = batch.batch_size, batch.max_seq_length, self.n_agents
+        obs = batch["obs"]
+        if a.rgb_input:
+            feat = self.agent.rgb_preprocess(obs.reshape(B * T * n, 3, a.obs_dims[0], a.obs_dims[1]).float())
+        else:
+            feat = obs.reshape(B * T * n, -1)
+        acts = batch["actions"].squeeze(-1)                                            # [B, T, n]
+        # history features of step t come from t - 1; at t = 0 they are zero: action -1 has an all-zero one-hot
+        prev = lambda x, fill: th.cat([th.full_like(x[:, :1], fill), x[:, :-1]], dim=1)
+        inputs = self.assemble_inputs(feat, prev(acts, -1).reshape(B * T, n), prev(batch["reward"], 0).reshape(B * T, n),
+                                      prev(batch["actions_inc"].squeeze(-1), 0).reshape(B * T, n, n),
+                                      batch["agent_pos"].reshape(B * T, n, 2), False).reshape(B, T, n, -1)
+        onehot = F.one_hot(acts, num_classes=a.n_actions)
+        return self.agent.unroll(inputs, onehot, batch["agent_pos"] / self.pos_scale, batch["agent_orientation"],
+                                 batch["reward"], batch["clean_num"], batch["apple_den"])
+
     def _build_inputs(self, batch, t):
         if self.args.rgb_input:
             feat = self.encode_obs(batch["obs"][:, t])

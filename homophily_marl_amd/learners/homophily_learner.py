@@ -9,11 +9,14 @@ Differences in HOW, not WHAT:
     documented exact-value rule cluster = 2 * rewards_t + clean_num_t, which also removes the GPU->CPU sync of :194;
   * data parallel: loss denominators and gradients are all-reduced over the process group (RCCL) before clipping.
 """
+from types import SimpleNamespace
+
 import torch as th
 import torch.distributed as dist
 from torch.optim import Adam
 
 from .. import ops
+from ..components.episode_buffer import EpisodeBatch
 from ..controllers import REGISTRY as mac_REGISTRY
 
 NEG = -9999999
@@ -36,8 +39,14 @@ class HomophilyLearner:
         self.params_env = mac.parameters_env()
         self.params_inc = mac.parameters_inc()
         self.last_target_update_episode = 0
-        self.optimiser_env = Adam(params=self.params_env, lr=args.lr_env)
-        self.optimiser_inc = Adam(params=self.params_inc, lr=args.lr_inc)
+        # train_graph: capture the step as hipGraphs (torch.cuda.CUDAGraph); needs capturable Adam (same arithmetic,
+        # the step counter lives on the device)
+        self.use_graph = bool(getattr(args, "train_graph", False)) and str(self.device).startswith("cuda")
+        self.optimiser_env = Adam(params=self.params_env, lr=args.lr_env, capturable=self.use_graph)
+        self.optimiser_inc = Adam(params=self.params_inc, lr=args.lr_inc, capturable=self.use_graph)
+        self._flat_grad = None
+        self._graph = None
+        self._graph_calls = 0
         # target network: a second controller with the same weights (the reference deep-copies the controller, :47)
         self.target_mac = mac_REGISTRY[args.mac](scheme, None, args)
         self.target_mac.load_state(mac)
@@ -49,30 +58,8 @@ class HomophilyLearner:
     # ---- network unroll ---------------------------------------------------------------------------------------
     @staticmethod
     def unroll(mac, batch):
-        """q_env [B, T, n, A], q_inc [B, T, n, n, 3] for t = 0..T-1 (homophily_learner.py:68-76): encoder batched over
-        time, recurrences stepped."""
-        B, T, n = batch.batch_size, batch.max_seq_length, mac.n_agents
-        a = mac.args
-        obs = batch["obs"]
-        if a.rgb_input:
-            feat = mac.agent.rgb_preprocess(obs.reshape(B * T * n, 3, a.obs_dims[0], a.obs_dims[1]).float()).reshape(B, T, n, -1)
-        else:
-            feat = obs.reshape(B, T, n, -1)
-        acts = batch["actions"].squeeze(-1)
-        acts_inc = batch["actions_inc"].squeeze(-1)
-        mac.init_hidden(B)
-        q_env, q_inc = [], []
-        for t in range(T):
-            ft = feat[:, t].reshape(B * n, -1)
-            if t == 0:
-                mac.agent_inputs = mac.assemble_inputs(ft, None, None, None, batch["agent_pos"][:, 0], True)
-            else:
-                mac.agent_inputs = mac.assemble_inputs(ft, acts[:, t - 1], batch["reward"][:, t - 1], acts_inc[:, t - 1],
-                                                       batch["agent_pos"][:, t], False)
-            qe, mac.h_env, _ = mac.agent.forward_env(mac.agent_inputs, mac.h_env, True)
-            q_env.append(qe.reshape(B, n, -1))
-            q_inc.append(mac.forward_inc(batch, t, batch["actions"][:, t], learning_mode=True))
-        return th.stack(q_env, dim=1), th.stack(q_inc, dim=1)
+        """q_env [B, T, n, A], q_inc [B, T, n, n, 3] for t = 0..T-1 (the loops of homophily_learner.py:68-91)."""
+        return mac.unroll(batch)
 
     def _global(self, x):
         """sum of a scalar tensor over the data-parallel group (loss denominators)."""
@@ -82,7 +69,51 @@ class HomophilyLearner:
         return x
 
     # ---- one optimisation step ---------------------------------------------------------------------------------
-    def cal_loss_and_step(self, batch):
+    # Three stages so that the data-parallel collectives sit BETWEEN capturable pieces:
+    #   denominators(batch)            batch data only -> global mask / sim-mask sums        [+ all-reduce of 2 scalars]
+    #   forward_backward(batch, dens)  losses with global denominators, backward into the flat gradient buffer
+    #                                                                                       [+ ONE all-reduce of it]
+    #   clip_and_step()                clip inc, clip env, Adam inc, Adam env (homophily_learner.py:223-226)
+    def _sim_inputs(self, batch):
+        """windowed activity flags -> similarity mask (homophily_learner.py:184-206,214); depends on batch data only."""
+        a, n, h = self.args, self.n_agents, self.sim_horizon
+        rewards = batch["reward"][:, :-1] / a.reward_scale
+        clean_num = (batch["clean_num"][:, :-1] > 0).float()
+        cn_cum, rw_cum = th.cumsum(clean_num, dim=1), th.cumsum(rewards, dim=1)
+        cn_h, rw_h = cn_cum.clone(), rw_cum.clone()
+        cn_h[:, h:] -= cn_cum[:, :-h]
+        rw_h[:, h:] -= rw_cum[:, :-h]
+        clean_num_t, rewards_t = (cn_h > 0).float(), (rw_h > 0).float()
+        which_cluster = 2 * rewards_t + clean_num_t            # exact-value clustering rule (replaces x-means, :194-203)
+        is_idle = clean_num_t + rewards_t
+        idle_agent = (is_idle.unsqueeze(2) * is_idle.unsqueeze(3)).unsqueeze(-1)
+        similarity = (which_cluster.unsqueeze(2) == which_cluster.unsqueeze(3)).unsqueeze(-1).float() * idle_agent
+        return th.relu(similarity) * self.env_sim_mask * self.inc_sim_mask * self.oth_sim_mask
+
+    def _td_mask(self, batch):
+        terminated = batch["terminated"][:, :-1].float()
+        mask = batch["filled"][:, :-1].float()
+        mask[:, 1:] = mask[:, 1:] * (1 - terminated[:, :-1])                   # [bs, t-1, 1]
+        return mask.expand(-1, -1, self.n_agents)
+
+    def denominators(self, batch):
+        """[mask.sum(), sim_mask.sum()] of the GLOBAL batch (all-reduced over the data-parallel group)."""
+        d = th.stack([self._td_mask(batch).sum(), self._sim_inputs(batch).sum()])
+        if self.distributed:
+            dist.all_reduce(d, op=dist.ReduceOp.SUM)
+        return d
+
+    def _bind_flat_grad(self):
+        """All gradients are views into ONE persistent flat fp32 buffer: zeroing is one memset, the data-parallel
+        all-reduce is one collective on the buffer itself, and graph replays see stable addresses."""
+        if self._flat_grad is None:
+            self._flat_grad = th.zeros(sum(p.numel() for p in self.params), dtype=th.float32, device=self.params[0].device)
+            off = 0
+            for p in self.params:
+                p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+                off += p.numel()
+
+    def forward_backward(self, batch, dens):
         a = self.args
         n = self.n_agents
         logs = {}
@@ -92,9 +123,9 @@ class HomophilyLearner:
         actions_inc_all = batch["actions_inc"]                                 # [bs, t, n, n, 1]
         clean_num = (batch["clean_num"][:, :-1] > 0).float()
         terminated = batch["terminated"][:, :-1].float()
-        mask = batch["filled"][:, :-1].float()
-        mask[:, 1:] = mask[:, 1:] * (1 - terminated[:, :-1])                   # [bs, t-1, 1]
         avail_actions = batch["avail_actions"]
+        mask = self._td_mask(batch)
+        sim_mask = self._sim_inputs(batch)
 
         q_env, q_inc = self.unroll(self.mac, batch)
         with th.no_grad():
@@ -114,15 +145,14 @@ class HomophilyLearner:
                           + q_inc[:, :-1, :, :, 2] * receive_negative.unsqueeze(2)) / (n - 1)
         else:
             chosen_inc = th.gather(q_inc[:, :-1], dim=-1, index=actions_inc).squeeze(-1)   # [bs, t-1, n, n]
-        target_q_env[avail_actions[:, 1:] == 0] = NEG
+        target_q_env = target_q_env.masked_fill(avail_actions[:, 1:] == 0, NEG)
         other = (target_q_inc[..., 0] * recv_zero_all[:, 1:].unsqueeze(2) + target_q_inc[..., 1] * recv_pos_all[:, 1:].unsqueeze(2)
                  + target_q_inc[..., 2] * recv_neg_all[:, 1:].unsqueeze(2))
         target_next_inc = th.gather(target_q_inc, dim=-1, index=actions_inc_all[:, 1:]).squeeze(-1)
         if a.double_q:
-            qe, qi = q_env.detach().clone(), q_inc.detach()
-            qe[avail_actions == 0] = NEG
+            qe = q_env.detach().masked_fill(avail_actions == 0, NEG)
             best_env = qe[:, 1:].max(dim=-1, keepdim=True)[1]
-            best_inc = qi[:, 1:].max(dim=-1, keepdim=True)[1]
+            best_inc = q_inc.detach()[:, 1:].max(dim=-1, keepdim=True)[1]
             tmax_env = th.gather(target_q_env, dim=-1, index=best_env)          # [bs, t-1, n, 1]
             tmax_inc_self = th.gather(target_q_inc, dim=-1, index=best_inc).squeeze(-1)
         else:
@@ -134,67 +164,80 @@ class HomophilyLearner:
         targets_inc = rewards_for_inc + a.gamma_inc * (1 - terminated) * (tmax_inc * self.inc_mask).sum(dim=-1)
         td_env = chosen_env.sum(dim=-1) - targets_env.detach()
         td_inc = (chosen_inc * self.inc_mask).sum(dim=-1) - targets_inc.detach()
-        mask = mask.expand_as(td_env)
-        mask_sum = self._global(mask.sum())
-        value_loss_env = ((td_env * mask) ** 2).sum() / mask_sum
-        value_loss_inc = ((td_inc * mask) ** 2).sum() / mask_sum
+        value_loss_env = ((td_env * mask) ** 2).sum() / dens[0]
+        value_loss_inc = ((td_inc * mask) ** 2).sum() / dens[0]
 
-        # similarity loss (:184-217)
-        h = self.sim_horizon
-        cn_cum, rw_cum = th.cumsum(clean_num, dim=1), th.cumsum(rewards, dim=1)
-        cn_h, rw_h = cn_cum.clone(), rw_cum.clone()
-        cn_h[:, h:] -= cn_cum[:, :-h]
-        rw_h[:, h:] -= rw_cum[:, :-h]
-        clean_num_t, rewards_t = (cn_h > 0).float(), (rw_h > 0).float()
-        which_cluster = 2 * rewards_t + clean_num_t            # exact-value clustering rule (replaces x-means, :194-203)
-        is_idle = clean_num_t + rewards_t
-        idle_agent = (is_idle.unsqueeze(2) * is_idle.unsqueeze(3)).unsqueeze(-1)
-        similarity = (which_cluster.unsqueeze(2) == which_cluster.unsqueeze(3)).unsqueeze(-1).float() * idle_agent
+        # similarity loss (:208-217)
         p_inc = th.softmax(q_inc, dim=-1)[:, :-1]                              # [bs, t-1, n(i), n(j), 3]
         # probability agent i assigns to the incentive action agent k actually gave to j: [bs, t-1, i, k, j]
         idx = actions_inc.squeeze(-1).unsqueeze(2).expand(-1, -1, n, -1, -1)   # [bs, t-1, (i), k, j]
         p_ikj = th.gather(p_inc.unsqueeze(3).expand(-1, -1, -1, n, -1, -1), dim=-1, index=idx.unsqueeze(-1)).squeeze(-1)
-        sim_mask = th.relu(similarity.detach()) * self.env_sim_mask * self.inc_sim_mask * self.oth_sim_mask
-        sim_loss = (th.clamp_min(-th.log(p_ikj), a.sim_threshold) * sim_mask).sum() / (1 + self._global(sim_mask.sum()))
+        sim_loss = (th.clamp_min(-th.log(p_ikj), a.sim_threshold) * sim_mask).sum() / (1 + dens[1])
 
-        # step (:220-226)
-        self.optimiser_inc.zero_grad()
-        self.optimiser_env.zero_grad()
+        self._bind_flat_grad()
+        self._flat_grad.zero_()                                                # optimiser_{inc,env}.zero_grad() (:220-221)
         (value_loss_inc + value_loss_env + sim_loss * a.sim_loss_weight).backward()
-        if self.distributed:
-            self._allreduce_grads()
-        th.nn.utils.clip_grad_norm_(self.params_inc, a.grad_norm_clip)
-        th.nn.utils.clip_grad_norm_(self.params_env, a.grad_norm_clip)
-        self.optimiser_inc.step()
-        self.optimiser_env.step()
 
         with th.no_grad():
-            q_env_taken = chosen_env.squeeze(-1)
             q_inc_taken = th.gather(q_inc[:, :-1], dim=-1, index=actions_inc).squeeze(-1)
             logs["incentives_to_cleanup_per"] = (clean_num * receive_value).sum() / (clean_num.sum() + 1e-6)
             logs["incentives_to_harvest_per"] = (rewards * receive_value).sum() / (rewards.sum() + 1e-6)
             logs["value_give_mean"] = give_value.mean()
             logs["value_receive_mean"] = receive_value.mean()
-            logs["q_env_taken_mean"] = q_env_taken.mean()
+            logs["q_env_taken_mean"] = chosen_env.mean()
             logs["q_inc_taken_mean"] = q_inc_taken.mean()
             logs["loss_value_env"] = value_loss_env.detach()
             logs["loss_value_inc"] = value_loss_inc.detach()
             logs["loss_sim"] = sim_loss.detach()
         return logs
 
-    def _allreduce_grads(self):
-        """One all-reduce (sum) of a flat fp32 gradient buffer over RCCL / xGMI: the losses above are normalised by the
-        GLOBAL denominators, so the summed shard gradients equal the gradient of the loss on the concatenated batch."""
-        grads = [p.grad for p in self.params if p.grad is not None]
-        flat = th.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        off = 0
-        for g in grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+    def clip_and_step(self):
+        a = self.args
+        th.nn.utils.clip_grad_norm_(self.params_inc, a.grad_norm_clip)
+        th.nn.utils.clip_grad_norm_(self.params_env, a.grad_norm_clip)
+        self.optimiser_inc.step()
+        self.optimiser_env.step()
+
+    def cal_loss_and_step(self, batch):
+        dens = self.denominators(batch)
+        logs = self.forward_backward(batch, dens)
+        if self.distributed:
+            dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)   # ONE flat fp32 collective (RCCL over xGMI)
+        self.clip_and_step()
+        return logs
+
+    # ---- hipGraph path ---------------------------------------------------------------------------------------------
+    def _graph_step(self, batch):
+        """Replay of the captured step on a static copy of the sampled batch.  The first two calls run eagerly (warm-up
+        of allocator, hipBLASLt / MIOpen plans and Adam state), the third captures forward_backward and clip_and_step
+        as two graphs with the gradient all-reduce between them."""
+        self._graph_calls += 1
+        if self._graph_calls <= 2:
+            return self.cal_loss_and_step(batch)
+        if self._graph is None:
+            self._static_data = {k: v.clone() for k, v in batch.data.transition_data.items()}
+            self._static_batch = EpisodeBatch(batch.scheme, batch.groups, batch.batch_size, batch.max_seq_length,
+                                              data=SimpleNamespace(transition_data=self._static_data, episode_data={}),
+                                              device=batch.device)
+            self._static_dens = th.zeros(2, device=batch.device)
+            th.cuda.synchronize()
+            g1, g2 = th.cuda.CUDAGraph(), th.cuda.CUDAGraph()
+            with th.cuda.graph(g1):
+                self._static_logs = self.forward_backward(self._static_batch, self._static_dens)
+            with th.cuda.graph(g2, pool=g1.pool()):
+                self.clip_and_step()
+            self._graph = (g1, g2)
+        for k, v in batch.data.transition_data.items():
+            self._static_data[k].copy_(v)
+        self._static_dens.copy_(self.denominators(self._static_batch))
+        self._graph[0].replay()
+        if self.distributed:
+            dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+        self._graph[1].replay()
+        return self._static_logs
 
     def train(self, batch, t_env, episode_num):
-        logs = self.cal_loss_and_step(batch)
+        logs = self._graph_step(batch) if self.use_graph else self.cal_loss_and_step(batch)
         if (episode_num - self.last_target_update_episode) / self.args.target_update_interval >= 1.0:
             self._update_targets()
             self.last_target_update_episode = episode_num

@@ -91,6 +91,58 @@ class HomophilyAgent(nn.Module):
         cand = th.tanh(gi[..., 2 * H:] + r * gh[..., 2 * H:])
         return (1 - z) * cand + z * h
 
+    # ---- whole-sequence evaluation (learner) -------------------------------------------------------------------
+    def _gru_weights(self, head):
+        p = "rnn_%s_" % head
+        wi = th.cat([self._w(p + "ir_w"), self._w(p + "iz_w"), self._w(p + "in_w")], dim=2)
+        wh = th.cat([self._w(p + "hr_w"), self._w(p + "hz_w"), self._w(p + "hn_w")], dim=2)
+        bi = th.cat([self._b(p + "ir_b"), self._b(p + "iz_b"), self._b(p + "in_b")], dim=2)
+        bh = th.cat([self._b(p + "hr_b"), self._b(p + "hz_b"), self._b(p + "hn_b")], dim=2)
+        return wi, wh, bi, bh
+
+    def unroll(self, inputs, act_onehot, agent_pos, agent_orientation, reward, clean_num, apple_den):
+        """Evaluate both heads on whole episodes: inputs [B, T, n, in], act_onehot [B, T, n, A] (the env action taken at
+        t), agent_pos / agent_orientation [B, T, n, 2], reward / clean_num / apple_den [B, T, n].
+        Returns q_env [B, T, n, A], q_inc [B, T, n, n, 3] -- the values forward_env / forward_inc produce step by step
+        (homophily_agent.py:154-208) from zero hidden states.  Everything that does not depend on the recurrence (fc1,
+        the input-side GRU projections, both dueling heads) runs ONCE over all T; only h @ W_h and the gate arithmetic
+        are stepped, for the env and the inc head together in one batched GEMM over 2n "agents"."""
+        B, T, n = inputs.shape[0], inputs.shape[1], self.n_agents
+        H, A = self.hidden, self.n_actions
+        tm = lambda x: x.permute(2, 1, 0, 3).reshape(n, T * B, x.shape[-1])          # time-major rows [n, T*B, f]
+        x, act = tm(inputs), tm(act_onehot.to(inputs.dtype))
+        xe = F.leaky_relu(th.baddbmm(self._b("fc1_env_b"), x, self._w("fc1_env_w")))
+        xi = F.leaky_relu(th.baddbmm(self._b("fc1_inc_b"), th.cat([x, act], dim=-1), self._w("fc1_inc_w")))
+        wie, whe, bie, bhe = self._gru_weights("env")
+        wii, whi, bii, bhi = self._gru_weights("inc")
+        gi = th.cat([th.baddbmm(bie, xe, wie), th.baddbmm(bii, xi, wii)], dim=0).reshape(2 * n, T, B, 3 * H)
+        wh, bh = th.cat([whe, whi], dim=0), th.cat([bhe, bhi], dim=0)                 # [2n, H, 3H], [2n, 1, 3H]
+        h = inputs.new_zeros(2 * n, B, H)
+        hs = []
+        for t in range(T):
+            gh = th.baddbmm(bh, h, wh)
+            g = gi[:, t]
+            r = th.sigmoid(g[..., :H] + gh[..., :H])
+            z = th.sigmoid(g[..., H:2 * H] + gh[..., H:2 * H])
+            cand = th.tanh(g[..., 2 * H:] + r * gh[..., 2 * H:])
+            h = (1 - z) * cand + z * h
+            hs.append(h)
+        hs = th.stack(hs, dim=1)                                                       # [2n, T, B, H]
+        he, hi = hs[:n].reshape(n, T * B, H), hs[n:].reshape(n, T * B, H)
+        a = th.baddbmm(self._b("fc2_env_b"), he, self._w("fc2_env_w"))
+        v = th.baddbmm(self._b("fc2_env_v_b"), he, self._w("fc2_env_v_w"))
+        q_env = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, T, B, A).permute(2, 1, 0, 3)
+        # inc head: per ordered pair (i -> j) [h_i | onehot(a_j), pos_j, orient_j, r_j, clean_j, apple_den_j]
+        other = th.cat([act_onehot.to(inputs.dtype), agent_pos, agent_orientation, reward.unsqueeze(-1), clean_num.unsqueeze(-1),
+                        apple_den.unsqueeze(-1)], dim=-1).permute(1, 0, 2, 3).reshape(T * B, n, -1)     # [T*B, n(j), E]
+        E = other.shape[-1]
+        cat = th.cat([hi.unsqueeze(2).expand(n, T * B, n, H), other.unsqueeze(0).expand(n, T * B, n, E)], dim=-1)
+        cat = cat.reshape(n, T * B * n, H + E)
+        a = th.baddbmm(self._b("fc2_inc_b"), cat, self._w("fc2_inc_w"))
+        v = th.baddbmm(self._b("fc2_inc_v_b"), cat, self._w("fc2_inc_v_w"))
+        q_inc = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, T, B, n, -1).permute(2, 1, 0, 3, 4)
+        return q_env, q_inc
+
     # ---- heads --------------------------------------------------------------------------------------------------
     def forward_env(self, inputs, h_in, learning_mode=False):
         n, H = self.n_agents, self.hidden

@@ -36,7 +36,8 @@ def build_inputs_tail(out, offset, last_actions, last_reward, last_actions_inc, 
         o[..., offset + A + n] = 0
         o[..., offset + A + n + 1] = 0
     else:
-        o[..., offset:offset + A] = th.nn.functional.one_hot(last_actions, A).to(o.dtype)
+        valid = (last_actions >= 0).unsqueeze(-1)                        # index -1 = "no previous action": all-zero one-hot
+        o[..., offset:offset + A] = th.nn.functional.one_hot(last_actions.clamp(min=0), A).to(o.dtype) * valid
         o[..., offset + A + n] = th.sign(last_reward)
         m = last_actions_inc * (1 - th.eye(n, dtype=last_actions_inc.dtype, device=o.device))
         recv = (m == 1).sum(dim=1) - (m == 2).sum(dim=1)                 # giver dim summed -> per receiver

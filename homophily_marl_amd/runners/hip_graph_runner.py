@@ -1,0 +1,144 @@
+"""HipGraphRunner: the vectorised rollout of HipVecRunner with ONE hipGraph replay per timestep.
+
+Same data flow and stored batch as HipVecRunner / the reference loop (episode_runner.py:57-119); what changes is the
+mechanics that make a timestep capturable and replayable for every t:
+  * the episode storage is allocated once and indexed by a device-side time counter (index_copy_ along the time axis);
+  * the controller state (hidden states, previous action / reward / incentives, current observation) lives in static
+    tensors; the t == 0 history features are zeros because the previous action is -1 (all-zero one-hot);
+  * epsilon is a device scalar, the uniformly random available action is floor(u * k) through a constant index table
+    (no multinomial, no host sync);
+  * the fused env launch (ssd_step_observe through the C ABI) is issued on the capturing stream and becomes a graph node.
+The first episode runs eagerly (warm-up of MIOpen / hipBLASLt plans and the allocator); the graph is captured at the
+start of the second.  The returned EpisodeBatch is the persistent storage: consume (insert into the replay buffer)
+before the next run(), as the training loop does (run.py:184-185).
+"""
+import torch as th
+import torch.nn.functional as F
+
+from ..components.episode_buffer import EpisodeBatch
+from .hip_vec_runner import HipVecRunner
+
+
+class HipGraphRunner(HipVecRunner):
+    def setup(self, scheme, groups, preprocess, mac):
+        super().setup(scheme, groups, preprocess, mac)
+        self._scheme, self._groups, self._preprocess = scheme, groups, preprocess
+        self._graph = None
+        self._episodes = 0
+        self._ready = False
+
+    # ---- static state ---------------------------------------------------------------------------------------------
+    def _allocate(self):
+        a, N, n, T = self.args, self.batch_size, self.args.n_agents, self.episode_limit
+        dev = self.env.device
+        self.store = EpisodeBatch(self._scheme, self._groups, N, T + 1, preprocess=self._preprocess, device=self.args.device)
+        st = self.store.data.transition_data
+        st["filled"].fill_(1)                                           # fixed-length episodes: every slot is filled
+        st["avail_actions"].copy_(self.env.avail_actions_batch.unsqueeze(1).expand(-1, T + 1, -1, -1))
+        self.cur = self.env.native.obs_buffers(self.obs_fmt)            # obs / pos / orient written by the env kernel
+        self.t_dev = th.zeros(1, dtype=th.long, device=dev)
+        self.prev_actions = th.full((N, n), -1, dtype=th.long, device=dev)
+        self.prev_reward = th.zeros(N, n, device=dev)
+        self.prev_inc = th.zeros(N, n, n, dtype=th.long, device=dev)
+        H = a.rnn_hidden_dim
+        self.h_env = th.zeros(N, n, 1, H, device=dev)
+        self.h_inc = th.zeros(N, n, 1, H, device=dev)
+        self.eps = th.zeros((), device=dev)
+        self.ep_return = th.zeros(N, n, device=dev)
+        avail = self.env.avail_actions_batch[0, 0]
+        self.avail_idx = th.nonzero(avail).squeeze(-1)                  # constant table of available env actions
+        self.avail_mask = self.env.avail_actions_batch                  # [N, n, A]
+        self.inc_mask = (1 - th.eye(n, device=dev, dtype=th.long)).reshape(1, n, n)
+        self._ready = True
+
+    def _pick(self, q, avail_mask, idx_table, k):
+        """epsilon-greedy (action_selectors.py:44-68) without host sync: random AVAILABLE action = table[floor(u * k)]."""
+        if avail_mask is not None:
+            q = q.masked_fill(avail_mask == 0, -float("inf"))
+        greedy = q.argmax(dim=-1)
+        u = th.rand(greedy.shape, device=q.device)
+        r = th.clamp((th.rand(greedy.shape, device=q.device) * k).long(), max=k - 1)
+        rand = idx_table[r] if idx_table is not None else r
+        return th.where(u < self.eps, rand, greedy)
+
+    def _select(self, store_env_step):
+        """One controller evaluation on the current observation; with store_env_step also the env transition."""
+        a, mac, st = self.args, self.mac, self.store.data.transition_data
+        td = self.t_dev
+        obs, pos, orient = self.cur["obs"], self.cur["pos"], self.cur["orient"]
+        st["obs"].index_copy_(1, td, obs.unsqueeze(1))
+        st["agent_pos"].index_copy_(1, td, pos.unsqueeze(1))
+        st["agent_orientation"].index_copy_(1, td, orient.unsqueeze(1))
+        feat = mac.encode_obs(obs)
+        inputs = mac.assemble_inputs(feat, self.prev_actions, self.prev_reward, self.prev_inc, pos, False)
+        q_env, h_env, _ = mac.agent.forward_env(inputs, self.h_env)
+        self.h_env.copy_(h_env)
+        actions = self._pick(q_env, self.avail_mask, self.avail_idx, self.avail_idx.numel())      # [N, n]
+        pos_t, orient_t = pos.clone(), orient.clone()                   # forward_inc sees the PRE-step pose (controller :78-82)
+        if store_env_step:
+            out = self.env.step_batch((actions % a.n_actions).to(th.int32), observe=True, fmt=self.obs_fmt)
+            reward, clean, den = out["reward"], out["clean_num"], out["apple_den"]
+            st["reward"].index_copy_(1, td, reward.unsqueeze(1))
+            st["terminated"].index_copy_(1, td, out["terminated"].reshape(-1, 1, 1))
+            st["clean_num"].index_copy_(1, td, clean.unsqueeze(1))
+            st["apple_den"].index_copy_(1, td, den.unsqueeze(1))
+            self.ep_return += reward
+        else:   # slot T: the batch holds zeros for reward / clean_num / apple_den (episode_runner.py:108-119)
+            reward = clean = den = th.zeros_like(self.prev_reward)
+        onehot = F.one_hot(actions, num_classes=a.n_actions)
+        st["actions"].index_copy_(1, td, actions.reshape(actions.shape[0], 1, -1, 1))
+        st["actions_onehot"].index_copy_(1, td, onehot.float().unsqueeze(1))
+        q_inc, h_inc, _ = mac.agent.forward_inc(inputs, self.h_inc, onehot, pos_t / mac.pos_scale, orient_t, reward.unsqueeze(-1),
+                                                clean.unsqueeze(-1), den.unsqueeze(-1))
+        self.h_inc.copy_(h_inc)
+        actions_inc = self._pick(q_inc, None, None, a.n_inc_actions) * self.inc_mask              # [N, n, n]
+        st["actions_inc"].index_copy_(1, td, actions_inc.reshape(actions_inc.shape[0], 1, actions_inc.shape[1], -1, 1))
+        if store_env_step:
+            self.prev_actions.copy_(actions)
+            self.prev_reward.copy_(reward)
+            self.prev_inc.copy_(actions_inc)
+            td += 1
+
+    # ---- runner surface ---------------------------------------------------------------------------------------------
+    def begin_episode(self, test_mode=False):
+        if not self._ready:
+            self._allocate()
+        self._test_mode = test_mode
+        self.batch = self.store
+        self.env.reset_batch()
+        self.env.observe_batch(self.obs_fmt)                            # fills self.cur
+        self.t = 0
+        self.t_dev.zero_()
+        self.prev_actions.fill_(-1); self.prev_reward.zero_(); self.prev_inc.zero_()
+        self.h_env.zero_(); self.h_inc.zero_(); self.ep_return.zero_()
+        sel = self.mac.action_selector
+        sel.epsilon = 0.0 if test_mode else sel.schedule.eval(self.t_env)
+        zero_after = getattr(self.args, "epsilon_zero", None)
+        if zero_after is not None and self.t_env > zero_after:
+            sel.epsilon = 0.0
+        self.eps.fill_(sel.epsilon)
+        self._episodes += 1
+        if self._graph is None and self._episodes >= 2 and getattr(self.args, "rollout_graph", True):
+            th.cuda.synchronize()
+            g = th.cuda.CUDAGraph()
+            with th.no_grad(), th.cuda.graph(g):
+                self._select(True)
+            self._graph = g
+            # capture records but does not run: re-establish the episode start state
+            self.t_dev.zero_()
+
+    @th.no_grad()
+    def step_once(self):
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._select(True)
+        self.t += 1
+        return self.t >= self.episode_limit
+
+    @th.no_grad()
+    def finish_episode(self):
+        self._select(False)
+        self._out = dict(collective_return=self.env.native.out["collective_return"], equality=self.env.native.out["equality"])
+        self._ep_return = self.ep_return
+        return self._finish_stats()

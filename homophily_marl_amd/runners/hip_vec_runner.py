@@ -98,6 +98,10 @@ class HipVecRunner:
         actions_inc = self.mac.select_actions_inc(actions, self.batch, t_ep=self.t, t_env=self.t_env, test_mode=test_mode)
         self.batch.update({"actions_inc": actions_inc}, ts=self.t)
         self.batch.update({"actions": actions}, ts=self.t)
+        return self._finish_stats()
+
+    def _finish_stats(self):
+        test_mode = self._test_mode
         out, ep_return = self._out, self._ep_return
         stats = self.test_stats if test_mode else self.train_stats
         returns = self.test_returns if test_mode else self.train_returns

@@ -140,3 +140,62 @@ def test_vectorised_runner_and_one_training_iteration():
     ep = train_iteration(ctx, 0)
     assert ep == N and ctx.buffer.episodes_in_buffer == N
     ctx.runner.close_env()
+
+
+def test_graph_runner_equals_generic_runner_under_greedy_actions():
+    """hip_graph (one hipGraph replay per timestep, persistent storage) must store exactly what hip_vec stores: with
+    test_mode=True the action selection is greedy, hence deterministic given equal weights and env seeds."""
+    from homophily_marl_amd.run import load_config, setup
+    N, T = 32, 10
+    batches = {}
+    for runner in ("hip_vec", "hip_graph"):
+        th.manual_seed(0)
+        cfg = load_config("cleanup", overrides=dict(
+            runner=runner, batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False, store_state=False,
+            env_args=dict(num_agents=5, map="default5", episode_limit=T, seed=9), use_cuda=True, save_model=False, runner_stats=False))
+        ctx = setup(cfg)
+        out = []
+        for ep in range(3):                       # episode 1 eager, graph captured at episode 2, replayed in 2 and 3
+            b = ctx.runner.run(test_mode=True)
+            out.append({k: v.clone() for k, v in b.data.transition_data.items()})
+        batches[runner] = out
+        ctx.runner.close_env()
+    for ep in range(3):
+        for k in batches["hip_vec"][ep]:
+            assert th.equal(batches["hip_vec"][ep][k], batches["hip_graph"][ep][k]), (ep, k)
+
+
+def test_graph_captured_train_step_equals_eager():
+    from tests.learner_util import build, load_fixture
+    th.backends.cuda.matmul.allow_tf32 = False
+    z, meta = load_fixture("learner_harvest5.npz")
+    finals = []
+    for graph in (False, True):
+        args, batch, mac, learner = build(z, meta, device="cuda:0")
+        if graph:
+            # rebuild the learner with the graph flag (needs capturable Adam from construction)
+            from homophily_marl_amd.learners import REGISTRY as le_REGISTRY
+            from types import SimpleNamespace
+            args.train_graph = True
+            learner = le_REGISTRY[args.learner](mac, batch.scheme, SimpleNamespace(log_stat=lambda *a, **k: None, console_logger=None), args)
+            learner.cuda()
+            assert learner.use_graph
+        args.learner_log_interval = 10 ** 12
+        for i in range(5):                        # calls 1-2 eager, capture at 3, replay 3-5
+            learner.train(batch, 0, 0)
+        finals.append(th.cat([p.detach().reshape(-1) for p in mac.agent.parameters()]).cpu())
+        if graph:
+            assert learner._graph is not None
+    assert (finals[0] - finals[1]).abs().max() < 1e-5, (finals[0] - finals[1]).abs().max()
+
+
+def test_stepwise_forward_equals_time_batched_unroll():
+    from tests.learner_util import build, load_fixture
+    z, meta = load_fixture("learner_cleanup5.npz")
+    args, batch, mac, learner = build(z, meta, device="cuda:0")
+    with th.no_grad():
+        q_env, q_inc = mac.unroll(batch)
+        mac.init_hidden(batch.batch_size)
+        for t in range(batch.max_seq_length):
+            a, b, _ = mac.forward(batch, t)
+            assert (a - q_env[:, t]).abs().max() < 1e-5 and (b - q_inc[:, t]).abs().max() < 1e-5, t
