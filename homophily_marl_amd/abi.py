@@ -93,6 +93,11 @@ def _sigs(prefix, with_stream):
 HIP_SIGNATURES = _sigs("ssd_", True)
 HIP_SIGNATURES["ssd_step_observe"] = (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SsdTape), C.POINTER(SsdStepOut),
                                                 C.POINTER(SsdObsOut), C.c_void_p])
+HIP_SIGNATURES["ssd_encoder"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p])
+HIP_SIGNATURES["ssd_gru_gates"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
+HIP_SIGNATURES["ssd_dueling_pick"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32,
+                                               C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_poll_error"] = (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)])
 CPU_SIGNATURES = _sigs("ssd_cpu_", False)
 

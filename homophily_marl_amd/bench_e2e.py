@@ -55,6 +55,20 @@ def run_e2e(args, rank, world, local_rank):
     th.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert runner.env.native.poll_error() == 0
+    # Steady-state breakdown of one more rollout + train iteration (synchronised between phases; NOT part of `elapsed`)
+    def timed(fn):
+        th.cuda.synchronize(); t = time.perf_counter(); r = fn(); th.cuda.synchronize()
+        return r, 1e3 * (time.perf_counter() - t)
+    while state["in_episode"]:
+        one_step()
+    bd = {}
+    _, bd["begin_episode_ms"] = timed(lambda: runner.begin_episode(False))
+    _, bd["rollout_100_steps_ms"] = timed(lambda: [runner.step_once() for _ in range(T)])
+    batch, bd["finish_episode_ms"] = timed(runner.finish_episode)
+    _, bd["replay_insert_ms"] = timed(lambda: buf.insert_episode_batch(batch))
+    sample, bd["sample_ms"] = timed(lambda: buf.sample(a.batch_size)[:, :T + 1])
+    _, bd["learner_train_ms"] = timed(lambda: learner.train(sample, runner.t_env, state["episode"]))
+    bd = {k: round(v, 3) for k, v in bd.items()}
     # Kernel timing for the roofline: inside a hipGraph replay there is no host call to bracket, so the SAME kernel on the
     # SAME live env state is timed with HIP-event pairs (torch's current stream = the launch stream) right after the
     # timed region, with actions drawn like the policy's epsilon-random ones.
@@ -80,4 +94,4 @@ def run_e2e(args, rank, world, local_rank):
                 extra=dict(obs_format="f32[n_env,n,3,15,15]", kernel="ssd::k_env<MODE_STEP_OBS>", qnet_dtype="fp32",
                            train="1 learner.train(batch_size 16 x T 101) per 100-step rollout, double-Q + sim loss, 2x Adam",
                            buffer="device-resident ReplayBuffer, %d episodes" % buf.buffer_size,
-                           runner=args.runner, train_graph=bool(args.train_graph)))
+                           runner=args.runner, train_graph=bool(args.train_graph), breakdown_ms=bd))

@@ -274,7 +274,7 @@ int ssd_build_inputs(int32_t batch, int32_t n_agents, int32_t n_actions, int32_t
                      const float* last_reward, const int64_t* last_actions_inc, const float* pos, float pos_scale,
                      float* out, int32_t out_stride, int32_t out_offset, void* stream) {
     if (batch < 1 || n_agents < 1 || n_actions < 1 || !out || !pos) return fail(SSD_ERR_INVALID, "bad argument");
-    if (!t0 && (!last_actions || !last_reward || !last_actions_inc)) return fail(SSD_ERR_INVALID, "t > 0 needs the t-1 tensors");
+    if (!(t0 & 1) && (!last_actions || !last_reward || !last_actions_inc)) return fail(SSD_ERR_INVALID, "t > 0 needs the t-1 tensors");
     if (out_stride < out_offset + n_actions + n_agents + 4) return fail(SSD_ERR_INVALID, "out_stride too small");
     launch_build_inputs(batch, n_agents, n_actions, t0, last_actions, last_reward, last_actions_inc, pos, pos_scale, out,
                         out_stride, out_offset, (hipStream_t)stream);
@@ -290,6 +290,30 @@ int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int
         return fail(SSD_ERR_INVALID, "bad argument");
     launch_incentive_transfer(batch, T, n_agents, actions_inc, rewards, effect_ratio, cost_ratio, incentive, seq_len, give,
                               recv_pos, recv_neg, recv_zero, rewards_for_env, rewards_for_inc, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_encoder(const float* obs, int32_t rows, int32_t view_edge, int32_t conv_out, int32_t feat_out, const float* conv_w,
+                const float* conv_b, const float* lin_w, const float* lin_b, float* out, int32_t out_stride, int32_t n_agents,
+                int32_t agent_major, void* stream) {
+    if (!obs || !conv_w || !conv_b || !lin_w || !lin_b || !out || rows < 1 || view_edge < 3) return fail(SSD_ERR_INVALID, "bad argument");
+    if (conv_out != 6 || feat_out != 32) return fail(SSD_ERR_UNSUPPORTED, "ssd_encoder is instantiated for conv_out 6, obs_dim_net 32 (config/default.yaml:59-63)");
+    if (agent_major && (n_agents < 1 || rows % n_agents)) return fail(SSD_ERR_INVALID, "rows must be a multiple of n_agents");
+    launch_encoder(obs, rows, view_edge, conv_w, conv_b, lin_w, lin_b, out, out_stride, n_agents, agent_major, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_gru_gates(const float* gi, const float* gh, float* h, int32_t rows, int32_t hidden, void* stream) {
+    if (!gi || !gh || !h || rows < 1 || hidden < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    launch_gru_gates(gi, gh, h, rows, hidden, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uint8_t* avail, const float* epsilon, const int64_t* step,
+                     uint32_t seed, int32_t n_agents, int32_t batch, int32_t pairs, int64_t* actions, float* q_out, void* stream) {
+    if (!av || !epsilon || !step || !actions || rows < 1 || n_actions < 1 || n_agents < 1 || batch < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if (rows != (pairs ? n_agents * batch * n_agents : n_agents * batch)) return fail(SSD_ERR_INVALID, "rows must be n*B (or n*B*n for pairs)");
+    launch_dueling_pick(av, rows, n_actions, avail, epsilon, step, seed, n_agents, batch, pairs, actions, q_out, (hipStream_t)stream);
     return launched();
 }
 

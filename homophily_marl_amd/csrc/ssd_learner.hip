@@ -15,15 +15,17 @@ __global__ void k_build_inputs(int32_t rows, int32_t n, int32_t A, int32_t t0, c
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(idx / width), k = (int)(idx - (size_t)row * width);
         const int b = row / n, i = row - b * n;
+        const int agent_major = t0 & 2;
+        const int t_zero = t0 & 1;
         float v;
-        if (k < A) v = (!t0 && last_actions[row] == k) ? 1.f : 0.f;                  // one-hot of the last action (:137-141)
+        if (k < A) v = (!t_zero && last_actions[row] == k) ? 1.f : 0.f;                  // one-hot of the last action (:137-141)
         else if (k < A + n) v = (k - A == i) ? 1.f : 0.f;                            // agent id (:142-143)
         else if (k == A + n) {                                                       // sign(last reward) (:145-150)
-            const float r = t0 ? 0.f : last_reward[row];
+            const float r = t_zero ? 0.f : last_reward[row];
             v = (float)((r > 0.f) - (r < 0.f));
         } else if (k == A + n + 1) {                                                 // sign(#recv+ - #recv-) (:152-164)
             int recv = 0;
-            if (!t0)
+            if (!t_zero)
                 for (int g = 0; g < n; ++g) {
                     if (g == i) continue;                                            // inc_mask_actions: no self incentive
                     const int64_t x = last_actions_inc[((size_t)b * n + g) * n + i];
@@ -31,7 +33,8 @@ __global__ void k_build_inputs(int32_t rows, int32_t n, int32_t A, int32_t t0, c
                 }
             v = (float)((recv > 0) - (recv < 0));
         } else v = pos[(size_t)row * 2 + (k - A - n - 2)] / pos_scale;               // pos / ||(H, W)|| (:179-181)
-        out[(size_t)row * out_stride + out_offset + k] = v;
+        const size_t orow = agent_major ? (size_t)i * (rows / n) + b : (size_t)row;
+        out[orow * out_stride + out_offset + k] = v;
     }
 }
 

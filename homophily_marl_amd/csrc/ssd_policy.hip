@@ -1,0 +1,155 @@
+// ssd_policy.hip -- rollout-time (inference) pieces of the homophily controller that are not GEMMs.
+//   k_encoder       conv(3->C, k3, s1) + LeakyReLU + Linear(C*(V-2)^2 -> F) + LeakyReLU  (homophily_agent.py:20-27,213-214)
+//   k_gru_gates     r, z, n gates and the state update of the hand-written GRU cell       (homophily_agent.py:162-165,188-191)
+//   k_dueling_pick  q = v + a - mean(a) and the epsilon-greedy choice                    (homophily_agent.py:168-170,204-206;
+//                                                                                         action_selectors.py:44-68)
+// The per-agent matrix products stay in hipBLASLt (MFMA).  Everything here is elementwise / small-reduction work that
+// PyTorch would issue as 8-15 separate launches per head and timestep.
+#include "ssd_device.h"
+
+namespace ssd {
+
+__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.01f * x; }   // nn.LeakyReLU default slope
+
+// ---------------------------------------------------------------------------------------------------------------
+// Encoder.  One wave per observation row (env, agent).  The obs [3, V, V] f32 is staged in LDS; lanes own conv output
+// positions (p = lane, lane + 64, ...) and keep the C conv channels of their positions in registers; the linear layer
+// is accumulated per lane over its positions for all F outputs (W read coalesced: W_t[f][c * P + p], lanes = p) and
+// reduced across the wave with a butterfly.  Conv weights are wave-uniform (scalar loads).
+// out row stride / offset let the features land directly inside the agent-input matrix.
+// ---------------------------------------------------------------------------------------------------------------
+template <int C, int F>
+__global__ __launch_bounds__(256) void k_encoder(const float* __restrict__ obs, int rows, int V, const float* __restrict__ cw /*[C,3,3,3]*/,
+                                                 const float* __restrict__ cb /*[C]*/, const float* __restrict__ lw /*[F, C*P]*/,
+                                                 const float* __restrict__ lb /*[F]*/, float* __restrict__ out, int out_stride,
+                                                 int n_agents, int agent_major) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int VV = V * V, O = V - 2, P = O * O, K = C * P;
+    float* in = sm + wave * (3 * VV + 4);
+    const float* src = obs + (size_t)row * 3 * VV;
+    for (int i = lane; i < 3 * VV; i += 64) in[i] = src[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+    for (int p = lane; p < P; p += 64) {
+        const int y = p / O, x = p - y * O;
+        float c[C];
+#pragma unroll
+        for (int o = 0; o < C; ++o) c[o] = cb[o];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float v = in[ch * VV + (y + dy) * V + x + dx];
+#pragma unroll
+                    for (int o = 0; o < C; ++o) c[o] = fmaf(cw[((o * 3 + ch) * 3 + dy) * 3 + dx], v, c[o]);
+                }
+#pragma unroll
+        for (int o = 0; o < C; ++o) {
+            const float a = leaky(c[o]);
+            const float* w = lw + o * P + p;              // Flatten order of [C, O, O]: k = o * P + p
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] = fmaf(w[(size_t)f * K], a, acc[f]);
+        }
+    }
+    // wave reduction of the F partial sums; afterwards lane f holds output f
+    float mine = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        float v = acc[f];
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh);
+        if (lane == f) mine = v;
+    }
+    if (lane < F) {
+        size_t orow = row;
+        if (agent_major) { const int b = row / n_agents, i = row - b * n_agents; orow = (size_t)i * (rows / n_agents) + b; }
+        out[orow * out_stride + lane] = leaky(mine + lb[lane]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GRU gates: gi, gh [R, 3H] (input-side and hidden-side projections incl. biases), h [R, H] updated in place.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_gru_gates(const float* __restrict__ gi, const float* __restrict__ gh, float* __restrict__ h, int R, int H) {
+    const size_t total = (size_t)R * H;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = idx / H;
+        const int k = (int)(idx - r * H);
+        const float* a = gi + r * 3 * H;
+        const float* b = gh + r * 3 * H;
+        const float rg = 1.f / (1.f + __expf(-(a[k] + b[k])));
+        const float zg = 1.f / (1.f + __expf(-(a[H + k] + b[H + k])));
+        const float ng = tanhf(a[2 * H + k] + rg * b[2 * H + k]);
+        h[idx] = (1.f - zg) * ng + zg * h[idx];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Dueling head + epsilon-greedy.  av [R, A + 1]: A advantages then the state value.  avail [A] (u8, same for all rows,
+// nullptr = all available).  Random numbers: the counter generator of include/ssd_hip.h keyed by (seed, *step, row).
+// Row r of the [n(i), B, ...] agent-major input is written to the env-major position given by (out_b_stride, out_i_stride).
+// inc head: rows are (i, b, j); diagonal (i == j) forced to 0 (no self-incentive, homophily_controller.py:44-46).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32p(uint32_t x) {
+    x ^= x >> 17; x *= 0xed5ad4bbu; x ^= x >> 11; x *= 0xac4c1b51u; x ^= x >> 15; x *= 0x31848babu; x ^= x >> 14;
+    return x;
+}
+__global__ void k_dueling_pick(const float* __restrict__ av, int R, int A, const uint8_t* __restrict__ avail,
+                               const float* __restrict__ eps_p, const int64_t* __restrict__ step_p, uint32_t seed, int n_agents, int B,
+                               int pairs /*0: rows (i,b); 1: rows (i,b,j)*/, int64_t* __restrict__ actions, float* __restrict__ q_out) {
+    const float eps = *eps_p;
+    const uint32_t step = (uint32_t)*step_p;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        const float* a = av + (size_t)r * (A + 1);
+        float mean = 0.f;
+        for (int k = 0; k < A; ++k) mean += a[k];
+        mean /= (float)A;
+        const float v = a[A];
+        int best = 0, navail = 0;
+        float bq = -INFINITY;
+        for (int k = 0; k < A; ++k) {
+            const float q = v + a[k] - mean;
+            if (q_out) q_out[(size_t)r * A + k] = q;
+            const bool ok = !avail || avail[k];
+            navail += ok;
+            if (ok && q > bq) { bq = q; best = k; }          // first maximum, like torch.max / argmax
+        }
+        const uint32_t x0 = mix32p(seed ^ mix32p(step * 0x9E3779B9u + (uint32_t)r));
+        const uint32_t x1 = mix32p(x0 ^ 0x85EBCA6Bu);
+        int act = best;
+        if ((float)(x0 >> 8) * (1.0f / 16777216.0f) < eps) {
+            int pick = (int)(((uint64_t)x1 * (uint32_t)navail) >> 32);   // uniform over the available actions
+            for (int k = 0; k < A; ++k) { const bool ok = !avail || avail[k]; if (ok) { if (pick == 0) { act = k; break; } --pick; } }
+        }
+        size_t o;
+        if (!pairs) { const int i = r / B, b = r - i * B; o = (size_t)b * n_agents + i; }
+        else { const int i = r / (B * n_agents), rem = r - i * B * n_agents, b = rem / n_agents, j = rem - b * n_agents;
+               o = ((size_t)b * n_agents + i) * n_agents + j; if (i == j) act = 0; }
+        actions[o] = act;
+    }
+}
+
+void launch_encoder(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lw, const float* lb, float* out,
+                    int out_stride, int n_agents, int agent_major, hipStream_t s) {
+    const size_t lds = 4 * (size_t)(3 * V * V + 4) * sizeof(float);
+    hipLaunchKernelGGL((k_encoder<6, 32>), dim3((rows + 3) / 4), dim3(256), lds, s, obs, rows, V, cw, cb, lw, lb, out, out_stride, n_agents, agent_major);
+}
+void launch_gru_gates(const float* gi, const float* gh, float* h, int R, int H, hipStream_t s) {
+    size_t total = (size_t)R * H; int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_gru_gates, dim3(blocks), dim3(256), 0, s, gi, gh, h, R, H);
+}
+void launch_dueling_pick(const float* av, int R, int A, const uint8_t* avail, const float* eps, const int64_t* step, uint32_t seed,
+                         int n_agents, int B, int pairs, int64_t* actions, float* q_out, hipStream_t s) {
+    int blocks = (R + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_dueling_pick, dim3(blocks), dim3(256), 0, s, av, R, A, avail, eps, step, seed, n_agents, B, pairs, actions, q_out);
+}
+
+}  // namespace ssd

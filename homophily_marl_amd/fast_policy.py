@@ -1,0 +1,119 @@
+"""FastPolicy: rollout-time (no-grad) evaluation of the homophily controller for N vectorised envs.
+
+Computes what HomophilyMAC.select_actions_env / select_actions_inc compute (homophily_controller.py:30-65 on top of
+homophily_agent.py:154-208), organised for the GPU:
+  * agent-major activations [n, N, f] everywhere, so every per-agent layer is one batched GEMM (hipBLASLt / MFMA) on
+    contiguous operands -- no transposes, no per-step weight concatenation (weights are packed once per episode);
+  * the conv encoder, the GRU gate arithmetic and dueling + epsilon-greedy are the HIP kernels of csrc/ssd_policy.hip;
+  * the incentive head's pairwise layer [h_i | other_j] @ W is split into h_i @ W_h + other_j @ W_o, so the
+    [n, N * n, H + E] concatenation is never materialised.
+Action RNG: the package's counter generator (not torch's Philox); exploration draws are not parity-pinned.
+"""
+import ctypes as C
+
+import torch as th
+import torch.nn.functional as F
+
+from . import abi
+
+
+class FastPolicy:
+    def __init__(self, mac, n_env, avail_mask_u8, seed=0):
+        self.mac, self.agent, self.a = mac, mac.agent, mac.args
+        a = self.a
+        assert a.rgb_input and a.conv_out == 6 and a.obs_dim_net == 32 and a.conv_kernel == 3 and a.conv_stride == 1
+        self.lib = abi.load_library()
+        self.N, self.n, self.H, self.A = n_env, mac.n_agents, a.rnn_hidden_dim, a.n_actions
+        self.dev = next(self.agent.parameters()).device
+        self.inp = mac.input_shape
+        n, N, H = self.n, self.N, self.H
+        f32 = dict(dtype=th.float32, device=self.dev)
+        self.inputs = th.zeros(n, N, self.inp, **f32)          # [feat | tail], agent-major
+        self.h_env = th.zeros(n, N, H, **f32)
+        self.h_inc = th.zeros(n, N, H, **f32)
+        self.actions = th.zeros(N, n, dtype=th.long, device=self.dev)
+        self.actions_inc = th.zeros(N, n, n, dtype=th.long, device=self.dev)
+        self.avail = avail_mask_u8.to(device=self.dev, dtype=th.uint8).contiguous()
+        self.seed = seed & 0xFFFFFFFF
+        self.arange_n = th.arange(n, device=self.dev).unsqueeze(1)
+        self.pack()
+
+    def _stream(self):
+        return th.cuda.current_stream(self.dev).cuda_stream
+
+    @th.no_grad()
+    def pack(self):
+        """Snapshot the (possibly just trained) weights into GEMM-ready contiguous packs; values are copied in place so
+        that a captured graph keeps seeing the same addresses."""
+        ag, H, A = self.agent, self.H, self.A
+        w, b = ag._w, ag._b
+        packs = dict(
+            cw=ag.conv_to_fc[0].weight, cb=ag.conv_to_fc[0].bias, lw=ag.conv_to_fc[3].weight, lb=ag.conv_to_fc[3].bias,
+            w1e=w("fc1_env_w"), b1e=b("fc1_env_b"),
+            w2e=th.cat([w("fc2_env_w"), w("fc2_env_v_w")], dim=2), b2e=th.cat([b("fc2_env_b"), b("fc2_env_v_b")], dim=2),
+            w1i_x=w("fc1_inc_w")[:, :self.inp], w1i_a=w("fc1_inc_w")[:, self.inp:], b1i=b("fc1_inc_b"),
+        )
+        packs["wie"], packs["whe"], packs["bie"], packs["bhe"] = ag._gru_weights("env")
+        packs["wii"], packs["whi"], packs["bii"], packs["bhi"] = ag._gru_weights("inc")
+        w2i = th.cat([w("fc2_inc_w"), w("fc2_inc_v_w")], dim=2)                       # [n, H + E, 4]
+        packs["w2i_h"] = w2i[:, :H]
+        packs["w2i_o"] = w2i[:, H:].permute(1, 0, 2).reshape(w2i.shape[1] - H, -1)    # [E, n(i) * 4]
+        packs["b2i"] = th.cat([b("fc2_inc_b"), b("fc2_inc_v_b")], dim=2).unsqueeze(2)  # [n, 1, 1, 4]
+        if not hasattr(self, "p"):
+            self.p = {k: v.detach().clone().contiguous() for k, v in packs.items()}
+        else:
+            for k, v in packs.items():
+                self.p[k].copy_(v)
+
+    def reset(self):
+        self.h_env.zero_(); self.h_inc.zero_()
+
+    # ---- env head -----------------------------------------------------------------------------------------------
+    @th.no_grad()
+    def act_env(self, obs, prev_actions, prev_reward, prev_inc, pos, eps, step):
+        """obs f32 [N, n, 3, V, V]; prev_* of the previous timestep (prev_actions = -1 at t = 0); pos f32 [N, n, 2];
+        eps f32 scalar tensor, step i64 [1] tensor.  Returns actions i64 [N, n] (static buffer)."""
+        p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
+        V = obs.shape[-1]
+        st = self._stream()
+        abi.check(lib, lib.ssd_encoder(obs.data_ptr(), N * n, V, 6, 32, p["cw"].data_ptr(), p["cb"].data_ptr(), p["lw"].data_ptr(),
+                                       p["lb"].data_ptr(), self.inputs.data_ptr(), self.inp, n, 1, st))
+        abi.check(lib, lib.ssd_build_inputs(N, n, self.A, 2, prev_actions.data_ptr(), prev_reward.data_ptr(), prev_inc.data_ptr(),
+                                            pos.data_ptr(), float(self.mac.pos_scale), self.inputs.data_ptr(), self.inp, 32, st))
+        x = F.leaky_relu(th.baddbmm(p["b1e"], self.inputs, p["w1e"]))
+        gi = th.baddbmm(p["bie"], x, p["wie"])
+        gh = th.baddbmm(p["bhe"], self.h_env, p["whe"])
+        abi.check(lib, lib.ssd_gru_gates(gi.data_ptr(), gh.data_ptr(), self.h_env.data_ptr(), n * N, H, st))
+        av = th.baddbmm(p["b2e"], self.h_env, p["w2e"])                                # [n, N, A + 1]
+        abi.check(lib, lib.ssd_dueling_pick(av.data_ptr(), n * N, self.A, self.avail.data_ptr(), eps.data_ptr(), step.data_ptr(),
+                                            self.seed, n, N, 0, self.actions.data_ptr(), None, st))
+        self._keep = (x, gi, gh, av)
+        return self.actions
+
+    # ---- incentive head ---------------------------------------------------------------------------------------------
+    @th.no_grad()
+    def act_inc(self, actions, pos, orient, reward, clean_num, apple_den, eps, step):
+        """actions i64 [N, n] (the env actions just taken); pos / orient: the PRE-step pose [N, n, 2]; reward, clean_num,
+        apple_den [N, n] of this step.  Returns actions_inc i64 [N, n, n] with a zero diagonal (static buffer)."""
+        p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
+        st = self._stream()
+        x = th.baddbmm(p["b1i"], self.inputs, p["w1i_x"]) + p["w1i_a"][self.arange_n, actions.t()]    # one-hot(a) @ W_a = row gather
+        x = F.leaky_relu(x)
+        gi = th.baddbmm(p["bii"], x, p["wii"])
+        gh = th.baddbmm(p["bhi"], self.h_inc, p["whi"])
+        abi.check(lib, lib.ssd_gru_gates(gi.data_ptr(), gh.data_ptr(), self.h_inc.data_ptr(), n * N, H, st))
+        hpart = th.bmm(self.h_inc, p["w2i_h"])                                          # [n(i), N, 4]
+        other = th.cat([F.one_hot(actions, self.A).float(), pos / self.mac.pos_scale, orient, reward.unsqueeze(-1),
+                        clean_num.unsqueeze(-1), apple_den.unsqueeze(-1)], dim=-1)       # [N, n(j), E]
+        opart = (other.reshape(N * n, -1) @ p["w2i_o"]).reshape(N, n, n, 4).permute(2, 0, 1, 3)   # [n(i), N, n(j), 4]
+        av = (hpart.unsqueeze(2) + opart + p["b2i"]).contiguous()                        # [n(i), N, n(j), 4]
+        abi.check(lib, lib.ssd_dueling_pick(av.data_ptr(), n * N * n, self.a.n_inc_actions, None, eps.data_ptr(), step.data_ptr(),
+                                            self.seed ^ 0x5bd1e995, n, N, 1, self.actions_inc.data_ptr(), None, st))
+        self._keep2 = (x, gi, gh, av)
+        return self.actions_inc
+
+    # ---- reference-shaped Q access (tests) ---------------------------------------------------------------------------
+    @th.no_grad()
+    def q_values(self, av):
+        a = av[..., :-1]
+        return av[..., -1:] + a - a.mean(dim=-1, keepdim=True)

@@ -37,6 +37,7 @@ class HipGraphRunner(HipVecRunner):
         st["avail_actions"].copy_(self.env.avail_actions_batch.unsqueeze(1).expand(-1, T + 1, -1, -1))
         self.cur = self.env.native.obs_buffers(self.obs_fmt)            # obs / pos / orient written by the env kernel
         self.t_dev = th.zeros(1, dtype=th.long, device=dev)
+        self.rng_ctr = th.zeros(1, dtype=th.long, device=dev)          # never reset: exploration draws differ between episodes
         self.prev_actions = th.full((N, n), -1, dtype=th.long, device=dev)
         self.prev_reward = th.zeros(N, n, device=dev)
         self.prev_inc = th.zeros(N, n, n, dtype=th.long, device=dev)
@@ -49,6 +50,10 @@ class HipGraphRunner(HipVecRunner):
         self.avail_idx = th.nonzero(avail).squeeze(-1)                  # constant table of available env actions
         self.avail_mask = self.env.avail_actions_batch                  # [N, n, A]
         self.inc_mask = (1 - th.eye(n, device=dev, dtype=th.long)).reshape(1, n, n)
+        self.fast = None
+        if getattr(a, "fast_policy", True):
+            from ..fast_policy import FastPolicy
+            self.fast = FastPolicy(self.mac, N, avail, seed=int(self.env.native.cfg.seed) * 2654435761 + 12345)
         self._ready = True
 
     def _pick(self, q, avail_mask, idx_table, k):
@@ -69,11 +74,14 @@ class HipGraphRunner(HipVecRunner):
         st["obs"].index_copy_(1, td, obs.unsqueeze(1))
         st["agent_pos"].index_copy_(1, td, pos.unsqueeze(1))
         st["agent_orientation"].index_copy_(1, td, orient.unsqueeze(1))
-        feat = mac.encode_obs(obs)
-        inputs = mac.assemble_inputs(feat, self.prev_actions, self.prev_reward, self.prev_inc, pos, False)
-        q_env, h_env, _ = mac.agent.forward_env(inputs, self.h_env)
-        self.h_env.copy_(h_env)
-        actions = self._pick(q_env, self.avail_mask, self.avail_idx, self.avail_idx.numel())      # [N, n]
+        if self.fast is not None:
+            actions = self.fast.act_env(obs, self.prev_actions, self.prev_reward, self.prev_inc, pos, self.eps, self.rng_ctr)
+        else:
+            feat = mac.encode_obs(obs)
+            inputs = mac.assemble_inputs(feat, self.prev_actions, self.prev_reward, self.prev_inc, pos, False)
+            q_env, h_env, _ = mac.agent.forward_env(inputs, self.h_env)
+            self.h_env.copy_(h_env)
+            actions = self._pick(q_env, self.avail_mask, self.avail_idx, self.avail_idx.numel())      # [N, n]
         pos_t, orient_t = pos.clone(), orient.clone()                   # forward_inc sees the PRE-step pose (controller :78-82)
         if store_env_step:
             out = self.env.step_batch((actions % a.n_actions).to(th.int32), observe=True, fmt=self.obs_fmt)
@@ -88,10 +96,14 @@ class HipGraphRunner(HipVecRunner):
         onehot = F.one_hot(actions, num_classes=a.n_actions)
         st["actions"].index_copy_(1, td, actions.reshape(actions.shape[0], 1, -1, 1))
         st["actions_onehot"].index_copy_(1, td, onehot.float().unsqueeze(1))
-        q_inc, h_inc, _ = mac.agent.forward_inc(inputs, self.h_inc, onehot, pos_t / mac.pos_scale, orient_t, reward.unsqueeze(-1),
-                                                clean.unsqueeze(-1), den.unsqueeze(-1))
-        self.h_inc.copy_(h_inc)
-        actions_inc = self._pick(q_inc, None, None, a.n_inc_actions) * self.inc_mask              # [N, n, n]
+        if self.fast is not None:
+            actions_inc = self.fast.act_inc(actions, pos_t, orient_t, reward, clean, den, self.eps, self.rng_ctr)
+            self.rng_ctr += 1
+        else:
+            q_inc, h_inc, _ = mac.agent.forward_inc(inputs, self.h_inc, onehot, pos_t / mac.pos_scale, orient_t, reward.unsqueeze(-1),
+                                                    clean.unsqueeze(-1), den.unsqueeze(-1))
+            self.h_inc.copy_(h_inc)
+            actions_inc = self._pick(q_inc, None, None, a.n_inc_actions) * self.inc_mask              # [N, n, n]
         st["actions_inc"].index_copy_(1, td, actions_inc.reshape(actions_inc.shape[0], 1, actions_inc.shape[1], -1, 1))
         if store_env_step:
             self.prev_actions.copy_(actions)
@@ -111,6 +123,9 @@ class HipGraphRunner(HipVecRunner):
         self.t_dev.zero_()
         self.prev_actions.fill_(-1); self.prev_reward.zero_(); self.prev_inc.zero_()
         self.h_env.zero_(); self.h_inc.zero_(); self.ep_return.zero_()
+        if self.fast is not None:
+            self.fast.reset()
+            self.fast.pack()          # the learner may have stepped the weights since the last episode
         sel = self.mac.action_selector
         sel.epsilon = 0.0 if test_mode else sel.schedule.eval(self.t_env)
         zero_after = getattr(self.args, "epsilon_zero", None)

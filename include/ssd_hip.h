@@ -160,7 +160,8 @@ int ssd_get_info(const ssd_env* env, ssd_info* out);
 
 /* HomophilyMAC._build_inputs tail (controllers/homophily_controller.py:137-184): everything except the conv
  * encoder.  Writes [B*n, A + n + 1 + 1 + 2] = onehot(last action) | onehot(id) | sign(last reward) |
- * sign(#recv+ - #recv-) | pos/||(H,W)||.  t0 != 0 selects the t == 0 branch (zeros for the three history terms). */
+ * sign(#recv+ - #recv-) | pos/||(H,W)||.  t0 is a flag word: bit 0 selects the t == 0 branch (zeros for the three history
+ * terms; a last action of -1 has the same effect per row), bit 1 writes agent-major rows (i * batch + b) instead of (b * n + i). */
 int ssd_build_inputs(int32_t batch, int32_t n_agents, int32_t n_actions, int32_t t0,
                      const int64_t* last_actions /*[B,n]*/, const float* last_reward /*[B,n]*/,
                      const int64_t* last_actions_inc /*[B,n,n]*/, const float* pos /*[B,n,2]*/,
@@ -173,6 +174,24 @@ int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int
                            const float* rewards, float effect_ratio, float cost_ratio, float incentive,
                            float seq_len, float* give, float* recv_pos, float* recv_neg, float* recv_zero,
                            float* rewards_for_env, float* rewards_for_inc, void* stream);
+
+/* ---- rollout-time (inference) controller pieces that are not GEMMs (csrc/ssd_policy.hip) -----------------------------
+ * ssd_encoder: HomophilyAgent.rgb_preprocess (homophily_agent.py:20-27,213-214) = Conv2d(3, conv_out, 3, 1) + LeakyReLU +
+ *   Flatten + Linear(conv_out * (V-2)^2, feat_out) + LeakyReLU on obs f32 [rows, 3, V, V] -> out[row * out_stride + 0..feat_out).
+ *   agent_major: rows are (env b, agent i); write row (i * (rows / n_agents) + b) instead (per-agent batched GEMM layout).
+ * ssd_gru_gates: the gate arithmetic of the hand-written GRU cell (homophily_agent.py:162-165,188-191) on gi = x W_i + b_i,
+ *   gh = h W_h + b_h, both [rows, 3 * hidden] in (r, z, n) order; h [rows, hidden] is updated in place.
+ * ssd_dueling_pick: q = v + a - mean(a) (homophily_agent.py:168-170,204-206) on av [rows, n_actions + 1] (advantages, then the
+ *   value) followed by the epsilon-greedy choice of EpsilonGreedyActionSelector (action_selectors.py:44-68) with the available
+ *   mask avail u8[n_actions] (NULL = all).  epsilon f32 and step i64 are device scalars; rows are agent-major (i, b) or, with
+ *   pairs = 1, (i, b, j) with the diagonal i == j forced to 0 (homophily_controller.py:44-46); actions are written env-major
+ *   [batch, n] / [batch, n, n].  q_out (nullable) receives q [rows, n_actions]. */
+int ssd_encoder(const float* obs, int32_t rows, int32_t view_edge, int32_t conv_out, int32_t feat_out, const float* conv_w,
+                const float* conv_b, const float* lin_w, const float* lin_b, float* out, int32_t out_stride, int32_t n_agents,
+                int32_t agent_major, void* stream);
+int ssd_gru_gates(const float* gi, const float* gh, float* h, int32_t rows, int32_t hidden, void* stream);
+int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uint8_t* avail, const float* epsilon, const int64_t* step,
+                     uint32_t seed, int32_t n_agents, int32_t batch, int32_t pairs, int64_t* actions, float* q_out, void* stream);
 
 /* ---- COUNTER-mode generator (shared definition) ---------------------------------------------
  * Two levels, so that the expensive part is computed once per env and call (wave-uniform on the GPU):

@@ -152,7 +152,8 @@ def test_graph_runner_equals_generic_runner_under_greedy_actions():
         th.manual_seed(0)
         cfg = load_config("cleanup", overrides=dict(
             runner=runner, batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False, store_state=False,
-            env_args=dict(num_agents=5, map="default5", episode_limit=T, seed=9), use_cuda=True, save_model=False, runner_stats=False))
+            env_args=dict(num_agents=5, map="default5", episode_limit=T, seed=9), use_cuda=True, save_model=False, runner_stats=False,
+            fast_policy=False))      # same torch controller arithmetic in both runners -> bit-identical batches
         ctx = setup(cfg)
         out = []
         for ep in range(3):                       # episode 1 eager, graph captured at episode 2, replayed in 2 and 3
@@ -199,3 +200,61 @@ def test_stepwise_forward_equals_time_batched_unroll():
         for t in range(batch.max_seq_length):
             a, b, _ = mac.forward(batch, t)
             assert (a - q_env[:, t]).abs().max() < 1e-5 and (b - q_inc[:, t]).abs().max() < 1e-5, t
+
+
+def test_fast_policy_matches_torch_controller():
+    """FastPolicy (HIP encoder / GRU gates / dueling-pick + agent-major GEMMs) against the torch controller on the same
+    inputs: features, hidden states and greedy actions."""
+    from homophily_marl_amd.fast_policy import FastPolicy
+    from homophily_marl_amd.run import load_config, setup
+    N, n = 192, 5
+    th.manual_seed(1)
+    cfg = load_config("cleanup", overrides=dict(runner="hip_vec", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False,
+                                                 store_state=False, env_args=dict(num_agents=n, map="default5", episode_limit=20, seed=3),
+                                                 use_cuda=True, save_model=False, runner_stats=False))
+    ctx = setup(cfg)
+    mac, env = ctx.mac, ctx.runner.env
+    env.reset_batch()
+    g = th.Generator(device="cuda").manual_seed(0)
+    for _ in range(6):      # a few random steps so the observations are not the reset image
+        env.step_batch(th.randint(0, 9, (N, n), generator=g, device="cuda", dtype=th.int32), observe=False)
+    o = env.observe_batch()
+    obs, pos, orient = o["obs"].clone(), o["pos"].clone(), o["orient"].clone()
+    prev_a = th.randint(-1, 9, (N, n), generator=g, device="cuda")
+    prev_r = th.randint(-1, 2, (N, n), generator=g, device="cuda").float()
+    prev_i = th.randint(0, 3, (N, n, n), generator=g, device="cuda")
+    h0e = th.randn(N, n, 1, 64, generator=g, device="cuda") * 0.3
+    h0i = th.randn(N, n, 1, 64, generator=g, device="cuda") * 0.3
+    avail = env.avail_actions_batch[0, 0]
+    fp = FastPolicy(mac, N, avail, seed=7)
+    fp.h_env.copy_(h0e.squeeze(2).transpose(0, 1)); fp.h_inc.copy_(h0i.squeeze(2).transpose(0, 1))
+    eps, step = th.zeros((), device="cuda"), th.zeros(1, dtype=th.long, device="cuda")
+    with th.no_grad():
+        feat = mac.encode_obs(obs)
+        safe_prev = prev_a.clamp(min=0)
+        inputs = mac.assemble_inputs(feat, prev_a, prev_r, prev_i, pos, False)
+        q_env, h_env, _ = mac.agent.forward_env(inputs, h0e)
+        act = fp.act_env(obs, prev_a, prev_r, prev_i, pos, eps, step).clone()
+        assert (fp.inputs.transpose(0, 1).reshape(N * n, -1) - inputs).abs().max() < 2e-5
+        assert (fp.h_env.transpose(0, 1) - h_env.squeeze(2)).abs().max() < 2e-5
+        ref_act = q_env.masked_fill(avail.view(1, 1, -1) == 0, -float("inf")).argmax(-1)
+        assert (act == ref_act).float().mean() > 0.999
+        reward = th.randint(-1, 2, (N, n), generator=g, device="cuda").float()
+        clean = th.randint(0, 3, (N, n), generator=g, device="cuda").float()
+        den = th.rand(N, n, generator=g, device="cuda")
+        q_inc, h_inc, _ = mac.agent.forward_inc(inputs, h0i, th.nn.functional.one_hot(ref_act, 9), pos / mac.pos_scale, orient,
+                                                reward.unsqueeze(-1), clean.unsqueeze(-1), den.unsqueeze(-1))
+        ainc = fp.act_inc(ref_act, pos, orient, reward, clean, den, eps, step).clone()
+        assert (fp.h_inc.transpose(0, 1) - h_inc.squeeze(2)).abs().max() < 2e-5
+        ref_inc = q_inc.argmax(-1) * (1 - th.eye(n, device="cuda", dtype=th.long))
+        assert (ainc == ref_inc).float().mean() > 0.999
+        assert (ainc.diagonal(dim1=1, dim2=2) == 0).all()
+        # exploration: with eps = 1 every action is random, available, and the inc diagonal stays 0
+        eps.fill_(1.0)
+        cnt = th.zeros(9, device="cuda")
+        for s in range(20):
+            step.fill_(s)
+            a = fp.act_env(obs, prev_a, prev_r, prev_i, pos, eps, step)
+            cnt += th.bincount(a.reshape(-1), minlength=9).float()
+        assert cnt[[5, 6, 7]].sum() == 0 and (cnt[[0, 1, 2, 3, 4, 8]] / cnt.sum() - 1 / 6).abs().max() < 0.02
+    env.close()
