@@ -94,7 +94,20 @@ HIP_SIGNATURES = _sigs("ssd_", True)
 HIP_SIGNATURES["ssd_step_observe"] = (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SsdTape), C.POINTER(SsdStepOut),
                                                 C.POINTER(SsdObsOut), C.c_void_p])
 HIP_SIGNATURES["ssd_encoder"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p])
+                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.c_void_p])
+
+
+class SsdStoreStep(C.Structure):
+    _fields_ = [("t_index", C.c_void_p), ("n_env", C.c_int32), ("n_agents", C.c_int32), ("n_actions", C.c_int32), ("t_slots", C.c_int32),
+                ("pos", C.c_void_p), ("orient", C.c_void_p), ("reward", C.c_void_p), ("clean_num", C.c_void_p), ("apple_den", C.c_void_p),
+                ("terminated", C.c_void_p), ("actions", C.c_void_p), ("actions_inc", C.c_void_p),
+                ("dst_pos", C.c_void_p), ("dst_orient", C.c_void_p), ("dst_reward", C.c_void_p), ("dst_clean_num", C.c_void_p),
+                ("dst_apple_den", C.c_void_p), ("dst_actions_onehot", C.c_void_p), ("dst_terminated", C.c_void_p),
+                ("dst_actions", C.c_void_p), ("dst_actions_inc", C.c_void_p)]
+
+
+HIP_SIGNATURES["ssd_store_step_launch"] = (C.c_int, [C.POINTER(SsdStoreStep), C.c_void_p])
 HIP_SIGNATURES["ssd_gru_gates"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_dueling_pick"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32,
                                                C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])

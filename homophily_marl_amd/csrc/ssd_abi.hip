@@ -295,11 +295,20 @@ int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int
 
 int ssd_encoder(const float* obs, int32_t rows, int32_t view_edge, int32_t conv_out, int32_t feat_out, const float* conv_w,
                 const float* conv_b, const float* lin_w, const float* lin_b, float* out, int32_t out_stride, int32_t n_agents,
-                int32_t agent_major, void* stream) {
+                int32_t agent_major, float* store_obs, int64_t store_env_stride, const int64_t* store_t, void* stream) {
     if (!obs || !conv_w || !conv_b || !lin_w || !lin_b || !out || rows < 1 || view_edge < 3) return fail(SSD_ERR_INVALID, "bad argument");
     if (conv_out != 6 || feat_out != 32) return fail(SSD_ERR_UNSUPPORTED, "ssd_encoder is instantiated for conv_out 6, obs_dim_net 32 (config/default.yaml:59-63)");
-    if (agent_major && (n_agents < 1 || rows % n_agents)) return fail(SSD_ERR_INVALID, "rows must be a multiple of n_agents");
-    launch_encoder(obs, rows, view_edge, conv_w, conv_b, lin_w, lin_b, out, out_stride, n_agents, agent_major, (hipStream_t)stream);
+    if ((agent_major || store_obs) && (n_agents < 1 || rows % n_agents)) return fail(SSD_ERR_INVALID, "rows must be a multiple of n_agents");
+    if (store_obs && !store_t) return fail(SSD_ERR_INVALID, "store_obs needs store_t");
+    if (4 * 4 * (3 * view_edge * view_edge + 4) * 4 > 160 * 1024) return fail(SSD_ERR_INVALID, "view too large for the encoder's LDS staging");
+    launch_encoder(obs, rows, view_edge, conv_w, conv_b, lin_w, lin_b, out, out_stride, n_agents, agent_major, store_obs,
+                   (long)store_env_stride, store_t, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_store_step_launch(const ssd_store_step* a, void* stream) {
+    if (!a || !a->t_index || a->n_env < 1 || a->n_agents < 1 || a->t_slots < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    launch_store_step(a, (hipStream_t)stream);
     return launched();
 }
 

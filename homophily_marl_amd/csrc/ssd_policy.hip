@@ -18,60 +18,128 @@ __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.01f * x
 // reduced across the wave with a butterfly.  Conv weights are wave-uniform (scalar loads).
 // out row stride / offset let the features land directly inside the agent-input matrix.
 // ---------------------------------------------------------------------------------------------------------------
-template <int C, int F>
+template <int C, int F, int RPW>
 __global__ __launch_bounds__(256) void k_encoder(const float* __restrict__ obs, int rows, int V, const float* __restrict__ cw /*[C,3,3,3]*/,
                                                  const float* __restrict__ cb /*[C]*/, const float* __restrict__ lw /*[F, C*P]*/,
                                                  const float* __restrict__ lb /*[F]*/, float* __restrict__ out, int out_stride,
-                                                 int n_agents, int agent_major) {
+                                                 int n_agents, int agent_major, float* __restrict__ store, long store_env_stride,
+                                                 const int64_t* __restrict__ store_t) {
+    // RPW rows per wave: every linear weight fetched from L2 is used for RPW rows (the weight matrix is 130 KB; one row
+    // per wave re-read it 20 480 times per timestep).
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= rows) return;
-    const int VV = V * V, O = V - 2, P = O * O, K = C * P;
-    float* in = sm + wave * (3 * VV + 4);
-    const float* src = obs + (size_t)row * 3 * VV;
-    for (int i = lane; i < 3 * VV; i += 64) in[i] = src[i];
+    const int row0 = (blockIdx.x * 4 + wave) * RPW;
+    if (row0 >= rows) return;
+    const int VV = V * V, O = V - 2, P = O * O, K = C * P, L = 3 * VV;
+    float* in = sm + wave * RPW * (L + 4);
+    // stage RPW observations in LDS; optionally copy them into the episode storage obs[env, t] on the way
+    // (rows of one env are contiguous: obs element (row, e) of env b = row / n sits at b * env_stride + t * n * L + (row % n) * L + e)
+    const long t_off = store ? (long)(*store_t) * n_agents * L : 0;
+    for (int q = 0; q < RPW; ++q) {
+        const int row = row0 + q;
+        if (row < rows) {
+            const float* src = obs + (size_t)row * L;
+            float* dst = nullptr;
+            if (store) { const int b = row / n_agents, i = row - b * n_agents; dst = store + (long)b * store_env_stride + t_off + (long)i * L; }
+            for (int e = lane; e < L; e += 64) { const float v = src[e]; in[q * (L + 4) + e] = v; if (dst) dst[e] = v; }
+        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    float acc[F];
+    float acc[RPW][F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+    for (int q = 0; q < RPW; ++q)
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[q][f] = 0.f;
     for (int p = lane; p < P; p += 64) {
         const int y = p / O, x = p - y * O;
-        float c[C];
+        float c[RPW][C];
 #pragma unroll
-        for (int o = 0; o < C; ++o) c[o] = cb[o];
+        for (int q = 0; q < RPW; ++q)
+#pragma unroll
+            for (int o = 0; o < C; ++o) c[q][o] = cb[o];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const float v = in[ch * VV + (y + dy) * V + x + dx];
+                    float v[RPW];
 #pragma unroll
-                    for (int o = 0; o < C; ++o) c[o] = fmaf(cw[((o * 3 + ch) * 3 + dy) * 3 + dx], v, c[o]);
+                    for (int q = 0; q < RPW; ++q) v[q] = in[q * (L + 4) + ch * VV + (y + dy) * V + x + dx];
+#pragma unroll
+                    for (int o = 0; o < C; ++o) {
+                        const float w = cw[((o * 3 + ch) * 3 + dy) * 3 + dx];
+#pragma unroll
+                        for (int q = 0; q < RPW; ++q) c[q][o] = fmaf(w, v[q], c[q][o]);
+                    }
                 }
 #pragma unroll
         for (int o = 0; o < C; ++o) {
-            const float a = leaky(c[o]);
+            float a[RPW];
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) a[q] = leaky(c[q][o]);
             const float* w = lw + o * P + p;              // Flatten order of [C, O, O]: k = o * P + p
 #pragma unroll
-            for (int f = 0; f < F; ++f) acc[f] = fmaf(w[(size_t)f * K], a, acc[f]);
+            for (int f = 0; f < F; ++f) {
+                const float wf = w[(size_t)f * K];
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) acc[q][f] = fmaf(wf, a[q], acc[q][f]);
+            }
         }
     }
-    // wave reduction of the F partial sums; afterwards lane f holds output f
-    float mine = 0.f;
+    // wave reduction of the F partial sums per row; afterwards lane f holds output f
 #pragma unroll
-    for (int f = 0; f < F; ++f) {
-        float v = acc[f];
+    for (int q = 0; q < RPW; ++q) {
+        float mine = 0.f;
 #pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh);
-        if (lane == f) mine = v;
+        for (int f = 0; f < F; ++f) {
+            float v = acc[q][f];
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh);
+            if (lane == f) mine = v;
+        }
+        const int row = row0 + q;
+        if (lane < F && row < rows) {
+            size_t orow = row;
+            if (agent_major) { const int b = row / n_agents, i = row - b * n_agents; orow = (size_t)i * (rows / n_agents) + b; }
+            out[orow * out_stride + lane] = leaky(mine + lb[lane]);
+        }
     }
-    if (lane < F) {
-        size_t orow = row;
-        if (agent_major) { const int b = row / n_agents, i = row - b * n_agents; orow = (size_t)i * (rows / n_agents) + b; }
-        out[orow * out_stride + lane] = leaky(mine + lb[lane]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Store step: the small per-timestep fields of the episode storage [N, T+1, ...] in one launch (the reference issues one
+// EpisodeBatch.update per field, episode_runner.py:67,80-93).  Destination element = base[(b * slots + t) * width + k].
+// ---------------------------------------------------------------------------------------------------------------
+struct StoreStep {
+    const int64_t* t;
+    int N, n, A, slots;
+    const float *pos, *orient, *reward, *clean, *den;        // [N, n, 2] x2, [N, n] x3 (nullable: skipped)
+    const uint8_t* term;                                      // [N]
+    const int64_t *actions, *actions_inc;                     // [N, n], [N, n, n]
+    float *d_pos, *d_orient, *d_reward, *d_clean, *d_den, *d_onehot;
+    uint8_t* d_term;
+    int64_t *d_actions, *d_actions_inc;
+};
+__global__ void k_store_step(StoreStep s) {
+    const long t = *s.t;
+    const int n = s.n, A = s.A;
+    const int per_env = n * (2 + 2 + 1 + 1 + 1 + 1 + A + n) + 1;
+    const long total = (long)s.N * per_env;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long b = idx / per_env;
+        int k = (int)(idx - b * per_env);
+        const long bt = b * s.slots + t;
+        if (k < 2 * n) { if (s.pos) s.d_pos[bt * 2 * n + k] = s.pos[b * 2 * n + k]; continue; } k -= 2 * n;
+        if (k < 2 * n) { if (s.orient) s.d_orient[bt * 2 * n + k] = s.orient[b * 2 * n + k]; continue; } k -= 2 * n;
+        if (k < n) { if (s.reward) s.d_reward[bt * n + k] = s.reward[b * n + k]; continue; } k -= n;
+        if (k < n) { if (s.clean) s.d_clean[bt * n + k] = s.clean[b * n + k]; continue; } k -= n;
+        if (k < n) { if (s.den) s.d_den[bt * n + k] = s.den[b * n + k]; continue; } k -= n;
+        if (k < n) { if (s.actions) s.d_actions[bt * n + k] = s.actions[b * n + k]; continue; } k -= n;
+        if (k < n * A) { if (s.actions) { const int i = k / A, a = k - i * A; s.d_onehot[(bt * n + i) * A + a] = s.actions[b * n + i] == a ? 1.f : 0.f; } continue; } k -= n * A;
+        if (k < n * n) { if (s.actions_inc) s.d_actions_inc[bt * n * n + k] = s.actions_inc[b * n * n + k]; continue; } k -= n * n;
+        if (s.term) s.d_term[bt] = s.term[b];
     }
 }
 
@@ -138,9 +206,24 @@ __global__ void k_dueling_pick(const float* __restrict__ av, int R, int A, const
 }
 
 void launch_encoder(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lw, const float* lb, float* out,
-                    int out_stride, int n_agents, int agent_major, hipStream_t s) {
-    const size_t lds = 4 * (size_t)(3 * V * V + 4) * sizeof(float);
-    hipLaunchKernelGGL((k_encoder<6, 32>), dim3((rows + 3) / 4), dim3(256), lds, s, obs, rows, V, cw, cb, lw, lb, out, out_stride, n_agents, agent_major);
+                    int out_stride, int n_agents, int agent_major, float* store, long store_env_stride, const int64_t* store_t,
+                    hipStream_t s) {
+    constexpr int RPW = 4;
+    const size_t lds = 4 * RPW * (size_t)(3 * V * V + 4) * sizeof(float);
+    const int rows_per_block = 4 * RPW;
+    hipLaunchKernelGGL((k_encoder<6, 32, RPW>), dim3((rows + rows_per_block - 1) / rows_per_block), dim3(256), lds, s, obs, rows, V, cw, cb,
+                       lw, lb, out, out_stride, n_agents, agent_major, store, store_env_stride, store_t);
+}
+void launch_store_step(const ssd_store_step* a, hipStream_t s) {
+    StoreStep k;
+    k.t = a->t_index; k.N = a->n_env; k.n = a->n_agents; k.A = a->n_actions; k.slots = a->t_slots;
+    k.pos = a->pos; k.orient = a->orient; k.reward = a->reward; k.clean = a->clean_num; k.den = a->apple_den; k.term = a->terminated;
+    k.actions = a->actions; k.actions_inc = a->actions_inc;
+    k.d_pos = a->dst_pos; k.d_orient = a->dst_orient; k.d_reward = a->dst_reward; k.d_clean = a->dst_clean_num; k.d_den = a->dst_apple_den;
+    k.d_onehot = a->dst_actions_onehot; k.d_term = a->dst_terminated; k.d_actions = a->dst_actions; k.d_actions_inc = a->dst_actions_inc;
+    const long total = (long)k.N * (k.n * (8 + k.A + k.n) + 1);
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_store_step, dim3(blocks), dim3(256), 0, s, k);
 }
 void launch_gru_gates(const float* gi, const float* gh, float* h, int R, int H, hipStream_t s) {
     size_t total = (size_t)R * H; int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;

@@ -70,14 +70,17 @@ class FastPolicy:
 
     # ---- env head -----------------------------------------------------------------------------------------------
     @th.no_grad()
-    def act_env(self, obs, prev_actions, prev_reward, prev_inc, pos, eps, step):
+    def act_env(self, obs, prev_actions, prev_reward, prev_inc, pos, eps, step, store_obs=None, store_t=None):
         """obs f32 [N, n, 3, V, V]; prev_* of the previous timestep (prev_actions = -1 at t = 0); pos f32 [N, n, 2];
         eps f32 scalar tensor, step i64 [1] tensor.  Returns actions i64 [N, n] (static buffer)."""
         p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
         V = obs.shape[-1]
         st = self._stream()
         abi.check(lib, lib.ssd_encoder(obs.data_ptr(), N * n, V, 6, 32, p["cw"].data_ptr(), p["cb"].data_ptr(), p["lw"].data_ptr(),
-                                       p["lb"].data_ptr(), self.inputs.data_ptr(), self.inp, n, 1, st))
+                                       p["lb"].data_ptr(), self.inputs.data_ptr(), self.inp, n, 1,
+                                       None if store_obs is None else store_obs.data_ptr(),
+                                       0 if store_obs is None else store_obs.stride(0),
+                                       None if store_t is None else store_t.data_ptr(), st))
         abi.check(lib, lib.ssd_build_inputs(N, n, self.A, 2, prev_actions.data_ptr(), prev_reward.data_ptr(), prev_inc.data_ptr(),
                                             pos.data_ptr(), float(self.mac.pos_scale), self.inputs.data_ptr(), self.inp, 32, st))
         x = F.leaky_relu(th.baddbmm(p["b1e"], self.inputs, p["w1e"]))

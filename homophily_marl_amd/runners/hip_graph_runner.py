@@ -12,8 +12,12 @@ The first episode runs eagerly (warm-up of MIOpen / hipBLASLt plans and the allo
 start of the second.  The returned EpisodeBatch is the persistent storage: consume (insert into the replay buffer)
 before the next run(), as the training loop does (run.py:184-185).
 """
+import ctypes as C
+
 import torch as th
 import torch.nn.functional as F
+
+from .. import abi
 
 from ..components.episode_buffer import EpisodeBatch
 from .hip_vec_runner import HipVecRunner
@@ -54,6 +58,8 @@ class HipGraphRunner(HipVecRunner):
         if getattr(a, "fast_policy", True):
             from ..fast_policy import FastPolicy
             self.fast = FastPolicy(self.mac, N, avail, seed=int(self.env.native.cfg.seed) * 2654435761 + 12345)
+            self._zeros_nn = th.zeros(N, n, device=dev)
+            self._ss, self._ss_last = self._make_store_args(True), self._make_store_args(False)
         self._ready = True
 
     def _pick(self, q, avail_mask, idx_table, k):
@@ -66,22 +72,63 @@ class HipGraphRunner(HipVecRunner):
         rand = idx_table[r] if idx_table is not None else r
         return th.where(u < self.eps, rand, greedy)
 
+    def _select_fast(self, store_env_step):
+        """_select with the FastPolicy kernels: the encoder writes obs[:, t] into the storage while it reads it, and ONE
+        store-step launch writes the nine small fields."""
+        a, st, fp = self.args, self.store.data.transition_data, self.fast
+        td = self.t_dev
+        obs, pos, orient = self.cur["obs"], self.cur["pos"], self.cur["orient"]
+        actions = fp.act_env(obs, self.prev_actions, self.prev_reward, self.prev_inc, pos, self.eps, self.rng_ctr,
+                             store_obs=st["obs"], store_t=td)
+        pos_t, orient_t = pos.clone(), orient.clone()                   # forward_inc sees the PRE-step pose (controller :78-82)
+        ss = self._ss if store_env_step else self._ss_last
+        if store_env_step:
+            out = self.env.step_batch(actions.to(th.int32), observe=True, fmt=self.obs_fmt)
+            reward, clean, den = out["reward"], out["clean_num"], out["apple_den"]
+            self.ep_return += reward
+        else:
+            reward = clean = den = self._zeros_nn
+        actions_inc = fp.act_inc(actions, pos_t, orient_t, reward, clean, den, self.eps, self.rng_ctr)
+        self.rng_ctr += 1
+        ss.pos, ss.orient = pos_t.data_ptr(), orient_t.data_ptr()
+        self._keep_pose = (pos_t, orient_t)
+        abi.check(fp.lib, fp.lib.ssd_store_step_launch(C.byref(ss), th.cuda.current_stream(self.env.device).cuda_stream))
+        if store_env_step:
+            self.prev_actions.copy_(actions)
+            self.prev_reward.copy_(reward)
+            self.prev_inc.copy_(actions_inc)
+            td += 1
+
+    def _make_store_args(self, with_step_outputs):
+        st, out, fp = self.store.data.transition_data, self.env.native.out, self.fast
+        ss = abi.SsdStoreStep()
+        ss.t_index = self.t_dev.data_ptr()
+        ss.n_env, ss.n_agents, ss.n_actions, ss.t_slots = self.batch_size, self.args.n_agents, self.args.n_actions, self.episode_limit + 1
+        ss.actions, ss.actions_inc = fp.actions.data_ptr(), fp.actions_inc.data_ptr()
+        ss.dst_pos, ss.dst_orient = st["agent_pos"].data_ptr(), st["agent_orientation"].data_ptr()
+        ss.dst_actions, ss.dst_actions_onehot, ss.dst_actions_inc = st["actions"].data_ptr(), st["actions_onehot"].data_ptr(), st["actions_inc"].data_ptr()
+        if with_step_outputs:
+            ss.reward, ss.clean_num, ss.apple_den, ss.terminated = (out["reward"].data_ptr(), out["clean_num"].data_ptr(),
+                                                                      out["apple_den"].data_ptr(), out["terminated"].data_ptr())
+            ss.dst_reward, ss.dst_clean_num, ss.dst_apple_den, ss.dst_terminated = (st["reward"].data_ptr(), st["clean_num"].data_ptr(),
+                                                                                    st["apple_den"].data_ptr(), st["terminated"].data_ptr())
+        return ss
+
     def _select(self, store_env_step):
         """One controller evaluation on the current observation; with store_env_step also the env transition."""
+        if self.fast is not None:
+            return self._select_fast(store_env_step)
         a, mac, st = self.args, self.mac, self.store.data.transition_data
         td = self.t_dev
         obs, pos, orient = self.cur["obs"], self.cur["pos"], self.cur["orient"]
         st["obs"].index_copy_(1, td, obs.unsqueeze(1))
         st["agent_pos"].index_copy_(1, td, pos.unsqueeze(1))
         st["agent_orientation"].index_copy_(1, td, orient.unsqueeze(1))
-        if self.fast is not None:
-            actions = self.fast.act_env(obs, self.prev_actions, self.prev_reward, self.prev_inc, pos, self.eps, self.rng_ctr)
-        else:
-            feat = mac.encode_obs(obs)
-            inputs = mac.assemble_inputs(feat, self.prev_actions, self.prev_reward, self.prev_inc, pos, False)
-            q_env, h_env, _ = mac.agent.forward_env(inputs, self.h_env)
-            self.h_env.copy_(h_env)
-            actions = self._pick(q_env, self.avail_mask, self.avail_idx, self.avail_idx.numel())      # [N, n]
+        feat = mac.encode_obs(obs)
+        inputs = mac.assemble_inputs(feat, self.prev_actions, self.prev_reward, self.prev_inc, pos, False)
+        q_env, h_env, _ = mac.agent.forward_env(inputs, self.h_env)
+        self.h_env.copy_(h_env)
+        actions = self._pick(q_env, self.avail_mask, self.avail_idx, self.avail_idx.numel())      # [N, n]
         pos_t, orient_t = pos.clone(), orient.clone()                   # forward_inc sees the PRE-step pose (controller :78-82)
         if store_env_step:
             out = self.env.step_batch((actions % a.n_actions).to(th.int32), observe=True, fmt=self.obs_fmt)
@@ -96,14 +143,10 @@ class HipGraphRunner(HipVecRunner):
         onehot = F.one_hot(actions, num_classes=a.n_actions)
         st["actions"].index_copy_(1, td, actions.reshape(actions.shape[0], 1, -1, 1))
         st["actions_onehot"].index_copy_(1, td, onehot.float().unsqueeze(1))
-        if self.fast is not None:
-            actions_inc = self.fast.act_inc(actions, pos_t, orient_t, reward, clean, den, self.eps, self.rng_ctr)
-            self.rng_ctr += 1
-        else:
-            q_inc, h_inc, _ = mac.agent.forward_inc(inputs, self.h_inc, onehot, pos_t / mac.pos_scale, orient_t, reward.unsqueeze(-1),
-                                                    clean.unsqueeze(-1), den.unsqueeze(-1))
-            self.h_inc.copy_(h_inc)
-            actions_inc = self._pick(q_inc, None, None, a.n_inc_actions) * self.inc_mask              # [N, n, n]
+        q_inc, h_inc, _ = mac.agent.forward_inc(inputs, self.h_inc, onehot, pos_t / mac.pos_scale, orient_t, reward.unsqueeze(-1),
+                                                clean.unsqueeze(-1), den.unsqueeze(-1))
+        self.h_inc.copy_(h_inc)
+        actions_inc = self._pick(q_inc, None, None, a.n_inc_actions) * self.inc_mask              # [N, n, n]
         st["actions_inc"].index_copy_(1, td, actions_inc.reshape(actions_inc.shape[0], 1, actions_inc.shape[1], -1, 1))
         if store_env_step:
             self.prev_actions.copy_(actions)

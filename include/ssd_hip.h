@@ -188,7 +188,26 @@ int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int
  *   [batch, n] / [batch, n, n].  q_out (nullable) receives q [rows, n_actions]. */
 int ssd_encoder(const float* obs, int32_t rows, int32_t view_edge, int32_t conv_out, int32_t feat_out, const float* conv_w,
                 const float* conv_b, const float* lin_w, const float* lin_b, float* out, int32_t out_stride, int32_t n_agents,
-                int32_t agent_major, void* stream);
+                int32_t agent_major, float* store_obs, int64_t store_env_stride, const int64_t* store_t, void* stream);
+/* store_obs (nullable): additionally copy the observation of row (env b, agent i) to
+ * store_obs[b * store_env_stride + (*store_t) * n_agents * 3VV + i * 3VV ...], i.e. into obs[b, t] of an episode storage
+ * f32 [n_env, T+1, n, 3, V, V] (EpisodeBatch.update of the "obs" key, episode_runner.py:59-67) with store_env_stride =
+ * (T+1) * n * 3VV and the time index read from device memory. */
+
+/* One launch for the small per-timestep fields of an episode storage [n_env, t_slots, ...] (the EpisodeBatch.update calls of
+ * episode_runner.py:59-93): every non-NULL source is written to dst[(b * t_slots + *t_index), ...]; actions also as one-hot. */
+typedef struct ssd_store_step {
+    const int64_t* t_index;     /* device scalar */
+    int32_t n_env, n_agents, n_actions, t_slots;
+    const float *pos, *orient;                       /* [n_env, n, 2] */
+    const float *reward, *clean_num, *apple_den;     /* [n_env, n] */
+    const uint8_t* terminated;                       /* [n_env] */
+    const int64_t *actions, *actions_inc;            /* [n_env, n], [n_env, n, n] */
+    float *dst_pos, *dst_orient, *dst_reward, *dst_clean_num, *dst_apple_den, *dst_actions_onehot;
+    uint8_t* dst_terminated;
+    int64_t *dst_actions, *dst_actions_inc;
+} ssd_store_step;
+int ssd_store_step_launch(const ssd_store_step* args, void* stream);
 int ssd_gru_gates(const float* gi, const float* gh, float* h, int32_t rows, int32_t hidden, void* stream);
 int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uint8_t* avail, const float* epsilon, const int64_t* step,
                      uint32_t seed, int32_t n_agents, int32_t batch, int32_t pairs, int64_t* actions, float* q_out, void* stream);

@@ -258,3 +258,37 @@ def test_fast_policy_matches_torch_controller():
             cnt += th.bincount(a.reshape(-1), minlength=9).float()
         assert cnt[[5, 6, 7]].sum() == 0 and (cnt[[0, 1, 2, 3, 4, 8]] / cnt.sum() - 1 / 6).abs().max() < 0.02
     env.close()
+
+
+def test_fast_graph_runner_stores_a_consistent_batch():
+    """hip_graph + FastPolicy (encoder-fused obs store, store-step kernel): the stored batch must be self-consistent
+    with the env dynamics (replayed on the CPU oracle with the stored actions), exactly like the generic runner's."""
+    from homophily_marl_amd.run import load_config, setup
+    from oracle.oracle_py import OracleEnv
+    N, T, n = 48, 14, 5
+    th.manual_seed(0)
+    cfg = load_config("cleanup", overrides=dict(
+        runner="hip_graph", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False, store_state=False,
+        env_args=dict(num_agents=n, map="default5", episode_limit=T, seed=21), use_cuda=True, save_model=False, runner_stats=False))
+    ctx = setup(cfg)
+    orc = OracleEnv("cleanup", map="default5", num_agents=n, n_env=N, view_size=7, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=21)
+    for ep in range(3):                                  # eager, captured, replayed
+        batch = ctx.runner.run(test_mode=False)
+        assert ctx.runner.fast is not None and (ep == 0 or ctx.runner._graph is not None)
+        orc.reset()
+        acts = batch["actions"].squeeze(-1).cpu().numpy()
+        for t in range(T):
+            ob = orc.observe()
+            assert (batch["obs"][:, t].cpu().numpy() == ob["obs"]).all(), (ep, t)
+            assert (batch["agent_pos"][:, t].cpu().numpy() == ob["pos"]).all() and (batch["agent_orientation"][:, t].cpu().numpy() == ob["orient"]).all()
+            o = orc.step(acts[:, t])
+            for k in ("reward", "clean_num", "apple_den"):
+                assert (batch[k][:, t].cpu().numpy() == o[k]).all(), (ep, t, k)
+            assert (batch["terminated"][:, t, 0].cpu().numpy() == o["terminated"]).all()
+        assert (batch["obs"][:, T].cpu().numpy() == orc.observe()["obs"]).all()
+        assert np.isin(acts, [0, 1, 2, 3, 4, 8]).all()
+        ai = batch["actions_inc"].squeeze(-1)
+        assert (ai.diagonal(dim1=2, dim2=3) == 0).all() and int(ai.max()) <= 2 and int(ai.min()) >= 0
+        assert (batch["actions_onehot"].argmax(-1) == batch["actions"].squeeze(-1)).all() and (batch["actions_onehot"].sum(-1) == 1).all()
+        assert int(batch["filled"].sum()) == N * (T + 1)
+    ctx.runner.close_env()
