@@ -306,6 +306,17 @@ int ssd_encoder(const float* obs, int32_t rows, int32_t view_edge, int32_t conv_
     return launched();
 }
 
+int ssd_conv_leaky(const float* obs, int32_t rows, int32_t view_edge, int32_t conv_out, const float* conv_w, const float* conv_b,
+                   float* out, int32_t n_agents, int32_t agent_major, float* store_obs, int64_t store_env_stride,
+                   const int64_t* store_t, void* stream) {
+    if (!obs || !conv_w || !conv_b || !out || rows < 1 || view_edge < 3 || n_agents < 1 || rows % n_agents) return fail(SSD_ERR_INVALID, "bad argument");
+    if (conv_out != 6) return fail(SSD_ERR_UNSUPPORTED, "ssd_conv_leaky is instantiated for conv_out 6 (config/default.yaml:59)");
+    if (store_obs && !store_t) return fail(SSD_ERR_INVALID, "store_obs needs store_t");
+    launch_conv_leaky(obs, rows, view_edge, conv_w, conv_b, out, n_agents, agent_major, store_obs, (long)store_env_stride, store_t,
+                      (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_store_step_launch(const ssd_store_step* a, void* stream) {
     if (!a || !a->t_index || a->n_env < 1 || a->n_agents < 1 || a->t_slots < 1) return fail(SSD_ERR_INVALID, "bad argument");
     launch_store_step(a, (hipStream_t)stream);

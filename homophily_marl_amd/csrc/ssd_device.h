@@ -96,6 +96,8 @@ void launch_incentive_transfer(int32_t B, int32_t T, int32_t n, const int64_t* a
 void launch_encoder(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lw, const float* lb, float* out,
                     int out_stride, int n_agents, int agent_major, float* store, long store_env_stride, const int64_t* store_t,
                     hipStream_t s);
+void launch_conv_leaky(const float* obs, int rows, int V, const float* cw, const float* cb, float* out, int n_agents, int agent_major,
+                       float* store, long store_env_stride, const int64_t* store_t, hipStream_t s);
 void launch_store_step(const ssd_store_step* a, hipStream_t s);
 void launch_gru_gates(const float* gi, const float* gh, float* h, int R, int H, hipStream_t s);
 void launch_dueling_pick(const float* av, int R, int A, const uint8_t* avail, const float* eps, const int64_t* step, uint32_t seed,

@@ -109,6 +109,43 @@ __global__ __launch_bounds__(256) void k_encoder(const float* __restrict__ obs, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// conv(3 -> C, k3, s1) + LeakyReLU only: one workgroup per observation row, the row staged in LDS, one thread per conv
+// output k = o * P + p (Flatten order).  HBM-bound (2.7 KB in, 4 KB out per row).  The Linear layer behind it is a plain
+// [rows, C*P] x [C*P, F] GEMM and goes to hipBLASLt.  Rows can be written agent-major, and the observation can be
+// copied into the episode storage obs[env, t] on the way (see k_encoder).
+// ---------------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void k_conv_leaky(const float* __restrict__ obs, int rows, int V, const float* __restrict__ cw,
+                                                    const float* __restrict__ cb, float* __restrict__ out, int n_agents, int agent_major,
+                                                    float* __restrict__ store, long store_env_stride, const int64_t* __restrict__ store_t) {
+    extern __shared__ float sm[];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int VV = V * V, O = V - 2, P = O * O, K = C * P, L = 3 * VV;
+    float* in = sm;               // [L]
+    float* w = sm + L;            // [C * 27] + [C]
+    const float* src = obs + (size_t)row * L;
+    const int b = row / n_agents, i = row - b * n_agents;
+    float* dst = store ? store + (long)b * store_env_stride + (long)(*store_t) * n_agents * L + (long)i * L : nullptr;
+    for (int e = tid; e < L; e += 256) { const float v = src[e]; in[e] = v; if (dst) dst[e] = v; }
+    for (int e = tid; e < C * 27; e += 256) w[e] = cw[e];
+    if (tid < C) w[C * 27 + tid] = cb[tid];
+    __syncthreads();
+    const size_t orow = agent_major ? (size_t)i * (rows / n_agents) + b : (size_t)row;
+    for (int k = tid; k < K; k += 256) {
+        const int o = k / P, p = k - o * P, y = p / O, x = p - y * O;
+        float acc = w[C * 27 + o];
+        const float* wo = w + o * 27;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc = fmaf(wo[(ch * 3 + dy) * 3 + dx], in[ch * VV + (y + dy) * V + x + dx], acc);
+        out[orow * K + k] = leaky(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Store step: the small per-timestep fields of the episode storage [N, T+1, ...] in one launch (the reference issues one
 // EpisodeBatch.update per field, episode_runner.py:67,80-93).  Destination element = base[(b * slots + t) * width + k].
 // ---------------------------------------------------------------------------------------------------------------
@@ -208,11 +245,17 @@ __global__ void k_dueling_pick(const float* __restrict__ av, int R, int A, const
 void launch_encoder(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lw, const float* lb, float* out,
                     int out_stride, int n_agents, int agent_major, float* store, long store_env_stride, const int64_t* store_t,
                     hipStream_t s) {
-    constexpr int RPW = 4;
+    constexpr int RPW = 1;
     const size_t lds = 4 * RPW * (size_t)(3 * V * V + 4) * sizeof(float);
     const int rows_per_block = 4 * RPW;
     hipLaunchKernelGGL((k_encoder<6, 32, RPW>), dim3((rows + rows_per_block - 1) / rows_per_block), dim3(256), lds, s, obs, rows, V, cw, cb,
                        lw, lb, out, out_stride, n_agents, agent_major, store, store_env_stride, store_t);
+}
+void launch_conv_leaky(const float* obs, int rows, int V, const float* cw, const float* cb, float* out, int n_agents, int agent_major,
+                       float* store, long store_env_stride, const int64_t* store_t, hipStream_t s) {
+    const size_t lds = (size_t)(3 * V * V + 6 * 27 + 6) * sizeof(float);
+    hipLaunchKernelGGL((k_conv_leaky<6>), dim3(rows), dim3(256), lds, s, obs, rows, V, cw, cb, out, n_agents, agent_major, store,
+                       store_env_stride, store_t);
 }
 void launch_store_step(const ssd_store_step* a, hipStream_t s) {
     StoreStep k;

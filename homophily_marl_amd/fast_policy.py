@@ -49,6 +49,7 @@ class FastPolicy:
         w, b = ag._w, ag._b
         packs = dict(
             cw=ag.conv_to_fc[0].weight, cb=ag.conv_to_fc[0].bias, lw=ag.conv_to_fc[3].weight, lb=ag.conv_to_fc[3].bias,
+            lw_t=ag.conv_to_fc[3].weight.t(),
             w1e=w("fc1_env_w"), b1e=b("fc1_env_b"),
             w2e=th.cat([w("fc2_env_w"), w("fc2_env_v_w")], dim=2), b2e=th.cat([b("fc2_env_b"), b("fc2_env_v_b")], dim=2),
             w1i_x=w("fc1_inc_w")[:, :self.inp], w1i_a=w("fc1_inc_w")[:, self.inp:], b1i=b("fc1_inc_b"),
@@ -76,11 +77,16 @@ class FastPolicy:
         p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
         V = obs.shape[-1]
         st = self._stream()
-        abi.check(lib, lib.ssd_encoder(obs.data_ptr(), N * n, V, 6, 32, p["cw"].data_ptr(), p["cb"].data_ptr(), p["lw"].data_ptr(),
-                                       p["lb"].data_ptr(), self.inputs.data_ptr(), self.inp, n, 1,
-                                       None if store_obs is None else store_obs.data_ptr(),
-                                       0 if store_obs is None else store_obs.stride(0),
-                                       None if store_t is None else store_t.data_ptr(), st))
+        K = 6 * (V - 2) * (V - 2)
+        if getattr(self, "_conv", None) is None or self._conv.shape[1] != K:
+            self._conv = th.empty(n * N, K, dtype=th.float32, device=self.dev)           # agent-major rows
+        abi.check(lib, lib.ssd_conv_leaky(obs.data_ptr(), N * n, V, 6, p["cw"].data_ptr(), p["cb"].data_ptr(), self._conv.data_ptr(), n, 1,
+                                          None if store_obs is None else store_obs.data_ptr(),
+                                          0 if store_obs is None else store_obs.stride(0),
+                                          None if store_t is None else store_t.data_ptr(), st))
+        feat = self.inputs.view(n * N, self.inp)[:, :32]                                 # Linear + LeakyReLU straight into the input matrix
+        th.addmm(p["lb"], self._conv, p["lw_t"], out=feat)
+        F.leaky_relu_(feat)
         abi.check(lib, lib.ssd_build_inputs(N, n, self.A, 2, prev_actions.data_ptr(), prev_reward.data_ptr(), prev_inc.data_ptr(),
                                             pos.data_ptr(), float(self.mac.pos_scale), self.inputs.data_ptr(), self.inp, 32, st))
         x = F.leaky_relu(th.baddbmm(p["b1e"], self.inputs, p["w1e"]))

@@ -194,6 +194,12 @@ int ssd_encoder(const float* obs, int32_t rows, int32_t view_edge, int32_t conv_
  * f32 [n_env, T+1, n, 3, V, V] (EpisodeBatch.update of the "obs" key, episode_runner.py:59-67) with store_env_stride =
  * (T+1) * n * 3VV and the time index read from device memory. */
 
+/* ssd_conv_leaky: only the Conv2d(3, conv_out, 3, 1) + LeakyReLU + Flatten part of rgb_preprocess: out f32 [rows, conv_out*(V-2)^2]
+ * (row order as agent_major says); the Linear layer behind it is a plain GEMM.  store_* as in ssd_encoder. */
+int ssd_conv_leaky(const float* obs, int32_t rows, int32_t view_edge, int32_t conv_out, const float* conv_w, const float* conv_b,
+                   float* out, int32_t n_agents, int32_t agent_major, float* store_obs, int64_t store_env_stride,
+                   const int64_t* store_t, void* stream);
+
 /* One launch for the small per-timestep fields of an episode storage [n_env, t_slots, ...] (the EpisodeBatch.update calls of
  * episode_runner.py:59-93): every non-NULL source is written to dst[(b * t_slots + *t_index), ...]; actions also as one-hot. */
 typedef struct ssd_store_step {
