@@ -77,8 +77,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SSD_DIST_BACKEND", "nccl")     # "nccl" = RCCL; "gloo" only for rehearsing >1 rank on one GPU
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = 0
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

@@ -89,6 +89,27 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
         if (overflow) { delete E; return fail(SSD_ERR_INVALID, "too many apple / waste sites (max 256)"); }
         S.reset_grid[i] = code;
     }
+    // compute_probabilities (cleanup.py:189-204) for every possible waste count, reference operation order, plain fp64
+    for (int current = 0; current <= SSD_MAX_SITES; ++current) {
+        volatile double wd = 0, pa = 0, pw = 0;
+        const int potential = S.n_waste;
+        if (potential > 0) {
+            const int free_area = potential - current;
+            volatile double q = (double)free_area / (double)potential;
+            wd = 1 - q;
+        }
+        if (!(wd >= S.thr_dep)) {
+            pw = S.p_waste;
+            if (wd <= S.thr_res) pa = S.p_apple;
+            else {
+                volatile double num = wd - S.thr_res, den = S.thr_dep - S.thr_res;
+                volatile double frac = num / den;
+                volatile double one_minus = 1 - frac;
+                pa = one_minus * S.p_apple;
+            }
+        }
+        S.tab_p_apple[current] = pa; S.tab_p_waste[current] = pw;
+    }
     E->n_spawn = (int)spawn.size();
     if ((int)spawn.size() < S.n) { delete E; return fail(SSD_ERR_INVALID, "There are not enough spawn points! Check your map?"); }
     // spawn_point() returns the LAST free spawn point (map_env.py:779-784): agent a gets the a-th from the end.

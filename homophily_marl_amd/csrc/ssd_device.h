@@ -9,15 +9,19 @@
 namespace ssd {
 
 constexpr int kWave = 64;
-constexpr int kWavesPerBlock = 4;
+#ifndef SSD_WAVES_PER_BLOCK
+#define SSD_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = SSD_WAVES_PER_BLOCK;
 constexpr int kBlock = kWave * kWavesPerBlock;
 
 enum : int { C_EMPTY = 0, C_WALL = 1, C_APPLE = 2, C_WASTE = 3, C_RIVER = 4, C_STREAM = 5 };
 enum : int { O_LEFT = 0, O_RIGHT = 1, O_UP = 2, O_DOWN = 3 };
 enum : int { MODE_RESET = 0, MODE_STEP = 1, MODE_STEP_OBS = 2, MODE_OBS = 3 };
 
-// Static description of the world, one per handle, resident in HBM and read through the scalar cache.
-struct DevSpec {
+// Scalars of the world description.  Passed to the kernels BY VALUE (kernel-argument segment), so a wave has them after
+// one scalar load instead of kernarg -> pointer -> fields.
+struct DevHead {
     int32_t kind, H, W, HW, GS;          // GS = grid row stride in bytes (HW rounded up to 16)
     int32_t n, N, V, v, VV, VVp;         // VVp = V*V rounded up to 4
     int32_t Wp, PMS;                     // padded class map: row stride W + 2v, bytes (H + 2v) * Wp rounded up to 16
@@ -26,8 +30,16 @@ struct DevSpec {
     int32_t n_apple, n_waste;
     uint32_t env_id_base, seed_lo, seed_hi;
     uint32_t magic_W, magic_V, magic_VV, magic_3VV, magic_HW;  // floor(2^32/d)+1: q = umulhi(x, magic), exact for x < 2^16
+};
+
+// Static description of the world, one per handle, resident in HBM (tables and site lists; read through the caches).
+struct DevSpec : DevHead {
     double thr_dep, thr_res, p_waste, p_apple;
     double harvest_p[4];
+    // compute_probabilities (cleanup.py:189-204) tabulated on the host by the number of waste cells on the map: the
+    // same fp64 expression evaluated once per possible count (-ffp-contract=off), so the kernel needs no fp64 division
+    double tab_p_apple[SSD_MAX_SITES + 1];
+    double tab_p_waste[SSD_MAX_SITES + 1];
     uint16_t apple[SSD_MAX_SITES];       // cell index of each apple site, row-major scan order
     uint16_t waste[SSD_MAX_SITES];
     uint16_t spawn_cell[SSD_MAX_AGENTS]; // spawn cell of agent a under random_spawn_point = False

@@ -86,7 +86,8 @@ struct Rng {
 
 // Everything one wave knows about its env.
 struct Env {
-    const DevSpec* S;
+    const DevSpec* S;   // tables (HBM)
+    const DevHead* h;   // scalars (kernel arguments)
     uint8_t* g;     // LDS grid [GS]
     uint8_t* occ;   // LDS agent overlay [GS]: 0 or the agent char (1..9) of the highest id standing there
     uint8_t* pm;    // LDS padded class map [PMS] (observe) / scratch (step)
@@ -132,7 +133,7 @@ __device__ __forceinline__ void resolve_moves(Env& E, int T, uint64_t mover_mask
         bool bad = lane < nm && (Oi >= n || !((mover_mask >> (Oi & 63)) & 1));
         if (ballot(bad)) { if (lane == 0) atomicOr(R.err, ERR_BAD_TAPE); Oi = 0; }
     } else {
-        uint32_t key = R.u32(SSD_STREAM_MOVE, (uint32_t)lane);
+        uint32_t key = R.u32(SSD_STREAM_MOVE, (uint32_t)lane) >> 8;
         int ork = 0;
         for (int b = 0; b < n; ++b) {
             uint32_t kb = (uint32_t)rl((int)key, b);
@@ -245,9 +246,9 @@ __device__ __forceinline__ void move_phase(Env& E, int act, const Rng& R, const 
 // Returns the number of cells cleaned by agent f; 15 lanes = 3 beams x 5 cells.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int clean_beams(Env& E, int f) {
-    const int W = E.W, H = E.S->H;
+    const int W = E.W, H = E.h->H;
     const int pf = rl(E.P, f), of = rl(E.O, f);
-    const int pr = (int)udiv((uint32_t)pf, E.S->magic_W), pc = pf - pr * W;
+    const int pr = (int)udiv((uint32_t)pf, E.h->magic_W), pc = pf - pr * W;
     const int dr = of == O_LEFT ? -1 : of == O_RIGHT ? 1 : 0;
     const int dc = of == O_UP ? -1 : of == O_DOWN ? 1 : 0;
     const int rr = -dc, rc = dr;                      // rotate_right(dir) = np.dot([[0,-1],[1,0]], dir)
@@ -275,34 +276,37 @@ __device__ __forceinline__ int clean_beams(Env& E, int f) {
 // ---------------------------------------------------------------------------------------------------------------
 // custom_map_update: Cleanup (cleanup.py:146-204) / Harvest (harvest.py:86-122).  Returns the uniforms consumed.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
-    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
-    return ((uint64_t)hi << 32) | lo;
+// wave-wide unsigned minimum with DPP (no LDS crossbar): quad swaps, row rotations, then row broadcasts; lane 63 ends with
+// the minimum of all 64 lanes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_min(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = dpp_min<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+    v = dpp_min<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+    v = dpp_min<0x124, 0xF>(v);    // row_ror:4
+    v = dpp_min<0x128, 0xF>(v);    // row_ror:8
+    v = dpp_min<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
+    v = dpp_min<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t* tape_waste) {
     const DevSpec* S = E.S;
+    const DevHead* h = E.h;
     const int lane = E.lane;
-    // compute_probabilities (cleanup.py:189-204), fp64, reference operation order
-    double p_apple = 0, p_waste = 0, wd = 0;
-    const int potential = S->n_waste;
-    if (potential > 0) {
-        const int current = count_cells(E, C_WASTE, false);
-        const int free_area = potential - current;
-        wd = 1 - (double)free_area / (double)potential;
-    }
-    if (!(wd >= S->thr_dep)) {
-        p_waste = S->p_waste;
-        if (wd <= S->thr_res) p_apple = S->p_apple;
-        else p_apple = (1 - (wd - S->thr_res) / (S->thr_dep - S->thr_res)) * S->p_apple;
-    }
+    // compute_probabilities (cleanup.py:189-204): looked up by the waste count in the host-built fp64 tables
+    const int current = h->n_waste > 0 ? count_cells(E, C_WASTE, false) : 0;
+    const double p_apple = S->tab_p_apple[current], p_waste = S->tab_p_waste[current];
     int k = 0;
     // apples: one draw per site that holds neither an agent nor an apple, in site order (cleanup.py:168-174).
     // Apple sites and waste sites are disjoint, so writing 'A' at once is equivalent to the deferred update_map.
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
-        if (ch * kWave < S->n_apple) {
-            const bool in = ch * kWave + lane < S->n_apple;
+        if (ch * kWave < h->n_apple) {
+            const bool in = ch * kWave + lane < h->n_apple;
             const int cell = E.ap[ch];
             const bool elig = in && E.occ[cell] == 0 && E.g[cell] != C_APPLE;
             const uint64_t bal = ballot(elig);
@@ -315,7 +319,7 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
     }
     // waste: at most one spawn, first free site in shuffled order whose draw succeeds (cleanup.py:177-186)
     if (!(fabs(p_waste) <= 1e-8)) {                           // np.isclose(p, 0)
-        const int nw = S->n_waste;
+        const int nw = h->n_waste;
         uint16_t* scratch = (uint16_t*)E.pm;                  // tape mode: rank of each site in the shuffled list
         if (R.tape) {
             for (int base = 0; base < nw; base += kWave) {
@@ -328,19 +332,19 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
             }
             wsync();
         }
-        // free sites and their sort keys (<= 4 chunks of 64 sites)
+        // free sites and their sort keys (<= 4 chunks of 64 sites): composite (24-bit key << 8) | site, unique per site
         int nfree = 0;
-        uint64_t best[4];
+        uint32_t best[4];
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
-            best[ch] = ~0ull;
+            best[ch] = ~0u;
             const int s = ch * kWave + lane;
             if (ch * kWave < nw) {
                 const bool fr = s < nw && E.g[E.ws[ch]] != C_WASTE;
                 nfree += popc64(ballot(fr));
                 if (fr) {
-                    const uint32_t key = R.tape ? (uint32_t)scratch[s] : R.u32(SSD_STREAM_WASTE, (uint32_t)s);
-                    best[ch] = ((uint64_t)key << 32) | (uint32_t)s;
+                    const uint32_t key = R.tape ? (uint32_t)scratch[s] : (R.u32(SSD_STREAM_WASTE, (uint32_t)s) >> 8);
+                    best[ch] = (key << 8) | (uint32_t)s;
                 }
             }
         }
@@ -355,18 +359,16 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
         k += J >= 0 ? J + 1 : nfree;
         if (J >= 0) {
             // the (J+1)-th smallest (key, site) among the free sites
-            uint64_t sel = ~0ull;
+            uint32_t sel = ~0u;
             for (int it = 0; it <= J; ++it) {
-                uint64_t mn = best[0];
+                uint32_t mn = best[0];
 #pragma unroll
                 for (int ch = 1; ch < 4; ++ch) mn = best[ch] < mn ? best[ch] : mn;
+                sel = wave_min_u32(mn);
 #pragma unroll
-                for (int sh = 32; sh >= 1; sh >>= 1) { uint64_t o = shfl_xor64(mn, sh); mn = o < mn ? o : mn; }
-                sel = mn;
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch) if (best[ch] == sel) best[ch] = ~0ull;
+                for (int ch = 0; ch < 4; ++ch) if (best[ch] == sel) best[ch] = ~0u;
             }
-            const int s = (int)(uint32_t)sel;
+            const int s = (int)(sel & 0xFFu);
             if (lane == 0) E.g[S->waste[s]] = C_WASTE;
         }
     }
@@ -376,18 +378,19 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
 
 __device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R) {
     const DevSpec* S = E.S;
-    const int lane = E.lane, W = E.W, H = S->H;
+    const DevHead* h = E.h;
+    const int lane = E.lane, W = E.W, H = h->H;
     int k = 0;
     uint32_t spawn_bits = 0;  // decisions are applied after ALL sites were examined (synchronous update, harvest.py:86-90)
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
-        if (ch * kWave < S->n_apple) {
-            const bool in = ch * kWave + lane < S->n_apple;
+        if (ch * kWave < h->n_apple) {
+            const bool in = ch * kWave + lane < h->n_apple;
             const int cell = E.ap[ch];
             const bool elig = in && E.occ[cell] == 0 && E.g[cell] != C_APPLE;
             const uint64_t bal = ballot(elig);
             if (elig) {
-                const int r = (int)udiv((uint32_t)cell, S->magic_W), c = cell - r * W;
+                const int r = (int)udiv((uint32_t)cell, h->magic_W), c = cell - r * W;
                 int num = 0;  // offsets with j*j + k*k <= APPLE_RADIUS (= 2): the 3x3 block (harvest.py:108-116)
 #pragma unroll
                 for (int j = -1; j <= 1; ++j)
@@ -506,7 +509,8 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
     constexpr bool CODE = FMT == SSD_OBS_CODE;
     constexpr int EPV = 16 / (int)sizeof(T);
     const DevSpec* S = E.S;
-    const int lane = E.lane, n = E.n, W = E.W, V = S->V, VV = S->VV, Wp = S->Wp;
+    const DevHead* h = E.h;
+    const int lane = E.lane, n = E.n, W = E.W, V = h->V, VV = h->VV, Wp = h->Wp;
     const int A = CODE ? VV : 3 * VV;                             // elements per agent
     const int L = n * A;
     const size_t off = (size_t)env * L;                           // element offset of this env's block
@@ -517,12 +521,12 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
     const uint8_t* src = E.pl + head + delta;                     // EPV-byte aligned
     const int nvec = (L - head) / EPV;
     // Rows of a window are dealt to lanes 2^vshift at a time: lane = (row in group, column).
-    const int sh = S->vshift, j = lane & ((1 << sh) - 1), il = lane >> sh, rpi = kWave >> sh;
+    const int sh = h->vshift, j = lane & ((1 << sh) - 1), il = lane >> sh, rpi = kWave >> sh;
     const bool jv = j < V;
     int q_done = 0;
     for (int a = 0; a < n; ++a) {
         const int pa = rl(E.P, a), oa = rl(E.O, a);
-        const int pr = (int)udiv((uint32_t)pa, S->magic_W), pc = pa - pr * W;
+        const int pr = (int)udiv((uint32_t)pa, h->magic_W), pc = pa - pr * W;
         // rotate_view = np.rot90(view, k), k = 0 UP, 1 LEFT, 2 DOWN, 3 RIGHT (map_env.py:795-815): output (i, j) reads
         // view (x, y) = UP (i, j); LEFT (j, V-1-i); DOWN (V-1-i, V-1-j); RIGHT (V-1-j, i).  In the padded class map the
         // window's top-left is (pr, pc), so the source index is the affine form base + i * ci + j * cj.
@@ -568,12 +572,13 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
 template <bool FULL>
 __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& oo) {
     const DevSpec* S = E.S;
-    const int lane = E.lane, n = E.n, W = E.W, v = S->v, Wp = S->Wp;
+    const DevHead* h = E.h;
+    const int lane = E.lane, n = E.n, W = E.W, v = h->v, Wp = h->Wp;
     uint8_t* lut = E.pl + lds_planes_bytes(*S);  // 48 bytes behind the planes
     if (FULL) { if (lane < 48) lut[lane] = S->lut[lane]; }
     // pass 0: zero-padded class map, pm[(r + v) * Wp + (c + v)] = class of map cell (r, c); the padding IS
     // return_view's zero padding (utility_funcs.py:93-116), so the window gather needs no bounds test
-    for (int i = lane * 16; i < S->PMS; i += kWave * 16) *(uint4*)(E.pm + i) = make_uint4(0, 0, 0, 0);
+    for (int i = lane * 16; i < h->PMS; i += kWave * 16) *(uint4*)(E.pm + i) = make_uint4(0, 0, 0, 0);
     wsync();
     for (int cell0 = lane; cell0 < E.HW; cell0 += 4 * kWave) {
         int gc[4], oc[4];
@@ -586,8 +591,8 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
         for (int u = 0; u < 4; ++u) {
             const int cell = cell0 + u * kWave;
             if (cell < E.HW) {
-                const int r = (int)udiv((uint32_t)cell, S->magic_W), c = cell - r * W;
-                E.pm[(r + v) * Wp + c + v] = (uint8_t)class_of<FULL>(gc[u], oc[u], S->kind);
+                const int r = (int)udiv((uint32_t)cell, h->magic_W), c = cell - r * W;
+                E.pm[(r + v) * Wp + c + v] = (uint8_t)class_of<FULL>(gc[u], oc[u], h->kind);
             }
         }
     }
@@ -605,14 +610,14 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
         const int L = 3 * E.HW;
         const size_t off = (size_t)env * L;
         emit<float>(oo.state + off, off, L, lane, [&](int f) -> uint32_t {
-            const int ch = (int)udiv((uint32_t)f, S->magic_HW);
+            const int ch = (int)udiv((uint32_t)f, h->magic_HW);
             const int cell = f - ch * E.HW;
-            const int r = (int)udiv((uint32_t)cell, S->magic_W), c = cell - r * W;
+            const int r = (int)udiv((uint32_t)cell, h->magic_W), c = cell - r * W;
             return class_value<FULL>(lut, E.pm[(r + v) * Wp + c + v], ch);
         });
     }
     if (E.ag) {
-        const int pr = (int)udiv((uint32_t)E.P, S->magic_W), pc = E.P - pr * W;
+        const int pr = (int)udiv((uint32_t)E.P, h->magic_W), pc = E.P - pr * W;
         const size_t o2 = ((size_t)env * n + lane) * 2;
         if (oo.pos) { oo.pos[o2] = (float)pr; oo.pos[o2 + 1] = (float)pc; }                 // get_agent_pos (:917-918)
         if (oo.orient) {                                                                    // ORIENTATIONS vector (:920-921)
@@ -627,14 +632,15 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
 // MODE_OBS (get_obs & co, :917-957)
 // ---------------------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, DevState st, const int32_t* __restrict__ actions,
+__global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec* __restrict__ S, DevState st, const int32_t* __restrict__ actions,
                                                  const uint8_t* __restrict__ env_mask, DevTape tape, DevStepOut so,
                                                  DevObsOut oo, int lds_stride) {
     extern __shared__ uint4 smem[];
     const int lane = threadIdx.x & 63;
+    const DevHead* h = &hd;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: per-env addresses live in SGPRs
     const int env = blockIdx.x * kWavesPerBlock + wave;
-    if (env >= S->N) return;
+    if (env >= h->N) return;
     if (MODE == MODE_RESET && env_mask && !env_mask[env]) return;
 
     // Speed only (never correctness): the 4 waves that share a SIMD get distinct static priorities from their hardware
@@ -648,11 +654,11 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
     }
 
     Env E;
-    E.S = S; E.lane = lane; E.n = S->n; E.W = S->W; E.HW = S->HW; E.GS = S->GS;
+    E.S = S; E.h = h; E.lane = lane; E.n = h->n; E.W = h->W; E.HW = h->HW; E.GS = h->GS;
     E.g = (uint8_t*)smem + (size_t)wave * lds_stride;
     E.occ = E.g + E.GS;
     E.pm = E.occ + E.GS;
-    E.pl = E.pm + S->PMS;
+    E.pl = E.pm + h->PMS;
     E.ag = lane < E.n;
     const int n = E.n, GS = E.GS;
     STAMP(0);
@@ -667,18 +673,18 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
     const int ep_step0 = MODE == MODE_RESET ? 0 : st.ep_step[env];
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
-        E.ap[ch] = (MODE != MODE_OBS && ch * kWave + lane < S->n_apple) ? S->apple[ch * kWave + lane] : 0;
-        E.ws[ch] = (MODE != MODE_OBS && ch * kWave + lane < S->n_waste) ? S->waste[ch * kWave + lane] : 0;
+        E.ap[ch] = (MODE != MODE_OBS && ch * kWave + lane < h->n_apple) ? S->apple[ch * kWave + lane] : 0;
+        E.ws[ch] = (MODE != MODE_OBS && ch * kWave + lane < h->n_waste) ? S->waste[ch * kWave + lane] : 0;
     }
     Rng R;
-    R.tape = S->rng_mode == SSD_RNG_TAPE;
+    R.tape = h->rng_mode == SSD_RNG_TAPE;
     R.ustride = tape.ustride;
     R.tape_u = R.tape ? tape.uniforms + (size_t)env * tape.ustride : nullptr;
     R.err = st.err;
     R.b[0] = R.b[1] = R.b[2] = R.b[3] = 0;
-    if (MODE != MODE_OBS && !R.tape) philox4(0u, 0u, S->env_id_base + (uint32_t)env, epoch, S->seed_lo, S->seed_hi, R.b);
+    if (MODE != MODE_OBS && !R.tape) philox4(0u, 0u, h->env_id_base + (uint32_t)env, epoch, h->seed_lo, h->seed_hi, R.b);
     const uint8_t* tape_order = tape.move_order ? tape.move_order + (size_t)env * n : nullptr;
-    const uint8_t* tape_waste = tape.waste_order ? tape.waste_order + (size_t)env * S->n_waste : nullptr;
+    const uint8_t* tape_waste = tape.waste_order ? tape.waste_order + (size_t)env * h->n_waste : nullptr;
 
     int act = 4, ep_r = 0;
     if (E.ag) {
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
             // setup_agents: agent a takes the last spawn point still free (map_env.py:771-784) = spawn_cell[a];
             // spawn_rotation (:786-793)
             E.P = S->spawn_cell[lane];
-            if (S->spawn_rotation >= 0) E.O = S->spawn_rotation;
+            if (h->spawn_rotation >= 0) E.O = h->spawn_rotation;
             else if (R.tape) E.O = tape.spawn_rot[(size_t)env * n + lane] & 3;
             else E.O = (int)(R.u32(SSD_STREAM_SPAWN_ROT, (uint32_t)lane) >> 30);
         } else {
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
         }
         if (MODE == MODE_STEP || MODE == MODE_STEP_OBS) {
             act = actions[(size_t)env * n + lane];
-            if ((unsigned)act >= (unsigned)S->n_actions) { atomicOr(st.err, ERR_BAD_ACTION); act = 4; }  // KeyError in action_map
+            if ((unsigned)act >= (unsigned)h->n_actions) { atomicOr(st.err, ERR_BAD_ACTION); act = 4; }  // KeyError in action_map
         }
     } else {
         E.P = -1 - lane; E.O = 0;
@@ -709,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
     if (MODE == MODE_RESET) {
         if (E.ag) E.occ[E.P] = (uint8_t)agent_char(lane);   // spawn cells are distinct
         wsync();
-        n_draws = S->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste) : spawn_harvest(E, R);   // map_env.py:313
+        n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste) : spawn_harvest(E, R);   // map_env.py:313
         ep_r = 0;
         if (lane == 0) {
             st.ep_step[env] = 0; st.epoch[env] = epoch + 1;
@@ -737,21 +743,21 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
             for (uint64_t m = fire; m; m &= m - 1) {
                 const int f = first_lane(m);
                 const int af = rl(act, f);
-                if (S->kind == SSD_ENV_CLEANUP && af == 8) {                      // CLEAN (cleanup.py:135-143)
+                if (h->kind == SSD_ENV_CLEANUP && af == 8) {                      // CLEAN (cleanup.py:135-143)
                     const int c = clean_beams(E, f);
                     if (lane == f) cleaned = c;
                 } else if (lane == f) reward -= 1;                                // fire_beam('F') (agent.py:188-190,239-241)
             }
         }
         STAMP(4);
-        n_draws = S->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste) : spawn_harvest(E, R);   // map_env.py:263
+        n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste) : spawn_harvest(E, R);   // map_env.py:263
         STAMP(5);
         // scalars (map_env.py:291-292, 883-914)
         const int apples = count_cells(E, C_APPLE, true);
         const float den = (float)((double)apples / (double)E.HW);
         ep_r += reward;
         const int step = ep_step0 + 1;
-        const bool term = step >= S->episode_limit;
+        const bool term = step >= h->episode_limit;
         if (E.ag) {
             const size_t o = (size_t)env * n + lane;
             if (so.reward) so.reward[o] = (float)reward;
@@ -787,14 +793,14 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevSpec* __restrict__ S, D
         // ---- write the state back ----
         for (int i = lane * 16; i < GS; i += kWave * 16) *(uint4*)(ggrid + i) = *(const uint4*)(E.g + i);
         if (E.ag) {
-            const int pr = (int)udiv((uint32_t)E.P, S->magic_W), pc = E.P - pr * E.W;
+            const int pr = (int)udiv((uint32_t)E.P, h->magic_W), pc = E.P - pr * E.W;
             st.arec[(size_t)env * n + lane] = (uint32_t)pr | ((uint32_t)pc << 8) | ((uint32_t)E.O << 16);
             st.ep_reward[(size_t)env * n + lane] = ep_r;
         }
     }
     STAMP(7);
     if (MODE == MODE_STEP_OBS || MODE == MODE_OBS) {
-        if (S->obs_color == SSD_COLOR_FULL) observe_phase<true>(E, env, oo);
+        if (h->obs_color == SSD_COLOR_FULL) observe_phase<true>(E, env, oo);
         else observe_phase<false>(E, env, oo);
     }
     STAMP(10);
@@ -806,10 +812,10 @@ void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, c
     const int stride = lds_per_wave(hs);
     const size_t lds = (size_t)stride * kWavesPerBlock;
     switch (mode) {
-        case MODE_RESET: hipLaunchKernelGGL(k_env<MODE_RESET>, dim3(blocks), dim3(kBlock), lds, stream, spec, st, actions, env_mask, tape, so, oo, stride); break;
-        case MODE_STEP: hipLaunchKernelGGL(k_env<MODE_STEP>, dim3(blocks), dim3(kBlock), lds, stream, spec, st, actions, env_mask, tape, so, oo, stride); break;
-        case MODE_STEP_OBS: hipLaunchKernelGGL(k_env<MODE_STEP_OBS>, dim3(blocks), dim3(kBlock), lds, stream, spec, st, actions, env_mask, tape, so, oo, stride); break;
-        default: hipLaunchKernelGGL(k_env<MODE_OBS>, dim3(blocks), dim3(kBlock), lds, stream, spec, st, actions, env_mask, tape, so, oo, stride); break;
+        case MODE_RESET: hipLaunchKernelGGL(k_env<MODE_RESET>, dim3(blocks), dim3(kBlock), lds, stream, (const DevHead&)hs, spec, st, actions, env_mask, tape, so, oo, stride); break;
+        case MODE_STEP: hipLaunchKernelGGL(k_env<MODE_STEP>, dim3(blocks), dim3(kBlock), lds, stream, (const DevHead&)hs, spec, st, actions, env_mask, tape, so, oo, stride); break;
+        case MODE_STEP_OBS: hipLaunchKernelGGL(k_env<MODE_STEP_OBS>, dim3(blocks), dim3(kBlock), lds, stream, (const DevHead&)hs, spec, st, actions, env_mask, tape, so, oo, stride); break;
+        default: hipLaunchKernelGGL(k_env<MODE_OBS>, dim3(blocks), dim3(kBlock), lds, stream, (const DevHead&)hs, spec, st, actions, env_mask, tape, so, oo, stride); break;
     }
 }
 
@@ -817,7 +823,8 @@ void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, c
 // state export / import (parity tests, KATs, warm starts)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void k_export(DevSpec const* S, DevState st, ssd_state d) {
-    const int N = S->N, n = S->n, HW = S->HW, GS = S->GS;
+    const DevHead* h = S;
+    const int N = h->N, n = h->n, HW = h->HW, GS = h->GS;
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
     if (d.grid) for (size_t i = tid; i < (size_t)N * HW; i += nt) { size_t e = i / HW; d.grid[i] = st.grid[e * GS + (i - e * HW)]; }
     for (size_t i = tid; i < (size_t)N * n; i += nt) {
@@ -833,7 +840,8 @@ __global__ void k_export(DevSpec const* S, DevState st, ssd_state d) {
 }
 
 __global__ void k_import(DevSpec const* S, DevState st, ssd_state s) {
-    const int N = S->N, n = S->n, HW = S->HW, GS = S->GS;
+    const DevHead* h = S;
+    const int N = h->N, n = h->n, HW = h->HW, GS = h->GS;
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
     if (s.grid) for (size_t i = tid; i < (size_t)N * HW; i += nt) {
         size_t e = i / HW;
@@ -844,7 +852,7 @@ __global__ void k_import(DevSpec const* S, DevState st, ssd_state s) {
         uint32_t rec = st.arec[i];
         if (s.pos) {
             int r = s.pos[2 * i], c = s.pos[2 * i + 1];
-            r = r < 0 ? 0 : r >= S->H ? S->H - 1 : r; c = c < 0 ? 0 : c >= S->W ? S->W - 1 : c;
+            r = r < 0 ? 0 : r >= h->H ? h->H - 1 : r; c = c < 0 ? 0 : c >= h->W ? h->W - 1 : c;
             rec = (rec & ~0xFFFFu) | (uint32_t)r | ((uint32_t)c << 8);
         }
         if (s.orient) rec = (rec & ~0x30000u) | ((uint32_t)(s.orient[i] & 3) << 16);

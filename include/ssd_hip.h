@@ -226,7 +226,7 @@ int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uin
  *   mix32(x): x ^= x >> 17; x *= 0xed5ad4bb; x ^= x >> 11; x *= 0xac4c1b51; x ^= x >> 15; x *= 0x31848bab; x ^= x >> 14
  *             (the "triple32" integer hash, a bijection on 32 bits)
  *   uniform number k of the call: u = (x(UNIFORM, k) >> 8) * 2^-24 as double, compared `u < p` in fp64
- *   shuffles: stable sort of the items by (x(stream, item index), item index)
+ *   shuffles: stable sort of the items by (x(stream, item index) >> 8, item index)   (24-bit key: key | index fits 32 bits)
  *   spawn rotation of agent a: x(SPAWN_ROT, a) >> 30                                                            */
 enum { SSD_STREAM_UNIFORM = 0, SSD_STREAM_MOVE = 1, SSD_STREAM_WASTE = 2, SSD_STREAM_SPAWN_ROT = 3 };
 

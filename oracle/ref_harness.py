@@ -127,7 +127,7 @@ class RefEnv:
                 lst[:] = [by[i] for i in self.force_move_order]
             elif counter:
                 idx = [int(a.split("-")[1]) for a, _ in lst]
-                order = sorted(range(len(lst)), key=lambda i: (u32(STREAM_MOVE, idx[i]), idx[i]))
+                order = sorted(range(len(lst)), key=lambda i: (u32(STREAM_MOVE, idx[i]) >> 8, idx[i]))
                 lst[:] = [lst[i] for i in order]
             else:
                 o_shuffle(lst)
@@ -154,7 +154,7 @@ class RefEnv:
                 raise NotImplementedError("random_spawn_point shuffles are not part of tape v1")
             if counter:
                 idx = [self.waste_index[tuple(p)] for p in lst]
-                order = sorted(range(len(lst)), key=lambda i: (u32(STREAM_WASTE, idx[i]), idx[i]))
+                order = sorted(range(len(lst)), key=lambda i: (u32(STREAM_WASTE, idx[i]) >> 8, idx[i]))
                 lst[:] = [lst[i] for i in order]
             else:
                 o_pyshuffle(lst)
