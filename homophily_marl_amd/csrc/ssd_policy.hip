@@ -114,12 +114,13 @@ __global__ __launch_bounds__(256) void k_encoder(const float* __restrict__ obs, 
 // [rows, C*P] x [C*P, F] GEMM and goes to hipBLASLt.  Rows can be written agent-major, and the observation can be
 // copied into the episode storage obs[env, t] on the way (see k_encoder).
 // ---------------------------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(256) void k_conv_leaky(const float* __restrict__ obs, int rows, int V, const float* __restrict__ cw,
+template <int C, int VT>   // VT: compile-time view edge (0 = runtime), so the index divisions become multiplies
+__global__ __launch_bounds__(256) void k_conv_leaky(const float* __restrict__ obs, int rows, int Vrt, const float* __restrict__ cw,
                                                     const float* __restrict__ cb, float* __restrict__ out, int n_agents, int agent_major,
                                                     float* __restrict__ store, long store_env_stride, const int64_t* __restrict__ store_t) {
     extern __shared__ float sm[];
     const int row = blockIdx.x, tid = threadIdx.x;
+    const int V = VT ? VT : Vrt;
     const int VV = V * V, O = V - 2, P = O * O, K = C * P, L = 3 * VV;
     float* in = sm;               // [L]
     float* w = sm + L;            // [C * 27] + [C]
@@ -254,8 +255,9 @@ void launch_encoder(const float* obs, int rows, int V, const float* cw, const fl
 void launch_conv_leaky(const float* obs, int rows, int V, const float* cw, const float* cb, float* out, int n_agents, int agent_major,
                        float* store, long store_env_stride, const int64_t* store_t, hipStream_t s) {
     const size_t lds = (size_t)(3 * V * V + 6 * 27 + 6) * sizeof(float);
-    hipLaunchKernelGGL((k_conv_leaky<6>), dim3(rows), dim3(256), lds, s, obs, rows, V, cw, cb, out, n_agents, agent_major, store,
-                       store_env_stride, store_t);
+    if (V == 15) hipLaunchKernelGGL((k_conv_leaky<6, 15>), dim3(rows), dim3(256), lds, s, obs, rows, V, cw, cb, out, n_agents, agent_major, store, store_env_stride, store_t);
+    else if (V == 31) hipLaunchKernelGGL((k_conv_leaky<6, 31>), dim3(rows), dim3(256), lds, s, obs, rows, V, cw, cb, out, n_agents, agent_major, store, store_env_stride, store_t);
+    else hipLaunchKernelGGL((k_conv_leaky<6, 0>), dim3(rows), dim3(256), lds, s, obs, rows, V, cw, cb, out, n_agents, agent_major, store, store_env_stride, store_t);
 }
 void launch_store_step(const ssd_store_step* a, hipStream_t s) {
     StoreStep k;
