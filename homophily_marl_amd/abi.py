@@ -111,6 +111,8 @@ HIP_SIGNATURES["ssd_conv_leaky"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, 
                                              C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_store_step_launch"] = (C.c_int, [C.POINTER(SsdStoreStep), C.c_void_p])
 HIP_SIGNATURES["ssd_gru_gates"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
+HIP_SIGNATURES["ssd_gru_gates_fwd"] = (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_void_p])
+HIP_SIGNATURES["ssd_gru_gates_bwd"] = (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_dueling_pick"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32,
                                                C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_poll_error"] = (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)])

@@ -350,6 +350,19 @@ int ssd_gru_gates(const float* gi, const float* gh, float* h, int32_t rows, int3
     return launched();
 }
 
+int ssd_gru_gates_fwd(const float* gi, const float* gh, const float* h, float* h_new, float* rzn, int32_t rows, int32_t hidden, void* stream) {
+    if (!gi || !gh || !h || !h_new || !rzn || rows < 1 || hidden < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    launch_gru_fwd_train(gi, gh, h, h_new, rzn, rows, hidden, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_gru_gates_bwd(const float* dh_new, const float* rzn, const float* gh, const float* h, float* d_gi, float* d_gh, float* dh_prev,
+                      int32_t rows, int32_t hidden, void* stream) {
+    if (!dh_new || !rzn || !gh || !h || !d_gi || !d_gh || !dh_prev || rows < 1 || hidden < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    launch_gru_bwd(dh_new, rzn, gh, h, d_gi, d_gh, dh_prev, rows, hidden, (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uint8_t* avail, const float* epsilon, const int64_t* step,
                      uint32_t seed, int32_t n_agents, int32_t batch, int32_t pairs, int64_t* actions, float* q_out, void* stream) {
     if (!av || !epsilon || !step || !actions || rows < 1 || n_actions < 1 || n_agents < 1 || batch < 1) return fail(SSD_ERR_INVALID, "bad argument");

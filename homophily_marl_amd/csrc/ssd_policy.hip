@@ -198,6 +198,47 @@ __global__ void k_gru_gates(const float* __restrict__ gi, const float* __restric
     }
 }
 
+// Training variants: forward keeps (r, z, n) for the backward pass; backward maps dL/dh_new to dL/dgi, dL/dgh, dL/dh_prev.
+//   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) n + z h
+__global__ void k_gru_fwd_train(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ h,
+                                float* __restrict__ h_new, float* __restrict__ rzn, int R, int H) {
+    const size_t total = (size_t)R * H;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = idx / H;
+        const int k = (int)(idx - r * H);
+        const float* a = gi + r * 3 * H;
+        const float* b = gh + r * 3 * H;
+        const float rg = 1.f / (1.f + expf(-(a[k] + b[k])));
+        const float zg = 1.f / (1.f + expf(-(a[H + k] + b[H + k])));
+        const float ng = tanhf(a[2 * H + k] + rg * b[2 * H + k]);
+        float* s = rzn + r * 3 * H;
+        s[k] = rg; s[H + k] = zg; s[2 * H + k] = ng;
+        h_new[idx] = (1.f - zg) * ng + zg * h[idx];
+    }
+}
+__global__ void k_gru_bwd(const float* __restrict__ dh, const float* __restrict__ rzn, const float* __restrict__ gh,
+                          const float* __restrict__ h, float* __restrict__ d_gi, float* __restrict__ d_gh, float* __restrict__ dh_prev,
+                          int R, int H) {
+    const size_t total = (size_t)R * H;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = idx / H;
+        const int k = (int)(idx - r * H);
+        const float* s = rzn + r * 3 * H;
+        const float rg = s[k], zg = s[H + k], ng = s[2 * H + k];
+        const float g = dh[idx];
+        const float ghn = gh[r * 3 * H + 2 * H + k];
+        const float d_n = g * (1.f - zg) * (1.f - ng * ng);       // through tanh
+        const float d_z = g * (h[idx] - ng) * zg * (1.f - zg);    // through sigmoid
+        const float d_r = d_n * ghn * rg * (1.f - rg);
+        float* a = d_gi + r * 3 * H;
+        float* b = d_gh + r * 3 * H;
+        a[k] = d_r; b[k] = d_r;
+        a[H + k] = d_z; b[H + k] = d_z;
+        a[2 * H + k] = d_n; b[2 * H + k] = d_n * rg;
+        dh_prev[idx] = g * zg;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Dueling head + epsilon-greedy.  av [R, A + 1]: A advantages then the state value.  avail [A] (u8, same for all rows,
 // nullptr = all available).  Random numbers: the counter generator of include/ssd_hip.h keyed by (seed, *step, row).
@@ -273,6 +314,15 @@ void launch_store_step(const ssd_store_step* a, hipStream_t s) {
 void launch_gru_gates(const float* gi, const float* gh, float* h, int R, int H, hipStream_t s) {
     size_t total = (size_t)R * H; int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_gru_gates, dim3(blocks), dim3(256), 0, s, gi, gh, h, R, H);
+}
+void launch_gru_fwd_train(const float* gi, const float* gh, const float* h, float* h_new, float* rzn, int R, int H, hipStream_t s) {
+    size_t total = (size_t)R * H; int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_gru_fwd_train, dim3(blocks), dim3(256), 0, s, gi, gh, h, h_new, rzn, R, H);
+}
+void launch_gru_bwd(const float* dh, const float* rzn, const float* gh, const float* h, float* d_gi, float* d_gh, float* dh_prev, int R,
+                    int H, hipStream_t s) {
+    size_t total = (size_t)R * H; int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_gru_bwd, dim3(blocks), dim3(256), 0, s, dh, rzn, gh, h, d_gi, d_gh, dh_prev, R, H);
 }
 void launch_dueling_pick(const float* av, int R, int A, const uint8_t* avail, const float* eps, const int64_t* step, uint32_t seed,
                          int n_agents, int B, int pairs, int64_t* actions, float* q_out, hipStream_t s) {

@@ -10,6 +10,8 @@ import torch as th
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import ops
+
 
 class HomophilyAgent(nn.Module):
     def __init__(self, input_shape, args):
@@ -116,16 +118,12 @@ class HomophilyAgent(nn.Module):
         wie, whe, bie, bhe = self._gru_weights("env")
         wii, whi, bii, bhi = self._gru_weights("inc")
         gi = th.cat([th.baddbmm(bie, xe, wie), th.baddbmm(bii, xi, wii)], dim=0).reshape(2 * n, T, B, 3 * H)
+        gi = gi.transpose(0, 1).contiguous()                                           # [T, 2n, B, 3H]: gi[t] is one contiguous block
         wh, bh = th.cat([whe, whi], dim=0), th.cat([bhe, bhi], dim=0)                 # [2n, H, 3H], [2n, 1, 3H]
         h = inputs.new_zeros(2 * n, B, H)
         hs = []
         for t in range(T):
-            gh = th.baddbmm(bh, h, wh)
-            g = gi[:, t]
-            r = th.sigmoid(g[..., :H] + gh[..., :H])
-            z = th.sigmoid(g[..., H:2 * H] + gh[..., H:2 * H])
-            cand = th.tanh(g[..., 2 * H:] + r * gh[..., 2 * H:])
-            h = (1 - z) * cand + z * h
+            h = ops.gru_gates(gi[t], th.baddbmm(bh, h, wh), h)                        # fused gate kernel on the GPU
             hs.append(h)
         hs = th.stack(hs, dim=1)                                                       # [2n, T, B, H]
         he, hi = hs[:n].reshape(n, T * B, H), hs[n:].reshape(n, T * B, H)

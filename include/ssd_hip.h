@@ -215,6 +215,11 @@ typedef struct ssd_store_step {
 } ssd_store_step;
 int ssd_store_step_launch(const ssd_store_step* args, void* stream);
 int ssd_gru_gates(const float* gi, const float* gh, float* h, int32_t rows, int32_t hidden, void* stream);
+/* Training forms of the GRU gate arithmetic: forward also stores (r, z, n) [rows, 3 * hidden]; backward turns dL/dh_new into
+ * dL/dgi, dL/dgh [rows, 3 * hidden] and the direct part of dL/dh_prev [rows, hidden]. */
+int ssd_gru_gates_fwd(const float* gi, const float* gh, const float* h, float* h_new, float* rzn, int32_t rows, int32_t hidden, void* stream);
+int ssd_gru_gates_bwd(const float* dh_new, const float* rzn, const float* gh, const float* h, float* d_gi, float* d_gh, float* dh_prev,
+                      int32_t rows, int32_t hidden, void* stream);
 int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uint8_t* avail, const float* epsilon, const int64_t* step,
                      uint32_t seed, int32_t n_agents, int32_t batch, int32_t pairs, int64_t* actions, float* q_out, void* stream);
 
