@@ -154,7 +154,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": result["dtype"], "data": "synthetic",
             "config": dict({"workload": result["workload"], "env": "cleanup", "map": "default5", "n_agents": n,
                             "n_env_per_gpu": N, "episode_limit": T, "rng": "counter(philox4x32-10, seed 1)",
-                            "parallelism": "dp%d (env shards, no data-path collective)" % world}, **result["extra"]),
+                            "parallelism": ("dp%d: env shards, no collective in the rollout" % world) +
+                                           ("; 1 flat-gradient all-reduce + 2 scalars per train step" if args.workload == "e2e" else "")},
+                           **result["extra"]),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_avg_us": result["kern_avg_us"], "kernel_median_us": result["kern_med_us"],
