@@ -18,7 +18,7 @@ from . import abi
 
 
 class FastPolicy:
-    def __init__(self, mac, n_env, avail_mask_u8, seed=0):
+    def __init__(self, mac, n_env, avail_mask_u8, seed=0, actions_out=None, actions_inc_out=None, share_packs_from=None):
         self.mac, self.agent, self.a = mac, mac.agent, mac.args
         a = self.a
         assert a.rgb_input and a.conv_out == 6 and a.obs_dim_net == 32 and a.conv_kernel == 3 and a.conv_stride == 1
@@ -31,12 +31,17 @@ class FastPolicy:
         self.inputs = th.zeros(n, N, self.inp, **f32)          # [feat | tail], agent-major
         self.h_env = th.zeros(n, N, H, **f32)
         self.h_inc = th.zeros(n, N, H, **f32)
-        self.actions = th.zeros(N, n, dtype=th.long, device=self.dev)
-        self.actions_inc = th.zeros(N, n, n, dtype=th.long, device=self.dev)
+        # outputs may be slices of a caller-owned full-batch buffer (env groups evaluated on separate streams)
+        self.actions = th.zeros(N, n, dtype=th.long, device=self.dev) if actions_out is None else actions_out
+        self.actions_inc = th.zeros(N, n, n, dtype=th.long, device=self.dev) if actions_inc_out is None else actions_inc_out
+        assert self.actions.is_contiguous() and self.actions_inc.is_contiguous()
         self.avail = avail_mask_u8.to(device=self.dev, dtype=th.uint8).contiguous()
         self.seed = seed & 0xFFFFFFFF
         self.arange_n = th.arange(n, device=self.dev).unsqueeze(1)
-        self.pack()
+        if share_packs_from is not None:
+            self.p = share_packs_from.p          # same weights: one packed copy serves every group
+        else:
+            self.pack()
 
     def _stream(self):
         return th.cuda.current_stream(self.dev).cuda_stream

@@ -57,7 +57,25 @@ class HipGraphRunner(HipVecRunner):
         self.fast = None
         if getattr(a, "fast_policy", True):
             from ..fast_policy import FastPolicy
-            self.fast = FastPolicy(self.mac, N, avail, seed=int(self.env.native.cfg.seed) * 2654435761 + 12345)
+            # Optionally the policy work of a timestep is evaluated per env GROUP on separate streams (fork/join inside the
+            # captured graph) around the single full-batch env launch.  Measured on MI355X / ROCm 7.2: no gain (the graph
+            # runs the branches back to back), so the default is one group.
+            G = int(getattr(a, "policy_groups", 1))
+            if N % G or N // G < 1:
+                G = 1
+            self.groups, hsz = G, N // G
+            self.actions_full = th.zeros(N, n, dtype=th.long, device=dev)
+            self.actions_inc_full = th.zeros(N, n, n, dtype=th.long, device=dev)
+            seed = int(self.env.native.cfg.seed) * 2654435761 + 12345
+            self.fasts = []
+            for g in range(G):
+                sl = slice(g * hsz, (g + 1) * hsz)
+                self.fasts.append(FastPolicy(self.mac, hsz, avail, seed=seed + 0x9E3779B1 * g, actions_out=self.actions_full[sl],
+                                             actions_inc_out=self.actions_inc_full[sl],
+                                             share_packs_from=self.fasts[0] if g else None))
+            self.fast = self.fasts[0]
+            self.gslices = [slice(g * hsz, (g + 1) * hsz) for g in range(G)]
+            self.side_streams = [th.cuda.Stream(device=dev) for _ in range(G)] if G > 1 else []
             self._zeros_nn = th.zeros(N, n, device=dev)
             self._ss, self._ss_last = self._make_store_args(True), self._make_store_args(False)
         self._ready = True
@@ -72,14 +90,32 @@ class HipGraphRunner(HipVecRunner):
         rand = idx_table[r] if idx_table is not None else r
         return th.where(u < self.eps, rand, greedy)
 
+    def _fork(self, fn):
+        """run fn(g) for every env group, each on its own stream, then join (capturable fork/join)."""
+        if self.groups == 1:
+            fn(0)
+            return
+        main = th.cuda.current_stream(self.env.device)
+        for g, s in enumerate(self.side_streams):
+            s.wait_stream(main)
+            with th.cuda.stream(s):
+                fn(g)
+        for s in self.side_streams:
+            main.wait_stream(s)
+
     def _select_fast(self, store_env_step):
         """_select with the FastPolicy kernels: the encoder writes obs[:, t] into the storage while it reads it, and ONE
         store-step launch writes the nine small fields."""
-        a, st, fp = self.args, self.store.data.transition_data, self.fast
+        st = self.store.data.transition_data
         td = self.t_dev
         obs, pos, orient = self.cur["obs"], self.cur["pos"], self.cur["orient"]
-        actions = fp.act_env(obs, self.prev_actions, self.prev_reward, self.prev_inc, pos, self.eps, self.rng_ctr,
-                             store_obs=st["obs"], store_t=td)
+
+        def env_head(g):
+            sl = self.gslices[g]
+            self.fasts[g].act_env(obs[sl], self.prev_actions[sl], self.prev_reward[sl], self.prev_inc[sl], pos[sl], self.eps,
+                                  self.rng_ctr, store_obs=st["obs"][sl], store_t=td)
+        self._fork(env_head)
+        actions = self.actions_full
         pos_t, orient_t = pos.clone(), orient.clone()                   # forward_inc sees the PRE-step pose (controller :78-82)
         ss = self._ss if store_env_step else self._ss_last
         if store_env_step:
@@ -88,11 +124,16 @@ class HipGraphRunner(HipVecRunner):
             self.ep_return += reward
         else:
             reward = clean = den = self._zeros_nn
-        actions_inc = fp.act_inc(actions, pos_t, orient_t, reward, clean, den, self.eps, self.rng_ctr)
+
+        def inc_head(g):
+            sl = self.gslices[g]
+            self.fasts[g].act_inc(actions[sl], pos_t[sl], orient_t[sl], reward[sl], clean[sl], den[sl], self.eps, self.rng_ctr)
+        self._fork(inc_head)
+        actions_inc = self.actions_inc_full
         self.rng_ctr += 1
         ss.pos, ss.orient = pos_t.data_ptr(), orient_t.data_ptr()
         self._keep_pose = (pos_t, orient_t)
-        abi.check(fp.lib, fp.lib.ssd_store_step_launch(C.byref(ss), th.cuda.current_stream(self.env.device).cuda_stream))
+        abi.check(self.fast.lib, self.fast.lib.ssd_store_step_launch(C.byref(ss), th.cuda.current_stream(self.env.device).cuda_stream))
         if store_env_step:
             self.prev_actions.copy_(actions)
             self.prev_reward.copy_(reward)
@@ -104,7 +145,7 @@ class HipGraphRunner(HipVecRunner):
         ss = abi.SsdStoreStep()
         ss.t_index = self.t_dev.data_ptr()
         ss.n_env, ss.n_agents, ss.n_actions, ss.t_slots = self.batch_size, self.args.n_agents, self.args.n_actions, self.episode_limit + 1
-        ss.actions, ss.actions_inc = fp.actions.data_ptr(), fp.actions_inc.data_ptr()
+        ss.actions, ss.actions_inc = self.actions_full.data_ptr(), self.actions_inc_full.data_ptr()
         ss.dst_pos, ss.dst_orient = st["agent_pos"].data_ptr(), st["agent_orientation"].data_ptr()
         ss.dst_actions, ss.dst_actions_onehot, ss.dst_actions_inc = st["actions"].data_ptr(), st["actions_onehot"].data_ptr(), st["actions_inc"].data_ptr()
         if with_step_outputs:
@@ -167,8 +208,9 @@ class HipGraphRunner(HipVecRunner):
         self.prev_actions.fill_(-1); self.prev_reward.zero_(); self.prev_inc.zero_()
         self.h_env.zero_(); self.h_inc.zero_(); self.ep_return.zero_()
         if self.fast is not None:
-            self.fast.reset()
-            self.fast.pack()          # the learner may have stepped the weights since the last episode
+            for fp in self.fasts:
+                fp.reset()
+            self.fast.pack()          # the learner may have stepped the weights since the last episode (packs are shared)
         sel = self.mac.action_selector
         sel.epsilon = 0.0 if test_mode else sel.schedule.eval(self.t_env)
         zero_after = getattr(self.args, "epsilon_zero", None)

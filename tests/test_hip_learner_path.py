@@ -260,7 +260,8 @@ def test_fast_policy_matches_torch_controller():
     env.close()
 
 
-def test_fast_graph_runner_stores_a_consistent_batch():
+@pytest.mark.parametrize("groups", [1, 2])
+def test_fast_graph_runner_stores_a_consistent_batch(groups):
     """hip_graph + FastPolicy (encoder-fused obs store, store-step kernel): the stored batch must be self-consistent
     with the env dynamics (replayed on the CPU oracle with the stored actions), exactly like the generic runner's."""
     from homophily_marl_amd.run import load_config, setup
@@ -269,7 +270,8 @@ def test_fast_graph_runner_stores_a_consistent_batch():
     th.manual_seed(0)
     cfg = load_config("cleanup", overrides=dict(
         runner="hip_graph", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False, store_state=False,
-        env_args=dict(num_agents=n, map="default5", episode_limit=T, seed=21), use_cuda=True, save_model=False, runner_stats=False))
+        env_args=dict(num_agents=n, map="default5", episode_limit=T, seed=21), use_cuda=True, save_model=False, runner_stats=False,
+        policy_groups=groups))
     ctx = setup(cfg)
     orc = OracleEnv("cleanup", map="default5", num_agents=n, n_env=N, view_size=7, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=21)
     for ep in range(3):                                  # eager, captured, replayed
