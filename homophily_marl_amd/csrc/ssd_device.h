@@ -54,6 +54,7 @@ struct DevState {
     int32_t* ep_reward;  // [N, n]
     int32_t* ep_step;    // [N]
     uint32_t* epoch;     // [N]
+    uint32_t* counts;    // [N] waste cells << 16 | apple cells of the grid, 0xFFFFFFFF = unknown (recount)
     int32_t* err;        // [1] sticky error bits
     unsigned long long* stamps;  // diagnostic builds only (-DSSD_STAMPS): [N, 16] s_memtime per phase; else null
 };
@@ -84,8 +85,8 @@ enum : int { ERR_BAD_ACTION = 1, ERR_BAD_TAPE = 2, ERR_KEYERROR = 4, ERR_TAPE_OV
 
 // LDS bytes one wave needs: grid | agent overlay | padded class map | output planes (+16 alignment slack) | colour lut.
 // The class map + planes region doubles as scratch for the tape-mode waste ranks (2 * 256 bytes) during the step.
-__host__ __device__ inline int lds_planes_bytes(const DevSpec& s) { return ((s.n * 3 * s.VV + 16) + 15) & ~15; }
-__host__ __device__ inline int lds_per_wave(const DevSpec& s) {
+__host__ __device__ inline int lds_planes_bytes(const DevHead& s) { return ((s.n * 3 * s.VV + 16) + 15) & ~15; }
+__host__ __device__ inline int lds_per_wave(const DevHead& s) {
     int obs = s.PMS + lds_planes_bytes(s);
     if (obs < 512) obs = 512;
     return 2 * s.GS + obs + 64;

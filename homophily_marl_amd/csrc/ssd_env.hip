@@ -293,12 +293,12 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-__device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t* tape_waste) {
+__device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t* tape_waste, int& n_waste_cells, int& n_apple_cells) {
     const DevSpec* S = E.S;
     const DevHead* h = E.h;
     const int lane = E.lane;
     // compute_probabilities (cleanup.py:189-204): looked up by the waste count in the host-built fp64 tables
-    const int current = h->n_waste > 0 ? count_cells(E, C_WASTE, false) : 0;
+    const int current = h->n_waste > 0 ? n_waste_cells : 0;    // kept incrementally in the env state
     const double p_apple = S->tab_p_apple[current], p_waste = S->tab_p_waste[current];
     int k = 0;
     // apples: one draw per site that holds neither an agent nor an apple, in site order (cleanup.py:168-174).
@@ -310,10 +310,13 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
             const int cell = E.ap[ch];
             const bool elig = in && E.occ[cell] == 0 && E.g[cell] != C_APPLE;
             const uint64_t bal = ballot(elig);
+            bool grow = false;
             if (elig && p_apple > 0) {
                 const double u = R.uniform(k + (int)lanes_below(bal));
-                if (u < p_apple) E.g[cell] = C_APPLE;
+                grow = u < p_apple;
+                if (grow) E.g[cell] = C_APPLE;
             }
+            if (p_apple > 0) n_apple_cells += popc64(ballot(grow));
             k += popc64(bal);
         }
     }
@@ -370,13 +373,14 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
             }
             const int s = (int)(sel & 0xFFu);
             if (lane == 0) E.g[S->waste[s]] = C_WASTE;
+            n_waste_cells += 1;
         }
     }
     wsync();
     return k;
 }
 
-__device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R) {
+__device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R, int& n_apple_cells) {
     const DevSpec* S = E.S;
     const DevHead* h = E.h;
     const int lane = E.lane, W = E.W, H = h->H;
@@ -403,6 +407,7 @@ __device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R) {
                 const double u = R.uniform(k + (int)lanes_below(bal));
                 if (u < p) spawn_bits |= 1u << ch;
             }
+            n_apple_cells += popc64(ballot((spawn_bits >> ch) & 1));
             k += popc64(bal);
         }
     }
@@ -523,6 +528,10 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
     // Rows of a window are dealt to lanes 2^vshift at a time: lane = (row in group, column).
     const int sh = h->vshift, j = lane & ((1 << sh) - 1), il = lane >> sh, rpi = kWave >> sh;
     const bool jv = j < V;
+    if (!CODE && !FULL) {   // simplified palette: at most one of the three channel bytes of a cell is non-zero -> zero all, set one
+        for (int i = lane * 16; i < lds_planes_bytes(*h); i += kWave * 16) *(uint4*)(E.pl + i) = make_uint4(0, 0, 0, 0);
+        wsync();
+    }
     int q_done = 0;
     for (int a = 0; a < n; ++a) {
         const int pa = rl(E.P, a), oa = rl(E.O, a);
@@ -551,9 +560,8 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
                         E.pl[du] = (uint8_t)(c == 2 ? 1 : c == 1 ? 2 : c == 4 ? 3 : 0);
                     } else if (FULL) {
                         E.pl[du] = lut[c * 3]; E.pl[du + VV] = lut[c * 3 + 1]; E.pl[du + 2 * VV] = lut[c * 3 + 2];
-                    } else {
-                        E.pl[du] = (uint8_t)(0 - (c & 1)); E.pl[du + VV] = (uint8_t)(0 - ((c >> 1) & 1));
-                        E.pl[du + 2 * VV] = (uint8_t)(0 - ((c >> 2) & 1));
+                    } else if (c) {
+                        E.pl[du + (c >> 1) * VV] = 255;     // class bit 1 / 2 / 4 = channel R / G / B = plane 0 / 1 / 2
                     }
                 }
             }
@@ -631,7 +639,8 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
 // the kernel: MODE_RESET (_reset, map_env.py:297-326), MODE_STEP / MODE_STEP_OBS (_step + step, :227-295,:874-915),
 // MODE_OBS (get_obs & co, :917-957)
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE>
+// NT: compile-time number of agents (0 = runtime): the per-agent readlane loops unroll completely
+template <int MODE, int NT>
 __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec* __restrict__ S, DevState st, const int32_t* __restrict__ actions,
                                                  const uint8_t* __restrict__ env_mask, DevTape tape, DevStepOut so,
                                                  DevObsOut oo, int lds_stride) {
@@ -654,7 +663,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
     }
 
     Env E;
-    E.S = S; E.h = h; E.lane = lane; E.n = h->n; E.W = h->W; E.HW = h->HW; E.GS = h->GS;
+    E.S = S; E.h = h; E.lane = lane; E.n = NT ? NT : h->n; E.W = h->W; E.HW = h->HW; E.GS = h->GS;
     E.g = (uint8_t*)smem + (size_t)wave * lds_stride;
     E.occ = E.g + E.GS;
     E.pm = E.occ + E.GS;
@@ -671,6 +680,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
     }
     const uint32_t epoch = st.epoch[env];
     const int ep_step0 = MODE == MODE_RESET ? 0 : st.ep_step[env];
+    const uint32_t counts0 = (MODE == MODE_STEP || MODE == MODE_STEP_OBS) ? st.counts[env] : 0u;
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
         E.ap[ch] = (MODE != MODE_OBS && ch * kWave + lane < h->n_apple) ? S->apple[ch * kWave + lane] : 0;
@@ -715,9 +725,13 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
     if (MODE == MODE_RESET) {
         if (E.ag) E.occ[E.P] = (uint8_t)agent_char(lane);   // spawn cells are distinct
         wsync();
-        n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste) : spawn_harvest(E, R);   // map_env.py:313
+        int n_waste_cells = h->kind == SSD_ENV_CLEANUP ? h->n_waste : 0;       // custom_reset: all waste present / all apples grown
+        int n_apple_cells = h->kind == SSD_ENV_CLEANUP ? 0 : h->n_apple;
+        n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste, n_waste_cells, n_apple_cells)
+                                             : spawn_harvest(E, R, n_apple_cells);                        // map_env.py:313
         ep_r = 0;
         if (lane == 0) {
+            st.counts[env] = ((uint32_t)n_waste_cells << 16) | (uint32_t)n_apple_cells;
             st.ep_step[env] = 0; st.epoch[env] = epoch + 1;
             if (so.n_draws) so.n_draws[env] = n_draws;
             if (R.tape && n_draws > R.ustride) atomicOr(st.err, ERR_TAPE_OVERRUN);
@@ -725,6 +739,11 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
     }
     if (MODE == MODE_STEP || MODE == MODE_STEP_OBS) {
         int reward = 0, cleaned = 0;
+        // waste / apple cell counts of the grid: carried in the env state and updated by what this step changes
+        // (recounted when the state was imported)
+        int n_waste_cells, n_apple_cells;
+        if (counts0 == 0xFFFFFFFFu) { n_waste_cells = count_cells(E, C_WASTE, false); n_apple_cells = count_cells(E, C_APPLE, false); }
+        else { n_waste_cells = (int)(counts0 >> 16); n_apple_cells = (int)(counts0 & 0xFFFFu); }
         move_phase(E, act, R, tape_order);                                       // map_env.py:251
         STAMP(2);
         // consume (map_env.py:253-256, agent.py:195-201,250-256) runs in id order, so only the lowest id on a cell eats;
@@ -732,7 +751,9 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
         {
             bool lower = false, higher = false;
             for (int b = 0; b < n; ++b) { const int pb = rl(E.P, b); lower |= (b < lane && pb == E.P); higher |= (b > lane && pb == E.P); }
-            if (E.ag && !lower && E.g[E.P] == C_APPLE) { reward += 1; E.g[E.P] = C_EMPTY; }
+            const bool eats = E.ag && !lower && E.g[E.P] == C_APPLE;
+            if (eats) { reward += 1; E.g[E.P] = C_EMPTY; }
+            n_apple_cells -= popc64(ballot(eats));
             if (E.ag && !higher) E.occ[E.P] = (uint8_t)agent_char(lane);
         }
         wsync();
@@ -746,14 +767,17 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
                 if (h->kind == SSD_ENV_CLEANUP && af == 8) {                      // CLEAN (cleanup.py:135-143)
                     const int c = clean_beams(E, f);
                     if (lane == f) cleaned = c;
+                    n_waste_cells -= c;
                 } else if (lane == f) reward -= 1;                                // fire_beam('F') (agent.py:188-190,239-241)
             }
         }
         STAMP(4);
-        n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste) : spawn_harvest(E, R);   // map_env.py:263
+        n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste, n_waste_cells, n_apple_cells)
+                                             : spawn_harvest(E, R, n_apple_cells);                        // map_env.py:263
         STAMP(5);
-        // scalars (map_env.py:291-292, 883-914)
-        const int apples = count_cells(E, C_APPLE, true);
+        // scalars (map_env.py:291-292, 883-914).  After the consume loop no agent stands on an apple and nothing spawns
+        // under an agent, so the apples visible in map_with_agents are all apples of the grid.
+        const int apples = n_apple_cells;
         const float den = (float)((double)apples / (double)E.HW);
         ep_r += reward;
         const int step = ep_step0 + 1;
@@ -775,6 +799,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
             if (lane == 0) { if (so.collective) so.collective[env] = (float)sum; if (so.equality) so.equality[env] = (float)eq; }
         }
         if (lane == 0) {
+            st.counts[env] = ((uint32_t)n_waste_cells << 16) | (uint32_t)n_apple_cells;
             st.ep_step[env] = step; st.epoch[env] = epoch + 1;
             if (so.terminated) so.terminated[env] = term ? 1 : 0;
             if (so.n_draws) so.n_draws[env] = n_draws;
@@ -811,12 +836,20 @@ void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, c
     const int blocks = (hs.N + kWavesPerBlock - 1) / kWavesPerBlock;
     const int stride = lds_per_wave(hs);
     const size_t lds = (size_t)stride * kWavesPerBlock;
+#define SSD_LAUNCH(M, NT_) hipLaunchKernelGGL((k_env<M, NT_>), dim3(blocks), dim3(kBlock), lds, stream, (const DevHead&)hs, spec, st, actions, env_mask, tape, so, oo, stride)
+#define SSD_LAUNCH_N(M)                                                                                   \
+    do {                                                                                                  \
+        if (hs.n == 5) SSD_LAUNCH(M, 5); else if (hs.n == 10) SSD_LAUNCH(M, 10);                          \
+        else if (hs.n == 3) SSD_LAUNCH(M, 3); else SSD_LAUNCH(M, 0);                                      \
+    } while (0)
     switch (mode) {
-        case MODE_RESET: hipLaunchKernelGGL(k_env<MODE_RESET>, dim3(blocks), dim3(kBlock), lds, stream, (const DevHead&)hs, spec, st, actions, env_mask, tape, so, oo, stride); break;
-        case MODE_STEP: hipLaunchKernelGGL(k_env<MODE_STEP>, dim3(blocks), dim3(kBlock), lds, stream, (const DevHead&)hs, spec, st, actions, env_mask, tape, so, oo, stride); break;
-        case MODE_STEP_OBS: hipLaunchKernelGGL(k_env<MODE_STEP_OBS>, dim3(blocks), dim3(kBlock), lds, stream, (const DevHead&)hs, spec, st, actions, env_mask, tape, so, oo, stride); break;
-        default: hipLaunchKernelGGL(k_env<MODE_OBS>, dim3(blocks), dim3(kBlock), lds, stream, (const DevHead&)hs, spec, st, actions, env_mask, tape, so, oo, stride); break;
+        case MODE_RESET: SSD_LAUNCH(MODE_RESET, 0); break;
+        case MODE_STEP: SSD_LAUNCH_N(MODE_STEP); break;
+        case MODE_STEP_OBS: SSD_LAUNCH_N(MODE_STEP_OBS); break;
+        default: SSD_LAUNCH_N(MODE_OBS); break;
     }
+#undef SSD_LAUNCH_N
+#undef SSD_LAUNCH
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -862,6 +895,7 @@ __global__ void k_import(DevSpec const* S, DevState st, ssd_state s) {
     for (size_t i = tid; i < (size_t)N; i += nt) {
         if (s.ep_step) st.ep_step[i] = s.ep_step[i];
         if (s.epoch) st.epoch[i] = s.epoch[i];
+        if (s.grid || s.pos) st.counts[i] = 0xFFFFFFFFu;   // imported grid / agents: recount at the next step
     }
 }
 
