@@ -108,27 +108,34 @@ def main():
 
         for t in range(args.warmup):
             one_step(t)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        # kernel time for the roofline: HIP events (torch's current stream = the launch stream) bracketing every run of
+        # back-to-back k_env<STEP_OBS> launches between two resets; average = bracket time / launches in it
+        ev, run_len = [], []
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        open_ev = None
         for t in range(args.steps):
             if (args.warmup + t) % T == 0:
+                if open_ev is not None:
+                    e = torch.cuda.Event(enable_timing=True); e.record(); ev.append((open_ev, e)); open_ev = None
                 env.reset()
-            ev[t][0].record()
+            if open_ev is None:
+                open_ev = torch.cuda.Event(enable_timing=True); open_ev.record(); run_len.append(0)
             env.step_observe(acts[t % n_act], out=bufs)
-            ev[t][1].record()
+            run_len[-1] += 1
+        e = torch.cuda.Event(enable_timing=True); e.record(); ev.append((open_ev, e))
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         assert env.poll_error() == 0
-        kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
-        kern_avg_us = 1e3 * sum(kern_ms) / len(kern_ms)
-        kern_med_us = 1e3 * kern_ms[len(kern_ms) // 2]
+        per_launch = sorted(1e3 * a.elapsed_time(b) / k for (a, b), k in zip(ev, run_len))
+        kern_avg_us = sum(1e3 * a.elapsed_time(b) for a, b in ev) / sum(run_len)
+        kern_med_us = per_launch[len(per_launch) // 2]
         bytes_per_launch = algorithmic_bytes_per_env_step(env.H, env.W, n, env.V) * N
         result = dict(elapsed=elapsed, kern_avg_us=kern_avg_us, kern_med_us=kern_med_us, bytes_per_launch=bytes_per_launch,
                       dtype="u8", workload="cleanup_default5_env_step_observe_fp32obs",

@@ -150,6 +150,8 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&E->st.ep_step, N * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&E->st.epoch, N * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&E->st.err, 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&E->st.rng_base, N * 16);
+    if (e == hipSuccess) e = hipMemset(E->st.rng_base, 0, N * 16);
     if (e == hipSuccess) e = hipMalloc((void**)&E->st.counts, N * 4);
     if (e == hipSuccess) e = hipMemset(E->st.counts, 0xFF, N * 4);
     if (e == hipSuccess) e = hipMemcpy(E->dspec, &S, sizeof(DevSpec), hipMemcpyHostToDevice);
@@ -188,7 +190,7 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
 int ssd_destroy(ssd_env* E) {
     if (!E) return SSD_OK;
     (void)hipFree(E->dspec); (void)hipFree(E->st.grid); (void)hipFree(E->st.arec); (void)hipFree(E->st.ep_reward);
-    (void)hipFree(E->st.ep_step); (void)hipFree(E->st.epoch); (void)hipFree(E->st.err); (void)hipFree(E->st.counts);
+    (void)hipFree(E->st.ep_step); (void)hipFree(E->st.epoch); (void)hipFree(E->st.err); (void)hipFree(E->st.counts); (void)hipFree(E->st.rng_base);
     delete E;
     return SSD_OK;
 }

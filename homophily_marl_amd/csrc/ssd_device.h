@@ -54,6 +54,7 @@ struct DevState {
     int32_t* ep_reward;  // [N, n]
     int32_t* ep_step;    // [N]
     uint32_t* epoch;     // [N]
+    uint4* rng_base;     // [N] Philox base words of the current episode (COUNTER mode), written by reset / import
     uint32_t* counts;    // [N] waste cells << 16 | apple cells of the grid, 0xFFFFFFFF = unknown (recount)
     int32_t* err;        // [1] sticky error bits
     unsigned long long* stamps;  // diagnostic builds only (-DSSD_STAMPS): [N, 16] s_memtime per phase; else null

@@ -74,7 +74,7 @@ struct Rng {
     bool tape;
     const double* tape_u;  // this env's row
     int ustride;
-    uint32_t b[4];         // Philox base words, one per stream (wave-uniform)
+    uint32_t b[4];         // Philox base words of the episode, one per stream (wave-uniform), pre-xored with (call << 16)
     int32_t* err;
     __device__ __forceinline__ uint32_t u32(int stream, uint32_t k) const { return mix32(b[stream] ^ k); }
     // np.random.rand(1)[0] number k of this call (cleanup.py:172,183; harvest.py:119)
@@ -692,7 +692,16 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
     R.tape_u = R.tape ? tape.uniforms + (size_t)env * tape.ustride : nullptr;
     R.err = st.err;
     R.b[0] = R.b[1] = R.b[2] = R.b[3] = 0;
-    if (MODE != MODE_OBS && !R.tape) philox4(0u, 0u, h->env_id_base + (uint32_t)env, epoch, h->seed_lo, h->seed_hi, R.b);
+    if (MODE == MODE_RESET && !R.tape) {
+        // a new episode: derive its Philox base (once per episode, scalar unit) and keep it in the env state
+        philox4(0u, 0u, h->env_id_base + (uint32_t)env, epoch + 1u, h->seed_lo, h->seed_hi, R.b);
+        if (lane == 0) st.rng_base[env] = make_uint4(R.b[0], R.b[1], R.b[2], R.b[3]);
+    } else if ((MODE == MODE_STEP || MODE == MODE_STEP_OBS) && !R.tape) {
+        const uint4 bw = st.rng_base[env];
+        const uint32_t call = ((uint32_t)(ep_step0 + 1)) << 16;      // call index inside the episode (reset = 0)
+        R.b[0] = __builtin_amdgcn_readfirstlane(bw.x) ^ call; R.b[1] = __builtin_amdgcn_readfirstlane(bw.y) ^ call;
+        R.b[2] = __builtin_amdgcn_readfirstlane(bw.z) ^ call; R.b[3] = __builtin_amdgcn_readfirstlane(bw.w) ^ call;
+    }
     const uint8_t* tape_order = tape.move_order ? tape.move_order + (size_t)env * n : nullptr;
     const uint8_t* tape_waste = tape.waste_order ? tape.waste_order + (size_t)env * h->n_waste : nullptr;
 
@@ -800,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
         }
         if (lane == 0) {
             st.counts[env] = ((uint32_t)n_waste_cells << 16) | (uint32_t)n_apple_cells;
-            st.ep_step[env] = step; st.epoch[env] = epoch + 1;
+            st.ep_step[env] = step;
             if (so.terminated) so.terminated[env] = term ? 1 : 0;
             if (so.n_draws) so.n_draws[env] = n_draws;
             if (R.tape && n_draws > R.ustride) atomicOr(st.err, ERR_TAPE_OVERRUN);
@@ -894,7 +903,12 @@ __global__ void k_import(DevSpec const* S, DevState st, ssd_state s) {
     }
     for (size_t i = tid; i < (size_t)N; i += nt) {
         if (s.ep_step) st.ep_step[i] = s.ep_step[i];
-        if (s.epoch) st.epoch[i] = s.epoch[i];
+        if (s.epoch) {
+            st.epoch[i] = s.epoch[i];
+            uint32_t b[4];
+            philox4(0u, 0u, h->env_id_base + (uint32_t)i, s.epoch[i], h->seed_lo, h->seed_hi, b);
+            st.rng_base[i] = make_uint4(b[0], b[1], b[2], b[3]);
+        }
         if (s.grid || s.pos) st.counts[i] = 0xFFFFFFFFu;   // imported grid / agents: recount at the next step
     }
 }

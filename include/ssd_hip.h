@@ -118,7 +118,7 @@ typedef struct ssd_state {
     uint8_t* orient;            /* [n_env, n] */
     int32_t* ep_reward;         /* [n_env, n] cumulative episode reward (self.rewards, map_env.py:885-888) */
     int32_t* ep_step;           /* [n_env] self._episode_steps */
-    uint32_t* epoch;            /* [n_env] COUNTER-mode call counter (reset/step calls completed) */
+    uint32_t* epoch;            /* [n_env] COUNTER-mode episode counter (resets so far) */
 } ssd_state;
 
 typedef struct ssd_env ssd_env; /* opaque */
@@ -224,15 +224,17 @@ int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uin
                      uint32_t seed, int32_t n_agents, int32_t batch, int32_t pairs, int64_t* actions, float* q_out, void* stream);
 
 /* ---- COUNTER-mode generator (shared definition) ---------------------------------------------
- * Two levels, so that the expensive part is computed once per env and call (wave-uniform on the GPU):
- *   b[0..3] = philox4x32_10(counter = {0, 0, env_global_id, epoch}, key = {seed_lo, seed_hi})
- *             epoch = number of reset/step calls this env has completed before the current call
- *   x(stream, k) = mix32(b[stream] ^ k),  stream = SSD_STREAM_*  (one Philox word per stream)
+ * Two levels, so that the expensive part is computed once per EPISODE (by the reset call) and kept in the env state:
+ *   episode = number of resets of this env including the one that opened the current episode (1, 2, ...)
+ *   b[0..3] = philox4x32_10(counter = {0, 0, env_global_id, episode}, key = {seed_lo, seed_hi})
+ *   c       = call index inside the episode: 0 for the reset call, (steps completed so far) + 1 for a step call
+ *   x(stream, k) = mix32(b[stream] ^ (c << 16) ^ k),  stream = SSD_STREAM_*  (one Philox word per stream; k, c < 65536)
  *   mix32(x): x ^= x >> 17; x *= 0xed5ad4bb; x ^= x >> 11; x *= 0xac4c1b51; x ^= x >> 15; x *= 0x31848bab; x ^= x >> 14
  *             (the "triple32" integer hash, a bijection on 32 bits)
  *   uniform number k of the call: u = (x(UNIFORM, k) >> 8) * 2^-24 as double, compared `u < p` in fp64
  *   shuffles: stable sort of the items by (x(stream, item index) >> 8, item index)   (24-bit key: key | index fits 32 bits)
- *   spawn rotation of agent a: x(SPAWN_ROT, a) >> 30                                                            */
+ *   spawn rotation of agent a: x(SPAWN_ROT, a) >> 30
+ * ssd_state.epoch carries `episode`; importing it re-derives b.                                                        */
 enum { SSD_STREAM_UNIFORM = 0, SSD_STREAM_MOVE = 1, SSD_STREAM_WASTE = 2, SSD_STREAM_SPAWN_ROT = 3 };
 
 #ifdef __cplusplus

@@ -34,7 +34,7 @@ def lib():
         _LIB.ssd_cpu_philox.restype = C.c_uint32
         _LIB.ssd_cpu_philox.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int]
         _LIB.ssd_cpu_counter_u32.restype = C.c_uint32
-        _LIB.ssd_cpu_counter_u32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        _LIB.ssd_cpu_counter_u32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     return _LIB
 
 
@@ -146,5 +146,5 @@ def philox(c0, c1, c2, c3, seed, word=0):
     return lib().ssd_cpu_philox(c0, c1, c2, c3, seed, word)
 
 
-def counter_u32(seed, env, epoch, stream, k):
-    return lib().ssd_cpu_counter_u32(seed, env, epoch, stream, k)
+def counter_u32(seed, env, episode, c, stream, k):
+    return lib().ssd_cpu_counter_u32(seed, env, episode, c, stream, k)

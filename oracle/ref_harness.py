@@ -53,14 +53,15 @@ def mix32(x):
 _BASE_CACHE = {}
 
 
-def ctr_u32(seed, env, epoch, stream, k):
-    """x(stream, k) of the COUNTER-mode generator (include/ssd_hip.h), independent pure-Python statement."""
-    key = (seed, env, epoch)
+def ctr_u32(seed, env, episode, c, stream, k):
+    """x(stream, k) of the COUNTER-mode generator (include/ssd_hip.h) for call index c of episode `episode`;
+    independent pure-Python statement."""
+    key = (seed, env, episode)
     if key not in _BASE_CACHE:
         if len(_BASE_CACHE) > 4096:
             _BASE_CACHE.clear()
-        _BASE_CACHE[key] = philox4x32_10((0, 0, env & M32, epoch & M32), (seed & M32, (seed >> 32) & M32))
-    return mix32(_BASE_CACHE[key][stream] ^ (k & M32))
+        _BASE_CACHE[key] = philox4x32_10((0, 0, env & M32, episode & M32), (seed & M32, (seed >> 32) & M32))
+    return mix32(_BASE_CACHE[key][stream] ^ ((c << 16) & M32) ^ (k & M32))
 
 
 def import_reference():
@@ -102,6 +103,7 @@ class RefEnv:
                                           is_replay=False, view_size=view_size, map=map, extra_args=ea, seed=seed)
         self.kind, self.n, self.mode, self.seed, self.env_id = env, num_agents, mode, seed, env_id
         self.epoch = 0
+        self.call_index = 0
         self.force_move_order = None
         self.H, self.W = self.env.world_map.shape
         if env == "cleanup":
@@ -118,7 +120,7 @@ class RefEnv:
         rec = self.rec = CallRecord()
         o_shuffle, o_rand, o_randint, o_pyshuffle = np.random.shuffle, np.random.rand, np.random.randint, random.shuffle
         counter = self.mode == "counter"
-        u32 = lambda stream, k: ctr_u32(self.seed, self.env_id, self.epoch, stream, k)
+        u32 = lambda stream, k: ctr_u32(self.seed, self.env_id, self.epoch, self.call_index, stream, k)
 
         def np_shuffle(lst):
             if self.force_move_order is not None:   # KAT generation: impose a chosen shuffle result
@@ -166,15 +168,17 @@ class RefEnv:
             yield rec
         finally:
             np.random.shuffle, np.random.rand, np.random.randint, random.shuffle = o_shuffle, o_rand, o_randint, o_pyshuffle
-            self.epoch += 1
 
     # ---- env API ------------------------------------------------------------------------------------------
     def reset(self):
+        self.epoch += 1                 # episode counter of the COUNTER contract
+        self.call_index = 0
         with self._intercept() as rec:
             self.env.reset()
         return rec
 
     def step(self, actions):
+        self.call_index = self.env._episode_steps + 1
         with self._intercept() as rec:
             reward, terminated, info = self.env.step(list(actions))
         # the reference aliases the first returned reward array with self.rewards and mutates it later

@@ -37,10 +37,11 @@ def test_counter_generator_matches_its_python_statement(oracle_lib):
     # the two-level generator of include/ssd_hip.h: C oracle == independent pure-Python statement
     from oracle.oracle_py import counter_u32
     from oracle.ref_harness import ctr_u32
-    for seed, env, epoch in ((0, 0, 0), (0xDEADBEEFCAFE, 4097, 12345), (2 ** 64 - 1, 2 ** 32 - 1, 7)):
-        for stream in range(4):
-            for k in (0, 1, 2, 63, 64, 1000, 2 ** 31):
-                assert counter_u32(seed, env, epoch, stream, k) == ctr_u32(seed, env, epoch, stream, k)
+    for seed, env, episode in ((0, 0, 0), (0xDEADBEEFCAFE, 4097, 12345), (2 ** 64 - 1, 2 ** 32 - 1, 7)):
+        for c in (0, 1, 100, 65535):
+            for stream in range(4):
+                for k in (0, 1, 2, 63, 64, 1000, 65535):
+                    assert counter_u32(seed, env, episode, c, stream, k) == ctr_u32(seed, env, episode, c, stream, k)
 
 
 def test_reset_spawn_points(oracle_lib):
