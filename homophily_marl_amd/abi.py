@@ -107,6 +107,20 @@ class SsdStoreStep(C.Structure):
                 ("dst_actions", C.c_void_p), ("dst_actions_inc", C.c_void_p)]
 
 
+class SsdPolicyHead(C.Structure):
+    """include/ssd_hip.h: ssd_policy_head (fused controller step, one launch per head)."""
+    _fields_ = [("n_env", C.c_int32), ("n_agents", C.c_int32), ("n_actions", C.c_int32), ("input_shape", C.c_int32),
+                ("pos_scale", C.c_float), ("seed", C.c_uint32),
+                ("inputs", C.c_void_p), ("h", C.c_void_p), ("weights", C.c_void_p), ("avail", C.c_void_p), ("epsilon", C.c_void_p),
+                ("step", C.c_void_p), ("prev_actions", C.c_void_p), ("prev_reward", C.c_void_p), ("prev_actions_inc", C.c_void_p),
+                ("pos", C.c_void_p), ("actions", C.c_void_p), ("pos_pre", C.c_void_p), ("orient_pre", C.c_void_p),
+                ("reward", C.c_void_p), ("clean_num", C.c_void_p), ("apple_den", C.c_void_p), ("out_actions", C.c_void_p),
+                ("q_out", C.c_void_p)]
+
+
+POLICY_IMAGE_FLOATS = 464 * 68 + 464 + 64
+HIP_SIGNATURES["ssd_policy_head_env"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.c_void_p])
+HIP_SIGNATURES["ssd_policy_head_inc"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.c_void_p])
 HIP_SIGNATURES["ssd_conv_leaky"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_store_step_launch"] = (C.c_int, [C.POINTER(SsdStoreStep), C.c_void_p])

@@ -375,4 +375,21 @@ int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uin
     return launched();
 }
 
+static int policy_head(const ssd_policy_head* a, int inc, void* stream) {
+    if (!a || !a->inputs || !a->h || !a->weights || !a->epsilon || !a->step || !a->out_actions) return fail(SSD_ERR_INVALID, "bad argument");
+    if (a->n_env < 1 || a->n_agents < 1 || a->n_actions < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if (inc ? (!a->actions || !a->pos_pre || !a->orient_pre || !a->reward || !a->clean_num || !a->apple_den)
+            : (!a->prev_actions || !a->prev_reward || !a->prev_actions_inc || !a->pos)) return fail(SSD_ERR_INVALID, "missing head input");
+    // layout limits of the fused kernel: 32 encoder features + tail (+ one-hot action for inc) within 64 columns, 16 fc2 rows
+    if (a->input_shape != 32 + a->n_actions + a->n_agents + 4 || a->input_shape + a->n_actions > 64 || a->n_actions + 7 > 16)
+        return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_head: input_shape must be 32 + n_actions + n + 4 and fit 64 columns");
+    if ((reinterpret_cast<uintptr_t>(a->inputs) | reinterpret_cast<uintptr_t>(a->h) | reinterpret_cast<uintptr_t>(a->weights)) & 15)
+        return fail(SSD_ERR_INVALID, "inputs / h / weights must be 16-byte aligned");
+    const int rc = launch_policy_head(a, inc, (hipStream_t)stream);
+    if (rc) return fail(SSD_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS) failed");
+    return launched();
+}
+int ssd_policy_head_env(const ssd_policy_head* a, void* stream) { return policy_head(a, 0, stream); }
+int ssd_policy_head_inc(const ssd_policy_head* a, void* stream) { return policy_head(a, 1, stream); }
+
 }  // extern "C"

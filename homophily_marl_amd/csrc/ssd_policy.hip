@@ -5,11 +5,9 @@
 //                                                                                         action_selectors.py:44-68)
 // The per-agent matrix products stay in hipBLASLt (MFMA).  Everything here is elementwise / small-reduction work that
 // PyTorch would issue as 8-15 separate launches per head and timestep.
-#include "ssd_device.h"
+#include "ssd_policy_common.h"
 
 namespace ssd {
-
-__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.01f * x; }   // nn.LeakyReLU default slope
 
 // ---------------------------------------------------------------------------------------------------------------
 // Encoder.  One wave per observation row (env, agent).  The obs [3, V, V] f32 is staged in LDS; lanes own conv output
@@ -245,10 +243,6 @@ __global__ void k_gru_bwd(const float* __restrict__ dh, const float* __restrict_
 // Row r of the [n(i), B, ...] agent-major input is written to the env-major position given by (out_b_stride, out_i_stride).
 // inc head: rows are (i, b, j); diagonal (i == j) forced to 0 (no self-incentive, homophily_controller.py:44-46).
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t mix32p(uint32_t x) {
-    x ^= x >> 17; x *= 0xed5ad4bbu; x ^= x >> 11; x *= 0xac4c1b51u; x ^= x >> 15; x *= 0x31848babu; x ^= x >> 14;
-    return x;
-}
 __global__ void k_dueling_pick(const float* __restrict__ av, int R, int A, const uint8_t* __restrict__ avail,
                                const float* __restrict__ eps_p, const int64_t* __restrict__ step_p, uint32_t seed, int n_agents, int B,
                                int pairs /*0: rows (i,b); 1: rows (i,b,j)*/, int64_t* __restrict__ actions, float* __restrict__ q_out) {
@@ -256,26 +250,7 @@ __global__ void k_dueling_pick(const float* __restrict__ av, int R, int A, const
     const uint32_t step = (uint32_t)*step_p;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
         const float* a = av + (size_t)r * (A + 1);
-        float mean = 0.f;
-        for (int k = 0; k < A; ++k) mean += a[k];
-        mean /= (float)A;
-        const float v = a[A];
-        int best = 0, navail = 0;
-        float bq = -INFINITY;
-        for (int k = 0; k < A; ++k) {
-            const float q = v + a[k] - mean;
-            if (q_out) q_out[(size_t)r * A + k] = q;
-            const bool ok = !avail || avail[k];
-            navail += ok;
-            if (ok && q > bq) { bq = q; best = k; }          // first maximum, like torch.max / argmax
-        }
-        const uint32_t x0 = mix32p(seed ^ mix32p(step * 0x9E3779B9u + (uint32_t)r));
-        const uint32_t x1 = mix32p(x0 ^ 0x85EBCA6Bu);
-        int act = best;
-        if ((float)(x0 >> 8) * (1.0f / 16777216.0f) < eps) {
-            int pick = (int)(((uint64_t)x1 * (uint32_t)navail) >> 32);   // uniform over the available actions
-            for (int k = 0; k < A; ++k) { const bool ok = !avail || avail[k]; if (ok) { if (pick == 0) { act = k; break; } --pick; } }
-        }
+        int act = dueling_pick_row(a, a[A], A, avail, eps, step, seed, (uint32_t)r, q_out ? q_out + (size_t)r * A : nullptr);
         size_t o;
         if (!pairs) { const int i = r / B, b = r - i * B; o = (size_t)b * n_agents + i; }
         else { const int i = r / (B * n_agents), rem = r - i * B * n_agents, b = rem / n_agents, j = rem - b * n_agents;

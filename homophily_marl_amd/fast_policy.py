@@ -18,7 +18,7 @@ from . import abi
 
 
 class FastPolicy:
-    def __init__(self, mac, n_env, avail_mask_u8, seed=0, actions_out=None, actions_inc_out=None, share_packs_from=None):
+    def __init__(self, mac, n_env, avail_mask_u8, seed=0, actions_out=None, actions_inc_out=None, share_packs_from=None, fused=True):
         self.mac, self.agent, self.a = mac, mac.agent, mac.args
         a = self.a
         assert a.rgb_input and a.conv_out == 6 and a.obs_dim_net == 32 and a.conv_kernel == 3 and a.conv_stride == 1
@@ -28,7 +28,10 @@ class FastPolicy:
         self.inp = mac.input_shape
         n, N, H = self.n, self.N, self.H
         f32 = dict(dtype=th.float32, device=self.dev)
-        self.inputs = th.zeros(n, N, self.inp, **f32)          # [feat | tail], agent-major
+        # fused: one launch per head (csrc/ssd_policy_fused.hip), inputs padded to 64 columns; otherwise the per-layer
+        # composition below (batched hipBLASLt GEMMs + the small kernels of csrc/ssd_policy.hip)
+        self.fused = bool(fused) and H == 64 and self.inp + self.A <= 64 and self.A + 7 <= 16
+        self.inputs = th.zeros(n, N, 64 if self.fused else self.inp, **f32)          # [feat | tail (| 0)], agent-major
         self.h_env = th.zeros(n, N, H, **f32)
         self.h_inc = th.zeros(n, N, H, **f32)
         # outputs may be slices of a caller-owned full-batch buffer (env groups evaluated on separate streams)
@@ -65,18 +68,55 @@ class FastPolicy:
         packs["w2i_h"] = w2i[:, :H]
         packs["w2i_o"] = w2i[:, H:].permute(1, 0, 2).reshape(w2i.shape[1] - H, -1)    # [E, n(i) * 4]
         packs["b2i"] = th.cat([b("fc2_inc_b"), b("fc2_inc_v_b")], dim=2).unsqueeze(2)  # [n, 1, 1, 4]
+        packs["img_env"], packs["img_inc"] = self._image("env"), self._image("inc")
         if not hasattr(self, "p"):
             self.p = {k: v.detach().clone().contiguous() for k, v in packs.items()}
         else:
             for k, v in packs.items():
                 self.p[k].copy_(v)
 
+    def _image(self, head):
+        """Per-agent weight image of the fused head kernel (layout: include/ssd_hip.h, ssd_policy_head)."""
+        ag, n, H = self.agent, self.n, self.H
+        w, b = ag._w, ag._b
+        img = th.zeros(n, abi.POLICY_IMAGE_FLOATS, dtype=th.float32, device=self.dev)
+        W = img[:, :464 * 68].view(n, 464, 68)
+        w1 = w("fc1_%s_w" % head)                                                      # [n, in, 64]
+        W[:, 0:64, :w1.shape[1]] = w1.transpose(1, 2)
+        wi, wh, bi, bh = ag._gru_weights(head)
+        W[:, 64:256, :H] = wi.transpose(1, 2)
+        W[:, 256:448, :H] = wh.transpose(1, 2)
+        w2 = th.cat([w("fc2_%s_w" % head), w("fc2_%s_v_w" % head)], dim=2)             # env [n, 64, A + 1]; inc [n, 64 + E, 4]
+        b2 = th.cat([b("fc2_%s_b" % head), b("fc2_%s_v_b" % head)], dim=2)
+        k = w2.shape[2]
+        W[:, 448:448 + k, :H] = w2[:, :H].transpose(1, 2)
+        B = img[:, 464 * 68:]
+        B[:, 0:64] = b("fc1_%s_b" % head)[:, 0]
+        B[:, 64:256], B[:, 256:448] = bi[:, 0], bh[:, 0]
+        B[:, 448:448 + k] = b2[:, 0]
+        if head == "inc":
+            E = w2.shape[1] - H
+            B[:, 464:464 + E * 4] = w2[:, H:].reshape(n, E * 4)
+        return img
+
+    def _head_args(self, inc, eps, step, q_out=None):
+        a = abi.SsdPolicyHead()
+        a.n_env, a.n_agents, a.n_actions, a.input_shape = self.N, self.n, self.A, self.inp
+        a.pos_scale = float(self.mac.pos_scale)
+        a.seed = (self.seed ^ 0x5bd1e995) if inc else self.seed
+        a.inputs = self.inputs.data_ptr()
+        a.h = (self.h_inc if inc else self.h_env).data_ptr()
+        a.weights = self.p["img_inc" if inc else "img_env"].data_ptr()
+        a.epsilon, a.step = eps.data_ptr(), step.data_ptr()
+        a.q_out = None if q_out is None else q_out.data_ptr()
+        return a
+
     def reset(self):
         self.h_env.zero_(); self.h_inc.zero_()
 
     # ---- env head -----------------------------------------------------------------------------------------------
     @th.no_grad()
-    def act_env(self, obs, prev_actions, prev_reward, prev_inc, pos, eps, step, store_obs=None, store_t=None):
+    def act_env(self, obs, prev_actions, prev_reward, prev_inc, pos, eps, step, store_obs=None, store_t=None, q_out=None):
         """obs f32 [N, n, 3, V, V]; prev_* of the previous timestep (prev_actions = -1 at t = 0); pos f32 [N, n, 2];
         eps f32 scalar tensor, step i64 [1] tensor.  Returns actions i64 [N, n] (static buffer)."""
         p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
@@ -89,9 +129,17 @@ class FastPolicy:
                                           None if store_obs is None else store_obs.data_ptr(),
                                           0 if store_obs is None else store_obs.stride(0),
                                           None if store_t is None else store_t.data_ptr(), st))
-        feat = self.inputs.view(n * N, self.inp)[:, :32]                                 # Linear + LeakyReLU straight into the input matrix
+        feat = self.inputs.view(n * N, self.inputs.shape[-1])[:, :32]                    # Linear + LeakyReLU straight into the input matrix
         th.addmm(p["lb"], self._conv, p["lw_t"], out=feat)
         F.leaky_relu_(feat)
+        if self.fused:
+            ha = self._head_args(False, eps, step, q_out)
+            ha.avail = self.avail.data_ptr()
+            ha.prev_actions, ha.prev_reward, ha.prev_actions_inc, ha.pos = (prev_actions.data_ptr(), prev_reward.data_ptr(),
+                                                                          prev_inc.data_ptr(), pos.data_ptr())
+            ha.out_actions = self.actions.data_ptr()
+            abi.check(lib, lib.ssd_policy_head_env(C.byref(ha), st))
+            return self.actions
         abi.check(lib, lib.ssd_build_inputs(N, n, self.A, 2, prev_actions.data_ptr(), prev_reward.data_ptr(), prev_inc.data_ptr(),
                                             pos.data_ptr(), float(self.mac.pos_scale), self.inputs.data_ptr(), self.inp, 32, st))
         x = F.leaky_relu(th.baddbmm(p["b1e"], self.inputs, p["w1e"]))
@@ -100,17 +148,24 @@ class FastPolicy:
         abi.check(lib, lib.ssd_gru_gates(gi.data_ptr(), gh.data_ptr(), self.h_env.data_ptr(), n * N, H, st))
         av = th.baddbmm(p["b2e"], self.h_env, p["w2e"])                                # [n, N, A + 1]
         abi.check(lib, lib.ssd_dueling_pick(av.data_ptr(), n * N, self.A, self.avail.data_ptr(), eps.data_ptr(), step.data_ptr(),
-                                            self.seed, n, N, 0, self.actions.data_ptr(), None, st))
+                                            self.seed, n, N, 0, self.actions.data_ptr(), None if q_out is None else q_out.data_ptr(), st))
         self._keep = (x, gi, gh, av)
         return self.actions
 
     # ---- incentive head ---------------------------------------------------------------------------------------------
     @th.no_grad()
-    def act_inc(self, actions, pos, orient, reward, clean_num, apple_den, eps, step):
+    def act_inc(self, actions, pos, orient, reward, clean_num, apple_den, eps, step, q_out=None):
         """actions i64 [N, n] (the env actions just taken); pos / orient: the PRE-step pose [N, n, 2]; reward, clean_num,
         apple_den [N, n] of this step.  Returns actions_inc i64 [N, n, n] with a zero diagonal (static buffer)."""
         p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
         st = self._stream()
+        if self.fused:
+            ha = self._head_args(True, eps, step, q_out)
+            ha.actions, ha.pos_pre, ha.orient_pre = actions.data_ptr(), pos.data_ptr(), orient.data_ptr()
+            ha.reward, ha.clean_num, ha.apple_den = reward.data_ptr(), clean_num.data_ptr(), apple_den.data_ptr()
+            ha.out_actions = self.actions_inc.data_ptr()
+            abi.check(lib, lib.ssd_policy_head_inc(C.byref(ha), st))
+            return self.actions_inc
         x = th.baddbmm(p["b1i"], self.inputs, p["w1i_x"]) + p["w1i_a"][self.arange_n, actions.t()]    # one-hot(a) @ W_a = row gather
         x = F.leaky_relu(x)
         gi = th.baddbmm(p["bii"], x, p["wii"])
@@ -122,7 +177,7 @@ class FastPolicy:
         opart = (other.reshape(N * n, -1) @ p["w2i_o"]).reshape(N, n, n, 4).permute(2, 0, 1, 3)   # [n(i), N, n(j), 4]
         av = (hpart.unsqueeze(2) + opart + p["b2i"]).contiguous()                        # [n(i), N, n(j), 4]
         abi.check(lib, lib.ssd_dueling_pick(av.data_ptr(), n * N * n, self.a.n_inc_actions, None, eps.data_ptr(), step.data_ptr(),
-                                            self.seed ^ 0x5bd1e995, n, N, 1, self.actions_inc.data_ptr(), None, st))
+                                            self.seed ^ 0x5bd1e995, n, N, 1, self.actions_inc.data_ptr(), None if q_out is None else q_out.data_ptr(), st))
         self._keep2 = (x, gi, gh, av)
         return self.actions_inc
 

@@ -72,7 +72,8 @@ class HipGraphRunner(HipVecRunner):
                 sl = slice(g * hsz, (g + 1) * hsz)
                 self.fasts.append(FastPolicy(self.mac, hsz, avail, seed=seed + 0x9E3779B1 * g, actions_out=self.actions_full[sl],
                                              actions_inc_out=self.actions_inc_full[sl],
-                                             share_packs_from=self.fasts[0] if g else None))
+                                             share_packs_from=self.fasts[0] if g else None,
+                                             fused=bool(getattr(a, "fused_policy", True))))
             self.fast = self.fasts[0]
             self.gslices = [slice(g * hsz, (g + 1) * hsz) for g in range(G)]
             self.side_streams = [th.cuda.Stream(device=dev) for _ in range(G)] if G > 1 else []

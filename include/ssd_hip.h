@@ -223,6 +223,50 @@ int ssd_gru_gates_bwd(const float* dh_new, const float* rzn, const float* gh, co
 int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uint8_t* avail, const float* epsilon, const int64_t* step,
                      uint32_t seed, int32_t n_agents, int32_t batch, int32_t pairs, int64_t* actions, float* q_out, void* stream);
 
+/* ---- fused rollout-time controller step (csrc/ssd_policy_fused.hip) ------------------------------------------------------
+ * One launch per head and timestep for what HomophilyMAC.select_actions_env / select_actions_inc evaluate
+ * (homophily_controller.py:30-65, 127-184 on top of homophily_agent.py:154-208 and action_selectors.py:44-68):
+ *   env head: input tail (one-hot last action, agent id, sign of last reward, sign of received incentives, pos / scale)
+ *             -> fc1_env + LeakyReLU -> GRU cell -> dueling Q -> epsilon-greedy over the available actions
+ *   inc head: [inputs | one-hot(action)] -> fc1_inc + LeakyReLU -> GRU cell -> per ordered pair (i -> j)
+ *             [h_i | one-hot(a_j), pos_j / scale, orient_j, r_j, clean_j, apple_den_j] -> dueling Q -> epsilon-greedy, diagonal 0
+ * The per-agent (unshared) matrices are applied with f32-input MFMA (exact f32); hidden = 64 and n_feat = 32 are fixed.
+ * Activations are agent-major: inputs f32 [n, n_env, 64] (columns 0..31 = encoder output, written by ssd_policy_encode /
+ * the caller; the env head fills columns 32..63: tail then zeros), h f32 [n, n_env, 64] updated in place.
+ * weights: per agent one f32 image of SSD_POLICY_IMAGE_FLOATS floats (row stride 68, K padded to 64 with zeros):
+ *   rows   0.. 63  fc1 weight transposed  [out 64][in]            (in = input_shape, or input_shape + n_actions for inc)
+ *   rows  64..255  GRU input-side  weight transposed [3*64 (r, z, n)][64]
+ *   rows 256..447  GRU hidden-side weight transposed [3*64 (r, z, n)][64]
+ *   rows 448..463  fc2 transposed [16][64]: env: n_actions advantage rows then the value row; inc: the h part, 3 + 1 rows
+ *   then biases fc1[64], gru_i[192], gru_h[192], fc2[16], then (inc) the pair part of fc2 [16 (extra features)][4].
+ * Random numbers and the pick are those of ssd_dueling_pick (same seed / step / row indexing). q_out (nullable):
+ * env f32 [n, n_env, n_actions]; inc f32 [n, n_env, n, 3]. */
+#define SSD_POLICY_IMAGE_FLOATS (464 * 68 + 464 + 64)
+typedef struct ssd_policy_head {
+    int32_t n_env, n_agents, n_actions, input_shape;
+    float pos_scale;
+    uint32_t seed;
+    float* inputs;                 /* [n, n_env, 64] */
+    float* h;                      /* [n, n_env, 64] */
+    const float* weights;          /* [n, SSD_POLICY_IMAGE_FLOATS] */
+    const uint8_t* avail;          /* env: u8 [n_actions] or NULL */
+    const float* epsilon;          /* device scalar */
+    const int64_t* step;           /* device scalar */
+    /* env head: previous timestep (last action -1 = none) and the current position */
+    const int64_t* prev_actions;   /* [n_env, n] */
+    const float* prev_reward;      /* [n_env, n] */
+    const int64_t* prev_actions_inc; /* [n_env, n, n] */
+    const float* pos;              /* [n_env, n, 2] */
+    /* inc head: the env actions just taken, the PRE-step pose and this step's outcome */
+    const int64_t* actions;        /* [n_env, n] */
+    const float *pos_pre, *orient_pre;   /* [n_env, n, 2] */
+    const float *reward, *clean_num, *apple_den;   /* [n_env, n] */
+    int64_t* out_actions;          /* env: [n_env, n]; inc: [n_env, n, n] */
+    float* q_out;                  /* nullable */
+} ssd_policy_head;
+int ssd_policy_head_env(const ssd_policy_head* args, void* stream);
+int ssd_policy_head_inc(const ssd_policy_head* args, void* stream);
+
 /* ---- COUNTER-mode generator (shared definition) ---------------------------------------------
  * Two levels, so that the expensive part is computed once per EPISODE (by the reset call) and kept in the env state:
  *   episode = number of resets of this env including the one that opened the current episode (1, 2, ...)

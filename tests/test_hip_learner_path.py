@@ -202,12 +202,14 @@ def test_stepwise_forward_equals_time_batched_unroll():
             assert (a - q_env[:, t]).abs().max() < 1e-5 and (b - q_inc[:, t]).abs().max() < 1e-5, t
 
 
-def test_fast_policy_matches_torch_controller():
-    """FastPolicy (HIP encoder / GRU gates / dueling-pick + agent-major GEMMs) against the torch controller on the same
-    inputs: features, hidden states and greedy actions."""
+@pytest.mark.parametrize("fused,N", [(False, 192), (True, 192), (True, 203), (True, 9)])
+def test_fast_policy_matches_torch_controller(fused, N):
+    """FastPolicy against the torch controller on the same inputs: features, hidden states, Q values and greedy actions.
+    fused = one MFMA launch per head (ssd_policy_head_env / _inc), else HIP encoder / GRU gates / dueling-pick kernels around
+    agent-major GEMMs.  N = 203, 9: ragged last 16-row tile."""
     from homophily_marl_amd.fast_policy import FastPolicy
     from homophily_marl_amd.run import load_config, setup
-    N, n = 192, 5
+    n = 5
     th.manual_seed(1)
     cfg = load_config("cleanup", overrides=dict(runner="hip_vec", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False,
                                                  store_state=False, env_args=dict(num_agents=n, map="default5", episode_limit=20, seed=3),
@@ -226,7 +228,9 @@ def test_fast_policy_matches_torch_controller():
     h0e = th.randn(N, n, 1, 64, generator=g, device="cuda") * 0.3
     h0i = th.randn(N, n, 1, 64, generator=g, device="cuda") * 0.3
     avail = env.avail_actions_batch[0, 0]
-    fp = FastPolicy(mac, N, avail, seed=7)
+    fp = FastPolicy(mac, N, avail, seed=7, fused=fused)
+    assert fp.fused == fused
+    qe, qi = th.zeros(n, N, 9, device="cuda"), th.zeros(n, N, n, 3, device="cuda")
     fp.h_env.copy_(h0e.squeeze(2).transpose(0, 1)); fp.h_inc.copy_(h0i.squeeze(2).transpose(0, 1))
     eps, step = th.zeros((), device="cuda"), th.zeros(1, dtype=th.long, device="cuda")
     with th.no_grad():
@@ -234,8 +238,10 @@ def test_fast_policy_matches_torch_controller():
         safe_prev = prev_a.clamp(min=0)
         inputs = mac.assemble_inputs(feat, prev_a, prev_r, prev_i, pos, False)
         q_env, h_env, _ = mac.agent.forward_env(inputs, h0e)
-        act = fp.act_env(obs, prev_a, prev_r, prev_i, pos, eps, step).clone()
-        assert (fp.inputs.transpose(0, 1).reshape(N * n, -1) - inputs).abs().max() < 2e-5
+        act = fp.act_env(obs, prev_a, prev_r, prev_i, pos, eps, step, q_out=qe).clone()
+        assert (fp.inputs[..., :mac.input_shape].transpose(0, 1).reshape(N * n, -1) - inputs).abs().max() < 2e-5
+        assert (fp.inputs[..., mac.input_shape:] == 0).all()
+        assert (qe.transpose(0, 1) - q_env).abs().max() < 5e-5
         assert (fp.h_env.transpose(0, 1) - h_env.squeeze(2)).abs().max() < 2e-5
         ref_act = q_env.masked_fill(avail.view(1, 1, -1) == 0, -float("inf")).argmax(-1)
         assert (act == ref_act).float().mean() > 0.999
@@ -244,7 +250,8 @@ def test_fast_policy_matches_torch_controller():
         den = th.rand(N, n, generator=g, device="cuda")
         q_inc, h_inc, _ = mac.agent.forward_inc(inputs, h0i, th.nn.functional.one_hot(ref_act, 9), pos / mac.pos_scale, orient,
                                                 reward.unsqueeze(-1), clean.unsqueeze(-1), den.unsqueeze(-1))
-        ainc = fp.act_inc(ref_act, pos, orient, reward, clean, den, eps, step).clone()
+        ainc = fp.act_inc(ref_act, pos, orient, reward, clean, den, eps, step, q_out=qi).clone()
+        assert (qi.transpose(0, 1) - q_inc).abs().max() < 5e-5
         assert (fp.h_inc.transpose(0, 1) - h_inc.squeeze(2)).abs().max() < 2e-5
         ref_inc = q_inc.argmax(-1) * (1 - th.eye(n, device="cuda", dtype=th.long))
         assert (ainc == ref_inc).float().mean() > 0.999
@@ -256,7 +263,7 @@ def test_fast_policy_matches_torch_controller():
             step.fill_(s)
             a = fp.act_env(obs, prev_a, prev_r, prev_i, pos, eps, step)
             cnt += th.bincount(a.reshape(-1), minlength=9).float()
-        assert cnt[[5, 6, 7]].sum() == 0 and (cnt[[0, 1, 2, 3, 4, 8]] / cnt.sum() - 1 / 6).abs().max() < 0.02
+        assert cnt[[5, 6, 7]].sum() == 0 and (cnt[[0, 1, 2, 3, 4, 8]] / cnt.sum() - 1 / 6).abs().max() < (0.02 if N >= 192 else 0.06)
     env.close()
 
 
