@@ -375,6 +375,20 @@ int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uin
     return launched();
 }
 
+int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
+                      const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, float* store_obs,
+                      int64_t store_env_stride, const int64_t* store_t, void* stream) {
+    if (!obs || !conv_w || !conv_b || !lin_w_packed || !lin_b || !out || rows < 1 || n_agents < 1 || rows % n_agents || out_stride < 32)
+        return fail(SSD_ERR_INVALID, "bad argument");
+    if (view_edge != 15) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode is instantiated for view_size 7 (15 x 15 windows); use ssd_conv_leaky + GEMM");
+    if ((reinterpret_cast<uintptr_t>(obs) | reinterpret_cast<uintptr_t>(lin_w_packed)) & 15) return fail(SSD_ERR_INVALID, "obs / lin_w_packed must be 16-byte aligned");
+    if (store_obs && !store_t) return fail(SSD_ERR_INVALID, "store_obs needs store_t");
+    const int rc = launch_policy_encode(obs, rows, view_edge, conv_w, conv_b, lin_w_packed, lin_b, out, out_stride, n_agents, agent_major,
+                                        store_obs, (long)store_env_stride, store_t, (hipStream_t)stream);
+    if (rc) return fail(SSD_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS) failed");
+    return launched();
+}
+
 static int policy_head(const ssd_policy_head* a, int inc, void* stream) {
     if (!a || !a->inputs || !a->h || !a->weights || !a->epsilon || !a->step || !a->out_actions) return fail(SSD_ERR_INVALID, "bad argument");
     if (a->n_env < 1 || a->n_agents < 1 || a->n_actions < 1) return fail(SSD_ERR_INVALID, "bad argument");

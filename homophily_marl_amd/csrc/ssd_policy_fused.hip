@@ -257,4 +257,150 @@ static int launch_head(const ssd_policy_head* p, int inc, hipStream_t s) {
 
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) { return launch_head(p, inc, s); }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Encoder: Conv2d(3, 6, 3, 1) + LeakyReLU + Flatten + Linear(6 (V-2)^2, 32) + LeakyReLU (homophily_agent.py:20-27,213-214) in one
+// launch, the 4 KB/row conv activations never leaving the CU (the unfused form writes and re-reads 83 MB per timestep).
+//   * workgroup = 4 waves = 16 observation rows; the rows (contiguous in HBM) are staged in LDS with 16-byte loads and, on the
+//     way, copied into the episode storage obs[b, t];
+//   * conv on the VALU: thread = (row, output line y) keeps its 3 x 3 x V input window in registers and produces the V-2 outputs
+//     of the line for one output channel at a time (27 scalar-operand FMAs per output, weights through the scalar cache);
+//   * per output channel the [16 rows, (V-2)^2] activations go to a double-buffered LDS chunk and are contracted with the
+//     matching slice of the Linear weight by v_mfma_f32_16x16x4_f32 (transposed product as in k_head: weight = A operand,
+//     streamed from L2 as float4 from a zero-padded [6][32][176] repack; activations = B operand, ds_read_b128); the four waves
+//     split the K groups and their partial sums are added in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct EncK {
+    const float* obs; int rows;
+    const float *cw, *cb, *lwp, *lb;
+    float* out; int out_stride, n, agent_major;
+    float* store; long store_env_stride; const int64_t* store_t;
+};
+
+template <int V>
+__global__ __launch_bounds__(256, 2) void k_encode(EncK a) {
+    constexpr int O = V - 2, P = O * O, L = 3 * V * V, PG = (P + 15) / 16, PP = PG * 16, CS = PP + 4, ITEMS = 16 * O;
+    static_assert(ITEMS <= 256 && (16 * L) % 4 == 0 && CS % 4 == 0 && (CS % 32) != 0, "tile shape");
+    extern __shared__ float lds[];
+    float* tile = lds;                  // [16][L], contiguous like the source rows
+    float* cbuf = lds + 16 * L;         // [2][16][CS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    const int nrows = a.rows - row0 < 16 ? a.rows - row0 : 16;
+    {
+        const float* src = a.obs + (size_t)row0 * L;
+        const int total = nrows * L;
+        for (int e4 = tid; e4 < 16 * L / 4; e4 += 256) {
+            f32x4 v;
+            if (4 * e4 + 3 < total) v = *reinterpret_cast<const f32x4*>(src + 4 * e4);
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = 4 * e4 + r < total ? src[4 * e4 + r] : 0.f;
+            *reinterpret_cast<f32x4*>(tile + 4 * e4) = v;
+        }
+        for (int e = tid; e < 2 * 16 * (CS - P); e += 256) {          // K padding of the chunks: zero (0 x weight pad 0)
+            const int rr = e / (CS - P), j = e - rr * (CS - P);
+            cbuf[rr * CS + P + j] = 0.f;
+        }
+    }
+    __syncthreads();
+    if (a.store) {
+        const long t_off = (long)(*a.store_t) * a.n * L;
+        for (int r = 0; r < nrows; ++r) {
+            const int row = row0 + r, b = row / a.n, i = row - b * a.n;
+            float* dst = a.store + (long)b * a.store_env_stride + t_off + (long)i * L;
+            for (int e = tid; e < L; e += 256) dst[e] = tile[r * L + e];
+        }
+    }
+    const bool active = tid < ITEMS;
+    const int row_l = active ? tid / O : 0, y = active ? tid - row_l * O : 0;
+    float in[3][3][V];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int x = 0; x < V; ++x) in[ch][dy][x] = tile[row_l * L + ch * V * V + (y + dy) * V + x];
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
+    for (int oc = 0; oc < 6; ++oc) {
+        // this wave's slices of the Linear weight for channel oc (prefetched: consumed after the barrier)
+        f32x4 af[3][2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = wave + 4 * j;
+            if (c < PG)
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+                    af[j][ft] = *reinterpret_cast<const f32x4*>(a.lwp + ((size_t)(oc * 32 + 16 * ft + m) * PP + 16 * c + 4 * q));
+        }
+        float* cb_w = cbuf + (oc & 1) * 16 * CS;
+        if (active) {
+            float o[O];
+            const float bias = a.cb[oc];
+#pragma unroll
+            for (int x = 0; x < O; ++x) o[x] = bias;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float w = a.cw[((oc * 3 + ch) * 3 + dy) * 3 + dx];
+#pragma unroll
+                        for (int x = 0; x < O; ++x) o[x] = fmaf(w, in[ch][dy][x + dx], o[x]);
+                    }
+#pragma unroll
+            for (int x = 0; x < O; ++x) cb_w[row_l * CS + y * O + x] = leaky(o[x]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = wave + 4 * j;
+            if (c < PG) {
+                const f32x4 bf = *reinterpret_cast<const f32x4*>(cb_w + m * CS + 16 * c + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][ft][r], bf[r], acc[ft], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                                   // the observation tile is dead: reuse it for the reduction
+    f32x4* red = reinterpret_cast<f32x4*>(tile);
+    red[(wave * 2 + 0) * 64 + lane] = acc[0];
+    red[(wave * 2 + 1) * 64 + lane] = acc[1];
+    __syncthreads();
+    if (wave == 0 && m < nrows) {
+        const int row = row0 + m, b = row / a.n, i = row - b * a.n;
+        const size_t orow = a.agent_major ? (size_t)i * (a.rows / a.n) + b : (size_t)row;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            f32x4 s = red[(0 * 2 + ft) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) s += red[(w * 2 + ft) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.out[orow * a.out_stride + 16 * ft + 4 * q + r] = leaky(s[r] + a.lb[16 * ft + 4 * q + r]);
+        }
+    }
+}
+
+int launch_policy_encode(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lwp, const float* lb, float* out,
+                         int out_stride, int n_agents, int agent_major, float* store, long store_env_stride, const int64_t* store_t,
+                         hipStream_t s) {
+    if (V != 15) return -2;
+    constexpr int L = 3 * 15 * 15, CS = 176 + 4;
+    const size_t lds = (size_t)(16 * L + 2 * 16 * CS) * sizeof(float);
+    static bool attr_done_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    if (!attr_done_dev[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        attr_done_dev[dev] = true;
+    }
+    EncK k{obs, rows, cw, cb, lwp, lb, out, out_stride, n_agents, agent_major, store, store_env_stride, store_t};
+    hipLaunchKernelGGL(k_encode<15>, dim3((rows + 15) / 16), dim3(256), lds, s, k);
+    return 0;
+}
+
 }  // namespace ssd

@@ -58,6 +58,8 @@ class FastPolicy:
         packs = dict(
             cw=ag.conv_to_fc[0].weight, cb=ag.conv_to_fc[0].bias, lw=ag.conv_to_fc[3].weight, lb=ag.conv_to_fc[3].bias,
             lw_t=ag.conv_to_fc[3].weight.t(),
+            # Linear weight per conv channel, K zero-padded 169 -> 176 (ssd_policy_encode; include/ssd_hip.h)
+            lwp=F.pad(ag.conv_to_fc[3].weight.reshape(32, 6, -1).permute(1, 0, 2), (0, (-ag.conv_to_fc[3].weight.shape[1] // 6) % 16)),
             w1e=w("fc1_env_w"), b1e=b("fc1_env_b"),
             w2e=th.cat([w("fc2_env_w"), w("fc2_env_v_w")], dim=2), b2e=th.cat([b("fc2_env_b"), b("fc2_env_v_b")], dim=2),
             w1i_x=w("fc1_inc_w")[:, :self.inp], w1i_a=w("fc1_inc_w")[:, self.inp:], b1i=b("fc1_inc_b"),
@@ -122,16 +124,20 @@ class FastPolicy:
         p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
         V = obs.shape[-1]
         st = self._stream()
-        K = 6 * (V - 2) * (V - 2)
-        if getattr(self, "_conv", None) is None or self._conv.shape[1] != K:
-            self._conv = th.empty(n * N, K, dtype=th.float32, device=self.dev)           # agent-major rows
-        abi.check(lib, lib.ssd_conv_leaky(obs.data_ptr(), N * n, V, 6, p["cw"].data_ptr(), p["cb"].data_ptr(), self._conv.data_ptr(), n, 1,
-                                          None if store_obs is None else store_obs.data_ptr(),
-                                          0 if store_obs is None else store_obs.stride(0),
-                                          None if store_t is None else store_t.data_ptr(), st))
-        feat = self.inputs.view(n * N, self.inputs.shape[-1])[:, :32]                    # Linear + LeakyReLU straight into the input matrix
-        th.addmm(p["lb"], self._conv, p["lw_t"], out=feat)
-        F.leaky_relu_(feat)
+        so = (None if store_obs is None else store_obs.data_ptr(), 0 if store_obs is None else store_obs.stride(0),
+              None if store_t is None else store_t.data_ptr())
+        if self.fused and V == 15:      # conv + Linear in one launch (f32 MFMA), features straight into the input matrix
+            abi.check(lib, lib.ssd_policy_encode(obs.data_ptr(), N * n, V, p["cw"].data_ptr(), p["cb"].data_ptr(), p["lwp"].data_ptr(),
+                                                 p["lb"].data_ptr(), self.inputs.data_ptr(), self.inputs.shape[-1], n, 1, so[0], so[1], so[2], st))
+        else:
+            K = 6 * (V - 2) * (V - 2)
+            if getattr(self, "_conv", None) is None or self._conv.shape[1] != K:
+                self._conv = th.empty(n * N, K, dtype=th.float32, device=self.dev)           # agent-major rows
+            abi.check(lib, lib.ssd_conv_leaky(obs.data_ptr(), N * n, V, 6, p["cw"].data_ptr(), p["cb"].data_ptr(), self._conv.data_ptr(), n, 1,
+                                              so[0], so[1], so[2], st))
+            feat = self.inputs.view(n * N, self.inputs.shape[-1])[:, :32]                    # Linear + LeakyReLU straight into the input matrix
+            th.addmm(p["lb"], self._conv, p["lw_t"], out=feat)
+            F.leaky_relu_(feat)
         if self.fused:
             ha = self._head_args(False, eps, step, q_out)
             ha.avail = self.avail.data_ptr()

@@ -266,6 +266,12 @@ typedef struct ssd_policy_head {
 } ssd_policy_head;
 int ssd_policy_head_env(const ssd_policy_head* args, void* stream);
 int ssd_policy_head_inc(const ssd_policy_head* args, void* stream);
+/* ssd_policy_encode: ssd_encoder (rgb_preprocess, homophily_agent.py:20-27,213-214) for 15 x 15 windows with the Linear layer on
+ * f32-input MFMA; same arguments, except that the Linear weight f32 [32, 6 * 169] is passed re-packed per conv channel and
+ * zero padded: lin_w_packed f32 [6][32][176], lin_w_packed[c][f][p] = lin_w[f][c * 169 + p] for p < 169, else 0. */
+int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
+                      const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, float* store_obs,
+                      int64_t store_env_stride, const int64_t* store_t, void* stream);
 
 /* ---- COUNTER-mode generator (shared definition) ---------------------------------------------
  * Two levels, so that the expensive part is computed once per EPISODE (by the reset call) and kept in the env state:
