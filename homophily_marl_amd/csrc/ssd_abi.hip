@@ -228,7 +228,10 @@ static int make_oo(const ssd_env* E, const ssd_obs_out* o, DevObsOut* d) {
         if (((uintptr_t)o->obs & 15) != 0) return fail(SSD_ERR_INVALID, "obs must be 16-byte aligned");
     }
     if (o->state && ((uintptr_t)o->state & 15) != 0) return fail(SSD_ERR_INVALID, "state must be 16-byte aligned");
+    if (o->obs_env_stride < 0 || o->obs_slot_stride < 0 || (!o->obs_env_stride && o->obs_slot_stride))
+        return fail(SSD_ERR_INVALID, "obs_env_stride / obs_slot_stride");
     d->obs = o->obs; d->fmt = o->obs_format; d->state = o->state; d->pos = o->pos; d->orient = o->orient;
+    d->env_stride = (long)o->obs_env_stride; d->slot_stride = (long)o->obs_slot_stride;
     d->stamps = E->st.stamps;
     return SSD_OK;
 }
@@ -273,6 +276,7 @@ int ssd_step_observe(ssd_env* E, const int32_t* actions, const ssd_tape* tape, s
 #ifdef SSD_STAMPS
 // diagnostic build only: device buffer [n_env, 16] of u64 receiving the phase stamps
 int ssd_debug_set_stamps(ssd_env* E, unsigned long long* buf) { E->st.stamps = buf; return SSD_OK; }
+int ssd_debug_set_policy_stamps(unsigned long long* buf) { ssd::set_policy_stamps(buf); return SSD_OK; }
 #endif
 
 int ssd_poll_error(ssd_env* E, int32_t* bits) {
@@ -344,6 +348,8 @@ int ssd_conv_leaky(const float* obs, int32_t rows, int32_t view_edge, int32_t co
 
 int ssd_store_step_launch(const ssd_store_step* a, void* stream) {
     if (!a || !a->t_index || a->n_env < 1 || a->n_agents < 1 || a->t_slots < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if (a->next_t_out && a->next_t_out == a->t_index) return fail(SSD_ERR_INVALID, "next_t_out must not alias t_index");
+    if ((a->prev_reward || a->ep_return) && !a->reward) return fail(SSD_ERR_INVALID, "prev_reward / ep_return need reward");
     launch_store_step(a, (hipStream_t)stream);
     return launched();
 }
@@ -376,15 +382,17 @@ int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uin
 }
 
 int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
-                      const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, float* store_obs,
-                      int64_t store_env_stride, const int64_t* store_t, void* stream) {
+                      const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, int64_t obs_env_stride,
+                      int64_t obs_slot_stride, const int64_t* slot_t, int64_t* slot_t_copy, void* stream) {
     if (!obs || !conv_w || !conv_b || !lin_w_packed || !lin_b || !out || rows < 1 || n_agents < 1 || rows % n_agents || out_stride < 32)
         return fail(SSD_ERR_INVALID, "bad argument");
     if (view_edge != 15) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode is instantiated for view_size 7 (15 x 15 windows); use ssd_conv_leaky + GEMM");
-    if ((reinterpret_cast<uintptr_t>(obs) | reinterpret_cast<uintptr_t>(lin_w_packed)) & 15) return fail(SSD_ERR_INVALID, "obs / lin_w_packed must be 16-byte aligned");
-    if (store_obs && !store_t) return fail(SSD_ERR_INVALID, "store_obs needs store_t");
+    if (reinterpret_cast<uintptr_t>(lin_w_packed) & 15) return fail(SSD_ERR_INVALID, "lin_w_packed must be 16-byte aligned");
+    if (obs_env_stride < 0 || obs_slot_stride < 0 || (obs_slot_stride && (!obs_env_stride || !slot_t)))
+        return fail(SSD_ERR_INVALID, "obs_env_stride / obs_slot_stride / slot_t");
+    if (slot_t_copy && (!slot_t || slot_t_copy == slot_t)) return fail(SSD_ERR_INVALID, "slot_t_copy needs a distinct slot_t");
     const int rc = launch_policy_encode(obs, rows, view_edge, conv_w, conv_b, lin_w_packed, lin_b, out, out_stride, n_agents, agent_major,
-                                        store_obs, (long)store_env_stride, store_t, (hipStream_t)stream);
+                                        (long)obs_env_stride, (long)obs_slot_stride, slot_t, slot_t_copy, (hipStream_t)stream);
     if (rc) return fail(SSD_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS) failed");
     return launched();
 }
@@ -392,6 +400,7 @@ int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const f
 static int policy_head(const ssd_policy_head* a, int inc, void* stream) {
     if (!a || !a->inputs || !a->h || !a->weights || !a->epsilon || !a->step || !a->out_actions) return fail(SSD_ERR_INVALID, "bad argument");
     if (a->n_env < 1 || a->n_agents < 1 || a->n_actions < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if (!inc && a->pos_copy && (!a->orient || !a->orient_copy)) return fail(SSD_ERR_INVALID, "pos_copy needs orient and orient_copy");
     if (inc ? (!a->actions || !a->pos_pre || !a->orient_pre || !a->reward || !a->clean_num || !a->apple_den)
             : (!a->prev_actions || !a->prev_reward || !a->prev_actions_inc || !a->pos)) return fail(SSD_ERR_INVALID, "missing head input");
     // layout limits of the fused kernel: 32 encoder features + tail (+ one-hot action for inc) within 64 columns, 16 fc2 rows

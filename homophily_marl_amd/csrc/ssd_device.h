@@ -79,6 +79,7 @@ struct DevObsOut {
     void* obs;
     int32_t fmt;
     float *state, *pos, *orient;
+    long env_stride, slot_stride;  // placement of obs inside an episode storage (elements); 0, 0 = dense
     unsigned long long* stamps;  // diagnostic builds only
 };
 
@@ -118,8 +119,11 @@ void launch_gru_fwd_train(const float* gi, const float* gh, const float* h, floa
 void launch_gru_bwd(const float* dh, const float* rzn, const float* gh, const float* h, float* d_gi, float* d_gh, float* dh_prev, int R,
                     int H, hipStream_t s);
 int launch_policy_encode(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lwp, const float* lb, float* out,
-                         int out_stride, int n_agents, int agent_major, float* store, long store_env_stride, const int64_t* store_t,
-                         hipStream_t s);
+                         int out_stride, int n_agents, int agent_major, long env_stride, long slot_stride, const int64_t* slot_t,
+                         int64_t* slot_t_copy, hipStream_t s);
+#ifdef SSD_STAMPS
+void set_policy_stamps(unsigned long long* buf);
+#endif
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s);
 void launch_dueling_pick(const float* av, int R, int A, const uint8_t* avail, const float* eps, const int64_t* step, uint32_t seed,
                          int n_agents, int B, int pairs, int64_t* actions, float* q_out, hipStream_t s);

@@ -93,6 +93,7 @@ struct Env {
     uint8_t* pm;    // LDS padded class map [PMS] (observe) / scratch (step)
     uint8_t* pl;    // LDS output planes
     int lane, n, W, HW, GS;
+    int obs_slot;   // the env's step counter after this call (time slot of the observation in an episode storage)
     bool ag;        // lane < n
     int P;          // my agent's cell (r * W + c); unique negative for non-agent lanes
     int O;          // orientation
@@ -518,7 +519,8 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
     const int lane = E.lane, n = E.n, W = E.W, V = h->V, VV = h->VV, Wp = h->Wp;
     const int A = CODE ? VV : 3 * VV;                             // elements per agent
     const int L = n * A;
-    const size_t off = (size_t)env * L;                           // element offset of this env's block
+    // element offset of this env's block: dense, or slot ep_step of an episode storage [n_env, t_slots, n, ...]
+    const size_t off = oo.env_stride ? (size_t)env * (size_t)oo.env_stride + (size_t)E.obs_slot * (size_t)oo.slot_stride : (size_t)env * L;
     int head = (int)((EPV - (off % EPV)) % EPV);
     if (head > L) head = L;
     const int delta = (EPV - head % EPV) % EPV;
@@ -681,6 +683,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
     const uint32_t epoch = st.epoch[env];
     const int ep_step0 = MODE == MODE_RESET ? 0 : st.ep_step[env];
     const uint32_t counts0 = (MODE == MODE_STEP || MODE == MODE_STEP_OBS) ? st.counts[env] : 0u;
+    E.obs_slot = MODE == MODE_STEP_OBS ? ep_step0 + 1 : ep_step0;
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
         E.ap[ch] = (MODE != MODE_OBS && ch * kWave + lane < h->n_apple) ? S->apple[ch * kWave + lane] : 0;

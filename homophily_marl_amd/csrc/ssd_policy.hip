@@ -157,6 +157,9 @@ struct StoreStep {
     float *d_pos, *d_orient, *d_reward, *d_clean, *d_den, *d_onehot;
     uint8_t* d_term;
     int64_t *d_actions, *d_actions_inc;
+    int64_t *p_act, *p_inc;
+    float *p_rew, *ep_ret;
+    int64_t *next_t, *ctr_inc;
 };
 __global__ void k_store_step(StoreStep s) {
     const long t = *s.t;
@@ -169,13 +172,26 @@ __global__ void k_store_step(StoreStep s) {
         const long bt = b * s.slots + t;
         if (k < 2 * n) { if (s.pos) s.d_pos[bt * 2 * n + k] = s.pos[b * 2 * n + k]; continue; } k -= 2 * n;
         if (k < 2 * n) { if (s.orient) s.d_orient[bt * 2 * n + k] = s.orient[b * 2 * n + k]; continue; } k -= 2 * n;
-        if (k < n) { if (s.reward) s.d_reward[bt * n + k] = s.reward[b * n + k]; continue; } k -= n;
+        if (k < n) {
+            if (s.reward) {
+                const float r = s.reward[b * n + k];
+                s.d_reward[bt * n + k] = r;
+                if (s.p_rew) s.p_rew[b * n + k] = r;
+                if (s.ep_ret) s.ep_ret[b * n + k] += r;
+            }
+            continue;
+        } k -= n;
         if (k < n) { if (s.clean) s.d_clean[bt * n + k] = s.clean[b * n + k]; continue; } k -= n;
         if (k < n) { if (s.den) s.d_den[bt * n + k] = s.den[b * n + k]; continue; } k -= n;
-        if (k < n) { if (s.actions) s.d_actions[bt * n + k] = s.actions[b * n + k]; continue; } k -= n;
+        if (k < n) { if (s.actions) { const int64_t v = s.actions[b * n + k]; s.d_actions[bt * n + k] = v; if (s.p_act) s.p_act[b * n + k] = v; } continue; } k -= n;
         if (k < n * A) { if (s.actions) { const int i = k / A, a = k - i * A; s.d_onehot[(bt * n + i) * A + a] = s.actions[b * n + i] == a ? 1.f : 0.f; } continue; } k -= n * A;
-        if (k < n * n) { if (s.actions_inc) s.d_actions_inc[bt * n * n + k] = s.actions_inc[b * n * n + k]; continue; } k -= n * n;
+        if (k < n * n) { if (s.actions_inc) { const int64_t v = s.actions_inc[b * n * n + k]; s.d_actions_inc[bt * n * n + k] = v; if (s.p_inc) s.p_inc[b * n * n + k] = v; } continue; } k -= n * n;
         if (s.term) s.d_term[bt] = s.term[b];
+    }
+    // counters this kernel does not read: no ordering against the other blocks is needed
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (s.next_t) *s.next_t = t + 1;
+        if (s.ctr_inc) *s.ctr_inc += 1;
     }
 }
 
@@ -282,6 +298,8 @@ void launch_store_step(const ssd_store_step* a, hipStream_t s) {
     k.actions = a->actions; k.actions_inc = a->actions_inc;
     k.d_pos = a->dst_pos; k.d_orient = a->dst_orient; k.d_reward = a->dst_reward; k.d_clean = a->dst_clean_num; k.d_den = a->dst_apple_den;
     k.d_onehot = a->dst_actions_onehot; k.d_term = a->dst_terminated; k.d_actions = a->dst_actions; k.d_actions_inc = a->dst_actions_inc;
+    k.p_act = a->prev_actions; k.p_inc = a->prev_actions_inc; k.p_rew = a->prev_reward; k.ep_ret = a->ep_return;
+    k.next_t = a->next_t_out; k.ctr_inc = a->counter_inc;
     const long total = (long)k.N * (k.n * (8 + k.A + k.n) + 1);
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_store_step, dim3(blocks), dim3(256), 0, s, k);

@@ -25,6 +25,22 @@ namespace ssd {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// Diagnostic build (-DSSD_STAMPS, tools/pstamps.py): per-wave s_memtime stamps of the kernel phases, [wave][16] u64.
+#ifdef SSD_STAMPS
+static unsigned long long* g_policy_stamps = nullptr;
+#define PSTAMP_DECL unsigned long long* stamps;
+#define PSTAMP_SET(k) (k).stamps = g_policy_stamps
+#define PSTAMP(i) do { if (a.stamps && lane == 0) a.stamps[(size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PNOW() __builtin_amdgcn_s_memtime()
+#define PSTAMP_VAL(i, v) do { if (a.stamps && lane == 0) a.stamps[(size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * 16 + (i)] = (v); } while (0)
+#else
+#define PSTAMP_DECL
+#define PSTAMP_SET(k)
+#define PSTAMP(i)
+#define PNOW() 0ull
+#define PSTAMP_VAL(i, v)
+#endif
+
 constexpr int WS = 68;                         // LDS row stride of the transposed weights (floats)
 constexpr int ROW_FC1 = 0, ROW_WI = 64, ROW_WH = 256, ROW_FC2 = 448, W_ROWS = 464;
 constexpr int OFF_BIAS = W_ROWS * WS;          // fc1[64] | gru_i[192] | gru_h[192] | fc2[16]
@@ -53,6 +69,10 @@ struct HeadK {
     const float *pos_pre, *orient_pre, *reward, *clean, *den;
     int64_t* out_actions;
     float* q_out;
+    const float* orient;
+    int32_t* out_actions_i32;
+    float *pos_copy, *orient_copy;
+    PSTAMP_DECL
 };
 
 // acc[ot] += W^T[16 ot .. 16 ot + 15][:] x B   for OT output tiles; wt points at the first weight row of the block in LDS.
@@ -70,7 +90,13 @@ __device__ __forceinline__ void gemm_t(const float* wt, const f32x4 (&B)[4], f32
     }
 }
 
-__device__ __forceinline__ float sigmoid_fast(float x) { return 1.f / (1.f + __expf(-x)); }   // as k_gru_gates
+// sigmoid / tanh on v_exp_f32 + v_rcp_f32 (1 ulp each): ~2e-7 from the libm forms used by the per-layer path
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float ax = fminf(fabsf(x), 15.f);                            // 1 - 2 / (e^{2|x|} + 1), saturated
+    const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * ax) + 1.f);
+    return copysignf(t, x);
+}
 
 template <int INC>
 __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
@@ -79,17 +105,25 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
     const int agent = blockIdx.x / a.bpa, bia = blockIdx.x - agent * a.bpa;
     const int m = lane & 15, q = lane >> 4;
     const int N = a.N, n = a.n, A = a.A;
-    {   // stage this agent's weight image (already in LDS layout) -- flat 16-byte copy
+    PSTAMP(0);
+    {   // stage this agent's weight image (already in LDS layout): every load in flight before the first LDS write
         const f32x4* src = reinterpret_cast<const f32x4*>(a.weights + (size_t)agent * IMAGE);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int e = tid; e < IMAGE / 4; e += HEAD_WAVES * 64) dst[e] = src[e];
+        constexpr int PER = (IMAGE / 4 + HEAD_WAVES * 64 - 1) / (HEAD_WAVES * 64);
+        f32x4 tmp[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { const int e = tid + j * HEAD_WAVES * 64; if (e < IMAGE / 4) tmp[j] = src[e]; }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { const int e = tid + j * HEAD_WAVES * 64; if (e < IMAGE / 4) dst[e] = tmp[j]; }
     }
     __syncthreads();
+    PSTAMP(1);
+    bool first = true;
     float* scratch = lds + IMAGE + wave * SCRATCH;
     const float eps = *a.eps;
     const uint32_t step = (uint32_t)*a.step;
     const int tiles = (N + 15) >> 4;
-    for (int tile = bia * HEAD_WAVES + wave; tile < tiles; tile += a.bpa * HEAD_WAVES) {
+    for (int tile = wave * a.bpa + bia; tile < tiles; tile += a.bpa * HEAD_WAVES) {   // consecutive tiles go to different CUs
         const int b = tile * 16 + m;
         const bool valid = b < N;
         const int bc = valid ? b : N - 1;
@@ -110,6 +144,10 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
                 recv += (v == 1) - (v == 2);
             }
             const float px = a.pos[er * 2] / a.pos_scale, py = a.pos[er * 2 + 1] / a.pos_scale;
+            if (a.pos_copy && valid && q == 0) {                       // the pose BEFORE the env step (read by the inc head / the storage)
+                a.pos_copy[er * 2] = a.pos[er * 2]; a.pos_copy[er * 2 + 1] = a.pos[er * 2 + 1];
+                a.orient_copy[er * 2] = a.orient[er * 2]; a.orient_copy[er * 2 + 1] = a.orient[er * 2 + 1];
+            }
 #pragma unroll
             for (int ct = 2; ct < 4; ++ct) {
 #pragma unroll
@@ -140,6 +178,7 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
                 }
             }
         }
+        if (first) PSTAMP(2);
         // ---- fc1 + LeakyReLU -----------------------------------------------------------------------------------------------
         f32x4 x1[4];
 #pragma unroll
@@ -149,6 +188,7 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
         for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
             for (int r = 0; r < 4; ++r) x1[ot][r] = leaky(x1[ot][r]);
+        if (first) PSTAMP(3);
         // ---- GRU cell: r, z share one accumulator for the input and the hidden side; n needs both separately -------------------
         float* h_row = a.h + arow * 64;
         f32x4 hp[4];
@@ -165,8 +205,10 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
         }
         gemm_t<8>(lds + ROW_WI * WS, x1, g, m, q);
         gemm_t<4>(lds + (ROW_WI + 128) * WS, x1, g + 8, m, q);
+        if (first) PSTAMP(4);
         gemm_t<8>(lds + ROW_WH * WS, hp, g, m, q);
         gemm_t<4>(lds + (ROW_WH + 128) * WS, hp, g + 12, m, q);
+        if (first) PSTAMP(5);
         f32x4 hn[4];
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) {
@@ -174,11 +216,12 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
             for (int r = 0; r < 4; ++r) {
                 const float rg = sigmoid_fast(g[ft][r]);
                 const float zg = sigmoid_fast(g[4 + ft][r]);
-                const float ng = tanhf(g[8 + ft][r] + rg * g[12 + ft][r]);
+                const float ng = tanh_fast(g[8 + ft][r] + rg * g[12 + ft][r]);
                 hn[ft][r] = (1.f - zg) * ng + zg * hp[ft][r];
             }
             if (valid) *reinterpret_cast<f32x4*>(h_row + 16 * ft + 4 * q) = hn[ft];
         }
+        if (first) PSTAMP(6);
         // ---- fc2 (advantages + value, padded to 16 outputs) ---------------------------------------------------------------
         f32x4 o2 = *reinterpret_cast<const f32x4*>(lds + OFF_B2 + 4 * q);
         gemm_t<1>(lds + ROW_FC2 * WS, hn, &o2, m, q);
@@ -194,6 +237,7 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
                 const int act = dueling_pick_row(av, av[A], A, a.avail, eps, step, a.seed, r,
                                                  a.q_out ? a.q_out + (size_t)r * A : nullptr);
                 a.out_actions[(size_t)bb * n + agent] = act;
+                if (a.out_actions_i32) a.out_actions_i32[(size_t)bb * n + agent] = act;
             }
         } else {
             const float* w2o = lds + OFF_W2O;                          // [E][4]: 3 advantages + value per extra feature
@@ -222,7 +266,10 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
             }
         }
         __builtin_amdgcn_wave_barrier();                               // scratch is reused by the next tile
+        if (first) PSTAMP(7);
+        first = false;
     }
+    PSTAMP(8);
 }
 
 static int launch_head(const ssd_policy_head* p, int inc, hipStream_t s) {
@@ -233,10 +280,11 @@ static int launch_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     k.prev_actions = p->prev_actions; k.prev_reward = p->prev_reward; k.prev_inc = p->prev_actions_inc; k.pos = p->pos;
     k.actions = p->actions; k.pos_pre = p->pos_pre; k.orient_pre = p->orient_pre; k.reward = p->reward; k.clean = p->clean_num;
     k.den = p->apple_den; k.out_actions = p->out_actions; k.q_out = p->q_out;
+    PSTAMP_SET(k);
+    k.orient = p->orient; k.out_actions_i32 = p->out_actions_i32; k.pos_copy = p->pos_copy; k.orient_copy = p->orient_copy;
     const int tiles = (k.N + 15) / 16;
     int bpa = 256 / k.n;                                               // one workgroup per CU (the image fills most of the LDS)
-    const int need = (tiles + HEAD_WAVES - 1) / HEAD_WAVES;
-    if (bpa > need) bpa = need;
+    if (bpa > tiles) bpa = tiles;
     if (bpa < 1) bpa = 1;
     k.bpa = bpa;
     const size_t lds = (size_t)(IMAGE + HEAD_WAVES * SCRATCH) * sizeof(float);
@@ -256,12 +304,15 @@ static int launch_head(const ssd_policy_head* p, int inc, hipStream_t s) {
 }
 
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) { return launch_head(p, inc, s); }
+#ifdef SSD_STAMPS
+void set_policy_stamps(unsigned long long* buf) { g_policy_stamps = buf; }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Encoder: Conv2d(3, 6, 3, 1) + LeakyReLU + Flatten + Linear(6 (V-2)^2, 32) + LeakyReLU (homophily_agent.py:20-27,213-214) in one
 // launch, the 4 KB/row conv activations never leaving the CU (the unfused form writes and re-reads 83 MB per timestep).
-//   * workgroup = 4 waves = 16 observation rows; the rows (contiguous in HBM) are staged in LDS with 16-byte loads and, on the
-//     way, copied into the episode storage obs[b, t];
+//   * workgroup = 4 waves = 16 observation rows, staged in LDS; the rows are read where the env kernel wrote them -- a dense
+//     [rows, 3, V, V] buffer or directly time slot t of the episode storage [n_env, t_slots, n, 3, V, V] (no copy of obs);
 //   * conv on the VALU: thread = (row, output line y) keeps its 3 x 3 x V input window in registers and produces the V-2 outputs
 //     of the line for one output channel at a time (27 scalar-operand FMAs per output, weights through the scalar cache);
 //   * per output channel the [16 rows, (V-2)^2] activations go to a double-buffered LDS chunk and are contracted with the
@@ -269,107 +320,123 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) { retur
 //     streamed from L2 as float4 from a zero-padded [6][32][176] repack; activations = B operand, ds_read_b128); the four waves
 //     split the K groups and their partial sums are added in a fixed order (deterministic).
 // ---------------------------------------------------------------------------------------------------------------------------
+// LDS row stride of the conv activations [6][CS] (+ pad so that stride mod 32 = 4: conflict-free ds_read_b128 across rows)
+#define ENC_RS(V) (6 * ((((V) - 2) * ((V) - 2) + 15) / 16 * 16 + 4) + 12)
 struct EncK {
     const float* obs; int rows;
-    const float *cw, *cb, *lwp, *lb;
     float* out; int out_stride, n, agent_major;
-    float* store; long store_env_stride; const int64_t* store_t;
+    long env_stride, slot_stride; const int64_t* slot_t;   // row (b, i) = obs + b * env_stride + *slot_t * slot_stride + i * 3VV
+    int64_t* slot_t_copy;
+    PSTAMP_DECL
 };
 
 template <int V>
-__global__ __launch_bounds__(256, 2) void k_encode(EncK a) {
-    constexpr int O = V - 2, P = O * O, L = 3 * V * V, PG = (P + 15) / 16, PP = PG * 16, CS = PP + 4, ITEMS = 16 * O;
-    static_assert(ITEMS <= 256 && (16 * L) % 4 == 0 && CS % 4 == 0 && (CS % 32) != 0, "tile shape");
+__global__ __launch_bounds__(256, 2) void k_encode(EncK a, const float* __restrict__ cw, const float* __restrict__ cb,
+                                                    const float* __restrict__ lwp, const float* __restrict__ lb) {
+    // the weights are separate __restrict__ kernel arguments so that the wave-uniform conv weights come through the scalar cache
+    constexpr int O = V - 2, P = O * O, L = 3 * V * V, PG = (P + 15) / 16, PP = PG * 16, CS = PP + 4, RS = ENC_RS(V), ITEMS = 16 * O;
+    static_assert(ITEMS <= 256 && CS % 4 == 0 && RS % 4 == 0 && RS >= 6 * CS && 16 * RS >= 16 * L && (RS % 32 == 4 || RS % 32 == 20), "tile shape");
     extern __shared__ float lds[];
-    float* tile = lds;                  // [16][L], contiguous like the source rows
-    float* cbuf = lds + 16 * L;         // [2][16][CS]
+    float* tile = lds;                  // [16][L] observation rows ...
+    float* cbuf = lds;                  // ... later overwritten by the conv activations [16][RS]: row -> [6][CS]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int row0 = blockIdx.x * 16;
     const int nrows = a.rows - row0 < 16 ? a.rows - row0 : 16;
-    {
-        const float* src = a.obs + (size_t)row0 * L;
-        const int total = nrows * L;
-        for (int e4 = tid; e4 < 16 * L / 4; e4 += 256) {
-            f32x4 v;
-            if (4 * e4 + 3 < total) v = *reinterpret_cast<const f32x4*>(src + 4 * e4);
-            else
+    PSTAMP(0);
+    {   // stage the 16 rows: dword loads (rows are 4-byte aligned only), all in flight before the first LDS write
+        const long t_off = a.slot_t ? (long)(*a.slot_t) * a.slot_stride : 0;
+        if (a.slot_t_copy && blockIdx.x == 0 && tid == 0) *a.slot_t_copy = *a.slot_t;
+        constexpr int PR = (L + 255) / 256;
+        float tmp[16][PR];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = 4 * e4 + r < total ? src[4 * e4 + r] : 0.f;
-            *reinterpret_cast<f32x4*>(tile + 4 * e4) = v;
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r < nrows ? r : 0), b = row / a.n, i = row - b * a.n;
+            const float* src = a.obs + (long)b * a.env_stride + t_off + (long)i * L;
+#pragma unroll
+            for (int j = 0; j < PR; ++j) { const int e = tid + 256 * j; tmp[r][j] = (r < nrows && e < L) ? src[e] : 0.f; }
         }
-        for (int e = tid; e < 2 * 16 * (CS - P); e += 256) {          // K padding of the chunks: zero (0 x weight pad 0)
-            const int rr = e / (CS - P), j = e - rr * (CS - P);
-            cbuf[rr * CS + P + j] = 0.f;
-        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int j = 0; j < PR; ++j) { const int e = tid + 256 * j; if (e < L) tile[r * L + e] = tmp[r][j]; }
     }
     __syncthreads();
-    if (a.store) {
-        const long t_off = (long)(*a.store_t) * a.n * L;
-        for (int r = 0; r < nrows; ++r) {
-            const int row = row0 + r, b = row / a.n, i = row - b * a.n;
-            float* dst = a.store + (long)b * a.store_env_stride + t_off + (long)i * L;
-            for (int e = tid; e < L; e += 256) dst[e] = tile[r * L + e];
-        }
-    }
+    PSTAMP(1);
+    // ---- conv on the VALU: thread = (row, output line y); all 6 output channels of the line accumulate together, one input
+    //      channel (3 x V window rows in registers) at a time -- 78 independent accumulators, every input value read once
     const bool active = tid < ITEMS;
     const int row_l = active ? tid / O : 0, y = active ? tid - row_l * O : 0;
-    float in[3][3][V];
+    float acc[6][O];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch)
+    for (int oc = 0; oc < 6; ++oc)
+#pragma unroll
+        for (int x = 0; x < O; ++x) acc[oc][x] = cb[oc];
+#pragma unroll 1
+    for (int ch = 0; ch < 3; ++ch) {                                   // not unrolled: 54 scalar weights live at a time
+        float in[3][V];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int x = 0; x < V; ++x) in[ch][dy][x] = tile[row_l * L + ch * V * V + (y + dy) * V + x];
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 1
-    for (int oc = 0; oc < 6; ++oc) {
-        // this wave's slices of the Linear weight for channel oc (prefetched: consumed after the barrier)
-        f32x4 af[3][2];
+            for (int x = 0; x < V; ++x) in[dy][x] = tile[row_l * L + ch * V * V + (y + dy) * V + x];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int c = wave + 4 * j;
-            if (c < PG)
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int ft = 0; ft < 2; ++ft)
-                    af[j][ft] = *reinterpret_cast<const f32x4*>(a.lwp + ((size_t)(oc * 32 + 16 * ft + m) * PP + 16 * c + 4 * q));
-        }
-        float* cb_w = cbuf + (oc & 1) * 16 * CS;
-        if (active) {
-            float o[O];
-            const float bias = a.cb[oc];
+            for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-            for (int x = 0; x < O; ++x) o[x] = bias;
+                for (int oc = 0; oc < 6; ++oc) {
+                    const float w = cw[((oc * 3 + ch) * 3 + dy) * 3 + dx];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch)
+                    for (int x = 0; x < O; ++x) acc[oc][x] = fmaf(w, in[dy][x + dx], acc[oc][x]);
+                }
+    }
+    PSTAMP(2);
+    // this wave's slices of the Linear weight (float4 per lane from L2): requested now, consumed two barriers later
+    constexpr int NG = 6 * PG, PERW = (NG + 3) / 4;
+    f32x4 af[PERW][2];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
+    for (int j = 0; j < PERW; ++j) {
+        const int g = wave + 4 * j;
+        if (g < NG) {
+            const int oc = g / PG, c = g - oc * PG;
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const float w = a.cw[((oc * 3 + ch) * 3 + dy) * 3 + dx];
-#pragma unroll
-                        for (int x = 0; x < O; ++x) o[x] = fmaf(w, in[ch][dy][x + dx], o[x]);
-                    }
-#pragma unroll
-            for (int x = 0; x < O; ++x) cb_w[row_l * CS + y * O + x] = leaky(o[x]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int c = wave + 4 * j;
-            if (c < PG) {
-                const f32x4 bf = *reinterpret_cast<const f32x4*>(cb_w + m * CS + 16 * c + 4 * q);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int ft = 0; ft < 2; ++ft) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][ft][r], bf[r], acc[ft], 0, 0, 0);
-            }
+            for (int ft = 0; ft < 2; ++ft)
+                af[j][ft] = *reinterpret_cast<const f32x4*>(lwp + ((size_t)(oc * 32 + 16 * ft + m) * PP + 16 * c + 4 * q));
         }
     }
-    __syncthreads();                                                   // the observation tile is dead: reuse it for the reduction
-    f32x4* red = reinterpret_cast<f32x4*>(tile);
-    red[(wave * 2 + 0) * 64 + lane] = acc[0];
-    red[(wave * 2 + 1) * 64 + lane] = acc[1];
+    __syncthreads();                                                   // every window has been read: the tile becomes the chunk buffer
+    PSTAMP(3);
+    if (active) {
+#pragma unroll
+        for (int oc = 0; oc < 6; ++oc)
+#pragma unroll
+            for (int x = 0; x < O; ++x) cbuf[row_l * RS + oc * CS + y * O + x] = leaky(acc[oc][x]);
+    }
+    for (int e = tid; e < 16 * 6 * (CS - P); e += 256) {              // K padding of the chunks: zero (0 x weight pad 0)
+        const int rr = e / (CS - P), j = e - rr * (CS - P), r16 = rr / 6, oc = rr - r16 * 6;
+        cbuf[r16 * RS + oc * CS + P + j] = 0.f;
+    }
+    __syncthreads();
+    PSTAMP(4);
+    // ---- Linear on the matrix cores: the 6 * PG groups of 16 k are dealt round-robin to the 4 waves (weight slices: af, above)
+    f32x4 mac[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < PERW; ++j) {
+        const int g = wave + 4 * j;
+        if (g < NG) {
+            const int oc = g / PG, c = g - oc * PG;
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(cbuf + m * RS + oc * CS + 16 * c + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) mac[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][ft][r], bf[r], mac[ft], 0, 0, 0);
+        }
+    }
+    PSTAMP(5);
+    __syncthreads();                                                   // the chunks are dead: reuse the buffer for the reduction
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+    red[(wave * 2 + 0) * 64 + lane] = mac[0];
+    red[(wave * 2 + 1) * 64 + lane] = mac[1];
     __syncthreads();
     if (wave == 0 && m < nrows) {
         const int row = row0 + m, b = row / a.n, i = row - b * a.n;
@@ -380,17 +447,18 @@ __global__ __launch_bounds__(256, 2) void k_encode(EncK a) {
 #pragma unroll
             for (int w = 1; w < 4; ++w) s += red[(w * 2 + ft) * 64 + lane];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a.out[orow * a.out_stride + 16 * ft + 4 * q + r] = leaky(s[r] + a.lb[16 * ft + 4 * q + r]);
+            for (int r = 0; r < 4; ++r) a.out[orow * a.out_stride + 16 * ft + 4 * q + r] = leaky(s[r] + lb[16 * ft + 4 * q + r]);
         }
     }
+    PSTAMP(6);
 }
 
 int launch_policy_encode(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lwp, const float* lb, float* out,
-                         int out_stride, int n_agents, int agent_major, float* store, long store_env_stride, const int64_t* store_t,
-                         hipStream_t s) {
+                         int out_stride, int n_agents, int agent_major, long env_stride, long slot_stride, const int64_t* slot_t,
+                         int64_t* slot_t_copy, hipStream_t s) {
     if (V != 15) return -2;
-    constexpr int L = 3 * 15 * 15, CS = 176 + 4;
-    const size_t lds = (size_t)(16 * L + 2 * 16 * CS) * sizeof(float);
+    constexpr int L = 3 * 15 * 15;
+    const size_t lds = (size_t)(16 * ENC_RS(15)) * sizeof(float);
     static bool attr_done_dev[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
@@ -398,8 +466,9 @@ int launch_policy_encode(const float* obs, int rows, int V, const float* cw, con
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         attr_done_dev[dev] = true;
     }
-    EncK k{obs, rows, cw, cb, lwp, lb, out, out_stride, n_agents, agent_major, store, store_env_stride, store_t};
-    hipLaunchKernelGGL(k_encode<15>, dim3((rows + 15) / 16), dim3(256), lds, s, k);
+    EncK k{obs, rows, out, out_stride, n_agents, agent_major, env_stride ? env_stride : (long)n_agents * L, slot_stride, slot_t, slot_t_copy};
+    PSTAMP_SET(k);
+    hipLaunchKernelGGL(k_encode<15>, dim3((rows + 15) / 16), dim3(256), lds, s, k, cw, cb, lwp, lb);
     return 0;
 }
 

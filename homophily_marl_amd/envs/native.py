@@ -101,7 +101,18 @@ class NativeEnv:
         o = abi.SsdObsOut()
         o.obs, o.obs_format = _ptr(bufs.get("obs")), fmt
         o.state, o.pos, o.orient = _ptr(bufs.get("state")), _ptr(bufs.get("pos")), _ptr(bufs.get("orient"))
+        # obs placed inside an episode storage [n_env, t_slots, n, ...]: the env writes slot ep_step itself
+        o.obs_env_stride, o.obs_slot_stride = int(bufs.get("obs_env_stride", 0)), int(bufs.get("obs_slot_stride", 0))
         return o
+
+    def storage_obs_buffers(self, storage, fmt=abi.OBS_F32):
+        """Output buffers whose `obs` is an episode storage [n_env, t_slots, n, 3, V, V] (dense inner dims): every observe /
+        step_observe writes the env's block at time slot ep_step (include/ssd_hip.h: ssd_obs_out.obs_env_stride)."""
+        N, n, V = self.n_env, self.n, self.V
+        assert storage.shape[0] == N and tuple(storage.shape[2:]) == ((n, V, V) if fmt == abi.OBS_CODE else (n, 3, V, V))
+        assert storage[0, 0].is_contiguous() and storage.dtype == _OBS_DTYPE[fmt] and storage.device == self.device
+        dense = self.obs_buffers(fmt)
+        return dict(obs=storage, pos=dense["pos"], orient=dense["orient"], obs_env_stride=storage.stride(0), obs_slot_stride=storage.stride(1))
 
     # ------------------------------------------------------------------------------------------------------
     def reset(self, tape=None, env_mask=None):

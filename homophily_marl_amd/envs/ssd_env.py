@@ -58,18 +58,18 @@ class SSDHipEnv(MultiAgentEnv):
     def reset_batch(self, env_mask=None):
         self.native.reset(self._tape, env_mask)
 
-    def step_batch(self, actions, observe=True, fmt=abi.OBS_F32):
+    def step_batch(self, actions, observe=True, fmt=abi.OBS_F32, out=None):
         """actions int32 [n_env, n] on the device.  Returns dict(reward, clean_num, apple_den [n_env, n] f32,
         terminated u8 [n_env], collective_return, equality f32 [n_env]) and, with observe=True, the observation of the
         NEW state (obs, pos, orient) from the same launch."""
         if observe:
-            self._last = self.native.step_observe(actions, self._tape, fmt)
+            self._last = self.native.step_observe(actions, self._tape, fmt, out=out)   # out: e.g. native.storage_obs_buffers(...)
         else:
             self._last = self.native.step(actions, self._tape)
         return self._last
 
-    def observe_batch(self, fmt=abi.OBS_F32, want_state=False):
-        return self.native.observe(fmt, want_state)
+    def observe_batch(self, fmt=abi.OBS_F32, want_state=False, out=None):
+        return self.native.observe(fmt, want_state, out=out)
 
     # ---- reference single-env API -------------------------------------------------------------------------------
     def _one(self):

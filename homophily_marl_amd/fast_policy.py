@@ -118,18 +118,31 @@ class FastPolicy:
 
     # ---- env head -----------------------------------------------------------------------------------------------
     @th.no_grad()
-    def act_env(self, obs, prev_actions, prev_reward, prev_inc, pos, eps, step, store_obs=None, store_t=None, q_out=None):
+    def act_env(self, obs, prev_actions, prev_reward, prev_inc, pos, eps, step, store_obs=None, store_t=None, q_out=None,
+                orient=None, actions_i32=None, pos_copy=None, orient_copy=None, obs_in_storage=False, t_copy=None):
         """obs f32 [N, n, 3, V, V]; prev_* of the previous timestep (prev_actions = -1 at t = 0); pos f32 [N, n, 2];
-        eps f32 scalar tensor, step i64 [1] tensor.  Returns actions i64 [N, n] (static buffer)."""
+        eps f32 scalar tensor, step i64 [1] tensor.  Returns actions i64 [N, n] (static buffer).
+        store_obs / store_t: episode storage obs f32 [N, T+1, n, 3, V, V] and the device time index; the observation is copied
+        to store_obs[:, t] on the way -- or, with obs_in_storage (fused encoder only), it already IS there (the env wrote it,
+        NativeEnv.storage_obs_buffers) and `obs` is ignored.
+        Fused path only: actions_i32 also receives the actions as int32; pos_copy / orient_copy receive copies of pos / orient."""
         p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
-        V = obs.shape[-1]
+        V = (store_obs if obs_in_storage else obs).shape[-1]
         st = self._stream()
         so = (None if store_obs is None else store_obs.data_ptr(), 0 if store_obs is None else store_obs.stride(0),
               None if store_t is None else store_t.data_ptr())
         if self.fused and V == 15:      # conv + Linear in one launch (f32 MFMA), features straight into the input matrix
-            abi.check(lib, lib.ssd_policy_encode(obs.data_ptr(), N * n, V, p["cw"].data_ptr(), p["cb"].data_ptr(), p["lwp"].data_ptr(),
-                                                 p["lb"].data_ptr(), self.inputs.data_ptr(), self.inputs.shape[-1], n, 1, so[0], so[1], so[2], st))
+            enc = (p["cw"].data_ptr(), p["cb"].data_ptr(), p["lwp"].data_ptr(), p["lb"].data_ptr(), self.inputs.data_ptr(),
+                   self.inputs.shape[-1], n, 1)
+            if obs_in_storage:
+                abi.check(lib, lib.ssd_policy_encode(store_obs.data_ptr(), N * n, V, *enc, store_obs.stride(0), store_obs.stride(1), so[2],
+                                                     None if t_copy is None else t_copy.data_ptr(), st))
+            else:
+                abi.check(lib, lib.ssd_policy_encode(obs.data_ptr(), N * n, V, *enc, 0, 0, None, None, st))
+                if store_obs is not None:
+                    store_obs.index_copy_(1, store_t, obs.unsqueeze(1))
         else:
+            assert not obs_in_storage, "obs_in_storage needs the fused encoder (15 x 15 windows)"
             K = 6 * (V - 2) * (V - 2)
             if getattr(self, "_conv", None) is None or self._conv.shape[1] != K:
                 self._conv = th.empty(n * N, K, dtype=th.float32, device=self.dev)           # agent-major rows
@@ -144,6 +157,10 @@ class FastPolicy:
             ha.prev_actions, ha.prev_reward, ha.prev_actions_inc, ha.pos = (prev_actions.data_ptr(), prev_reward.data_ptr(),
                                                                           prev_inc.data_ptr(), pos.data_ptr())
             ha.out_actions = self.actions.data_ptr()
+            if actions_i32 is not None:
+                ha.out_actions_i32 = actions_i32.data_ptr()
+            if pos_copy is not None:
+                ha.orient, ha.pos_copy, ha.orient_copy = orient.data_ptr(), pos_copy.data_ptr(), orient_copy.data_ptr()
             abi.check(lib, lib.ssd_policy_head_env(C.byref(ha), st))
             return self.actions
         abi.check(lib, lib.ssd_build_inputs(N, n, self.A, 2, prev_actions.data_ptr(), prev_reward.data_ptr(), prev_inc.data_ptr(),

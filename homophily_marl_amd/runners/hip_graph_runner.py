@@ -55,6 +55,7 @@ class HipGraphRunner(HipVecRunner):
         self.avail_mask = self.env.avail_actions_batch                  # [N, n, A]
         self.inc_mask = (1 - th.eye(n, device=dev, dtype=th.long)).reshape(1, n, n)
         self.fast = None
+        self.direct_obs = False
         if getattr(a, "fast_policy", True):
             from ..fast_policy import FastPolicy
             # Optionally the policy work of a timestep is evaluated per env GROUP on separate streams (fork/join inside the
@@ -78,6 +79,13 @@ class HipGraphRunner(HipVecRunner):
             self.gslices = [slice(g * hsz, (g + 1) * hsz) for g in range(G)]
             self.side_streams = [th.cuda.Stream(device=dev) for _ in range(G)] if G > 1 else []
             self._zeros_nn = th.zeros(N, n, device=dev)
+            self.pos_t, self.orient_t = th.zeros(N, n, 2, device=dev), th.zeros(N, n, 2, device=dev)   # pose before the env step
+            self.actions_i32 = th.zeros(N, n, dtype=th.int32, device=dev)
+            self.t_store = th.zeros(1, dtype=th.long, device=dev)     # the encoder's copy of t_dev, read by the store-step launch
+            # fused encoder: the env kernel writes obs[:, t + 1] of the storage itself and the encoder reads it there (no obs copy)
+            self.direct_obs = self.fast.fused and self.cur["obs"].shape[-1] == 15 and self.obs_fmt == abi.OBS_F32
+            if self.direct_obs:
+                self.cur = self.env.native.storage_obs_buffers(st["obs"], self.obs_fmt)
             self._ss, self._ss_last = self._make_store_args(True), self._make_store_args(False)
         self._ready = True
 
@@ -111,18 +119,24 @@ class HipGraphRunner(HipVecRunner):
         td = self.t_dev
         obs, pos, orient = self.cur["obs"], self.cur["pos"], self.cur["orient"]
 
+        fused = self.fast.fused
+
         def env_head(g):
             sl = self.gslices[g]
-            self.fasts[g].act_env(obs[sl], self.prev_actions[sl], self.prev_reward[sl], self.prev_inc[sl], pos[sl], self.eps,
-                                  self.rng_ctr, store_obs=st["obs"][sl], store_t=td)
+            extra = dict(orient=orient[sl], actions_i32=self.actions_i32[sl], pos_copy=self.pos_t[sl], orient_copy=self.orient_t[sl]) if fused else {}
+            self.fasts[g].act_env(None if self.direct_obs else obs[sl], self.prev_actions[sl], self.prev_reward[sl], self.prev_inc[sl],
+                                  pos[sl], self.eps, self.rng_ctr, store_obs=st["obs"][sl], store_t=td, obs_in_storage=self.direct_obs,
+                                  t_copy=self.t_store if (self.direct_obs and g == 0) else None, **extra)
         self._fork(env_head)
         actions = self.actions_full
-        pos_t, orient_t = pos.clone(), orient.clone()                   # forward_inc sees the PRE-step pose (controller :78-82)
+        pos_t, orient_t = self.pos_t, self.orient_t                     # forward_inc sees the PRE-step pose (controller :78-82)
+        if not fused:
+            pos_t.copy_(pos); orient_t.copy_(orient)
+            self.actions_i32.copy_(actions)
         ss = self._ss if store_env_step else self._ss_last
         if store_env_step:
-            out = self.env.step_batch(actions.to(th.int32), observe=True, fmt=self.obs_fmt)
+            out = self.env.step_batch(self.actions_i32, observe=True, fmt=self.obs_fmt, out=self.cur if self.direct_obs else None)
             reward, clean, den = out["reward"], out["clean_num"], out["apple_den"]
-            self.ep_return += reward
         else:
             reward = clean = den = self._zeros_nn
 
@@ -130,16 +144,13 @@ class HipGraphRunner(HipVecRunner):
             sl = self.gslices[g]
             self.fasts[g].act_inc(actions[sl], pos_t[sl], orient_t[sl], reward[sl], clean[sl], den[sl], self.eps, self.rng_ctr)
         self._fork(inc_head)
-        actions_inc = self.actions_inc_full
-        self.rng_ctr += 1
-        ss.pos, ss.orient = pos_t.data_ptr(), orient_t.data_ptr()
-        self._keep_pose = (pos_t, orient_t)
+        # ONE launch: the nine small fields of slot t, the controller's "previous step" inputs, the episode return and the
+        # time / exploration counters (incremented after every block has read t)
         abi.check(self.fast.lib, self.fast.lib.ssd_store_step_launch(C.byref(ss), th.cuda.current_stream(self.env.device).cuda_stream))
-        if store_env_step:
-            self.prev_actions.copy_(actions)
-            self.prev_reward.copy_(reward)
-            self.prev_inc.copy_(actions_inc)
-            td += 1
+        if not self.direct_obs:     # without the encoder's t copy the counters are advanced by two small torch kernels
+            self.rng_ctr += 1
+            if store_env_step:
+                td += 1
 
     def _make_store_args(self, with_step_outputs):
         st, out, fp = self.store.data.transition_data, self.env.native.out, self.fast
@@ -147,13 +158,21 @@ class HipGraphRunner(HipVecRunner):
         ss.t_index = self.t_dev.data_ptr()
         ss.n_env, ss.n_agents, ss.n_actions, ss.t_slots = self.batch_size, self.args.n_agents, self.args.n_actions, self.episode_limit + 1
         ss.actions, ss.actions_inc = self.actions_full.data_ptr(), self.actions_inc_full.data_ptr()
+        ss.pos, ss.orient = self.pos_t.data_ptr(), self.orient_t.data_ptr()
         ss.dst_pos, ss.dst_orient = st["agent_pos"].data_ptr(), st["agent_orientation"].data_ptr()
+        if self.direct_obs:
+            ss.t_index, ss.counter_inc = self.t_store.data_ptr(), self.rng_ctr.data_ptr()
         ss.dst_actions, ss.dst_actions_onehot, ss.dst_actions_inc = st["actions"].data_ptr(), st["actions_onehot"].data_ptr(), st["actions_inc"].data_ptr()
         if with_step_outputs:
             ss.reward, ss.clean_num, ss.apple_den, ss.terminated = (out["reward"].data_ptr(), out["clean_num"].data_ptr(),
                                                                       out["apple_den"].data_ptr(), out["terminated"].data_ptr())
             ss.dst_reward, ss.dst_clean_num, ss.dst_apple_den, ss.dst_terminated = (st["reward"].data_ptr(), st["clean_num"].data_ptr(),
                                                                                     st["apple_den"].data_ptr(), st["terminated"].data_ptr())
+            ss.prev_actions, ss.prev_reward, ss.prev_actions_inc = (self.prev_actions.data_ptr(), self.prev_reward.data_ptr(),
+                                                                    self.prev_inc.data_ptr())
+            ss.ep_return = self.ep_return.data_ptr()
+            if self.direct_obs:
+                ss.next_t_out = self.t_dev.data_ptr()
         return ss
 
     def _select(self, store_env_step):
@@ -203,7 +222,7 @@ class HipGraphRunner(HipVecRunner):
         self._test_mode = test_mode
         self.batch = self.store
         self.env.reset_batch()
-        self.env.observe_batch(self.obs_fmt)                            # fills self.cur
+        self.env.observe_batch(self.obs_fmt, out=self.cur if getattr(self, "direct_obs", False) else None)   # fills self.cur (or obs[:, 0])
         self.t = 0
         self.t_dev.zero_()
         self.prev_actions.fill_(-1); self.prev_reward.zero_(); self.prev_inc.zero_()

@@ -109,6 +109,11 @@ typedef struct ssd_obs_out {
     float* state;
     float* pos;                 /* [n_env, n, 2] row, col as float */
     float* orient;              /* [n_env, n, 2] ORIENTATIONS vector as float */
+    /* Optional placement of `obs` inside an episode storage [n_env, t_slots, n, ...] (EpisodeBatch.update of the "obs" key,
+     * episode_runner.py:59-67, without the copy): env b's block is written at element offset
+     * b * obs_env_stride + ep_step * obs_slot_stride, ep_step being the env's step counter AFTER the call (0 after a reset).
+     * Both 0 (default): dense [n_env, n, ...].  GPU library only. */
+    int64_t obs_env_stride, obs_slot_stride;
 } ssd_obs_out;
 
 /* Raw env state for parity tests and KATs (Agent.set_pos etc. in the reference). */
@@ -212,6 +217,16 @@ typedef struct ssd_store_step {
     float *dst_pos, *dst_orient, *dst_reward, *dst_clean_num, *dst_apple_den, *dst_actions_onehot;
     uint8_t* dst_terminated;
     int64_t *dst_actions, *dst_actions_inc;
+    /* optional runner state carried to the next timestep by the same launch (all nullable): the "previous" action / reward /
+     * incentive inputs of the controller, the running episode return (+= reward), and two device counters that this launch
+     * does not read itself (so one thread can update them without a grid-wide barrier): *next_t_out = *t_index + 1 and
+     * *counter_inc += 1.  next_t_out must not alias t_index (ssd_policy_encode's slot_t_copy provides the second scalar). */
+    int64_t* prev_actions;          /* [n_env, n]    <- actions */
+    float* prev_reward;             /* [n_env, n]    <- reward */
+    int64_t* prev_actions_inc;      /* [n_env, n, n] <- actions_inc */
+    float* ep_return;               /* [n_env, n]    += reward */
+    int64_t* next_t_out;
+    int64_t* counter_inc;
 } ssd_store_step;
 int ssd_store_step_launch(const ssd_store_step* args, void* stream);
 int ssd_gru_gates(const float* gi, const float* gh, float* h, int32_t rows, int32_t hidden, void* stream);
@@ -263,15 +278,24 @@ typedef struct ssd_policy_head {
     const float *reward, *clean_num, *apple_den;   /* [n_env, n] */
     int64_t* out_actions;          /* env: [n_env, n]; inc: [n_env, n, n] */
     float* q_out;                  /* nullable */
+    /* env head, optional by-products for the runner (all nullable): the actions again as int32 (the env's action type), and
+     * copies of the current pose (pos, orient [n_env, n, 2]) taken before the env step overwrites it */
+    const float* orient;
+    int32_t* out_actions_i32;
+    float *pos_copy, *orient_copy;
 } ssd_policy_head;
 int ssd_policy_head_env(const ssd_policy_head* args, void* stream);
 int ssd_policy_head_inc(const ssd_policy_head* args, void* stream);
-/* ssd_policy_encode: ssd_encoder (rgb_preprocess, homophily_agent.py:20-27,213-214) for 15 x 15 windows with the Linear layer on
- * f32-input MFMA; same arguments, except that the Linear weight f32 [32, 6 * 169] is passed re-packed per conv channel and
- * zero padded: lin_w_packed f32 [6][32][176], lin_w_packed[c][f][p] = lin_w[f][c * 169 + p] for p < 169, else 0. */
+/* ssd_policy_encode: rgb_preprocess (homophily_agent.py:20-27,213-214) for 15 x 15 windows with the Linear layer on f32-input
+ * MFMA.  The Linear weight f32 [32, 6 * 169] is passed re-packed per conv channel and zero padded: lin_w_packed f32 [6][32][176],
+ * lin_w_packed[c][f][p] = lin_w[f][c * 169 + p] for p < 169, else 0.  out / out_stride / agent_major as in ssd_encoder.
+ * The observation of row (env b, agent i) is read at obs + b * obs_env_stride + (*slot_t) * obs_slot_stride + i * 3VV:
+ * obs_env_stride = 0 means dense [rows, 3, V, V]; with the strides of an episode storage [n_env, t_slots, n, 3, V, V] and the
+ * device time index slot_t the encoder reads obs[:, t] where ssd_step_observe put it (ssd_obs_out.obs_env_stride).
+ * slot_t_copy (nullable) receives *slot_t: a second copy of the time index for ssd_store_step_launch, which advances slot_t. */
 int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
-                      const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, float* store_obs,
-                      int64_t store_env_stride, const int64_t* store_t, void* stream);
+                      const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, int64_t obs_env_stride,
+                      int64_t obs_slot_stride, const int64_t* slot_t, int64_t* slot_t_copy, void* stream);
 
 /* ---- COUNTER-mode generator (shared definition) ---------------------------------------------
  * Two levels, so that the expensive part is computed once per EPISODE (by the reset call) and kept in the env state:

@@ -189,3 +189,29 @@ def test_partial_reset_and_error_paths():
     with pytest.raises(abi.SsdError):
         HipEnv("cleanup", map="default3", num_agents=5, n_env=2)
     e.close(); t.close()
+
+
+@pytest.mark.parametrize("fmt,n", [(abi.OBS_F32, 5), (abi.OBS_U8, 3), (abi.OBS_BF16, 5)])
+def test_obs_written_into_episode_storage(fmt, n):
+    """ssd_obs_out.obs_env_stride / obs_slot_stride: the env kernel places obs at storage[b, ep_step] (ragged 16-byte
+    alignment per block: 37 envs, odd block sizes) -- bit-identical to the dense output of the same state."""
+    import torch
+    from homophily_marl_amd.envs.native import NativeEnv
+    N, T = 37, 5
+    env = NativeEnv("cleanup", device=0, map="default%d" % n, num_agents=n, n_env=N, view_size=7, episode_limit=50,
+                    rng_mode=abi.RNG_COUNTER, seed=11)
+    dt = {abi.OBS_F32: torch.float32, abi.OBS_U8: torch.uint8, abi.OBS_BF16: torch.bfloat16}[fmt]
+    storage = torch.zeros(N, T + 1, n, 3, 15, 15, dtype=dt, device="cuda")
+    bufs = env.storage_obs_buffers(storage, fmt)
+    g = torch.Generator().manual_seed(1)
+    env.reset()
+    env.observe(fmt, out=bufs)
+    assert (storage[:, 0] == env.observe(fmt)["obs"]).all()
+    for t in range(T - 1):
+        acts = torch.randint(0, 9, (N, n), generator=g, dtype=torch.int32).cuda()
+        r = env.step_observe(acts, fmt=fmt, out=bufs)
+        assert r["obs"] is storage
+        dense = env.observe(fmt)["obs"]
+        assert (storage[:, t + 1] == dense).all(), t
+        assert (storage[:, t + 2:] == 0).all()          # later slots untouched
+    assert env.poll_error() == 0
