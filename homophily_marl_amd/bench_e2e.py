@@ -16,8 +16,11 @@ from .run import load_config, setup
 
 def run_e2e(args, rank, world, local_rank):
     N, n, T = args.n_env, 5, 100
+    # replay capacity: at least the reference's 5000 episodes (config/default.yaml), rounded up to a multiple of the env batch so
+    # that the runner can write its episodes straight into the buffer's slots (ReplayBuffer.reserve: insertion moves no data)
+    buffer_size = -(-5000 // N) * N
     cfg = load_config("cleanup", overrides=dict(
-        runner=args.runner, train_graph=args.train_graph, batch_size_run=N, batch_size=16, buffer_size=max(5000, N), buffer_cpu_only=False, store_state=False,
+        runner=args.runner, train_graph=args.train_graph, batch_size_run=N, batch_size=16, buffer_size=buffer_size, buffer_cpu_only=False, store_state=False,
         env_args=dict(num_agents=n, map="default5", episode_limit=T, view_size=7, seed=1), use_cuda=True, save_model=False,
         device_index=local_rank, env_id_base=rank * N, runner_stats=False, learner_log_interval=10 ** 12))
     th.manual_seed(0)                     # fixed-seed random-init weights, identical on every rank
@@ -41,9 +44,9 @@ def run_e2e(args, rank, world, local_rank):
             state["in_episode"] = False
 
     # Setup (not warm-up): build the hipGraphs.  The rollout graph is captured at the start of the 2nd episode and the two
-    # train-step graphs at the 3rd learner.train call, so 3 full iterations are run before the W warm-up steps; this is the
+    # train-step graphs at the 3rd learner.train call, so 4 full iterations (each replay slab is visited twice) are run before the W warm-up steps; this is the
     # analogue of compiling the step and is excluded from both the warm-up count and the timed region.
-    for _ in range(3 * T):
+    for _ in range(4 * T):
         one_step()
     for _ in range(args.warmup):
         one_step()
@@ -99,5 +102,5 @@ def run_e2e(args, rank, world, local_rank):
                 workload="cleanup_default5_rollout_plus_homophily_train",
                 extra=dict(obs_format="f32[n_env,n,3,15,15]", kernel="ssd::k_env<MODE_STEP_OBS>", qnet_dtype="fp32",
                            train="1 learner.train(batch_size 16 x T 101) per 100-step rollout, double-Q + sim loss, 2x Adam",
-                           buffer="device-resident ReplayBuffer, %d episodes" % buf.buffer_size,
+                           buffer="device-resident ReplayBuffer, %d episodes, %s" % (buf.buffer_size, "written in place by the runner" if getattr(runner, "_replay", None) is not None else "copy insertion"),
                            runner=args.runner, train_graph=bool(args.train_graph), breakdown_ms=bd))

@@ -157,8 +157,24 @@ class ReplayBuffer(EpisodeBatch):
         self.buffer_index = 0
         self.episodes_in_buffer = 0
 
+    def reserve(self, n):
+        """A view over the next n episode slots, for producers that write whole episodes in place (vectorised runners): hand
+        the filled view to insert_episode_batch, which then only advances the ring indices instead of copying.  None if the
+        slots would wrap around."""
+        if self.buffer_index + n > self.buffer_size:
+            return None
+        view = self[self.buffer_index:self.buffer_index + n]
+        view._reserved = (self, self.buffer_index)
+        return view
+
     def insert_episode_batch(self, ep_batch):
         n = ep_batch.batch_size
+        res = getattr(ep_batch, "_reserved", None)
+        if res is not None and res[0] is self and res[1] == self.buffer_index:      # written in place (reserve)
+            self.buffer_index += n
+            self.episodes_in_buffer = max(self.episodes_in_buffer, self.buffer_index)
+            self.buffer_index %= self.buffer_size
+            return
         if self.buffer_index + n <= self.buffer_size:
             where = slice(self.buffer_index, self.buffer_index + n)
             self.update(ep_batch.data.transition_data, where, slice(0, ep_batch.max_seq_length), mark_filled=False)

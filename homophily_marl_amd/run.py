@@ -77,6 +77,8 @@ def setup(config, logger=None):
     learner = le_REGISTRY[args.learner](mac, buffer.scheme, logger, args)
     if args.use_cuda:
         learner.cuda()
+    if getattr(args, "replay_in_place", True) and hasattr(runner, "set_replay_buffer"):
+        runner.set_replay_buffer(buffer)        # hip_graph: rollouts land in the replay buffer's own slots when the sizes allow
     return SimpleNamespace(args=args, logger=logger, runner=runner, buffer=buffer, mac=mac, learner=learner)
 
 

@@ -30,16 +30,23 @@ class HipGraphRunner(HipVecRunner):
         self._graph = None
         self._episodes = 0
         self._ready = False
+        self._bundles, self._own_store, self._replay = {}, None, None
+
+    def set_replay_buffer(self, buffer):
+        """Write training episodes directly into `buffer` (ReplayBuffer.reserve) when its size is a small multiple of the env
+        batch and it lives on the env's device; buffer.insert_episode_batch(batch) then moves no data."""
+        N = self.batch_size
+        ok = (buffer is not None and buffer.buffer_size % N == 0 and buffer.buffer_size // N <= 4
+              and th.device(buffer.device) == th.device(self.args.device) and buffer.max_seq_length == self.episode_limit + 1)
+        self._replay = buffer if ok else None
+        return ok
 
     # ---- static state ---------------------------------------------------------------------------------------------
     def _allocate(self):
         a, N, n, T = self.args, self.batch_size, self.args.n_agents, self.episode_limit
         dev = self.env.device
-        self.store = EpisodeBatch(self._scheme, self._groups, N, T + 1, preprocess=self._preprocess, device=self.args.device)
-        st = self.store.data.transition_data
-        st["filled"].fill_(1)                                           # fixed-length episodes: every slot is filled
-        st["avail_actions"].copy_(self.env.avail_actions_batch.unsqueeze(1).expand(-1, T + 1, -1, -1))
-        self.cur = self.env.native.obs_buffers(self.obs_fmt)            # obs / pos / orient written by the env kernel
+        self._dense_cur = self.env.native.obs_buffers(self.obs_fmt)     # obs / pos / orient written by the env kernel
+        self.cur = self._dense_cur
         self.t_dev = th.zeros(1, dtype=th.long, device=dev)
         self.rng_ctr = th.zeros(1, dtype=th.long, device=dev)          # never reset: exploration draws differ between episodes
         self.prev_actions = th.full((N, n), -1, dtype=th.long, device=dev)
@@ -83,11 +90,27 @@ class HipGraphRunner(HipVecRunner):
             self.actions_i32 = th.zeros(N, n, dtype=th.int32, device=dev)
             self.t_store = th.zeros(1, dtype=th.long, device=dev)     # the encoder's copy of t_dev, read by the store-step launch
             # fused encoder: the env kernel writes obs[:, t + 1] of the storage itself and the encoder reads it there (no obs copy)
-            self.direct_obs = self.fast.fused and self.cur["obs"].shape[-1] == 15 and self.obs_fmt == abi.OBS_F32
-            if self.direct_obs:
-                self.cur = self.env.native.storage_obs_buffers(st["obs"], self.obs_fmt)
-            self._ss, self._ss_last = self._make_store_args(True), self._make_store_args(False)
+            self.direct_obs = self.fast.fused and self.env.native.V == 15 and self.obs_fmt == abi.OBS_F32
         self._ready = True
+
+    def _bind_store(self, store):
+        """Select the episode storage of this episode.  Everything that holds pointers into a storage (output buffers of the env
+        kernel, store-step arguments, the captured graph) lives in a per-storage bundle created on first use."""
+        from types import SimpleNamespace
+        st = store.data.transition_data
+        key = st["obs"].data_ptr()
+        b = self._bundles.get(key)
+        self.store = store
+        if b is None:
+            st["filled"].fill_(1)                                       # fixed-length episodes: every slot is filled
+            st["avail_actions"].copy_(self.env.avail_actions_batch.unsqueeze(1).expand(-1, self.episode_limit + 1, -1, -1))
+            b = SimpleNamespace(graph=None, cur=self._dense_cur, ss=None, ss_last=None)
+            if self.fast is not None:
+                if self.direct_obs:
+                    b.cur = self.env.native.storage_obs_buffers(st["obs"], self.obs_fmt)
+                b.ss, b.ss_last = self._make_store_args(True), self._make_store_args(False)
+            self._bundles[key] = b
+        self._bundle, self.cur, self._ss, self._ss_last, self._graph = b, b.cur, b.ss, b.ss_last, b.graph
 
     def _pick(self, q, avail_mask, idx_table, k):
         """epsilon-greedy (action_selectors.py:44-68) without host sync: random AVAILABLE action = table[floor(u * k)]."""
@@ -220,6 +243,13 @@ class HipGraphRunner(HipVecRunner):
         if not self._ready:
             self._allocate()
         self._test_mode = test_mode
+        store = self._replay.reserve(self.batch_size) if (self._replay is not None and not test_mode) else None
+        if store is None:
+            if self._own_store is None:
+                self._own_store = EpisodeBatch(self._scheme, self._groups, self.batch_size, self.episode_limit + 1,
+                                               preprocess=self._preprocess, device=self.args.device)
+            store = self._own_store
+        self._bind_store(store)
         self.batch = self.store
         self.env.reset_batch()
         self.env.observe_batch(self.obs_fmt, out=self.cur if getattr(self, "direct_obs", False) else None)   # fills self.cur (or obs[:, 0])
@@ -243,7 +273,7 @@ class HipGraphRunner(HipVecRunner):
             g = th.cuda.CUDAGraph()
             with th.no_grad(), th.cuda.graph(g):
                 self._select(True)
-            self._graph = g
+            self._graph = self._bundle.graph = g
             # capture records but does not run: re-establish the episode start state
             self.t_dev.zero_()
 
