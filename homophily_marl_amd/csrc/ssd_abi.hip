@@ -381,6 +381,22 @@ int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uin
     return launched();
 }
 
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+int ssd_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int32_t T, int32_t G, int32_t B,
+                    void* stream) {
+    if (!gi || !wh || !bh || !hs || T < 1 || G < 1 || B < 1 || (!rzn) != (!ghn)) return fail(SSD_ERR_INVALID, "bad argument");
+    if (!al16(gi) || !al16(wh) || !al16(bh) || !al16(hs) || !al16(rzn) || !al16(ghn)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
+    launch_gru_seq_fwd(gi, wh, bh, hs, rzn, ghn, T, G, B, (hipStream_t)stream);
+    return launched();
+}
+int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* d_wh_part,
+                    float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream) {
+    if (!dhs || !hs || !rzn || !ghn || !wh || !d_gi || !d_wh_part || !d_bh_part || T < 1 || G < 1 || B < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if (!al16(dhs) || !al16(hs) || !al16(rzn) || !al16(ghn) || !al16(wh) || !al16(d_gi)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
+    launch_gru_seq_bwd(dhs, hs, rzn, ghn, wh, d_gi, d_wh_part, d_bh_part, T, G, B, (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
                       const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, int64_t obs_env_stride,
                       int64_t obs_slot_stride, const int64_t* slot_t, int64_t* slot_t_copy, void* stream) {

@@ -107,8 +107,8 @@ class HomophilyAgent(nn.Module):
         t), agent_pos / agent_orientation [B, T, n, 2], reward / clean_num / apple_den [B, T, n].
         Returns q_env [B, T, n, A], q_inc [B, T, n, n, 3] -- the values forward_env / forward_inc produce step by step
         (homophily_agent.py:154-208) from zero hidden states.  Everything that does not depend on the recurrence (fc1,
-        the input-side GRU projections, both dueling heads) runs ONCE over all T; only h @ W_h and the gate arithmetic
-        are stepped, for the env and the inc head together in one batched GEMM over 2n "agents"."""
+        the input-side GRU projections, both dueling heads) runs ONCE over all T; the recurrence itself (h @ W_h and the gate
+        arithmetic, env and inc head together as 2n weight sets) is one sequence kernel per direction on the GPU."""
         B, T, n = inputs.shape[0], inputs.shape[1], self.n_agents
         H, A = self.hidden, self.n_actions
         tm = lambda x: x.permute(2, 1, 0, 3).reshape(n, T * B, x.shape[-1])          # time-major rows [n, T*B, f]
@@ -120,12 +120,7 @@ class HomophilyAgent(nn.Module):
         gi = th.cat([th.baddbmm(bie, xe, wie), th.baddbmm(bii, xi, wii)], dim=0).reshape(2 * n, T, B, 3 * H)
         gi = gi.transpose(0, 1).contiguous()                                           # [T, 2n, B, 3H]: gi[t] is one contiguous block
         wh, bh = th.cat([whe, whi], dim=0), th.cat([bhe, bhi], dim=0)                 # [2n, H, 3H], [2n, 1, 3H]
-        h = inputs.new_zeros(2 * n, B, H)
-        hs = []
-        for t in range(T):
-            h = ops.gru_gates(gi[t], th.baddbmm(bh, h, wh), h)                        # fused gate kernel on the GPU
-            hs.append(h)
-        hs = th.stack(hs, dim=1)                                                       # [2n, T, B, H]
+        hs = ops.gru_sequence(gi, wh, bh)                                              # [2n, T, B, H]: one launch for the T steps
         he, hi = hs[:n].reshape(n, T * B, H), hs[n:].reshape(n, T * B, H)
         a = th.baddbmm(self._b("fc2_env_b"), he, self._w("fc2_env_w"))
         v = th.baddbmm(self._b("fc2_env_v_b"), he, self._w("fc2_env_v_w"))

@@ -101,6 +101,54 @@ class _GruGates(th.autograd.Function):
         return d_gi, d_gh, dh_prev
 
 
+class _GruSeq(th.autograd.Function):
+    """The whole recurrence h_t = GRU(gi_t, h_{t-1}) for t = 0..T-1 from h = 0 as one forward and one backward launch
+    (csrc/ssd_gru_seq.hip).  gi [T, G, B, 3H], wh [G, H, 3H], bh [G, 1, 3H] -> hs [G, T, B, H]."""
+
+    @staticmethod
+    def forward(ctx, gi, wh, bh):
+        lib = abi.load_library()
+        gi, wh, bh = gi.contiguous(), wh.contiguous(), bh.contiguous()
+        T, G, B, H3 = gi.shape
+        H = H3 // 3
+        hs = th.empty(G, T, B, H, dtype=gi.dtype, device=gi.device)
+        need = any(ctx.needs_input_grad)
+        rzn = th.empty_like(gi) if need else None
+        ghn = th.empty(T, G, B, H, dtype=gi.dtype, device=gi.device) if need else None
+        abi.check(lib, lib.ssd_gru_seq_fwd(gi.data_ptr(), wh.data_ptr(), bh.data_ptr(), hs.data_ptr(), None if rzn is None else rzn.data_ptr(),
+                                           None if ghn is None else ghn.data_ptr(), T, G, B, _stream(gi)))
+        if need:
+            ctx.save_for_backward(hs, rzn, ghn, wh)
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        lib = abi.load_library()
+        hs, rzn, ghn, wh = ctx.saved_tensors
+        dhs = dhs.contiguous()
+        T, G, B, H3 = rzn.shape
+        tiles = (B + 15) // 16
+        d_gi = th.empty_like(rzn) if B % 16 == 0 else th.zeros_like(rzn)
+        d_wh = th.empty(G, tiles, H3 // 3, H3, dtype=rzn.dtype, device=rzn.device)
+        d_bh = th.empty(G, tiles, H3, dtype=rzn.dtype, device=rzn.device)
+        abi.check(lib, lib.ssd_gru_seq_bwd(dhs.data_ptr(), hs.data_ptr(), rzn.data_ptr(), ghn.data_ptr(), wh.data_ptr(), d_gi.data_ptr(),
+                                           d_wh.data_ptr(), d_bh.data_ptr(), T, G, B, _stream(rzn)))
+        return d_gi, d_wh.sum(1) if tiles > 1 else d_wh[:, 0], (d_bh.sum(1) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)
+
+
+def gru_sequence(gi, wh, bh):
+    """hs [G, T, B, H]: the GRU states h_1..h_T for the input-side projections gi [T, G, B, 3H] from a zero initial state."""
+    T, G, B, H3 = gi.shape
+    if gi.is_cuda and H3 == 192:
+        return _GruSeq.apply(gi, wh, bh)
+    h = gi.new_zeros(G, B, H3 // 3)
+    hs = []
+    for t in range(T):
+        h = gru_gates(gi[t], th.baddbmm(bh, h, wh), h)
+        hs.append(h)
+    return th.stack(hs, dim=1)
+
+
 def gru_gates(gi, gh, h):
     """h' from the two projections and the previous state; [..., 3H], [..., 3H], [..., H] -> [..., H]."""
     if gi.is_cuda:

@@ -238,6 +238,18 @@ int ssd_gru_gates_bwd(const float* dh_new, const float* rzn, const float* gh, co
 int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uint8_t* avail, const float* epsilon, const int64_t* step,
                      uint32_t seed, int32_t n_agents, int32_t batch, int32_t pairs, int64_t* actions, float* q_out, void* stream);
 
+/* ---- the learner's recurrence over all T timesteps in one launch per direction (csrc/ssd_gru_seq.hip) -----------------------
+ * The GRU cell of HomophilyAgent (homophily_agent.py:162-165,188-191) unrolled from a zero state as the learner does
+ * (homophily_learner.py:68-91), hidden = 64.  gi f32 [T, G, B, 192] = x_t W_i + b_i in (r, z, n) order for G independent weight
+ * sets (agents x heads) and B sequences; wh [G, 64, 192], bh [G, 192]; hs f32 [G, T, B, 64] receives h_1..h_T.
+ * Training: rzn [T, G, B, 192] and ghn [T, G, B, 64] (both or neither) receive the gates and the hidden-side n pre-activation.
+ * Backward: dhs = dL/dhs -> d_gi [T, G, B, 192], d_wh_part [G, ceil(B/16), 64, 192], d_bh_part [G, ceil(B/16), 192] (partial sums
+ * per 16-row tile; the caller adds them over the tile axis). */
+int ssd_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int32_t T, int32_t G, int32_t B,
+                    void* stream);
+int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* d_wh_part,
+                    float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream);
+
 /* ---- fused rollout-time controller step (csrc/ssd_policy_fused.hip) ------------------------------------------------------
  * One launch per head and timestep for what HomophilyMAC.select_actions_env / select_actions_inc evaluate
  * (homophily_controller.py:30-65, 127-184 on top of homophily_agent.py:154-208 and action_selectors.py:44-68):

@@ -324,3 +324,35 @@ def test_fused_gru_gate_kernels_forward_and_backward():
     exp = [ref.detach(), gi.grad, gh.grad, h.grad]
     for a, b in zip(got, exp):
         assert (a - b).abs().max() < 2e-6, (a - b).abs().max()
+
+
+@pytest.mark.parametrize("T,G,B", [(7, 3, 16), (5, 10, 21), (3, 2, 5)])
+def test_gru_sequence_kernels_match_the_stepwise_recurrence(T, G, B):
+    """ssd_gru_seq_fwd / _bwd (one launch for all T) against a plain torch unroll of the cell (homophily_agent.py:162-165):
+    states and the gradients wrt the input projections, W_h and b_h; B = 21, 5: ragged 16-row tiles."""
+    from homophily_marl_amd import ops
+    g = th.Generator(device="cuda").manual_seed(T * 100 + B)
+    gi = (th.randn(T, G, B, 192, generator=g, device="cuda") * 0.7).requires_grad_()
+    wh = (th.randn(G, 64, 192, generator=g, device="cuda") * 0.15).requires_grad_()
+    bh = (th.randn(G, 1, 192, generator=g, device="cuda") * 0.1).requires_grad_()
+    wout = th.randn(G, T, B, 64, generator=g, device="cuda")
+    hs = ops.gru_sequence(gi, wh, bh)
+    (hs * wout).sum().backward()
+    got = [x.grad.clone() for x in (gi, wh, bh)]
+    for x in (gi, wh, bh):
+        x.grad = None
+    h = gi.new_zeros(G, B, 64)
+    ref = []
+    for t in range(T):
+        gh = th.baddbmm(bh, h, wh)
+        r = th.sigmoid(gi[t][..., :64] + gh[..., :64]); z = th.sigmoid(gi[t][..., 64:128] + gh[..., 64:128])
+        cand = th.tanh(gi[t][..., 128:] + r * gh[..., 128:])
+        h = (1 - z) * cand + z * h
+        ref.append(h)
+    ref = th.stack(ref, dim=1)
+    (ref * wout).sum().backward()
+    assert (hs - ref).abs().max() < 1e-5
+    for a, b, name in zip(got, (gi.grad, wh.grad, bh.grad), ("d_gi", "d_wh", "d_bh")):
+        assert (a - b).abs().max() < 2e-5 * max(1.0, b.abs().max().item()), name
+    with th.no_grad():       # inference form (no saved gates)
+        assert (ops.gru_sequence(gi, wh, bh) - ref).abs().max() < 1e-5

@@ -1,0 +1,21 @@
+"""Diagnostic: kernel mix of learner.train (graph-captured).  rocprofv3 --kernel-trace --stats -- python3 tools/train_prof.py"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch as th
+from homophily_marl_amd.run import load_config, setup
+N = int(os.environ.get("N_ENV", 512))
+cfg = load_config("cleanup", overrides=dict(runner="hip_graph", train_graph=int(os.environ.get("TRAIN_GRAPH", 1)), batch_size_run=N, batch_size=16, buffer_size=N,
+                                             buffer_cpu_only=False, store_state=False,
+                                             env_args=dict(num_agents=5, map="default5", episode_limit=100, seed=1),
+                                             use_cuda=True, save_model=False, runner_stats=False, learner_log_interval=10 ** 12))
+th.manual_seed(0)
+ctx = setup(cfg)
+batch = ctx.runner.run(False)
+ctx.buffer.insert_episode_batch(batch)
+sample = ctx.buffer.sample(16)[:, :101]
+for i in range(int(os.environ.get("TRAIN_CALLS", 40))):
+    if i == 10:
+        th.cuda.synchronize(); t0 = time.perf_counter()
+    ctx.learner.train(sample, 100 * N, i * N)
+th.cuda.synchronize()
+print("train: %.2f ms/call" % (1e3 * (time.perf_counter() - t0) / (int(os.environ.get("TRAIN_CALLS", 40)) - 10)), flush=True)
