@@ -310,18 +310,18 @@ void set_policy_stamps(unsigned long long* buf) { g_policy_stamps = buf; }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Encoder: Conv2d(3, 6, 3, 1) + LeakyReLU + Flatten + Linear(6 (V-2)^2, 32) + LeakyReLU (homophily_agent.py:20-27,213-214) in one
-// launch, the 4 KB/row conv activations never leaving the CU (the unfused form writes and re-reads 83 MB per timestep).
+// launch; the 4 KB/row conv activations never leave the registers (the unfused form writes and re-reads 83 MB per timestep).
 //   * workgroup = 4 waves = 16 observation rows, staged in LDS; the rows are read where the env kernel wrote them -- a dense
 //     [rows, 3, V, V] buffer or directly time slot t of the episode storage [n_env, t_slots, n, 3, V, V] (no copy of obs);
-//   * conv on the VALU: thread = (row, output line y) keeps its 3 x 3 x V input window in registers and produces the V-2 outputs
-//     of the line for one output channel at a time (27 scalar-operand FMAs per output, weights through the scalar cache);
-//   * per output channel the [16 rows, (V-2)^2] activations go to a double-buffered LDS chunk and are contracted with the
-//     matching slice of the Linear weight by v_mfma_f32_16x16x4_f32 (transposed product as in k_head: weight = A operand,
-//     streamed from L2 as float4 from a zero-padded [6][32][176] repack; activations = B operand, ds_read_b128); the four waves
-//     split the K groups and their partial sums are added in a fixed order (deterministic).
+//   * after the staging barrier the waves are independent.  The K = 6 * 169 reduction of the Linear layer is cut into groups of
+//     16 conv positions per channel; wave w takes the groups c = w, w + 4, w + 8 of every channel.  For a group, lane
+//     (row = l & 15, q = l >> 4) computes the conv outputs of ITS row at the 4 positions 16 c + 4 q + r for all 6 channels on the
+//     VALU (27 taps from LDS, weights through the scalar cache) -- which is exactly the B-operand layout of
+//     v_mfma_f32_16x16x4_f32 (transposed product as in k_head), so the activations go from the FMA result registers straight
+//     into the matrix core; the A operand (Linear weight slice, zero-padded [6][32][176] repack) streams from L2 as float4 and is
+//     requested before the group's FMAs;
+//   * the four partial [32, 16] results are added in a fixed order through LDS (deterministic).
 // ---------------------------------------------------------------------------------------------------------------------------
-// LDS row stride of the conv activations [6][CS] (+ pad so that stride mod 32 = 4: conflict-free ds_read_b128 across rows)
-#define ENC_RS(V) (6 * ((((V) - 2) * ((V) - 2) + 15) / 16 * 16 + 4) + 12)
 struct EncK {
     const float* obs; int rows;
     float* out; int out_stride, n, agent_major;
@@ -331,14 +331,12 @@ struct EncK {
 };
 
 template <int V>
-__global__ __launch_bounds__(256, 2) void k_encode(EncK a, const float* __restrict__ cw, const float* __restrict__ cb,
+__global__ __launch_bounds__(256, 3) void k_encode(EncK a, const float* __restrict__ cw, const float* __restrict__ cb,
                                                     const float* __restrict__ lwp, const float* __restrict__ lb) {
     // the weights are separate __restrict__ kernel arguments so that the wave-uniform conv weights come through the scalar cache
-    constexpr int O = V - 2, P = O * O, L = 3 * V * V, PG = (P + 15) / 16, PP = PG * 16, CS = PP + 4, RS = ENC_RS(V), ITEMS = 16 * O;
-    static_assert(ITEMS <= 256 && CS % 4 == 0 && RS % 4 == 0 && RS >= 6 * CS && 16 * RS >= 16 * L && (RS % 32 == 4 || RS % 32 == 20), "tile shape");
+    constexpr int O = V - 2, P = O * O, VV = V * V, L = 3 * VV, PG = (P + 15) / 16, PP = PG * 16;
     extern __shared__ float lds[];
-    float* tile = lds;                  // [16][L] observation rows ...
-    float* cbuf = lds;                  // ... later overwritten by the conv activations [16][RS]: row -> [6][CS]
+    float* tile = lds;                  // [16][L] observation rows; reused for the cross-wave reduction at the end
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int row0 = blockIdx.x * 16;
@@ -363,77 +361,60 @@ __global__ __launch_bounds__(256, 2) void k_encode(EncK a, const float* __restri
     }
     __syncthreads();
     PSTAMP(1);
-    // ---- conv on the VALU: thread = (row, output line y); all 6 output channels of the line accumulate together, one input
-    //      channel (3 x V window rows in registers) at a time -- 78 independent accumulators, every input value read once
-    const bool active = tid < ITEMS;
-    const int row_l = active ? tid / O : 0, y = active ? tid - row_l * O : 0;
-    float acc[6][O];
-#pragma unroll
-    for (int oc = 0; oc < 6; ++oc)
-#pragma unroll
-        for (int x = 0; x < O; ++x) acc[oc][x] = cb[oc];
+    f32x4 mac[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 1
-    for (int ch = 0; ch < 3; ++ch) {                                   // not unrolled: 54 scalar weights live at a time
-        float in[3][V];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int x = 0; x < V; ++x) in[dy][x] = tile[row_l * L + ch * V * V + (y + dy) * V + x];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                for (int oc = 0; oc < 6; ++oc) {
-                    const float w = cw[((oc * 3 + ch) * 3 + dy) * 3 + dx];
-#pragma unroll
-                    for (int x = 0; x < O; ++x) acc[oc][x] = fmaf(w, in[dy][x + dx], acc[oc][x]);
-                }
-    }
-    PSTAMP(2);
-    // this wave's slices of the Linear weight (float4 per lane from L2): requested now, consumed two barriers later
-    constexpr int NG = 6 * PG, PERW = (NG + 3) / 4;
-    f32x4 af[PERW][2];
-#pragma unroll
-    for (int j = 0; j < PERW; ++j) {
-        const int g = wave + 4 * j;
-        if (g < NG) {
-            const int oc = g / PG, c = g - oc * PG;
-#pragma unroll
-            for (int ft = 0; ft < 2; ++ft)
-                af[j][ft] = *reinterpret_cast<const f32x4*>(lwp + ((size_t)(oc * 32 + 16 * ft + m) * PP + 16 * c + 4 * q));
-        }
-    }
-    __syncthreads();                                                   // every window has been read: the tile becomes the chunk buffer
-    PSTAMP(3);
-    if (active) {
+    for (int c = wave; c < PG; c += 4) {
+        // Linear weight slices of this group, all 6 channels: requested now, consumed after the group's FMAs
+        f32x4 af[6][2];
 #pragma unroll
         for (int oc = 0; oc < 6; ++oc)
 #pragma unroll
-            for (int x = 0; x < O; ++x) cbuf[row_l * RS + oc * CS + y * O + x] = leaky(acc[oc][x]);
-    }
-    for (int e = tid; e < 16 * 6 * (CS - P); e += 256) {              // K padding of the chunks: zero (0 x weight pad 0)
-        const int rr = e / (CS - P), j = e - rr * (CS - P), r16 = rr / 6, oc = rr - r16 * 6;
-        cbuf[r16 * RS + oc * CS + P + j] = 0.f;
-    }
-    __syncthreads();
-    PSTAMP(4);
-    // ---- Linear on the matrix cores: the 6 * PG groups of 16 k are dealt round-robin to the 4 waves (weight slices: af, above)
-    f32x4 mac[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            for (int ft = 0; ft < 2; ++ft)
+                af[oc][ft] = *reinterpret_cast<const f32x4*>(lwp + ((size_t)(oc * 32 + 16 * ft + m) * PP + 16 * c + 4 * q));
+        int base[4];
+        bool ok[4];
 #pragma unroll
-    for (int j = 0; j < PERW; ++j) {
-        const int g = wave + 4 * j;
-        if (g < NG) {
-            const int oc = g / PG, c = g - oc * PG;
-            const f32x4 bf = *reinterpret_cast<const f32x4*>(cbuf + m * RS + oc * CS + 16 * c + 4 * q);
+        for (int r = 0; r < 4; ++r) {
+            const int p = 16 * c + 4 * q + r;
+            ok[r] = p < P;
+            const int pc = ok[r] ? p : 0, y = pc / O, x = pc - y * O;
+            base[r] = m * L + y * V + x;
+        }
+        float acc[6][4];
+#pragma unroll
+        for (int oc = 0; oc < 6; ++oc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[oc][r] = cb[oc];
+#pragma unroll 1
+        for (int ch = 0; ch < 3; ++ch) {                               // not unrolled: 54 scalar weights live at a time
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = tile[base[r] + ch * VV + dy * V + dx];
+#pragma unroll
+                    for (int oc = 0; oc < 6; ++oc) {
+                        const float w = cw[((oc * 3 + ch) * 3 + dy) * 3 + dx];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[oc][r] = fmaf(w, v[r], acc[oc][r]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int oc = 0; oc < 6; ++oc) {
+            f32x4 bop;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bop[r] = ok[r] ? leaky(acc[oc][r]) : 0.f;   // K padding: activation 0 (x weight pad 0)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int ft = 0; ft < 2; ++ft) mac[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][ft][r], bf[r], mac[ft], 0, 0, 0);
+                for (int ft = 0; ft < 2; ++ft) mac[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[oc][ft][r], bop[r], mac[ft], 0, 0, 0);
         }
     }
-    PSTAMP(5);
-    __syncthreads();                                                   // the chunks are dead: reuse the buffer for the reduction
+    PSTAMP(2);
+    __syncthreads();                                                   // every wave is done with the tile: reuse it for the reduction
     f32x4* red = reinterpret_cast<f32x4*>(lds);
     red[(wave * 2 + 0) * 64 + lane] = mac[0];
     red[(wave * 2 + 1) * 64 + lane] = mac[1];
@@ -450,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void k_encode(EncK a, const float* __restri
             for (int r = 0; r < 4; ++r) a.out[orow * a.out_stride + 16 * ft + 4 * q + r] = leaky(s[r] + lb[16 * ft + 4 * q + r]);
         }
     }
-    PSTAMP(6);
+    PSTAMP(3);
 }
 
 int launch_policy_encode(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lwp, const float* lb, float* out,
@@ -458,7 +439,7 @@ int launch_policy_encode(const float* obs, int rows, int V, const float* cw, con
                          int64_t* slot_t_copy, hipStream_t s) {
     if (V != 15) return -2;
     constexpr int L = 3 * 15 * 15;
-    const size_t lds = (size_t)(16 * ENC_RS(15)) * sizeof(float);
+    const size_t lds = (size_t)(16 * L) * sizeof(float);
     static bool attr_done_dev[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;

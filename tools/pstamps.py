@@ -64,7 +64,7 @@ for rep in range(3):
                                          th.cuda.current_stream().cuda_stream))
     th.cuda.synchronize()
     if rep == 2:
-        show("k_encode", [(0, "start"), (1, "stage+sync"), (2, "conv (VALU)"), (3, "barrier"), (4, "write chunks+sync"), (5, "linear (MFMA)"), (6, "reduce+out")],
+        show("k_encode", [(0, "start"), (1, "stage+sync"), (2, "conv+linear groups"), (3, "reduce+out")],
              N * n // 16 * 4)
     stamps.zero_()
     lib.ssd_debug_set_policy_stamps(None)
