@@ -118,7 +118,12 @@ class SsdPolicyHead(C.Structure):
                 ("pos", C.c_void_p), ("actions", C.c_void_p), ("pos_pre", C.c_void_p), ("orient_pre", C.c_void_p),
                 ("reward", C.c_void_p), ("clean_num", C.c_void_p), ("apple_den", C.c_void_p), ("out_actions", C.c_void_p),
                 ("q_out", C.c_void_p), ("orient", C.c_void_p), ("out_actions_i32", C.c_void_p), ("pos_copy", C.c_void_p),
-                ("orient_copy", C.c_void_p)]
+                ("orient_copy", C.c_void_p),
+                ("t_index", C.c_void_p), ("t_slots", C.c_int32),
+                ("dst_pos", C.c_void_p), ("dst_orient", C.c_void_p), ("dst_actions_onehot", C.c_void_p), ("dst_reward", C.c_void_p),
+                ("dst_clean_num", C.c_void_p), ("dst_apple_den", C.c_void_p), ("dst_terminated", C.c_void_p), ("terminated", C.c_void_p),
+                ("dst_actions", C.c_void_p), ("dst_actions_inc", C.c_void_p), ("prev_actions_out", C.c_void_p),
+                ("prev_actions_inc_out", C.c_void_p), ("prev_reward_out", C.c_void_p), ("ep_return", C.c_void_p), ("next_t_out", C.c_void_p)]
 
 
 POLICY_IMAGE_FLOATS = 464 * 68 + 464 + 64
@@ -127,7 +132,7 @@ HIP_SIGNATURES["ssd_policy_head_inc"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.c
 HIP_SIGNATURES["ssd_gru_seq_fwd"] = (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_bwd"] = (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 3 + [C.c_void_p])
 HIP_SIGNATURES["ssd_policy_encode"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p])
+                                                C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_conv_leaky"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_store_step_launch"] = (C.c_int, [C.POINTER(SsdStoreStep), C.c_void_p])

@@ -399,7 +399,7 @@ int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const f
 
 int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
                       const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, int64_t obs_env_stride,
-                      int64_t obs_slot_stride, const int64_t* slot_t, int64_t* slot_t_copy, void* stream) {
+                      int64_t obs_slot_stride, const int64_t* slot_t, int64_t* slot_t_copy, int64_t* counter_inc, void* stream) {
     if (!obs || !conv_w || !conv_b || !lin_w_packed || !lin_b || !out || rows < 1 || n_agents < 1 || rows % n_agents || out_stride < 32)
         return fail(SSD_ERR_INVALID, "bad argument");
     if (view_edge != 15) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode is instantiated for view_size 7 (15 x 15 windows); use ssd_conv_leaky + GEMM");
@@ -408,7 +408,7 @@ int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const f
         return fail(SSD_ERR_INVALID, "obs_env_stride / obs_slot_stride / slot_t");
     if (slot_t_copy && (!slot_t || slot_t_copy == slot_t)) return fail(SSD_ERR_INVALID, "slot_t_copy needs a distinct slot_t");
     const int rc = launch_policy_encode(obs, rows, view_edge, conv_w, conv_b, lin_w_packed, lin_b, out, out_stride, n_agents, agent_major,
-                                        (long)obs_env_stride, (long)obs_slot_stride, slot_t, slot_t_copy, (hipStream_t)stream);
+                                        (long)obs_env_stride, (long)obs_slot_stride, slot_t, slot_t_copy, counter_inc, (hipStream_t)stream);
     if (rc) return fail(SSD_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS) failed");
     return launched();
 }
@@ -416,7 +416,14 @@ int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const f
 static int policy_head(const ssd_policy_head* a, int inc, void* stream) {
     if (!a || !a->inputs || !a->h || !a->weights || !a->epsilon || !a->step || !a->out_actions) return fail(SSD_ERR_INVALID, "bad argument");
     if (a->n_env < 1 || a->n_agents < 1 || a->n_actions < 1) return fail(SSD_ERR_INVALID, "bad argument");
-    if (!inc && a->pos_copy && (!a->orient || !a->orient_copy)) return fail(SSD_ERR_INVALID, "pos_copy needs orient and orient_copy");
+    if (!inc && (a->pos_copy || a->dst_pos) && (!a->orient || (a->pos_copy && !a->orient_copy) || (a->dst_pos && !a->dst_orient)))
+        return fail(SSD_ERR_INVALID, "pos_copy / dst_pos need orient and their orient twin");
+    const bool files = a->dst_pos || a->dst_actions || a->dst_actions_inc || a->dst_reward || a->next_t_out;
+    if (files && (!a->t_index || a->t_slots < 1)) return fail(SSD_ERR_INVALID, "filing into the episode storage needs t_index and t_slots");
+    if (a->next_t_out && a->next_t_out == a->t_index) return fail(SSD_ERR_INVALID, "next_t_out must not alias t_index");
+    if (a->dst_actions && !a->dst_actions_onehot) return fail(SSD_ERR_INVALID, "dst_actions needs dst_actions_onehot");
+    if (a->dst_reward && (!a->dst_clean_num || !a->dst_apple_den)) return fail(SSD_ERR_INVALID, "dst_reward needs dst_clean_num and dst_apple_den");
+    if (a->dst_terminated && !a->terminated) return fail(SSD_ERR_INVALID, "dst_terminated needs terminated");
     if (inc ? (!a->actions || !a->pos_pre || !a->orient_pre || !a->reward || !a->clean_num || !a->apple_den)
             : (!a->prev_actions || !a->prev_reward || !a->prev_actions_inc || !a->pos)) return fail(SSD_ERR_INVALID, "missing head input");
     // layout limits of the fused kernel: 32 encoder features + tail (+ one-hot action for inc) within 64 columns, 16 fc2 rows

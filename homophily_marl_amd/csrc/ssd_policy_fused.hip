@@ -72,6 +72,13 @@ struct HeadK {
     const float* orient;
     int32_t* out_actions_i32;
     float *pos_copy, *orient_copy;
+    // filing into the episode storage (slot *t_index) and the runner state carried to the next step
+    const int64_t* t_index; int slots;
+    float *d_pos, *d_orient, *d_onehot, *d_reward, *d_clean, *d_den;
+    uint8_t* d_term; const uint8_t* term;
+    int64_t *d_actions, *d_actions_inc, *p_act, *p_inc;
+    float *p_rew, *ep_ret;
+    int64_t* next_t;
     PSTAMP_DECL
 };
 
@@ -122,6 +129,8 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
     float* scratch = lds + IMAGE + wave * SCRATCH;
     const float eps = *a.eps;
     const uint32_t step = (uint32_t)*a.step;
+    const long slot_t = a.t_index ? (long)*a.t_index : 0;
+    if (INC && a.next_t && blockIdx.x == 0 && tid == 0) *a.next_t = slot_t + 1;   // not read by this kernel (t_index is a copy)
     const int tiles = (N + 15) >> 4;
     for (int tile = wave * a.bpa + bia; tile < tiles; tile += a.bpa * HEAD_WAVES) {   // consecutive tiles go to different CUs
         const int b = tile * 16 + m;
@@ -144,9 +153,13 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
                 recv += (v == 1) - (v == 2);
             }
             const float px = a.pos[er * 2] / a.pos_scale, py = a.pos[er * 2 + 1] / a.pos_scale;
-            if (a.pos_copy && valid && q == 0) {                       // the pose BEFORE the env step (read by the inc head / the storage)
-                a.pos_copy[er * 2] = a.pos[er * 2]; a.pos_copy[er * 2 + 1] = a.pos[er * 2 + 1];
-                a.orient_copy[er * 2] = a.orient[er * 2]; a.orient_copy[er * 2 + 1] = a.orient[er * 2 + 1];
+            if (valid && q == 0 && (a.pos_copy || a.d_pos)) {          // the pose BEFORE the env step (inc head input, storage slot t)
+                const float p0 = a.pos[er * 2], p1 = a.pos[er * 2 + 1], o0 = a.orient[er * 2], o1 = a.orient[er * 2 + 1];
+                if (a.pos_copy) { a.pos_copy[er * 2] = p0; a.pos_copy[er * 2 + 1] = p1; a.orient_copy[er * 2] = o0; a.orient_copy[er * 2 + 1] = o1; }
+                if (a.d_pos) {
+                    const size_t sr = (((size_t)bc * a.slots + slot_t) * n + agent) * 2;
+                    a.d_pos[sr] = p0; a.d_pos[sr + 1] = p1; a.d_orient[sr] = o0; a.d_orient[sr + 1] = o1;
+                }
             }
 #pragma unroll
             for (int ct = 2; ct < 4; ++ct) {
@@ -238,6 +251,12 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
                                                  a.q_out ? a.q_out + (size_t)r * A : nullptr);
                 a.out_actions[(size_t)bb * n + agent] = act;
                 if (a.out_actions_i32) a.out_actions_i32[(size_t)bb * n + agent] = act;
+                if (a.p_act) a.p_act[(size_t)bb * n + agent] = act;
+                if (a.d_actions) {
+                    const size_t sr = ((size_t)bb * a.slots + slot_t) * n + agent;
+                    a.d_actions[sr] = act;
+                    for (int k = 0; k < A; ++k) a.d_onehot[sr * A + k] = k == act ? 1.f : 0.f;
+                }
             }
         } else {
             const float* w2o = lds + OFF_W2O;                          // [E][4]: 3 advantages + value per extra feature
@@ -263,6 +282,17 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
                 int act = dueling_pick_row(av, av[3], 3, nullptr, eps, step, a.seed, r, a.q_out ? a.q_out + (size_t)r * 3 : nullptr);
                 if (j == agent) act = 0;                               // no self incentive (homophily_controller.py:44-46)
                 a.out_actions[((size_t)bb * n + agent) * n + j] = act;
+                if (a.p_inc) a.p_inc[((size_t)bb * n + agent) * n + j] = act;
+                const size_t sr = ((size_t)bb * a.slots + slot_t) * n + agent;
+                if (a.d_actions_inc) a.d_actions_inc[sr * n + j] = act;
+                if (j == 0 && a.d_reward) {                            // once per (env, agent): this step's outcome
+                    const size_t ea = (size_t)bb * n + agent;
+                    const float rw = a.reward[ea];
+                    a.d_reward[sr] = rw; a.d_clean[sr] = a.clean[ea]; a.d_den[sr] = a.den[ea];
+                    if (a.p_rew) a.p_rew[ea] = rw;
+                    if (a.ep_ret) a.ep_ret[ea] += rw;
+                    if (agent == 0 && a.d_term) a.d_term[(size_t)bb * a.slots + slot_t] = a.term[bb];
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();                               // scratch is reused by the next tile
@@ -281,6 +311,11 @@ static int launch_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     k.actions = p->actions; k.pos_pre = p->pos_pre; k.orient_pre = p->orient_pre; k.reward = p->reward; k.clean = p->clean_num;
     k.den = p->apple_den; k.out_actions = p->out_actions; k.q_out = p->q_out;
     PSTAMP_SET(k);
+    k.t_index = p->t_index; k.slots = p->t_slots;
+    k.d_pos = p->dst_pos; k.d_orient = p->dst_orient; k.d_onehot = p->dst_actions_onehot; k.d_reward = p->dst_reward;
+    k.d_clean = p->dst_clean_num; k.d_den = p->dst_apple_den; k.d_term = p->dst_terminated; k.term = p->terminated;
+    k.d_actions = p->dst_actions; k.d_actions_inc = p->dst_actions_inc; k.p_act = p->prev_actions_out; k.p_inc = p->prev_actions_inc_out;
+    k.p_rew = p->prev_reward_out; k.ep_ret = p->ep_return; k.next_t = p->next_t_out;
     k.orient = p->orient; k.out_actions_i32 = p->out_actions_i32; k.pos_copy = p->pos_copy; k.orient_copy = p->orient_copy;
     const int tiles = (k.N + 15) / 16;
     int bpa = 256 / k.n;                                               // one workgroup per CU (the image fills most of the LDS)
@@ -327,6 +362,7 @@ struct EncK {
     float* out; int out_stride, n, agent_major;
     long env_stride, slot_stride; const int64_t* slot_t;   // row (b, i) = obs + b * env_stride + *slot_t * slot_stride + i * 3VV
     int64_t* slot_t_copy;
+    int64_t* counter_inc;
     PSTAMP_DECL
 };
 
@@ -344,7 +380,10 @@ __global__ __launch_bounds__(256, 3) void k_encode(EncK a, const float* __restri
     PSTAMP(0);
     {   // stage the 16 rows: dword loads (rows are 4-byte aligned only), all in flight before the first LDS write
         const long t_off = a.slot_t ? (long)(*a.slot_t) * a.slot_stride : 0;
-        if (a.slot_t_copy && blockIdx.x == 0 && tid == 0) *a.slot_t_copy = *a.slot_t;
+        if (blockIdx.x == 0 && tid == 0) {
+            if (a.slot_t_copy) *a.slot_t_copy = *a.slot_t;
+            if (a.counter_inc) *a.counter_inc += 1;
+        }
         constexpr int PR = (L + 255) / 256;
         float tmp[16][PR];
 #pragma unroll
@@ -436,7 +475,7 @@ __global__ __launch_bounds__(256, 3) void k_encode(EncK a, const float* __restri
 
 int launch_policy_encode(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lwp, const float* lb, float* out,
                          int out_stride, int n_agents, int agent_major, long env_stride, long slot_stride, const int64_t* slot_t,
-                         int64_t* slot_t_copy, hipStream_t s) {
+                         int64_t* slot_t_copy, int64_t* counter_inc, hipStream_t s) {
     if (V != 15) return -2;
     constexpr int L = 3 * 15 * 15;
     const size_t lds = (size_t)(16 * L) * sizeof(float);
@@ -447,7 +486,7 @@ int launch_policy_encode(const float* obs, int rows, int V, const float* cw, con
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         attr_done_dev[dev] = true;
     }
-    EncK k{obs, rows, out, out_stride, n_agents, agent_major, env_stride ? env_stride : (long)n_agents * L, slot_stride, slot_t, slot_t_copy};
+    EncK k{obs, rows, out, out_stride, n_agents, agent_major, env_stride ? env_stride : (long)n_agents * L, slot_stride, slot_t, slot_t_copy, counter_inc};
     PSTAMP_SET(k);
     hipLaunchKernelGGL(k_encode<15>, dim3((rows + 15) / 16), dim3(256), lds, s, k, cw, cb, lwp, lb);
     return 0;

@@ -51,54 +51,67 @@ class FastPolicy:
 
     @th.no_grad()
     def pack(self):
-        """Snapshot the (possibly just trained) weights into GEMM-ready contiguous packs; values are copied in place so
-        that a captured graph keeps seeing the same addresses."""
+        """Snapshot the (possibly just trained) weights into kernel-ready contiguous packs; values are copied in place so
+        that a captured graph keeps seeing the same addresses.  Fused path: the encoder weights and one LDS-layout weight
+        image per agent and head; per-layer path: GEMM-ready operands."""
         ag, H, A = self.agent, self.H, self.A
         w, b = ag._w, ag._b
+        lin = ag.conv_to_fc[3].weight
         packs = dict(
-            cw=ag.conv_to_fc[0].weight, cb=ag.conv_to_fc[0].bias, lw=ag.conv_to_fc[3].weight, lb=ag.conv_to_fc[3].bias,
-            lw_t=ag.conv_to_fc[3].weight.t(),
+            cw=ag.conv_to_fc[0].weight, cb=ag.conv_to_fc[0].bias, lb=ag.conv_to_fc[3].bias, lw_t=lin.t(),
             # Linear weight per conv channel, K zero-padded 169 -> 176 (ssd_policy_encode; include/ssd_hip.h)
-            lwp=F.pad(ag.conv_to_fc[3].weight.reshape(32, 6, -1).permute(1, 0, 2), (0, (-ag.conv_to_fc[3].weight.shape[1] // 6) % 16)),
-            w1e=w("fc1_env_w"), b1e=b("fc1_env_b"),
-            w2e=th.cat([w("fc2_env_w"), w("fc2_env_v_w")], dim=2), b2e=th.cat([b("fc2_env_b"), b("fc2_env_v_b")], dim=2),
-            w1i_x=w("fc1_inc_w")[:, :self.inp], w1i_a=w("fc1_inc_w")[:, self.inp:], b1i=b("fc1_inc_b"),
+            lwp=F.pad(lin.reshape(32, 6, -1).permute(1, 0, 2), (0, (-lin.shape[1] // 6) % 16)),
         )
-        packs["wie"], packs["whe"], packs["bie"], packs["bhe"] = ag._gru_weights("env")
-        packs["wii"], packs["whi"], packs["bii"], packs["bhi"] = ag._gru_weights("inc")
-        w2i = th.cat([w("fc2_inc_w"), w("fc2_inc_v_w")], dim=2)                       # [n, H + E, 4]
-        packs["w2i_h"] = w2i[:, :H]
-        packs["w2i_o"] = w2i[:, H:].permute(1, 0, 2).reshape(w2i.shape[1] - H, -1)    # [E, n(i) * 4]
-        packs["b2i"] = th.cat([b("fc2_inc_b"), b("fc2_inc_v_b")], dim=2).unsqueeze(2)  # [n, 1, 1, 4]
-        packs["img_env"], packs["img_inc"] = self._image("env"), self._image("inc")
+        if not self.fused:
+            packs.update(
+                w1e=w("fc1_env_w"), b1e=b("fc1_env_b"),
+                w2e=th.cat([w("fc2_env_w"), w("fc2_env_v_w")], dim=2), b2e=th.cat([b("fc2_env_b"), b("fc2_env_v_b")], dim=2),
+                w1i_x=w("fc1_inc_w")[:, :self.inp], w1i_a=w("fc1_inc_w")[:, self.inp:], b1i=b("fc1_inc_b"))
+            packs["wie"], packs["whe"], packs["bie"], packs["bhe"] = ag._gru_weights("env")
+            packs["wii"], packs["whi"], packs["bii"], packs["bhi"] = ag._gru_weights("inc")
+            w2i = th.cat([w("fc2_inc_w"), w("fc2_inc_v_w")], dim=2)                       # [n, H + E, 4]
+            packs["w2i_h"] = w2i[:, :H]
+            packs["w2i_o"] = w2i[:, H:].permute(1, 0, 2).reshape(w2i.shape[1] - H, -1)    # [E, n(i) * 4]
+            packs["b2i"] = th.cat([b("fc2_inc_b"), b("fc2_inc_v_b")], dim=2).unsqueeze(2)  # [n, 1, 1, 4]
         if not hasattr(self, "p"):
             self.p = {k: v.detach().clone().contiguous() for k, v in packs.items()}
+            if self.fused:
+                for head in ("env", "inc"):      # zero once: the K / row padding of the image is never written again
+                    self.p["img_" + head] = th.zeros(self.n, abi.POLICY_IMAGE_FLOATS, dtype=th.float32, device=self.dev)
         else:
             for k, v in packs.items():
                 self.p[k].copy_(v)
+        if self.fused:
+            self._image("env", self.p["img_env"])
+            self._image("inc", self.p["img_inc"])
 
-    def _image(self, head):
-        """Per-agent weight image of the fused head kernel (layout: include/ssd_hip.h, ssd_policy_head)."""
+    def _image(self, head, img):
+        """Fill the per-agent weight image of the fused head kernel in place (layout: include/ssd_hip.h, ssd_policy_head)."""
         ag, n, H = self.agent, self.n, self.H
         w, b = ag._w, ag._b
-        img = th.zeros(n, abi.POLICY_IMAGE_FLOATS, dtype=th.float32, device=self.dev)
         W = img[:, :464 * 68].view(n, 464, 68)
         w1 = w("fc1_%s_w" % head)                                                      # [n, in, 64]
         W[:, 0:64, :w1.shape[1]] = w1.transpose(1, 2)
-        wi, wh, bi, bh = ag._gru_weights(head)
-        W[:, 64:256, :H] = wi.transpose(1, 2)
-        W[:, 256:448, :H] = wh.transpose(1, 2)
-        w2 = th.cat([w("fc2_%s_w" % head), w("fc2_%s_v_w" % head)], dim=2)             # env [n, 64, A + 1]; inc [n, 64 + E, 4]
-        b2 = th.cat([b("fc2_%s_b" % head), b("fc2_%s_v_b" % head)], dim=2)
-        k = w2.shape[2]
-        W[:, 448:448 + k, :H] = w2[:, :H].transpose(1, 2)
+        p = "rnn_%s_" % head
+        for gi_, gate in enumerate("rzn"):
+            W[:, 64 + 64 * gi_:128 + 64 * gi_, :H] = w(p + "i%s_w" % gate).transpose(1, 2)
+            W[:, 256 + 64 * gi_:320 + 64 * gi_, :H] = w(p + "h%s_w" % gate).transpose(1, 2)
         B = img[:, 464 * 68:]
         B[:, 0:64] = b("fc1_%s_b" % head)[:, 0]
-        B[:, 64:256], B[:, 256:448] = bi[:, 0], bh[:, 0]
-        B[:, 448:448 + k] = b2[:, 0]
+        for gi_, gate in enumerate("rzn"):
+            B[:, 64 + 64 * gi_:128 + 64 * gi_] = b(p + "i%s_b" % gate)[:, 0]
+            B[:, 256 + 64 * gi_:320 + 64 * gi_] = b(p + "h%s_b" % gate)[:, 0]
+        wa, wv = w("fc2_%s_w" % head), w("fc2_%s_v_w" % head)                          # env [n, 64, A], [n, 64, 1]; inc [n, 64 + E, 3], [.., 1]
+        k = wa.shape[2]
+        W[:, 448:448 + k, :H] = wa[:, :H].transpose(1, 2)
+        W[:, 448 + k, :H] = wv[:, :H, 0]
+        B[:, 448:448 + k] = b("fc2_%s_b" % head)[:, 0]
+        B[:, 448 + k] = b("fc2_%s_v_b" % head)[:, 0, 0]
         if head == "inc":
-            E = w2.shape[1] - H
-            B[:, 464:464 + E * 4] = w2[:, H:].reshape(n, E * 4)
+            E = wa.shape[1] - H
+            O = B[:, 464:464 + E * 4].view(n, E, 4)
+            O[:, :, :k] = wa[:, H:]
+            O[:, :, k] = wv[:, H:, 0]
         return img
 
     def _head_args(self, inc, eps, step, q_out=None):
@@ -119,13 +132,16 @@ class FastPolicy:
     # ---- env head -----------------------------------------------------------------------------------------------
     @th.no_grad()
     def act_env(self, obs, prev_actions, prev_reward, prev_inc, pos, eps, step, store_obs=None, store_t=None, q_out=None,
-                orient=None, actions_i32=None, pos_copy=None, orient_copy=None, obs_in_storage=False, t_copy=None):
+                orient=None, actions_i32=None, pos_copy=None, orient_copy=None, obs_in_storage=False, t_copy=None, counter_inc=None,
+                file=None):
         """obs f32 [N, n, 3, V, V]; prev_* of the previous timestep (prev_actions = -1 at t = 0); pos f32 [N, n, 2];
         eps f32 scalar tensor, step i64 [1] tensor.  Returns actions i64 [N, n] (static buffer).
         store_obs / store_t: episode storage obs f32 [N, T+1, n, 3, V, V] and the device time index; the observation is copied
         to store_obs[:, t] on the way -- or, with obs_in_storage (fused encoder only), it already IS there (the env wrote it,
         NativeEnv.storage_obs_buffers) and `obs` is ignored.
-        Fused path only: actions_i32 also receives the actions as int32; pos_copy / orient_copy receive copies of pos / orient."""
+        Fused path only: actions_i32 also receives the actions as int32; pos_copy / orient_copy receive copies of pos / orient;
+        counter_inc: device i64 incremented by the encoder launch; file: dict of ssd_policy_head storage fields (pointers as ints)
+        with which the head files its results into the episode storage itself (include/ssd_hip.h)."""
         p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
         V = (store_obs if obs_in_storage else obs).shape[-1]
         st = self._stream()
@@ -136,9 +152,10 @@ class FastPolicy:
                    self.inputs.shape[-1], n, 1)
             if obs_in_storage:
                 abi.check(lib, lib.ssd_policy_encode(store_obs.data_ptr(), N * n, V, *enc, store_obs.stride(0), store_obs.stride(1), so[2],
-                                                     None if t_copy is None else t_copy.data_ptr(), st))
+                                                     None if t_copy is None else t_copy.data_ptr(),
+                                                     None if counter_inc is None else counter_inc.data_ptr(), st))
             else:
-                abi.check(lib, lib.ssd_policy_encode(obs.data_ptr(), N * n, V, *enc, 0, 0, None, None, st))
+                abi.check(lib, lib.ssd_policy_encode(obs.data_ptr(), N * n, V, *enc, 0, 0, None, None, None if counter_inc is None else counter_inc.data_ptr(), st))
                 if store_obs is not None:
                     store_obs.index_copy_(1, store_t, obs.unsqueeze(1))
         else:
@@ -161,6 +178,8 @@ class FastPolicy:
                 ha.out_actions_i32 = actions_i32.data_ptr()
             if pos_copy is not None:
                 ha.orient, ha.pos_copy, ha.orient_copy = orient.data_ptr(), pos_copy.data_ptr(), orient_copy.data_ptr()
+            for k, v in (file or {}).items():
+                setattr(ha, k, v)
             abi.check(lib, lib.ssd_policy_head_env(C.byref(ha), st))
             return self.actions
         abi.check(lib, lib.ssd_build_inputs(N, n, self.A, 2, prev_actions.data_ptr(), prev_reward.data_ptr(), prev_inc.data_ptr(),
@@ -177,7 +196,7 @@ class FastPolicy:
 
     # ---- incentive head ---------------------------------------------------------------------------------------------
     @th.no_grad()
-    def act_inc(self, actions, pos, orient, reward, clean_num, apple_den, eps, step, q_out=None):
+    def act_inc(self, actions, pos, orient, reward, clean_num, apple_den, eps, step, q_out=None, file=None):
         """actions i64 [N, n] (the env actions just taken); pos / orient: the PRE-step pose [N, n, 2]; reward, clean_num,
         apple_den [N, n] of this step.  Returns actions_inc i64 [N, n, n] with a zero diagonal (static buffer)."""
         p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
@@ -187,6 +206,8 @@ class FastPolicy:
             ha.actions, ha.pos_pre, ha.orient_pre = actions.data_ptr(), pos.data_ptr(), orient.data_ptr()
             ha.reward, ha.clean_num, ha.apple_den = reward.data_ptr(), clean_num.data_ptr(), apple_den.data_ptr()
             ha.out_actions = self.actions_inc.data_ptr()
+            for k, v in (file or {}).items():
+                setattr(ha, k, v)
             abi.check(lib, lib.ssd_policy_head_inc(C.byref(ha), st))
             return self.actions_inc
         x = th.baddbmm(p["b1i"], self.inputs, p["w1i_x"]) + p["w1i_a"][self.arange_n, actions.t()]    # one-hot(a) @ W_a = row gather

@@ -62,7 +62,7 @@ class HipGraphRunner(HipVecRunner):
         self.avail_mask = self.env.avail_actions_batch                  # [N, n, A]
         self.inc_mask = (1 - th.eye(n, device=dev, dtype=th.long)).reshape(1, n, n)
         self.fast = None
-        self.direct_obs = False
+        self.direct_obs = self.fold_store = False
         if getattr(a, "fast_policy", True):
             from ..fast_policy import FastPolicy
             # Optionally the policy work of a timestep is evaluated per env GROUP on separate streams (fork/join inside the
@@ -91,6 +91,7 @@ class HipGraphRunner(HipVecRunner):
             self.t_store = th.zeros(1, dtype=th.long, device=dev)     # the encoder's copy of t_dev, read by the store-step launch
             # fused encoder: the env kernel writes obs[:, t + 1] of the storage itself and the encoder reads it there (no obs copy)
             self.direct_obs = self.fast.fused and self.env.native.V == 15 and self.obs_fmt == abi.OBS_F32
+            self.fold_store = self.direct_obs and G == 1 and bool(getattr(a, "fold_store", True))
         self._ready = True
 
     def _bind_store(self, store):
@@ -104,11 +105,23 @@ class HipGraphRunner(HipVecRunner):
         if b is None:
             st["filled"].fill_(1)                                       # fixed-length episodes: every slot is filled
             st["avail_actions"].copy_(self.env.avail_actions_batch.unsqueeze(1).expand(-1, self.episode_limit + 1, -1, -1))
-            b = SimpleNamespace(graph=None, cur=self._dense_cur, ss=None, ss_last=None)
+            b = SimpleNamespace(graph=None, cur=self._dense_cur, ss=None, ss_last=None, file_env=None, file_inc=None, file_inc_last=None)
             if self.fast is not None:
                 if self.direct_obs:
                     b.cur = self.env.native.storage_obs_buffers(st["obs"], self.obs_fmt)
                 b.ss, b.ss_last = self._make_store_args(True), self._make_store_args(False)
+                if self.fold_store:     # the two heads file their results in the storage themselves: no store-step launch
+                    out, slots = self.env.native.out, self.episode_limit + 1
+                    common = dict(t_index=self.t_store.data_ptr(), t_slots=slots)
+                    b.file_env = dict(common, dst_pos=st["agent_pos"].data_ptr(), dst_orient=st["agent_orientation"].data_ptr(),
+                                      dst_actions=st["actions"].data_ptr(), dst_actions_onehot=st["actions_onehot"].data_ptr(),
+                                      prev_actions_out=self.prev_actions.data_ptr())
+                    b.file_inc_last = dict(common, dst_actions_inc=st["actions_inc"].data_ptr())
+                    b.file_inc = dict(b.file_inc_last, prev_actions_inc_out=self.prev_inc.data_ptr(), dst_reward=st["reward"].data_ptr(),
+                                      dst_clean_num=st["clean_num"].data_ptr(), dst_apple_den=st["apple_den"].data_ptr(),
+                                      dst_terminated=st["terminated"].data_ptr(), terminated=out["terminated"].data_ptr(),
+                                      prev_reward_out=self.prev_reward.data_ptr(), ep_return=self.ep_return.data_ptr(),
+                                      next_t_out=self.t_dev.data_ptr())
             self._bundles[key] = b
         self._bundle, self.cur, self._ss, self._ss_last, self._graph = b, b.cur, b.ss, b.ss_last, b.graph
 
@@ -136,7 +149,9 @@ class HipGraphRunner(HipVecRunner):
             main.wait_stream(s)
 
     def _select_fast(self, store_env_step):
-        """_select with the FastPolicy kernels: the encoder writes obs[:, t] into the storage while it reads it, and ONE
+        """_select with the FastPolicy kernels.  Fused path (default): k_encode reads obs[:, t] from the storage where the env
+        kernel put it, the two head kernels file actions / pose / rewards into slot t and carry the previous-step inputs, return
+        and counters themselves -- a timestep is 4 launches (encode, env head, env step+observe, inc head).  Otherwise one
         store-step launch writes the nine small fields."""
         st = self.store.data.transition_data
         td = self.t_dev
@@ -149,7 +164,8 @@ class HipGraphRunner(HipVecRunner):
             extra = dict(orient=orient[sl], actions_i32=self.actions_i32[sl], pos_copy=self.pos_t[sl], orient_copy=self.orient_t[sl]) if fused else {}
             self.fasts[g].act_env(None if self.direct_obs else obs[sl], self.prev_actions[sl], self.prev_reward[sl], self.prev_inc[sl],
                                   pos[sl], self.eps, self.rng_ctr, store_obs=st["obs"][sl], store_t=td, obs_in_storage=self.direct_obs,
-                                  t_copy=self.t_store if (self.direct_obs and g == 0) else None, **extra)
+                                  t_copy=self.t_store if (self.direct_obs and g == 0) else None,
+                                  counter_inc=self.rng_ctr if self.fold_store else None, file=self._bundle.file_env, **extra)
         self._fork(env_head)
         actions = self.actions_full
         pos_t, orient_t = self.pos_t, self.orient_t                     # forward_inc sees the PRE-step pose (controller :78-82)
@@ -165,8 +181,11 @@ class HipGraphRunner(HipVecRunner):
 
         def inc_head(g):
             sl = self.gslices[g]
-            self.fasts[g].act_inc(actions[sl], pos_t[sl], orient_t[sl], reward[sl], clean[sl], den[sl], self.eps, self.rng_ctr)
+            self.fasts[g].act_inc(actions[sl], pos_t[sl], orient_t[sl], reward[sl], clean[sl], den[sl], self.eps, self.rng_ctr,
+                                  file=self._bundle.file_inc if store_env_step else self._bundle.file_inc_last)
         self._fork(inc_head)
+        if self.fold_store:
+            return
         # ONE launch: the nine small fields of slot t, the controller's "previous step" inputs, the episode return and the
         # time / exploration counters (incremented after every block has read t)
         abi.check(self.fast.lib, self.fast.lib.ssd_store_step_launch(C.byref(ss), th.cuda.current_stream(self.env.device).cuda_stream))

@@ -295,6 +295,21 @@ typedef struct ssd_policy_head {
     const float* orient;
     int32_t* out_actions_i32;
     float *pos_copy, *orient_copy;
+    /* Optional: the head also files its results in the episode storage [n_env, t_slots, ...] at time slot *t_index (what
+     * ssd_store_step_launch does as a separate launch; every pointer nullable = skipped), and carries the runner state:
+     *   env head: dst_actions, dst_actions_onehot, dst_pos, dst_orient (the current pose), prev_actions_out <- actions
+     *   inc head: dst_actions_inc, prev_actions_inc_out <- actions_inc; dst_reward / dst_clean_num / dst_apple_den /
+     *             dst_terminated <- this step's reward, clean_num, apple_den, terminated; prev_reward_out <- reward;
+     *             ep_return += reward; *next_t_out = *t_index + 1 (next_t_out must not alias t_index). */
+    const int64_t* t_index;
+    int32_t t_slots;
+    float *dst_pos, *dst_orient, *dst_actions_onehot, *dst_reward, *dst_clean_num, *dst_apple_den;
+    uint8_t* dst_terminated;
+    const uint8_t* terminated;     /* [n_env] */
+    int64_t *dst_actions, *dst_actions_inc;
+    int64_t *prev_actions_out, *prev_actions_inc_out;
+    float *prev_reward_out, *ep_return;
+    int64_t* next_t_out;
 } ssd_policy_head;
 int ssd_policy_head_env(const ssd_policy_head* args, void* stream);
 int ssd_policy_head_inc(const ssd_policy_head* args, void* stream);
@@ -304,10 +319,12 @@ int ssd_policy_head_inc(const ssd_policy_head* args, void* stream);
  * The observation of row (env b, agent i) is read at obs + b * obs_env_stride + (*slot_t) * obs_slot_stride + i * 3VV:
  * obs_env_stride = 0 means dense [rows, 3, V, V]; with the strides of an episode storage [n_env, t_slots, n, 3, V, V] and the
  * device time index slot_t the encoder reads obs[:, t] where ssd_step_observe put it (ssd_obs_out.obs_env_stride).
- * slot_t_copy (nullable) receives *slot_t: a second copy of the time index for ssd_store_step_launch, which advances slot_t. */
+ * slot_t_copy (nullable) receives *slot_t: a second copy of the time index for the kernels that file results and advance slot_t
+ * (ssd_policy_head.t_index / next_t_out, ssd_store_step_launch).  counter_inc (nullable): *counter_inc += 1 (the exploration-draw
+ * counter read by the heads that follow; this kernel does not read it). */
 int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
                       const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, int64_t obs_env_stride,
-                      int64_t obs_slot_stride, const int64_t* slot_t, int64_t* slot_t_copy, void* stream);
+                      int64_t obs_slot_stride, const int64_t* slot_t, int64_t* slot_t_copy, int64_t* counter_inc, void* stream);
 
 /* ---- COUNTER-mode generator (shared definition) ---------------------------------------------
  * Two levels, so that the expensive part is computed once per EPISODE (by the reset call) and kept in the env state:
