@@ -60,7 +60,7 @@ for rep in range(3):
     lib_args = None
     # encoder alone
     abi.check(lib, lib.ssd_policy_encode(obs.data_ptr(), N * n, 15, fp.p["cw"].data_ptr(), fp.p["cb"].data_ptr(), fp.p["lwp"].data_ptr(),
-                                         fp.p["lb"].data_ptr(), fp.inputs.data_ptr(), 64, n, 1, 0, 0, None, None,
+                                         fp.p["lb"].data_ptr(), fp.inputs.data_ptr(), 64, n, 1, 0, 0, None, None, None,
                                          th.cuda.current_stream().cuda_stream))
     th.cuda.synchronize()
     if rep == 2:
