@@ -19,8 +19,6 @@
 //     free) feeds 4 MFMA steps, the activations are read / written as float4 per lane.
 // Launch: grid = n_agents * blocks_per_agent, 512 threads; every wave runs a bounded tile loop, no cross-wave dependencies
 // after the weight staging barrier.
-#include <cstdlib>
-
 #include "ssd_policy_common.h"
 
 namespace ssd {
@@ -304,264 +302,6 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
     PSTAMP(8);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// k_head2: the same head with the FOUR WAVES OF A WORKGROUP SHARING EACH TILE.  With one whole tile per wave (k_head) the 1280
-// tiles of a 4096-env launch leave a critical path of two 464-MFMA tiles on one SIMD.  Here wave w owns hidden features
-// 16 w .. 16 w + 15 of every tile: fc1 output tile w (16 MFMAs), the r / z / n gate columns of those features (2 x 48 MFMAs) and
-// the fc2 partial product over them (4 MFMAs) = 116 MFMAs per wave and tile, two tiles per pass so that every weight fragment
-// read from LDS feeds two MFMAs.  fc1's output and the fc2 partial sums cross the waves through LDS (two workgroup barriers
-// per pass); the pick and the filing of the results are spread over all 256 threads.
-// ---------------------------------------------------------------------------------------------------------------------------
-constexpr int H2_RT = 2;                                               // tiles per pass
-constexpr int H2_XBUF = IMAGE;                                         // [RT][16][WS] fc1 output, all 64 features
-constexpr int H2_PART = H2_XBUF + H2_RT * 16 * WS;                     // [RT][4 waves][16 rows][16 outs] fc2 partial sums
-constexpr int H2_LDS = H2_PART + H2_RT * 4 * 256;
-
-template <int INC>
-__global__ __launch_bounds__(256) void k_head2(HeadK a) {
-    extern __shared__ float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int agent = blockIdx.x / a.bpa, bia = blockIdx.x - agent * a.bpa;
-    const int m = lane & 15, q = lane >> 4;
-    const int N = a.N, n = a.n, A = a.A;
-    PSTAMP(0);
-    {   // stage this agent's weight image in two batches of 16-byte loads
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.weights + (size_t)agent * IMAGE);
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        constexpr int PER = (IMAGE / 4 + 255) / 256, HALF = (PER + 1) / 2;
-#pragma unroll
-        for (int h0 = 0; h0 < PER; h0 += HALF) {
-            f32x4 tmp[HALF];
-#pragma unroll
-            for (int j = 0; j < HALF; ++j) { const int e = tid + (h0 + j) * 256; if (h0 + j < PER && e < IMAGE / 4) tmp[j] = src[e]; }
-#pragma unroll
-            for (int j = 0; j < HALF; ++j) { const int e = tid + (h0 + j) * 256; if (h0 + j < PER && e < IMAGE / 4) dst[e] = tmp[j]; }
-        }
-    }
-    __syncthreads();
-    PSTAMP(1);
-    const float eps = *a.eps;
-    const uint32_t step = (uint32_t)*a.step;
-    const long slot_t = a.t_index ? (long)*a.t_index : 0;
-    if (INC && a.next_t && blockIdx.x == 0 && tid == 0) *a.next_t = slot_t + 1;   // not read by this kernel (t_index is a copy)
-    const int tiles = (N + 15) >> 4;
-    const int fo = 16 * wave + 4 * q;                                  // this lane's 4 hidden features
-    float* xbuf = lds + H2_XBUF;
-    float* part = lds + H2_PART;
-    for (int t0 = bia; t0 < tiles; t0 += H2_RT * a.bpa) {              // consecutive tiles go to different CUs
-        int tile[H2_RT]; bool tv[H2_RT];
-#pragma unroll
-        for (int rt = 0; rt < H2_RT; ++rt) { tile[rt] = t0 + rt * a.bpa; tv[rt] = tile[rt] < tiles; if (!tv[rt]) tile[rt] = t0; }
-        // ---- B operands: the 64 (zero padded) input features and the previous state of row m, per tile ------------------------
-        f32x4 x[H2_RT][4], hp[H2_RT][4];
-        bool valid[H2_RT]; size_t arow[H2_RT];
-#pragma unroll
-        for (int rt = 0; rt < H2_RT; ++rt) {
-            const int b = tile[rt] * 16 + m;
-            valid[rt] = tv[rt] && b < N;
-            const int bc = b < N ? b : N - 1;
-            arow[rt] = (size_t)agent * N + bc;
-            float* in_row = a.inputs + arow[rt] * 64;
-            if (!INC) {
-                x[rt][0] = *reinterpret_cast<const f32x4*>(in_row + 4 * q);
-                x[rt][1] = *reinterpret_cast<const f32x4*>(in_row + 16 + 4 * q);
-                const size_t er = (size_t)bc * n + agent;
-                const int pa = (int)a.prev_actions[er];
-                const float pr = a.prev_reward[er];
-                int recv = 0;
-                for (int g = 0; g < n; ++g) {
-                    if (g == agent) continue;                          // inc_mask_actions: no self incentive
-                    const int64_t v = a.prev_inc[((size_t)bc * n + g) * n + agent];
-                    recv += (v == 1) - (v == 2);
-                }
-                const float p0 = a.pos[er * 2], p1 = a.pos[er * 2 + 1];
-                const float px = p0 / a.pos_scale, py = p1 / a.pos_scale;
-                if (valid[rt] && wave == 0 && q == 0 && (a.pos_copy || a.d_pos)) {   // the pose BEFORE the env step
-                    const float o0 = a.orient[er * 2], o1 = a.orient[er * 2 + 1];
-                    if (a.pos_copy) { a.pos_copy[er * 2] = p0; a.pos_copy[er * 2 + 1] = p1; a.orient_copy[er * 2] = o0; a.orient_copy[er * 2 + 1] = o1; }
-                    if (a.d_pos) {
-                        const size_t sr = (((size_t)bc * a.slots + slot_t) * n + agent) * 2;
-                        a.d_pos[sr] = p0; a.d_pos[sr + 1] = p1; a.d_orient[sr] = o0; a.d_orient[sr + 1] = o1;
-                    }
-                }
-#pragma unroll
-                for (int ct = 2; ct < 4; ++ct) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = 16 * ct + 4 * q + r - 32;        // tail column (controller :137-184)
-                        float v = 0.f;
-                        if (j < A) v = pa == j ? 1.f : 0.f;
-                        else if (j < A + n) v = j - A == agent ? 1.f : 0.f;
-                        else if (j == A + n) v = (float)((pr > 0.f) - (pr < 0.f));
-                        else if (j == A + n + 1) v = (float)((recv > 0) - (recv < 0));
-                        else if (j == A + n + 2) v = px;
-                        else if (j == A + n + 3) v = py;
-                        x[rt][ct][r] = v;
-                    }
-                    if (valid[rt] && wave == 0) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = x[rt][ct];   // the inc head reads the full row
-                }
-            } else {
-                const int act = (int)a.actions[(size_t)bc * n + agent];
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    x[rt][ct] = *reinterpret_cast<const f32x4*>(in_row + 16 * ct + 4 * q);
-                    if (ct >= 2) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int k = 16 * ct + 4 * q + r - a.inp; // [inputs | one-hot(action)] (homophily_agent.py:181)
-                            if (k >= 0 && k < A) x[rt][ct][r] = act == k ? 1.f : 0.f;
-                        }
-                    }
-                }
-            }
-            const float* h_row = a.h + arow[rt] * 64;
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) hp[rt][ct] = *reinterpret_cast<const f32x4*>(h_row + 16 * ct + 4 * q);
-        }
-        // ---- fc1 + LeakyReLU: this wave's 16 output features, both tiles ------------------------------------------------------
-        {
-            f32x4 acc[H2_RT];
-#pragma unroll
-            for (int rt = 0; rt < H2_RT; ++rt) acc[rt] = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + fo);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(lds + (ROW_FC1 + 16 * wave + m) * WS + 16 * ct + 4 * q);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int rt = 0; rt < H2_RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[r], x[rt][ct][r], acc[rt], 0, 0, 0);
-            }
-#pragma unroll
-            for (int rt = 0; rt < H2_RT; ++rt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[rt][r] = leaky(acc[rt][r]);
-                *reinterpret_cast<f32x4*>(xbuf + (rt * 16 + m) * WS + fo) = acc[rt];
-            }
-        }
-        __syncthreads();
-        f32x4 x1[H2_RT][4];
-#pragma unroll
-        for (int rt = 0; rt < H2_RT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) x1[rt][ct] = *reinterpret_cast<const f32x4*>(xbuf + (rt * 16 + m) * WS + 16 * ct + 4 * q);
-        // ---- GRU gate columns of this wave's features: r, z accumulate input and hidden side together --------------------------
-        f32x4 gr[H2_RT], gz[H2_RT], gin[H2_RT], ghn[H2_RT];
-        {
-            const f32x4 br = *reinterpret_cast<const f32x4*>(lds + OFF_BI + fo) + *reinterpret_cast<const f32x4*>(lds + OFF_BH + fo);
-            const f32x4 bz = *reinterpret_cast<const f32x4*>(lds + OFF_BI + 64 + fo) + *reinterpret_cast<const f32x4*>(lds + OFF_BH + 64 + fo);
-            const f32x4 bi = *reinterpret_cast<const f32x4*>(lds + OFF_BI + 128 + fo), bh = *reinterpret_cast<const f32x4*>(lds + OFF_BH + 128 + fo);
-#pragma unroll
-            for (int rt = 0; rt < H2_RT; ++rt) { gr[rt] = br; gz[rt] = bz; gin[rt] = bi; ghn[rt] = bh; }
-        }
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            f32x4 wi[3], wh[3];
-#pragma unroll
-            for (int g3 = 0; g3 < 3; ++g3) {
-                wi[g3] = *reinterpret_cast<const f32x4*>(lds + (ROW_WI + 64 * g3 + 16 * wave + m) * WS + 16 * ct + 4 * q);
-                wh[g3] = *reinterpret_cast<const f32x4*>(lds + (ROW_WH + 64 * g3 + 16 * wave + m) * WS + 16 * ct + 4 * q);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int rt = 0; rt < H2_RT; ++rt) {
-                    gr[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[0][r], x1[rt][ct][r], gr[rt], 0, 0, 0);
-                    gz[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[1][r], x1[rt][ct][r], gz[rt], 0, 0, 0);
-                    gin[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[2][r], x1[rt][ct][r], gin[rt], 0, 0, 0);
-                    ghn[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[2][r], hp[rt][ct][r], ghn[rt], 0, 0, 0);
-                    gr[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[0][r], hp[rt][ct][r], gr[rt], 0, 0, 0);
-                    gz[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[1][r], hp[rt][ct][r], gz[rt], 0, 0, 0);
-                }
-        }
-        // ---- gates, new state, fc2 partial product over this wave's features ------------------------------------------------------
-        const f32x4 w2 = *reinterpret_cast<const f32x4*>(lds + (ROW_FC2 + m) * WS + fo);
-#pragma unroll
-        for (int rt = 0; rt < H2_RT; ++rt) {
-            const f32x4 hown = wave == 0 ? hp[rt][0] : wave == 1 ? hp[rt][1] : wave == 2 ? hp[rt][2] : hp[rt][3];
-            f32x4 hn;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float rg = sigmoid_fast(gr[rt][r]);
-                const float zg = sigmoid_fast(gz[rt][r]);
-                const float ng = tanh_fast(gin[rt][r] + rg * ghn[rt][r]);
-                hn[r] = (1.f - zg) * ng + zg * hown[r];
-            }
-            if (valid[rt]) *reinterpret_cast<f32x4*>(a.h + arow[rt] * 64 + fo) = hn;
-            f32x4 o2 = wave == 0 ? *reinterpret_cast<const f32x4*>(lds + OFF_B2 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[r], hn[r], o2, 0, 0, 0);
-            *reinterpret_cast<f32x4*>(part + ((rt * 4 + wave) * 16 + m) * 16 + 4 * q) = o2;   // part[rt][wave][row][out]
-        }
-        __syncthreads();
-        // ---- dueling + epsilon-greedy + filing, spread over the workgroup ----------------------------------------------------------
-        if (!INC) {
-            if (tid < H2_RT * 16) {
-                const int rt = tid >> 4, row = tid & 15, bb = tile[rt] * 16 + row;
-                if (tv[rt] && bb < N) {
-                    float av[16];
-                    for (int k = 0; k <= A; ++k) {
-                        float sacc = part[((rt * 4 + 0) * 16 + row) * 16 + k];
-#pragma unroll
-                        for (int w = 1; w < 4; ++w) sacc += part[((rt * 4 + w) * 16 + row) * 16 + k];
-                        av[k] = sacc;
-                    }
-                    const uint32_t r = (uint32_t)(agent * N + bb);
-                    const int act = dueling_pick_row(av, av[A], A, a.avail, eps, step, a.seed, r, a.q_out ? a.q_out + (size_t)r * A : nullptr);
-                    a.out_actions[(size_t)bb * n + agent] = act;
-                    if (a.out_actions_i32) a.out_actions_i32[(size_t)bb * n + agent] = act;
-                    if (a.p_act) a.p_act[(size_t)bb * n + agent] = act;
-                    if (a.d_actions) {
-                        const size_t sr = ((size_t)bb * a.slots + slot_t) * n + agent;
-                        a.d_actions[sr] = act;
-                        for (int k = 0; k < A; ++k) a.d_onehot[sr * A + k] = k == act ? 1.f : 0.f;
-                    }
-                }
-            }
-        } else {
-            const float* w2o = lds + OFF_W2O;                          // [E][4]: 3 advantages + value per extra feature
-            for (int it = tid; it < H2_RT * 16 * n; it += 256) {
-                const int rt = it / (16 * n), rem = it - rt * 16 * n, row = rem / n, j = rem - row * n, bb = tile[rt] * 16 + row;
-                if (!tv[rt] || bb >= N) continue;
-                const size_t ej = (size_t)bb * n + j;
-                // other_j = [one-hot(a_j), pos_j / scale, orient_j, r_j, clean_j, apple_den_j] (homophily_agent.py:194-201)
-                const int aj = (int)a.actions[ej];
-                float f[7];
-                f[0] = a.pos_pre[ej * 2] / a.pos_scale; f[1] = a.pos_pre[ej * 2 + 1] / a.pos_scale;
-                f[2] = a.orient_pre[ej * 2]; f[3] = a.orient_pre[ej * 2 + 1];
-                f[4] = a.reward[ej]; f[5] = a.clean[ej]; f[6] = a.den[ej];
-                float av[4];
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    float sacc = part[((rt * 4 + 0) * 16 + row) * 16 + o];
-#pragma unroll
-                    for (int w = 1; w < 4; ++w) sacc += part[((rt * 4 + w) * 16 + row) * 16 + o];
-                    sacc += w2o[aj * 4 + o];
-#pragma unroll
-                    for (int e = 0; e < 7; ++e) sacc = fmaf(f[e], w2o[(A + e) * 4 + o], sacc);
-                    av[o] = sacc;
-                }
-                const uint32_t r = (uint32_t)((agent * N + bb) * n + j);
-                int act = dueling_pick_row(av, av[3], 3, nullptr, eps, step, a.seed, r, a.q_out ? a.q_out + (size_t)r * 3 : nullptr);
-                if (j == agent) act = 0;                               // no self incentive (homophily_controller.py:44-46)
-                a.out_actions[((size_t)bb * n + agent) * n + j] = act;
-                if (a.p_inc) a.p_inc[((size_t)bb * n + agent) * n + j] = act;
-                const size_t sr = ((size_t)bb * a.slots + slot_t) * n + agent;
-                if (a.d_actions_inc) a.d_actions_inc[sr * n + j] = act;
-                if (j == 0 && a.d_reward) {                            // once per (env, agent): this step's outcome
-                    const size_t ea = (size_t)bb * n + agent;
-                    const float rw = a.reward[ea];
-                    a.d_reward[sr] = rw; a.d_clean[sr] = a.clean[ea]; a.d_den[sr] = a.den[ea];
-                    if (a.p_rew) a.p_rew[ea] = rw;
-                    if (a.ep_ret) a.ep_ret[ea] += rw;
-                    if (agent == 0 && a.d_term) a.d_term[(size_t)bb * a.slots + slot_t] = a.term[bb];
-                }
-            }
-        }
-        // the next pass writes xbuf before its first barrier and `part` after it: both are safe against this pass's readers
-    }
-    PSTAMP(8);
-}
-
 static int launch_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     HeadK k;
     k.N = p->n_env; k.n = p->n_agents; k.A = p->n_actions; k.inp = p->input_shape;
@@ -582,28 +322,19 @@ static int launch_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     if (bpa > tiles) bpa = tiles;
     if (bpa < 1) bpa = 1;
     k.bpa = bpa;
-    static const bool v1 = std::getenv("SSD_HEAD_V1") != nullptr;     // diagnostics: the one-tile-per-wave kernel
-    const size_t lds = (size_t)(v1 ? IMAGE + HEAD_WAVES * SCRATCH : H2_LDS) * sizeof(float);
+    const size_t lds = (size_t)(IMAGE + HEAD_WAVES * SCRATCH) * sizeof(float);
     static bool attr_done_dev[64] = {};                               // the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
     bool& attr_done = attr_done_dev[dev];
     if (!attr_done) {
-        const int l1 = (int)((IMAGE + HEAD_WAVES * SCRATCH) * sizeof(float)), l2 = (int)(H2_LDS * sizeof(float));
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head<0>), hipFuncAttributeMaxDynamicSharedMemorySize, l1);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head<1>), hipFuncAttributeMaxDynamicSharedMemorySize, l1);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, l2);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    if (v1) {
-        if (inc) hipLaunchKernelGGL(k_head<1>, dim3(k.n * bpa), dim3(HEAD_WAVES * 64), lds, s, k);
-        else hipLaunchKernelGGL(k_head<0>, dim3(k.n * bpa), dim3(HEAD_WAVES * 64), lds, s, k);
-    } else {
-        if (inc) hipLaunchKernelGGL(k_head2<1>, dim3(k.n * bpa), dim3(256), lds, s, k);
-        else hipLaunchKernelGGL(k_head2<0>, dim3(k.n * bpa), dim3(256), lds, s, k);
-    }
+    if (inc) hipLaunchKernelGGL(k_head<1>, dim3(k.n * bpa), dim3(HEAD_WAVES * 64), lds, s, k);
+    else hipLaunchKernelGGL(k_head<0>, dim3(k.n * bpa), dim3(HEAD_WAVES * 64), lds, s, k);
     return 0;
 }
 
