@@ -82,6 +82,15 @@ struct Rng {
         if (tape) return k < ustride ? tape_u[k] : 2.0;   // lanes past the first success read speculatively
         return (double)(u32(SSD_STREAM_UNIFORM, (uint32_t)k) >> 8) * (1.0 / 16777216.0);
     }
+    // `uniform(k) < p` without fp64 in the COUNTER path: the draw is m * 2^-24 with the 24-bit integer m, and p * 2^24 is an
+    // exact fp64 scaling, so m * 2^-24 < p  <=>  m < ceil(p * 2^24) = threshold(p)  (exactly, for every double p).
+    static __device__ __forceinline__ uint32_t threshold(double p) {
+        return p >= 1.0 ? (1u << 24) : !(p > 0.0) ? 0u : (uint32_t)ceil(p * 16777216.0);
+    }
+    __device__ __forceinline__ bool below(int k, double p, uint32_t thr) const {
+        if (tape) return (k < ustride ? tape_u[k] : 2.0) < p;
+        return (u32(SSD_STREAM_UNIFORM, (uint32_t)k) >> 8) < thr;
+    }
 };
 
 // Everything one wave knows about its env.
@@ -301,6 +310,7 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
     // compute_probabilities (cleanup.py:189-204): looked up by the waste count in the host-built fp64 tables
     const int current = h->n_waste > 0 ? n_waste_cells : 0;    // kept incrementally in the env state
     const double p_apple = S->tab_p_apple[current], p_waste = S->tab_p_waste[current];
+    const uint32_t t_apple = Rng::threshold(p_apple), t_waste = Rng::threshold(p_waste);
     int k = 0;
     // apples: one draw per site that holds neither an agent nor an apple, in site order (cleanup.py:168-174).
     // Apple sites and waste sites are disjoint, so writing 'A' at once is equivalent to the deferred update_map.
@@ -313,8 +323,7 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
             const uint64_t bal = ballot(elig);
             bool grow = false;
             if (elig && p_apple > 0) {
-                const double u = R.uniform(k + (int)lanes_below(bal));
-                grow = u < p_apple;
+                grow = R.below(k + (int)lanes_below(bal), p_apple, t_apple);
                 if (grow) E.g[cell] = C_APPLE;
             }
             if (p_apple > 0) n_apple_cells += popc64(ballot(grow));
@@ -356,7 +365,7 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
         int J = -1;
         for (int base = 0; base < nfree && J < 0; base += kWave) {
             const int j = base + lane;
-            const bool ok = j < nfree && R.uniform(k + j) < p_waste;
+            const bool ok = j < nfree && R.below(k + j, p_waste, t_waste);
             const uint64_t b = ballot(ok);
             if (b) J = base + first_lane(b);
         }
@@ -385,6 +394,9 @@ __device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R, int& n_apple_
     const DevSpec* S = E.S;
     const DevHead* h = E.h;
     const int lane = E.lane, W = E.W, H = h->H;
+    uint32_t t_harvest[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t_harvest[i] = Rng::threshold(S->harvest_p[i]);
     int k = 0;
     uint32_t spawn_bits = 0;  // decisions are applied after ALL sites were examined (synchronous update, harvest.py:86-90)
 #pragma unroll
@@ -404,9 +416,8 @@ __device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R, int& n_apple_
                         const int x = r + j, y = c + q;
                         if ((unsigned)x < (unsigned)H && (unsigned)y < (unsigned)W) num += E.g[x * W + y] == C_APPLE;
                     }
-                const double p = S->harvest_p[num < 3 ? num : 3];
-                const double u = R.uniform(k + (int)lanes_below(bal));
-                if (u < p) spawn_bits |= 1u << ch;
+                const int pi = num < 3 ? num : 3;
+                if (R.below(k + (int)lanes_below(bal), S->harvest_p[pi], t_harvest[pi])) spawn_bits |= 1u << ch;
             }
             n_apple_cells += popc64(ballot((spawn_bits >> ch) & 1));
             k += popc64(bal);
@@ -489,17 +500,19 @@ template <> struct Expand<uint8_t> {
     static __device__ __forceinline__ uint4 vec(const uint8_t* src, int q) { return *(const uint4*)(src + 16 * q); }
 };
 
-// vectors [q0, q1) of the env's block: out = dst + head, src = pl + head + delta.  4 vectors per lane per batch so that
-// 4 LDS reads are in flight before the first store issues.
+// vectors [q0, q1) of the env's block: out = dst + head, src = pl + head + delta.  U vectors per lane per batch so that U LDS
+// reads are in flight before the first store issues; U is sized to one agent's share of the block at V = 15 (169 / 85 / 43
+// vectors for f32 / bf16 / u8), so that the common call is ONE batch without dead slots.
 template <typename T>
 __device__ __forceinline__ void expand_range(const uint8_t* src, T* out, int q0, int q1, int lane) {
     constexpr int EPV = 16 / (int)sizeof(T);
-    for (int q = q0 + lane; q < q1; q += 4 * kWave) {
-        uint4 v[4];
+    constexpr int U = sizeof(T) == 4 ? 3 : sizeof(T) == 2 ? 2 : 1;
+    for (int q = q0 + lane; q < q1; q += U * kWave) {
+        uint4 v[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (q + u * kWave < q1) ? Expand<T>::vec(src, q + u * kWave) : make_uint4(0, 0, 0, 0);
+        for (int u = 0; u < U; ++u) v[u] = (q + u * kWave < q1) ? Expand<T>::vec(src, q + u * kWave) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
 #ifdef SSD_NOSTORE   // diagnostic only: keep the compute, drop (almost) every store
             if (v[u].x == 0x12345678u)
 #endif
@@ -590,6 +603,29 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
     // return_view's zero padding (utility_funcs.py:93-116), so the window gather needs no bounds test
     for (int i = lane * 16; i < h->PMS; i += kWave * 16) *(uint4*)(E.pm + i) = make_uint4(0, 0, 0, 0);
     wsync();
+    if (!FULL) {
+        // simplified palette: 4 cells per lane and trip, classes by byte-SWAR on the packed cell codes (all codes < 0x80):
+        // wall or agent -> 4, apple -> 2, waste (Cleanup) -> 1, else 0
+        const uint32_t waste_on = h->kind == SSD_ENV_CLEANUP ? 0x80808080u : 0u;
+        for (int i4 = lane * 4; i4 < E.HW; i4 += 4 * kWave) {
+            const uint32_t g4 = *(const uint32_t*)(E.g + i4), o4 = *(const uint32_t*)(E.occ + i4);
+            const uint32_t hi = 0x80808080u, lo = 0x7F7F7F7Fu;
+            const uint32_t wo = (((o4 + lo) | ~((g4 ^ 0x01010101u) + lo)) & hi);          // byte != 0 in occ, or code == '@'
+            const uint32_t ap = ~((g4 ^ 0x02020202u) + lo) & hi & ~wo;                    // code == 'A', nobody on it
+            const uint32_t wa = ~((g4 ^ 0x03030303u) + lo) & waste_on & ~wo;              // code == 'H'
+            const uint32_t cls4 = (wo >> 5) | (ap >> 6) | (wa >> 7);
+            const int r = (int)udiv((uint32_t)i4, h->magic_W);
+            int c = i4 - r * W, d = (r + v) * Wp + c + v;
+            // cells past H * W (the grid is padded to 16 bytes with code 0, nobody stands there) have class 0 and land in the
+            // map's zero padding below the last row: no bound test per cell
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                E.pm[d] = (uint8_t)(cls4 >> (8 * j));
+                ++c; ++d;
+                if (c == W) { c = 0; d += Wp - W; }
+            }
+        }
+    } else
     for (int cell0 = lane; cell0 < E.HW; cell0 += 4 * kWave) {
         int gc[4], oc[4];
 #pragma unroll
