@@ -110,6 +110,7 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
         }
         S.tab_p_apple[current] = pa; S.tab_p_waste[current] = pw;
     }
+    for (int a = 0; a <= SSD_MAX_SITES; ++a) S.tab_den[a] = (float)((double)a / (double)S.HW);
     E->n_spawn = (int)spawn.size();
     if ((int)spawn.size() < S.n) { delete E; return fail(SSD_ERR_INVALID, "There are not enough spawn points! Check your map?"); }
     // spawn_point() returns the LAST free spawn point (map_env.py:779-784): agent a gets the a-th from the end.

@@ -40,6 +40,7 @@ struct DevSpec : DevHead {
     // same fp64 expression evaluated once per possible count (-ffp-contract=off), so the kernel needs no fp64 division
     double tab_p_apple[SSD_MAX_SITES + 1];
     double tab_p_waste[SSD_MAX_SITES + 1];
+    float tab_den[SSD_MAX_SITES + 1];    // apple_den = (float)(apples / (H * W)) in fp64 (map_env.py:291-292) by the apple count
     uint16_t apple[SSD_MAX_SITES];       // cell index of each apple site, row-major scan order
     uint16_t waste[SSD_MAX_SITES];
     uint16_t spawn_cell[SSD_MAX_AGENTS]; // spawn cell of agent a under random_spawn_point = False
