@@ -548,6 +548,7 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
         wsync();
     }
     int q_done = 0;
+    const int dump = (int)(lut - E.pl);
     for (int a = 0; a < n; ++a) {
         const int pa = rl(E.P, a), oa = rl(E.O, a);
         const int pr = (int)udiv((uint32_t)pa, h->magic_W), pc = pa - pr * W;
@@ -565,19 +566,20 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
         // 4 row groups per batch: the 4 class reads are in flight together, then the plane bytes are written
         for (int i = il; i < V; i += 4 * rpi, sidx += 4 * sstep, d += 4 * dstep) {
             int cls[4];
+            bool ok[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) cls[u] = (jv && i + u * rpi < V) ? E.pm[sidx + u * sstep] : 0;
+            for (int u = 0; u < 4; ++u) { ok[u] = jv && i + u * rpi < V; cls[u] = E.pm[ok[u] ? sidx + u * sstep : 0]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (jv && i + u * rpi < V) {
-                    const int du = d + u * dstep, c = cls[u];
-                    if (CODE) {
-                        E.pl[du] = (uint8_t)(c == 2 ? 1 : c == 1 ? 2 : c == 4 ? 3 : 0);
-                    } else if (FULL) {
-                        E.pl[du] = lut[c * 3]; E.pl[du + VV] = lut[c * 3 + 1]; E.pl[du + 2 * VV] = lut[c * 3 + 2];
-                    } else if (c) {
-                        E.pl[du + (c >> 1) * VV] = 255;     // class bit 1 / 2 / 4 = channel R / G / B = plane 0 / 1 / 2
-                    }
+                const int du = d + u * dstep, c = cls[u];
+                if (CODE) {
+                    if (ok[u]) E.pl[du] = (uint8_t)(c == 2 ? 1 : c == 1 ? 2 : c == 4 ? 3 : 0);
+                } else if (FULL) {
+                    if (ok[u]) { E.pl[du] = lut[c * 3]; E.pl[du + VV] = lut[c * 3 + 1]; E.pl[du + 2 * VV] = lut[c * 3 + 2]; }
+                } else {
+                    // class bit 1 / 2 / 4 = channel R / G / B = plane 0 / 1 / 2.  Branch-free: empty cells and idle lanes write
+                    // their 255 into a dump byte behind the planes (the lut slot, unused with the simplified palette)
+                    E.pl[(ok[u] && c) ? du + __mul24(c >> 1, VV) : dump] = 255;
                 }
             }
         }
