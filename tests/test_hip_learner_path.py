@@ -202,11 +202,12 @@ def test_stepwise_forward_equals_time_batched_unroll():
             assert (a - q_env[:, t]).abs().max() < 1e-5 and (b - q_inc[:, t]).abs().max() < 1e-5, t
 
 
-@pytest.mark.parametrize("fused,N", [(False, 192), (True, 192), (True, 203), (True, 9)])
+@pytest.mark.parametrize("fused,N", [(False, 192), (True, 192), (True, 203), (True, 9), (True, 4096), (True, 3300)])
 def test_fast_policy_matches_torch_controller(fused, N):
     """FastPolicy against the torch controller on the same inputs: features, hidden states, Q values and greedy actions.
     fused = one MFMA launch per head (ssd_policy_head_env / _inc), else HIP encoder / GRU gates / dueling-pick kernels around
-    agent-major GEMMs.  N = 203, 9: ragged last 16-row tile."""
+    agent-major GEMMs.  N = 203, 9: ragged last 16-row tile; N = 4096, 3300: workgroups with 5 tiles (the fifth shared by four
+    waves), 3300 mixed with 4-tile workgroups and ragged."""
     from homophily_marl_amd.fast_policy import FastPolicy
     from homophily_marl_amd.run import load_config, setup
     n = 5
