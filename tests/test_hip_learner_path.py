@@ -206,8 +206,8 @@ def test_stepwise_forward_equals_time_batched_unroll():
 def test_fast_policy_matches_torch_controller(fused, N):
     """FastPolicy against the torch controller on the same inputs: features, hidden states, Q values and greedy actions.
     fused = one MFMA launch per head (ssd_policy_head_env / _inc), else HIP encoder / GRU gates / dueling-pick kernels around
-    agent-major GEMMs.  N = 203, 9: ragged last 16-row tile; N = 4096, 3300: workgroups with 5 tiles (the fifth shared by four
-    waves), 3300 mixed with 4-tile workgroups and ragged."""
+    agent-major GEMMs.  N = 203, 9: ragged last 16-row tile; N = 4096, 3300: workgroups that walk 4-6 tiles (more tiles than
+    CUs per agent), 3300 ragged."""
     from homophily_marl_amd.fast_policy import FastPolicy
     from homophily_marl_amd.run import load_config, setup
     n = 5
