@@ -202,28 +202,33 @@ def test_stepwise_forward_equals_time_batched_unroll():
             assert (a - q_env[:, t]).abs().max() < 1e-5 and (b - q_inc[:, t]).abs().max() < 1e-5, t
 
 
-@pytest.mark.parametrize("fused,N", [(False, 192), (True, 192), (True, 203), (True, 9), (True, 4096), (True, 3300)])
-def test_fast_policy_matches_torch_controller(fused, N):
+@pytest.mark.parametrize("fused,N,kind,n", [(False, 192, "cleanup", 5), (True, 192, "cleanup", 5), (True, 203, "cleanup", 5), (True, 9, "cleanup", 5),
+                                             (True, 4096, "cleanup", 5), (True, 3300, "cleanup", 5), (True, 203, "harvest", 5),
+                                             (True, 203, "cleanup", 10), (False, 64, "harvest", 10)])
+def test_fast_policy_matches_torch_controller(fused, N, kind, n):
     """FastPolicy against the torch controller on the same inputs: features, hidden states, Q values and greedy actions.
     fused = one MFMA launch per head (ssd_policy_head_env / _inc), else HIP encoder / GRU gates / dueling-pick kernels around
     agent-major GEMMs.  N = 203, 9: ragged last 16-row tile; N = 4096, 3300: workgroups that walk 4-6 tiles (more tiles than
-    CUs per agent), 3300 ragged."""
+    CUs per agent), 3300 ragged.  Harvest has 8 actions, n = 10 fills the 64 input columns of the inc head exactly."""
     from homophily_marl_amd.fast_policy import FastPolicy
     from homophily_marl_amd.run import load_config, setup
-    n = 5
     th.manual_seed(1)
-    cfg = load_config("cleanup", overrides=dict(runner="hip_vec", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False,
-                                                 store_state=False, env_args=dict(num_agents=n, map="default5", episode_limit=20, seed=3),
-                                                 use_cuda=True, save_model=False, runner_stats=False))
+    cfg = load_config(kind, overrides=dict(runner="hip_vec", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False,
+                                            store_state=False,
+                                            env_args=dict(num_agents=n, map="default10" if (kind == "harvest" or n == 10) else "default5",
+                                                          episode_limit=20, seed=3),
+                                            use_cuda=True, save_model=False, runner_stats=False))
     ctx = setup(cfg)
     mac, env = ctx.mac, ctx.runner.env
+    A = mac.args.n_actions
     env.reset_batch()
     g = th.Generator(device="cuda").manual_seed(0)
+    ok_actions = th.nonzero(env.avail_actions_batch[0, 0]).squeeze(-1).to(th.int32)
     for _ in range(6):      # a few random steps so the observations are not the reset image
-        env.step_batch(th.randint(0, 9, (N, n), generator=g, device="cuda", dtype=th.int32), observe=False)
+        env.step_batch(ok_actions[th.randint(0, ok_actions.numel(), (N, n), generator=g, device="cuda")].contiguous(), observe=False)
     o = env.observe_batch()
     obs, pos, orient = o["obs"].clone(), o["pos"].clone(), o["orient"].clone()
-    prev_a = th.randint(-1, 9, (N, n), generator=g, device="cuda")
+    prev_a = th.randint(-1, A, (N, n), generator=g, device="cuda")
     prev_r = th.randint(-1, 2, (N, n), generator=g, device="cuda").float()
     prev_i = th.randint(0, 3, (N, n, n), generator=g, device="cuda")
     h0e = th.randn(N, n, 1, 64, generator=g, device="cuda") * 0.3
@@ -231,7 +236,7 @@ def test_fast_policy_matches_torch_controller(fused, N):
     avail = env.avail_actions_batch[0, 0]
     fp = FastPolicy(mac, N, avail, seed=7, fused=fused)
     assert fp.fused == fused
-    qe, qi = th.zeros(n, N, 9, device="cuda"), th.zeros(n, N, n, 3, device="cuda")
+    qe, qi = th.zeros(n, N, A, device="cuda"), th.zeros(n, N, n, 3, device="cuda")
     fp.h_env.copy_(h0e.squeeze(2).transpose(0, 1)); fp.h_inc.copy_(h0i.squeeze(2).transpose(0, 1))
     eps, step = th.zeros((), device="cuda"), th.zeros(1, dtype=th.long, device="cuda")
     with th.no_grad():
@@ -249,7 +254,7 @@ def test_fast_policy_matches_torch_controller(fused, N):
         reward = th.randint(-1, 2, (N, n), generator=g, device="cuda").float()
         clean = th.randint(0, 3, (N, n), generator=g, device="cuda").float()
         den = th.rand(N, n, generator=g, device="cuda")
-        q_inc, h_inc, _ = mac.agent.forward_inc(inputs, h0i, th.nn.functional.one_hot(ref_act, 9), pos / mac.pos_scale, orient,
+        q_inc, h_inc, _ = mac.agent.forward_inc(inputs, h0i, th.nn.functional.one_hot(ref_act, A), pos / mac.pos_scale, orient,
                                                 reward.unsqueeze(-1), clean.unsqueeze(-1), den.unsqueeze(-1))
         ainc = fp.act_inc(ref_act, pos, orient, reward, clean, den, eps, step, q_out=qi).clone()
         assert (qi.transpose(0, 1) - q_inc).abs().max() < 5e-5
@@ -259,29 +264,34 @@ def test_fast_policy_matches_torch_controller(fused, N):
         assert (ainc.diagonal(dim1=1, dim2=2) == 0).all()
         # exploration: with eps = 1 every action is random, available, and the inc diagonal stays 0
         eps.fill_(1.0)
-        cnt = th.zeros(9, device="cuda")
+        cnt = th.zeros(A, device="cuda")
         for s in range(20):
             step.fill_(s)
             a = fp.act_env(obs, prev_a, prev_r, prev_i, pos, eps, step)
-            cnt += th.bincount(a.reshape(-1), minlength=9).float()
-        assert cnt[[5, 6, 7]].sum() == 0 and (cnt[[0, 1, 2, 3, 4, 8]] / cnt.sum() - 1 / 6).abs().max() < (0.02 if N >= 192 else 0.06)
+            cnt += th.bincount(a.reshape(-1), minlength=A).float()
+        on = avail.bool()
+        assert cnt[~on].sum() == 0 and (cnt[on] / cnt.sum() - 1 / on.sum()).abs().max() < (0.02 if N >= 192 else 0.06)
     env.close()
 
 
-@pytest.mark.parametrize("groups", [1, 2])
-def test_fast_graph_runner_stores_a_consistent_batch(groups):
+@pytest.mark.parametrize("groups,kind,n,view", [(1, "cleanup", 5, 7), (2, "cleanup", 5, 7), (1, "harvest", 5, 7), (1, "cleanup", 10, 7),
+                                                  (1, "harvest", 5, 15)])
+def test_fast_graph_runner_stores_a_consistent_batch(groups, kind, n, view):
     """hip_graph + FastPolicy (encoder-fused obs store, store-step kernel): the stored batch must be self-consistent
     with the env dynamics (replayed on the CPU oracle with the stored actions), exactly like the generic runner's."""
     from homophily_marl_amd.run import load_config, setup
     from oracle.oracle_py import OracleEnv
-    N, T, n = 48, 14, 5
+    N, T = 48, 14
+    mp = "default10" if (kind == "harvest" or n == 10) else "default5"
     th.manual_seed(0)
-    cfg = load_config("cleanup", overrides=dict(
+    cfg = load_config(kind, overrides=dict(
         runner="hip_graph", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False, store_state=False,
-        env_args=dict(num_agents=n, map="default5", episode_limit=T, seed=21), use_cuda=True, save_model=False, runner_stats=False,
+        env_args=dict(num_agents=n, map=mp, episode_limit=T, seed=21, view_size=view), use_cuda=True, save_model=False, runner_stats=False,
         policy_groups=groups))
     ctx = setup(cfg)
-    orc = OracleEnv("cleanup", map="default5", num_agents=n, n_env=N, view_size=7, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=21)
+    assert ctx.runner.env.native.V == 2 * view + 1       # 31 x 31 windows: per-layer encoder + store-step launch instead of the fused path
+    orc = OracleEnv(kind, map=mp, num_agents=n, n_env=N, view_size=view, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=21)
+    ok_actions = th.nonzero(ctx.runner.env.avail_actions_batch[0, 0]).squeeze(-1).cpu().numpy()
     for ep in range(3):                                  # eager, captured, replayed
         batch = ctx.runner.run(test_mode=False)
         assert ctx.runner.fast is not None and (ep == 0 or ctx.runner._graph is not None)
@@ -296,7 +306,7 @@ def test_fast_graph_runner_stores_a_consistent_batch(groups):
                 assert (batch[k][:, t].cpu().numpy() == o[k]).all(), (ep, t, k)
             assert (batch["terminated"][:, t, 0].cpu().numpy() == o["terminated"]).all()
         assert (batch["obs"][:, T].cpu().numpy() == orc.observe()["obs"]).all()
-        assert np.isin(acts, [0, 1, 2, 3, 4, 8]).all()
+        assert np.isin(acts, ok_actions).all()
         ai = batch["actions_inc"].squeeze(-1)
         assert (ai.diagonal(dim1=2, dim2=3) == 0).all() and int(ai.max()) <= 2 and int(ai.min()) >= 0
         assert (batch["actions_onehot"].argmax(-1) == batch["actions"].squeeze(-1)).all() and (batch["actions_onehot"].sum(-1) == 1).all()
