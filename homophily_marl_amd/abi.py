@@ -36,7 +36,7 @@ class SsdConfig(C.Structure):
 class SsdTape(C.Structure):
     _fields_ = [
         ("move_order", C.c_void_p), ("uniforms", C.c_void_p), ("uniforms_stride", C.c_int32),
-        ("waste_order", C.c_void_p), ("spawn_rot", C.c_void_p),
+        ("waste_order", C.c_void_p), ("spawn_rot", C.c_void_p), ("spawn_order", C.c_void_p),
     ]
 
 

@@ -49,7 +49,6 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
         const long per_wave = 2L * ((cfg->height * cfg->width + 15) & ~15) + pm + 16 + cfg->n_agents * 3L * V * V + 32 + 64;
         if (per_wave * 4 > 160 * 1024) return fail(SSD_ERR_INVALID, "map / view_size / n_agents exceed the LDS budget of one workgroup");
     }
-    if (cfg->random_spawn_point) return fail(SSD_ERR_UNSUPPORTED, "random_spawn_point is not supported in ABI v1");
     if (cfg->spawn_rotation > 3) return fail(SSD_ERR_INVALID, "spawn_rotation must be -1..3");
     if (cfg->env_kind != SSD_ENV_CLEANUP && cfg->env_kind != SSD_ENV_HARVEST) return fail(SSD_ERR_INVALID, "env_kind");
     if (cfg->rng_mode != SSD_RNG_TAPE && cfg->rng_mode != SSD_RNG_COUNTER) return fail(SSD_ERR_INVALID, "rng_mode");
@@ -112,6 +111,10 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
     }
     for (int a = 0; a <= SSD_MAX_SITES; ++a) S.tab_den[a] = (float)((double)a / (double)S.HW);
     E->n_spawn = (int)spawn.size();
+    S.random_spawn = cfg->random_spawn_point ? 1 : 0; S.n_spawn = (int)spawn.size();
+    S.spawn_len = (S.kind == SSD_ENV_CLEANUP ? 2 : 1) * S.n_spawn;   // Cleanup's constructor appends every point again (cleanup.py:79-80)
+    if (S.random_spawn && spawn.size() > SSD_MAX_SPAWN) { delete E; return fail(SSD_ERR_UNSUPPORTED, "random_spawn_point supports at most SSD_MAX_SPAWN spawn points"); }
+    for (size_t i = 0; i < spawn.size() && i < SSD_MAX_SPAWN; ++i) S.spawn_all[i] = (uint16_t)spawn[i];
     if ((int)spawn.size() < S.n) { delete E; return fail(SSD_ERR_INVALID, "There are not enough spawn points! Check your map?"); }
     // spawn_point() returns the LAST free spawn point (map_env.py:779-784): agent a gets the a-th from the end.
     for (int a = 0; a < S.n; ++a) S.spawn_cell[a] = (uint16_t)spawn[spawn.size() - 1 - a];
@@ -211,7 +214,8 @@ static int make_tape(const ssd_env* E, const ssd_tape* t, DevTape* d) {
         if (E->hs.spawn_rotation < 0 && !t->spawn_rot) return fail(SSD_ERR_INVALID, "TAPE mode with random rotation needs tape.spawn_rot");
         if (t->uniforms_stride < 1) return fail(SSD_ERR_INVALID, "tape.uniforms_stride");
     }
-    if (t) { d->move_order = t->move_order; d->uniforms = t->uniforms; d->ustride = t->uniforms_stride; d->waste_order = t->waste_order; d->spawn_rot = t->spawn_rot; }
+    if (t) { d->move_order = t->move_order; d->uniforms = t->uniforms; d->ustride = t->uniforms_stride; d->waste_order = t->waste_order; d->spawn_rot = t->spawn_rot;
+             d->spawn_order = t->spawn_order; }
     return SSD_OK;
 }
 static DevStepOut make_so(const ssd_step_out* o) {
@@ -245,6 +249,7 @@ static int launched(void) {
 int ssd_reset(ssd_env* E, const uint8_t* env_mask, const ssd_tape* tape, ssd_step_out* out, void* stream) {
     if (!E) return fail(SSD_ERR_INVALID, "null env");
     DevTape t; if (int rc = make_tape(E, tape, &t)) return rc;
+    if (E->hs.rng_mode == SSD_RNG_TAPE && E->hs.random_spawn && !t.spawn_order) return fail(SSD_ERR_INVALID, "TAPE mode with random_spawn_point needs tape.spawn_order");
     DevObsOut oo; std::memset(&oo, 0, sizeof oo);
     launch_env(MODE_RESET, E->dspec, E->hs, E->st, nullptr, env_mask, t, make_so(out), oo, (hipStream_t)stream);
     return launched();

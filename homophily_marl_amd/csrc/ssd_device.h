@@ -28,6 +28,7 @@ struct DevHead {
     int32_t vshift;                      // log2 of the power of two >= V: window rows are dealt to lanes 2^vshift at a time
     int32_t episode_limit, spawn_rotation, obs_color, rng_mode, n_actions;
     int32_t n_apple, n_waste;
+    int32_t random_spawn, n_spawn, spawn_len;   // extra_args.random_spawn_point; 'P' cells; length of the reference's spawn list
     uint32_t env_id_base, seed_lo, seed_hi;
     uint32_t magic_W, magic_V, magic_VV, magic_3VV, magic_HW;  // floor(2^32/d)+1: q = umulhi(x, magic), exact for x < 2^16
 };
@@ -44,6 +45,7 @@ struct DevSpec : DevHead {
     uint16_t apple[SSD_MAX_SITES];       // cell index of each apple site, row-major scan order
     uint16_t waste[SSD_MAX_SITES];
     uint16_t spawn_cell[SSD_MAX_AGENTS]; // spawn cell of agent a under random_spawn_point = False
+    uint16_t spawn_all[SSD_MAX_SPAWN];   // every spawn cell in row-major order (random_spawn_point = True)
     alignas(16) uint8_t reset_grid[SSD_MAX_CELLS];   // world after reset_map + custom_reset
     uint8_t lut[16 * 3];                 // full-colour LUT by class (0..5 cell codes, 5 + agent char)
 };
@@ -67,6 +69,7 @@ struct DevTape {
     int32_t ustride;
     const uint8_t* waste_order;
     const uint8_t* spawn_rot;
+    const uint8_t* spawn_order;
 };
 
 struct DevStepOut {

@@ -747,11 +747,42 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
     const uint8_t* tape_waste = tape.waste_order ? tape.waste_order + (size_t)env * h->n_waste : nullptr;
 
     int act = 4, ep_r = 0;
+    int spawn_p = 0;
+    if (MODE == MODE_RESET && h->random_spawn) {
+        // random_spawn_point: every agent's spawn_point() first shuffles the spawn list (map_env.py:776-777), then takes the LAST
+        // free point of that order = the free point with the largest (position in the order, id).  Lanes = spawn point ids; the
+        // agents are served one after the other (whole wave, reset only).
+        // The list holds every point once (Harvest) or twice (Cleanup, cleanup.py:79-80).  Lanes = list elements.
+        const int ns = h->n_spawn, len = h->spawn_len;
+        const bool sl = lane < len;
+        for (int a = 0; a < n; ++a) {
+            int pid;                                             // the point this lane's element stands for
+            uint32_t key;                                        // its rank in the shuffled list (any order-preserving key)
+            if (R.tape) {                                        // lane = position in the recorded list
+                pid = sl ? (int)tape.spawn_order[((size_t)env * n + a) * len + lane] : 0;
+                if (pid >= ns) { atomicOr(R.err, ERR_BAD_TAPE); pid = 0; }
+                key = (uint32_t)lane;
+            } else {                                             // lane = element e = copy * ns + id, sorted by (x >> 8, e)
+                pid = lane >= ns ? lane - ns : lane;
+                key = ((R.u32(SSD_STREAM_SPAWN_ROT, 256u + 32u * (uint32_t)a + (uint32_t)lane) >> 8) << 8) | (uint32_t)lane;
+            }
+            // occupancy is per POINT: a lane is a candidate while no earlier agent took its point
+            bool occupied = false;
+            for (int b = 0; b < a; ++b) occupied |= __builtin_amdgcn_readlane(spawn_p, b) == (sl ? (int)S->spawn_all[pid] : -1);
+            const uint32_t cand = (sl && !occupied) ? key + 1u : 0u;                               // 0 = not a candidate
+            const uint32_t best = ~wave_min_u32(~cand);                                            // wave max
+            const bool me = cand != 0u && cand == best;
+            const uint64_t who = ballot(me);
+            const int sel = who ? first_lane(who) : 0;
+            const int cell = __builtin_amdgcn_readlane(sl ? (int)S->spawn_all[pid] : 0, sel);
+            if (lane == a) spawn_p = cell;
+        }
+    }
     if (E.ag) {
         if (MODE == MODE_RESET) {
-            // setup_agents: agent a takes the last spawn point still free (map_env.py:771-784) = spawn_cell[a];
+            // setup_agents: agent a takes the last spawn point still free (map_env.py:771-784) = spawn_cell[a] without the shuffle;
             // spawn_rotation (:786-793)
-            E.P = S->spawn_cell[lane];
+            E.P = h->random_spawn ? spawn_p : (int)S->spawn_cell[lane];
             if (h->spawn_rotation >= 0) E.O = h->spawn_rotation;
             else if (R.tape) E.O = tape.spawn_rot[(size_t)env * n + lane] & 3;
             else E.O = (int)(R.u32(SSD_STREAM_SPAWN_ROT, (uint32_t)lane) >> 30);

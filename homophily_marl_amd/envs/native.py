@@ -69,7 +69,7 @@ class NativeEnv:
             return None
         return C.byref(tape)
 
-    def make_tape(self, move_order=None, uniforms=None, waste_order=None, spawn_rot=None):
+    def make_tape(self, move_order=None, uniforms=None, waste_order=None, spawn_rot=None, spawn_order=None):
         """Wrap device (or host -> copied) arrays into an ssd_tape; returns the struct (keeps the tensors alive)."""
         def dev(x, dt):
             if x is None:
@@ -77,10 +77,12 @@ class NativeEnv:
             return torch.as_tensor(x).to(device=self.device, dtype=dt).contiguous()
         t = abi.SsdTape()
         keep = dict(move_order=dev(move_order, torch.uint8), uniforms=dev(uniforms, torch.float64),
-                    waste_order=dev(waste_order, torch.uint8), spawn_rot=dev(spawn_rot, torch.uint8))
+                    waste_order=dev(waste_order, torch.uint8), spawn_rot=dev(spawn_rot, torch.uint8),
+                    spawn_order=dev(spawn_order, torch.uint8))
         t.move_order, t.uniforms = _ptr(keep["move_order"]), _ptr(keep["uniforms"])
         t.uniforms_stride = keep["uniforms"].shape[1] if keep["uniforms"] is not None else 0
         t.waste_order, t.spawn_rot = _ptr(keep["waste_order"]), _ptr(keep["spawn_rot"])
+        t.spawn_order = _ptr(keep["spawn_order"])
         t._keep = keep
         return t
 

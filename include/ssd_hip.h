@@ -32,6 +32,7 @@ extern "C" {
 
 #define SSD_MAX_AGENTS 10   /* maps hold at most 10 spawn points; agent ids >= 10 break the reference (map_env.py:370) */
 #define SSD_MAX_CELLS 1024  /* H*W upper bound (largest reference map is 48x18 = 864) */
+#define SSD_MAX_SPAWN 16    /* spawn points ('P' cells) under random_spawn_point (the reference maps hold 3 / 5 / 10) */
 #define SSD_MAX_SITES 256   /* apple / waste site list upper bound (largest: 206 apple sites) */
 
 typedef enum ssd_status {
@@ -57,7 +58,7 @@ typedef struct ssd_config {
     int32_t n_env;               /* envs in this handle (this rank's shard) */
     int32_t view_size;           /* v; window edge V = 2v+1 */
     int32_t episode_limit;       /* terminated iff steps >= episode_limit (map_env.py:890-894) */
-    int32_t random_spawn_point;  /* extra_args.random_spawn_point; 1 is SSD_ERR_UNSUPPORTED in ABI v1 */
+    int32_t random_spawn_point;  /* extra_args.random_spawn_point: 1 = every agent's spawn_point() shuffles the spawn list first */
     int32_t spawn_rotation;      /* extra_args.random_spawn_rotation: 0..3, or -1 = None = random */
     int32_t obs_color;           /* SSD_COLOR_* (extra_args.obs_color) */
     int32_t rng_mode;            /* SSD_RNG_* */
@@ -77,13 +78,18 @@ typedef struct ssd_config {
  *   uniforms    : every np.random.rand(1)[0] of the call in consumption order (cleanup.py:172,183, harvest.py:119).
  *   waste_order : self.waste_points after random.shuffle (cleanup.py:178) as indices into the row-major waste
  *                 site list; only read when the call shuffles.
- *   spawn_rot   : np.random.randint(4) per agent at reset (map_env.py:789); only read when spawn_rotation = -1. */
+ *   spawn_rot   : np.random.randint(4) per agent at reset (map_env.py:789); only read when spawn_rotation = -1.
+ *   spawn_order : self.spawn_points after the random.shuffle of agent a's spawn_point() call (map_env.py:776-777) as indices into
+ *                 the row-major list of distinct spawn points (map_env.py:140-146); the agent takes the LAST free point of that
+ *                 order.  spawn_list_len = n_spawn_points for Harvest and 2 * n_spawn_points for Cleanup, whose constructor appends
+ *                 every point a second time (cleanup.py:79-80): each point id then appears twice. */
 typedef struct ssd_tape {
     const uint8_t* move_order;   /* [n_env, n_agents] */
     const double* uniforms;      /* [n_env, uniforms_stride] */
     int32_t uniforms_stride;
     const uint8_t* waste_order;  /* [n_env, n_waste_sites] */
     const uint8_t* spawn_rot;    /* [n_env, n_agents] */
+    const uint8_t* spawn_order;  /* [n_env, n_agents, spawn_list_len]; only read by resets with random_spawn_point = 1 */
 } ssd_tape;
 
 /* Outputs of one transition.  Replaces the return of MapEnv.step (map_env.py:874-915):
@@ -337,6 +343,8 @@ int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const f
  *   uniform number k of the call: u = (x(UNIFORM, k) >> 8) * 2^-24 as double, compared `u < p` in fp64
  *   shuffles: stable sort of the items by (x(stream, item index) >> 8, item index)   (24-bit key: key | index fits 32 bits)
  *   spawn rotation of agent a: x(SPAWN_ROT, a) >> 30
+ *   spawn list shuffle of agent a (random_spawn_point): sort of the list elements e = copy * n_spawn_points + point id
+ *             (copy = 0, and 1 for Cleanup's duplicated list) by (x(SPAWN_ROT, 256 + 32 a + e) >> 8, e); at most SSD_MAX_SPAWN = 16 points
  * ssd_state.epoch carries `episode`; importing it re-derives b.                                                        */
 enum { SSD_STREAM_UNIFORM = 0, SSD_STREAM_MOVE = 1, SSD_STREAM_WASTE = 2, SSD_STREAM_SPAWN_ROT = 3 };
 

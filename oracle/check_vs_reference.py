@@ -63,9 +63,9 @@ def run_config(cfg, steps, seed, mode, extra_args, obs_every, episode_limit=50):
     avail = list(range(orc.n_actions)) if full_actions else [a for a in range(orc.n_actions) if a not in (5, 6, 7)]
 
     def tape_of(rec):
-        ta = RH.tape_arrays(rec, n, maxu, nw)
+        ta = RH.tape_arrays(rec, n, maxu, nw, ref.spawn_len)
         t, _ = make_tape(1, n, maxu, nw, ta["move_order"][None], ta["uniforms"][None], ta["waste_order"][None],
-                         ta["spawn_rot"][None])
+                         ta["spawn_rot"][None], ta["spawn_order"][None])
         return t, ta
 
     def compare(tag, t):
@@ -138,6 +138,7 @@ def main():
         dict(disable_rotation_action=False, disable_fire_action=False),  # all actions
         dict(disable_rotation_action=False, disable_fire_action=False, random_spawn_rotation=None, obs_color="full"),
         dict(random_spawn_rotation=3),
+        dict(random_spawn_point=True, random_spawn_rotation=None, disable_rotation_action=False, disable_fire_action=False),
     ]
     total = 0
     t0 = time.time()

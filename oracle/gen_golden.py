@@ -45,6 +45,11 @@ TRAJ = [
      dict(ALL, random_spawn_rotation=None), 42, 0.15),
     ("harvest10_v7_allact", dict(env="harvest", map="default10", num_agents=10, view_size=7), 2, 40,
      dict(ALL, obs_color="full"), 43, 0.2),
+    # random_spawn_point: every agent's spawn_point() shuffles the spawn list first (map_env.py:776-777); 3 resets each
+    ("cleanup5_randspawn", dict(env="cleanup", map="default5", num_agents=5, view_size=7), 3, 20,
+     dict(random_spawn_point=True, random_spawn_rotation=None), 51, 0.1),
+    ("harvest5_randspawn", dict(env="harvest", map="default10", num_agents=5, view_size=7), 3, 20,
+     dict(ALL, random_spawn_point=True), 52, 0.1),
 ]
 
 
@@ -61,8 +66,10 @@ def gen_traj(name, cfg, episodes, limit, ea, seed, p_tele):
     obs_rows = []
 
     def add(kind, acts, pre_pos, pre_orient, rec, reward, info, term):
-        ta = RH.tape_arrays(rec, n, maxu, nw)
+        ta = RH.tape_arrays(rec, n, maxu, nw, ref.spawn_len)
+        rsp = bool(ea and ea.get("random_spawn_point"))
         rows.append(dict(
+            **({"spawn_order": ta["spawn_order"]} if rsp else {}),
             kind=kind, actions=acts, pre_pos=pre_pos, pre_orient=pre_orient,
             move_order=ta["move_order"], uniforms=ta["uniforms"], n_uniforms=ta["n_uniforms"],
             waste_order=ta["waste_order"], shuffled=int(ta["shuffled"]), spawn_rot=ta["spawn_rot"],
@@ -160,7 +167,11 @@ def gen_kats():
 
 
 if __name__ == "__main__":
+    import sys
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])                  # optional: names of the trajectories to (re)generate
     for row in TRAJ:
-        gen_traj(*row)
-    gen_kats()
+        if not only or row[0] in only:
+            gen_traj(*row)
+    if not only or "kats" in only:
+        gen_kats()

@@ -42,7 +42,8 @@ def _p(a):
     return None if a is None else a.ctypes.data
 
 
-def make_tape(n_env, n_agents, max_uniforms, n_waste, move_order=None, uniforms=None, waste_order=None, spawn_rot=None):
+def make_tape(n_env, n_agents, max_uniforms, n_waste, move_order=None, uniforms=None, waste_order=None, spawn_rot=None,
+              spawn_order=None):
     """Allocate (or wrap) tape arrays; returns (SsdTape, dict of arrays kept alive)."""
     arrs = dict(
         move_order=np.full((n_env, n_agents), 0xFF, np.uint8) if move_order is None else np.ascontiguousarray(move_order, np.uint8),
@@ -54,6 +55,9 @@ def make_tape(n_env, n_agents, max_uniforms, n_waste, move_order=None, uniforms=
     t.move_order = _p(arrs["move_order"]); t.uniforms = _p(arrs["uniforms"])
     t.uniforms_stride = arrs["uniforms"].shape[1]
     t.waste_order = _p(arrs["waste_order"]); t.spawn_rot = _p(arrs["spawn_rot"])
+    if spawn_order is not None:
+        arrs["spawn_order"] = np.ascontiguousarray(spawn_order, np.uint8)      # [n_env, n_agents, n_spawn_points]
+        t.spawn_order = _p(arrs["spawn_order"])
     t._keep = arrs
     return t, arrs
 

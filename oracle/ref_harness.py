@@ -88,6 +88,7 @@ class CallRecord:
         self.uniforms = []          # f64 in consumption order
         self.waste_order = None     # list of site indices or None
         self.spawn_rot = []
+        self.spawn_order = []       # random_spawn_point: per agent, the spawn point ids after its shuffle
 
 
 class RefEnv:
@@ -110,6 +111,10 @@ class RefEnv:
             self.waste_index = {tuple(p): i for i, p in enumerate(self.env.waste_start_points)}
         else:
             self.waste_index = {}
+        # spawn point ids = row-major scan order (map_env.py:140-146); the live list may already be shuffled by the constructor
+        self.spawn_index = {p: i for i, p in enumerate(sorted({tuple(q) for q in self.env.spawn_points}))}
+        self.n_spawn = len(self.spawn_index)             # distinct points
+        self.spawn_len = len(self.env.spawn_points)      # list length: Cleanup appends every point twice (cleanup.py:79-80)
         self.n_waste = len(self.waste_index)
         self.n_apple = len(self.env.apple_points)
         self.rec = None
@@ -152,8 +157,21 @@ class RefEnv:
             return v
 
         def py_shuffle(lst):
-            if lst is not getattr(self.env, "waste_points", None):
-                raise NotImplementedError("random_spawn_point shuffles are not part of tape v1")
+            if lst is getattr(self.env, "spawn_points", None):      # spawn_point() of agent a (map_env.py:776-777)
+                a = len(rec.spawn_order)
+                if counter:
+                    seen, eid = {}, []                   # element id = copy * n_points + point id (equal points are interchangeable)
+                    for p in lst:
+                        sidx = self.spawn_index[tuple(p)]
+                        eid.append(seen.get(sidx, 0) * self.n_spawn + sidx)
+                        seen[sidx] = seen.get(sidx, 0) + 1
+                    order = sorted(range(len(lst)), key=lambda i: (u32(STREAM_SPAWN_ROT, 256 + 32 * a + eid[i]) >> 8, eid[i]))
+                    lst[:] = [lst[i] for i in order]
+                else:
+                    o_pyshuffle(lst)
+                rec.spawn_order.append([self.spawn_index[tuple(p)] for p in lst])
+                return
+            assert lst is getattr(self.env, "waste_points", None)
             if counter:
                 idx = [self.waste_index[tuple(p)] for p in lst]
                 order = sorted(range(len(lst)), key=lambda i: (u32(STREAM_WASTE, idx[i]) >> 8, idx[i]))
@@ -220,7 +238,7 @@ class RefEnv:
         return self.env.get_state()                  # f64 [3,H,W]
 
 
-def tape_arrays(rec, n_agents, max_uniforms, n_waste):
+def tape_arrays(rec, n_agents, max_uniforms, n_waste, n_spawn=0):
     """CallRecord -> fixed-shape arrays in the ssd_tape layout (one env)."""
     mo = np.full(n_agents, 0xFF, np.uint8)
     if rec.move_order is not None:
@@ -233,5 +251,8 @@ def tape_arrays(rec, n_agents, max_uniforms, n_waste):
         wo[:n_waste] = rec.waste_order
     sr = np.zeros(n_agents, np.uint8)
     sr[:len(rec.spawn_rot)] = rec.spawn_rot
-    return dict(move_order=mo, uniforms=u, waste_order=wo, spawn_rot=sr, n_uniforms=len(rec.uniforms),
+    so = np.full((n_agents, max(1, n_spawn)), 0xFF, np.uint8)
+    for a, order in enumerate(rec.spawn_order):
+        so[a, :len(order)] = order
+    return dict(move_order=mo, uniforms=u, waste_order=wo, spawn_rot=sr, spawn_order=so, n_uniforms=len(rec.uniforms),
                 shuffled=rec.waste_order is not None)

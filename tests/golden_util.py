@@ -27,7 +27,7 @@ def env_kwargs(meta, n_env=1, rng_mode=abi.RNG_TAPE, **kw):
 
 
 def replay(make_env, make_tape, path, n_env=1):
-    """make_env(env_name, **kwargs) -> backend; make_tape(n_env, n, U, Wn, mo, un, wo, sr) -> SsdTape-like accepted by
+    """make_env(env_name, **kwargs) -> backend; make_tape(n_env, n, U, Wn, mo, un, wo, sr[, spawn_order]) -> SsdTape-like accepted by
     the backend.  With n_env > 1 the same trajectory is replicated in every env (checks batch indexing)."""
     z, meta = load(path)
     n = meta["num_agents"]
@@ -38,7 +38,7 @@ def replay(make_env, make_tape, path, n_env=1):
     obs_at = {int(c): k for k, c in enumerate(z["obs_calls"])}
     for c in range(len(z["kind"])):
         tape = make_tape(n_env, n, U, Wn, rep(z["move_order"][c]), rep(z["uniforms"][c]), rep(z["waste_order"][c]),
-                         rep(z["spawn_rot"][c]))
+                         rep(z["spawn_rot"][c]), *((rep(z["spawn_order"][c]),) if "spawn_order" in z else ()))
         if z["kind"][c] == 0:
             o = env.reset(tape)
         else:

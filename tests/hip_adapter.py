@@ -19,7 +19,7 @@ def _np(d):
     return out
 
 
-def hip_tape(n_env, n, U, Wn, mo=None, un=None, wo=None, sr=None):
+def hip_tape(n_env, n, U, Wn, mo=None, un=None, wo=None, sr=None, so=None):
     dev = torch.device("cuda", 0)
     keep = dict(
         move_order=torch.as_tensor(np.full((n_env, n), 0xFF, np.uint8) if mo is None else np.ascontiguousarray(mo, np.uint8)).to(dev),
@@ -30,6 +30,9 @@ def hip_tape(n_env, n, U, Wn, mo=None, un=None, wo=None, sr=None):
     t.move_order, t.uniforms = keep["move_order"].data_ptr(), keep["uniforms"].data_ptr()
     t.uniforms_stride = keep["uniforms"].shape[1]
     t.waste_order, t.spawn_rot = keep["waste_order"].data_ptr(), keep["spawn_rot"].data_ptr()
+    if so is not None:
+        keep["spawn_order"] = torch.as_tensor(np.ascontiguousarray(so, np.uint8)).to(dev)
+        t.spawn_order = keep["spawn_order"].data_ptr()
     t._keep = keep
     return t
 

@@ -66,7 +66,8 @@ def _compare_state(tag, dev, orc):
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
-@pytest.mark.parametrize("opts", [None, dict(ALL, random_spawn_rotation=None, obs_color="full")], ids=["default", "allact_full"])
+@pytest.mark.parametrize("opts", [None, dict(ALL, random_spawn_rotation=None, obs_color="full"),
+                                  dict(ALL, random_spawn_point=True, random_spawn_rotation=None)], ids=["default", "allact_full", "randspawn"])
 def test_counter_mode_vs_oracle(name, opts):
     """Random actions, COUNTER RNG, 258 envs, 2 episodes of 40 steps; everything compared every step."""
     from oracle.oracle_py import OracleEnv
@@ -79,7 +80,7 @@ def test_counter_mode_vs_oracle(name, opts):
     n = cfg["num_agents"]
     rng = np.random.default_rng(len(name))
     avail = list(range(dev.n_actions)) if opts else [a for a in range(dev.n_actions) if a not in (5, 6, 7)]
-    simplified = not opts
+    simplified = not opts or opts.get("obs_color", "simplified") == "simplified"
     for ep in range(2):
         _compare_step(("reset", ep), dev.reset(), orc.reset(), keys=("n_draws",))
         _compare_state(("reset", ep), dev, orc)

@@ -77,8 +77,10 @@ def test_invalid_arguments(oracle_lib):
         OracleEnv("cleanup", map="default5", num_agents=11, n_env=1)
     with pytest.raises(abi.SsdError):
         OracleEnv("cleanup", map="default3", num_agents=5, n_env=1)   # 3 spawn points only (map_env.py:783)
+    from oracle.oracle_py import make_tape
+    t = OracleEnv("cleanup", map="default5", num_agents=5, n_env=1, extra_args=dict(random_spawn_point=True), rng_mode=abi.RNG_TAPE)
     with pytest.raises(abi.SsdError):
-        OracleEnv("cleanup", map="default5", num_agents=5, n_env=1, extra_args=dict(random_spawn_point=True))
+        t.reset(make_tape(1, 5, t.info.max_uniforms, t.info.n_waste_sites)[0])   # random_spawn_point needs tape.spawn_order
     with pytest.raises(AttributeError):
         OracleEnv("harvest", map="default", num_agents=5, n_env=1)    # harvest.py:20-22,118
     e = OracleEnv("harvest", map="default10", num_agents=5, n_env=1, rng_mode=abi.RNG_COUNTER)
