@@ -20,7 +20,7 @@ def run_e2e(args, rank, world, local_rank):
     # that the runner can write its episodes straight into the buffer's slots (ReplayBuffer.reserve: insertion moves no data)
     buffer_size = -(-5000 // N) * N
     cfg = load_config("cleanup", overrides=dict(
-        runner=args.runner, train_graph=args.train_graph, batch_size_run=N, batch_size=16, buffer_size=buffer_size, buffer_cpu_only=False, store_state=False,
+        runner=args.runner, train_graph=args.train_graph, steps_per_graph=getattr(args, "steps_per_graph", 10), batch_size_run=N, batch_size=16, buffer_size=buffer_size, buffer_cpu_only=False, store_state=False,
         env_args=dict(num_agents=n, map="default5", episode_limit=T, view_size=7, seed=1), use_cuda=True, save_model=False,
         device_index=local_rank, env_id_base=rank * N, runner_stats=False, learner_log_interval=10 ** 12))
     th.manual_seed(0)                     # fixed-seed random-init weights, identical on every rank
@@ -104,4 +104,5 @@ def run_e2e(args, rank, world, local_rank):
                 extra=dict(obs_format="f32[n_env,n,3,15,15]", kernel="ssd::k_env<MODE_STEP_OBS>", qnet_dtype="fp32",
                            train="1 learner.train(batch_size 16 x T 101) per 100-step rollout, double-Q + sim loss, 2x Adam",
                            buffer="device-resident ReplayBuffer, %d episodes, %s" % (buf.buffer_size, "written in place by the runner" if getattr(runner, "_replay", None) is not None else "copy insertion"),
-                           runner=args.runner, train_graph=bool(args.train_graph), breakdown_ms=bd))
+                           runner=args.runner, train_graph=bool(args.train_graph), steps_per_rollout_graph=int(getattr(runner, "_graph_steps", 1)),
+                           breakdown_ms=bd))

@@ -31,6 +31,7 @@ class HipGraphRunner(HipVecRunner):
         self._episodes = 0
         self._ready = False
         self._bundles, self._own_store, self._replay = {}, None, None
+        self._graph_steps = 1
 
     def set_replay_buffer(self, buffer):
         """Write training episodes directly into `buffer` (ReplayBuffer.reserve) when its size is a small multiple of the env
@@ -290,8 +291,15 @@ class HipGraphRunner(HipVecRunner):
         if self._graph is None and self._episodes >= 2 and getattr(self.args, "rollout_graph", True):
             th.cuda.synchronize()
             g = th.cuda.CUDAGraph()
+            # K consecutive timesteps per graph (the device-side time index makes every step of the replay land in its own
+            # slot); K divides the episode length, so an episode is episode_limit / K replays
+            K = max(1, int(getattr(self.args, "steps_per_graph", 10)))
+            while self.episode_limit % K:
+                K -= 1
+            self._graph_steps = K
             with th.no_grad(), th.cuda.graph(g):
-                self._select(True)
+                for _ in range(K):
+                    self._select(True)
             self._graph = self._bundle.graph = g
             # capture records but does not run: re-establish the episode start state
             self.t_dev.zero_()
@@ -299,7 +307,8 @@ class HipGraphRunner(HipVecRunner):
     @th.no_grad()
     def step_once(self):
         if self._graph is not None:
-            self._graph.replay()
+            if self.t % self._graph_steps == 0:       # one replay advances _graph_steps timesteps
+                self._graph.replay()
         else:
             self._select(True)
         self.t += 1
