@@ -139,6 +139,8 @@ class EpisodeBatch:
             raise IndexError("Indexing across Time must be contiguous")
         parsed = []
         for it in items:
+            if isinstance(it, (list, np.ndarray)):      # one host -> device transfer of the indices, not one per field
+                it = th.as_tensor(np.asarray(it), dtype=th.long, device=self.device)
             parsed.append(slice(it, it + 1) if isinstance(it, int) else it)
         return parsed
 

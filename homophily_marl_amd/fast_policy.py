@@ -53,7 +53,25 @@ class FastPolicy:
     def pack(self):
         """Snapshot the (possibly just trained) weights into kernel-ready contiguous packs; values are copied in place so
         that a captured graph keeps seeing the same addresses.  Fused path: the encoder weights and one LDS-layout weight
-        image per agent and head; per-layer path: GEMM-ready operands."""
+        image per agent and head; per-layer path: GEMM-ready operands.  The ~30 small copies are themselves replayed as one
+        hipGraph from the third call on (parameters and packs live at fixed addresses; optimisers update in place)."""
+        self._pack_calls = getattr(self, "_pack_calls", 0) + 1
+        g = getattr(self, "_pack_graph", None)
+        if g is not None:
+            g.replay()
+            return
+        if self._pack_calls == 3 and self.dev.type == "cuda" and not th.cuda.is_current_stream_capturing():
+            th.cuda.synchronize()
+            g = th.cuda.CUDAGraph()
+            with th.cuda.graph(g):
+                self._pack_eager()
+            self._pack_graph = g
+            g.replay()
+            return
+        self._pack_eager()
+
+    @th.no_grad()
+    def _pack_eager(self):
         ag, H, A = self.agent, self.H, self.A
         w, b = ag._w, ag._b
         lin = ag.conv_to_fc[3].weight
