@@ -20,9 +20,11 @@ class HomophilyMAC(nn.Module):
         super().__init__()
         self.n_agents = args.n_agents
         self.args = args
-        for flag in ("obs_others_last_action", "obs_distance"):
-            if getattr(args, flag, False):
-                raise NotImplementedError("%s is off in every shipped config (config/default.yaml:45-51)" % flag)
+        # the shipped flag set (config/default.yaml:45-51) has a HIP kernel for the input tail and the fused rollout kernels;
+        # any other combination of the _build_inputs flags is assembled with torch expressions
+        self.shipped_flags = bool(args.obs_last_action and args.obs_agent_id and args.obs_reward and args.obs_inc_reward
+                                  and args.obs_agent_pos and not getattr(args, "obs_others_last_action", False)
+                                  and not getattr(args, "obs_distance", False))
         self.input_shape = self._get_input_shape(scheme)
         self.agent = agent_REGISTRY[args.agent](self.input_shape, args)
         self.agent_output_type = args.agent_output_type
@@ -101,16 +103,42 @@ class HomophilyMAC(nn.Module):
         return self.agent.rgb_preprocess(obs.reshape(B * self.n_agents, 3, self.args.obs_dims[0], self.args.obs_dims[1]).float())
 
     def assemble_inputs(self, feat, last_actions, last_reward, last_actions_inc, pos, t0):
-        """[feat | onehot(last action) | onehot(id) | sign(r) | sign(received incentives) | pos / ||(H,W)||]."""
+        """[feat | onehot(last action) | onehot(id) | sign(r) | sign(received incentives) | others' last actions | 1 - distances |
+        pos / ||(H,W)||], each block present iff its flag is set (homophily_controller.py:137-184).  last_actions = -1 means
+        "no previous step" (all-zero one-hot); t0: the whole batch is at t = 0."""
         a = self.args
+        n, A = self.n_agents, a.n_actions
         B = pos.shape[0]
         F0 = feat.shape[1]
-        tail = th.empty(B * self.n_agents, self.input_shape - F0, dtype=th.float32, device=feat.device)
-        # the tail layout below assumes the shipped flag set; flags that are off drop their columns
-        assert a.obs_last_action and a.obs_agent_id and a.obs_reward and a.obs_inc_reward and a.obs_agent_pos, \
-            "assemble_inputs implements the shipped flag set (config/default.yaml:45-51)"
-        ops.build_inputs_tail(tail, 0, last_actions, last_reward, last_actions_inc, pos, self.pos_scale, a.n_actions, t0)
-        return th.cat([feat, tail], dim=1)
+        if self.shipped_flags:
+            tail = th.empty(B * n, self.input_shape - F0, dtype=th.float32, device=feat.device)
+            ops.build_inputs_tail(tail, 0, last_actions, last_reward, last_actions_inc, pos, self.pos_scale, A, t0)
+            return th.cat([feat, tail], dim=1)
+        dev = feat.device
+        if t0:
+            last_actions = th.full((B, n), -1, dtype=th.long, device=dev)
+            last_reward = th.zeros(B, n, device=dev)
+            last_actions_inc = th.zeros(B, n, n, dtype=th.long, device=dev)
+        had = (last_actions >= 0).unsqueeze(-1).float()                               # a previous step exists
+        onehot = F.one_hot(last_actions.clamp(min=0), A).float() * had                # [B, n, A]
+        parts = [feat.reshape(B, n, F0)]
+        if a.obs_last_action:
+            parts.append(onehot)
+        if a.obs_agent_id:
+            parts.append(th.eye(n, device=dev).unsqueeze(0).expand(B, -1, -1))
+        if a.obs_reward:
+            parts.append(th.sign(last_reward.float()).unsqueeze(-1))
+        if a.obs_inc_reward:
+            m = last_actions_inc * self.inc_mask_actions.squeeze(-1).to(last_actions_inc.dtype)   # [B, giver, receiver]
+            recv = (m == 1).sum(dim=1) - (m == 2).sum(dim=1)                          # [B, receiver]
+            parts.append(th.sign(recv.float()).unsqueeze(-1))
+        if getattr(a, "obs_others_last_action", False):                               # every agent sees all last actions, agent order
+            parts.append(onehot.reshape(B, 1, n * A).expand(-1, n, -1))
+        if getattr(a, "obs_distance", False):
+            parts.append(1.0 - (pos.unsqueeze(2) - pos.unsqueeze(1)).norm(dim=-1) / self.pos_scale)
+        if a.obs_agent_pos:
+            parts.append(pos / self.pos_scale)
+        return th.cat([x.reshape(B * n, -1).float() for x in parts], dim=1)
 
     def unroll(self, batch):
         """q_env [B, T, n, A], q_inc [B, T, n, n, 3] for every timestep of `batch` -- what calling forward(batch, t) for
@@ -151,6 +179,10 @@ class HomophilyMAC(nn.Module):
         if a.obs_agent_id:
             shape += self.n_agents
         shape += int(bool(a.obs_reward)) + int(bool(a.obs_inc_reward))
+        if getattr(a, "obs_others_last_action", False):
+            shape += scheme["actions_onehot"]["vshape"][0] * self.n_agents
+        if getattr(a, "obs_distance", False):
+            shape += self.n_agents
         if a.obs_agent_pos:
             shape += 2
         return shape

@@ -64,7 +64,7 @@ class HipGraphRunner(HipVecRunner):
         self.inc_mask = (1 - th.eye(n, device=dev, dtype=th.long)).reshape(1, n, n)
         self.fast = None
         self.direct_obs = self.fold_store = False
-        if getattr(a, "fast_policy", True):
+        if getattr(a, "fast_policy", True) and getattr(self.mac, "shipped_flags", True):   # FastPolicy implements the shipped input layout
             from ..fast_policy import FastPolicy
             # Optionally the policy work of a timestep is evaluated per env GROUP on separate streams (fork/join inside the
             # captured graph) around the single full-batch env launch.  Measured on MI355X / ROCm 7.2: no gain (the graph

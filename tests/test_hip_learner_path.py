@@ -367,3 +367,25 @@ def test_gru_sequence_kernels_match_the_stepwise_recurrence(T, G, B):
         assert (a - b).abs().max() < 2e-5 * max(1.0, b.abs().max().item()), name
     with th.no_grad():       # inference form (no saved gates)
         assert (ops.gru_sequence(gi, wh, bh) - ref).abs().max() < 1e-5
+
+
+def test_graph_runner_with_non_shipped_input_flags():
+    """obs_others_last_action / obs_distance switch the controller to the torch input assembly: the graph runner then takes the
+    generic (non-FastPolicy) timestep, still captured as a hipGraph, and a train step runs on its batch."""
+    from homophily_marl_amd.run import load_config, setup, train_iteration
+    N, T, n = 32, 10, 5
+    th.manual_seed(0)
+    cfg = load_config("cleanup", overrides=dict(
+        runner="hip_graph", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False, store_state=False,
+        obs_others_last_action=True, obs_distance=True,
+        env_args=dict(num_agents=n, map="default5", episode_limit=T, seed=5), use_cuda=True, save_model=False, runner_stats=False))
+    ctx = setup(cfg)
+    assert not ctx.mac.shipped_flags and ctx.mac.input_shape == 32 + 9 + n + 2 + 9 * n + n + 2
+    for ep in range(3):
+        batch = ctx.runner.run(test_mode=False)
+        assert ctx.runner.fast is None and (ep == 0 or ctx.runner._graph is not None)
+        acts = batch["actions"].squeeze(-1)
+        assert bool(th.isin(acts, th.tensor([0, 1, 2, 3, 4, 8], device=acts.device)).all())
+        assert int(batch["filled"].sum()) == N * (T + 1)
+    train_iteration(ctx, 0)
+    ctx.runner.close_env()

@@ -5,7 +5,9 @@ import numpy as np
 import pytest
 import torch as th
 
-from tests.learner_util import build, load_fixture, param_checksums
+import os
+
+from tests.learner_util import GOLDEN, build, load_fixture, param_checksums
 
 FIXTURES = ["learner_cleanup5.npz", "learner_harvest5.npz"]
 LOSS_TOL = 1e-5
@@ -76,3 +78,32 @@ def test_incentive_transfer_closed_form():
     assert (rp == (m == 1).sum(2)).all() and (rn == (m == 2).sum(2)).all() and (rz == 3 - rp - rn).all()
     assert th.equal(re, (r + (rp - rn)[:, :-1] * 1.0 * 1.0) / 6.0)
     assert th.equal(ri, (r - give * 0.1 * 1.0) / 6.0)
+
+
+def test_build_inputs_non_shipped_flag_sets():
+    """HomophilyMAC._build_inputs with flag combinations other than the shipped one (obs_others_last_action, obs_distance, blocks
+    switched off) against the reference controller's output on the cleanup fixture batch (oracle/gen_inputs_golden.py)."""
+    import json
+    from types import SimpleNamespace
+    from homophily_marl_amd.controllers import REGISTRY as mac_REGISTRY
+    z, meta = load_fixture("learner_cleanup5.npz")
+    zi = np.load(os.path.join(GOLDEN, "inputs_flags.npz"))
+    flag_sets = json.loads(bytes(zi["flag_sets"]).decode())
+    args, batch, _, _ = build(z, meta)
+    for i, flags in enumerate(flag_sets):
+        a = SimpleNamespace(**dict(vars(args), **flags))
+        mac = mac_REGISTRY[a.mac](batch.scheme, {"agents": a.n_agents}, a)
+        assert not mac.shipped_flags
+        for t in zi["ts"]:
+            ref = zi["tail_%d_t%d" % (i, t)]
+            with th.no_grad():
+                got = mac._build_inputs(batch, int(t))[:, a.obs_dim_net:].numpy()
+            assert got.shape == ref.shape == (batch.batch_size * a.n_agents, mac.input_shape - a.obs_dim_net), (i, t, got.shape, ref.shape)
+            assert np.abs(got - ref).max() < 1e-6, (i, int(t), flags)
+        # the time-batched form used by the learner (previous-step features shifted in time) agrees with the stepwise one
+        with th.no_grad():
+            q_env, q_inc = mac.unroll(batch)
+            mac.init_hidden(batch.batch_size)
+            for t in range(3):
+                qe, qi, _ = mac.forward(batch, t)
+                assert (qe - q_env[:, t]).abs().max() < 1e-5 and (qi - q_inc[:, t]).abs().max() < 1e-5
