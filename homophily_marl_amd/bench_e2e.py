@@ -44,9 +44,9 @@ def run_e2e(args, rank, world, local_rank):
             state["in_episode"] = False
 
     # Setup (not warm-up): build the hipGraphs.  The rollout graph is captured at the start of the 2nd episode and the two
-    # train-step graphs at the 3rd learner.train call, so 4 full iterations (each replay slab is visited twice) are run before the W warm-up steps; this is the
+    # train-step graphs at the 3rd learner.train call, so at least 4 full iterations (every replay slab is visited) are run before the W warm-up steps; this is the
     # analogue of compiling the step and is excluded from both the warm-up count and the timed region.
-    for _ in range(4 * T):
+    for _ in range(max(4, buffer_size // N + 2) * T):       # every replay slab gets its graph before the warm-up starts
         one_step()
     for _ in range(args.warmup):
         one_step()

@@ -34,10 +34,10 @@ class HipGraphRunner(HipVecRunner):
         self._graph_steps = 1
 
     def set_replay_buffer(self, buffer):
-        """Write training episodes directly into `buffer` (ReplayBuffer.reserve) when its size is a small multiple of the env
+        """Write training episodes directly into `buffer` (ReplayBuffer.reserve) when its size is a small multiple (<= 8) of the env
         batch and it lives on the env's device; buffer.insert_episode_batch(batch) then moves no data."""
         N = self.batch_size
-        ok = (buffer is not None and buffer.buffer_size % N == 0 and buffer.buffer_size // N <= 4
+        ok = (buffer is not None and buffer.buffer_size % N == 0 and buffer.buffer_size // N <= 8
               and th.device(buffer.device) == th.device(self.args.device) and buffer.max_seq_length == self.episode_limit + 1)
         self._replay = buffer if ok else None
         return ok
