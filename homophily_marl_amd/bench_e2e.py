@@ -19,8 +19,13 @@ def run_e2e(args, rank, world, local_rank):
     # replay capacity: at least the reference's 5000 episodes (config/default.yaml), rounded up to a multiple of the env batch so
     # that the runner can write its episodes straight into the buffer's slots (ReplayBuffer.reserve: insertion moves no data)
     buffer_size = -(-5000 // N) * N
+    # timesteps per rollout-graph replay: only if the timed region and the warm-up are whole numbers of replays, so that
+    # EXACTLY `steps` timesteps of work are inside the timed region
+    spg = int(getattr(args, "steps_per_graph", 10))
+    if spg < 1 or args.steps % spg or args.warmup % spg or T % spg:
+        spg = 1
     cfg = load_config("cleanup", overrides=dict(
-        runner=args.runner, train_graph=args.train_graph, steps_per_graph=getattr(args, "steps_per_graph", 10), batch_size_run=N, batch_size=16, buffer_size=buffer_size, buffer_cpu_only=False, store_state=False,
+        runner=args.runner, train_graph=args.train_graph, steps_per_graph=spg, batch_size_run=N, batch_size=16, buffer_size=buffer_size, buffer_cpu_only=False, store_state=False,
         env_args=dict(num_agents=n, map="default5", episode_limit=T, view_size=7, seed=1), use_cuda=True, save_model=False,
         device_index=local_rank, env_id_base=rank * N, runner_stats=False, learner_log_interval=10 ** 12))
     th.manual_seed(0)                     # fixed-seed random-init weights, identical on every rank
