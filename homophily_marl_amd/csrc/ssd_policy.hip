@@ -1,10 +1,14 @@
-// ssd_policy.hip -- rollout-time (inference) pieces of the homophily controller that are not GEMMs.
+// ssd_policy.hip -- the homophily controller one layer at a time: the pieces that are not GEMMs.
 //   k_encoder       conv(3->C, k3, s1) + LeakyReLU + Linear(C*(V-2)^2 -> F) + LeakyReLU  (homophily_agent.py:20-27,213-214)
+//   k_conv_leaky    the conv + LeakyReLU half of it (any window size)
 //   k_gru_gates     r, z, n gates and the state update of the hand-written GRU cell       (homophily_agent.py:162-165,188-191)
+//   k_gru_fwd_train / k_gru_bwd   the same with saved gates / its backward (per-step form; the learner uses ssd_gru_seq.hip)
 //   k_dueling_pick  q = v + a - mean(a) and the epsilon-greedy choice                    (homophily_agent.py:168-170,204-206;
 //                                                                                         action_selectors.py:44-68)
-// The per-agent matrix products stay in hipBLASLt (MFMA).  Everything here is elementwise / small-reduction work that
-// PyTorch would issue as 8-15 separate launches per head and timestep.
+//   k_store_step    the small per-step fields of the episode storage in one launch       (episode_runner.py:59-93)
+// In this per-layer composition the per-agent matrix products stay in hipBLASLt.  It is the second implementation of the
+// rollout-time controller (window sizes without a fused encoder, FastPolicy(fused=False)) and the cross-check of the fused
+// kernels in ssd_policy_fused.hip, which replace it on the hot path.
 #include "ssd_policy_common.h"
 
 namespace ssd {

@@ -1,12 +1,14 @@
 """FastPolicy: rollout-time (no-grad) evaluation of the homophily controller for N vectorised envs.
 
 Computes what HomophilyMAC.select_actions_env / select_actions_inc compute (homophily_controller.py:30-65 on top of
-homophily_agent.py:154-208), organised for the GPU:
-  * agent-major activations [n, N, f] everywhere, so every per-agent layer is one batched GEMM (hipBLASLt / MFMA) on
-    contiguous operands -- no transposes, no per-step weight concatenation (weights are packed once per episode);
-  * the conv encoder, the GRU gate arithmetic and dueling + epsilon-greedy are the HIP kernels of csrc/ssd_policy.hip;
-  * the incentive head's pairwise layer [h_i | other_j] @ W is split into h_i @ W_h + other_j @ W_o, so the
-    [n, N * n, H + E] concatenation is never materialised.
+homophily_agent.py:154-208) with agent-major activations [n, N, 64] and the weights re-packed once per episode:
+  * fused path (default; csrc/ssd_policy_fused.hip): k_encode (conv + Linear encoder, f32 MFMA, reads the observation where
+    the env kernel wrote it) and ONE launch per head -- k_head<env> (input tail + fc1 + GRU + dueling + epsilon-greedy) and
+    k_head<inc> (the same plus the per-pair term) -- which also file their results in the episode storage;
+  * per-layer path (fused=False, or window sizes without a fused encoder): every per-agent layer as one batched GEMM
+    (hipBLASLt) between the small kernels of csrc/ssd_policy.hip; the incentive head's pairwise layer [h_i | other_j] @ W is
+    split into h_i @ W_h + other_j @ W_o, so the [n, N * n, H + E] concatenation is never materialised.
+Both implement the shipped _build_inputs flag set (config/default.yaml:45-51).
 Action RNG: the package's counter generator (not torch's Philox); exploration draws are not parity-pinned.
 """
 import ctypes as C

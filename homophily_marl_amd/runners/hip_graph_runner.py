@@ -1,16 +1,20 @@
-"""HipGraphRunner: the vectorised rollout of HipVecRunner with ONE hipGraph replay per timestep.
+"""HipGraphRunner: the vectorised rollout of HipVecRunner as hipGraph replays (10 timesteps per replay by default).
 
 Same data flow and stored batch as HipVecRunner / the reference loop (episode_runner.py:57-119); what changes is the
 mechanics that make a timestep capturable and replayable for every t:
-  * the episode storage is allocated once and indexed by a device-side time counter (index_copy_ along the time axis);
-  * the controller state (hidden states, previous action / reward / incentives, current observation) lives in static
-    tensors; the t == 0 history features are zeros because the previous action is -1 (all-zero one-hot);
-  * epsilon is a device scalar, the uniformly random available action is floor(u * k) through a constant index table
-    (no multinomial, no host sync);
-  * the fused env launch (ssd_step_observe through the C ABI) is issued on the capturing stream and becomes a graph node.
-The first episode runs eagerly (warm-up of MIOpen / hipBLASLt plans and the allocator); the graph is captured at the
-start of the second.  The returned EpisodeBatch is the persistent storage: consume (insert into the replay buffer)
-before the next run(), as the training loop does (run.py:184-185).
+  * the episode storage is persistent and indexed by a device-side time counter; when the replay buffer's size is a small
+    multiple of the env batch the storage IS the next slots of the replay buffer (ReplayBuffer.reserve), so inserting the
+    finished batch moves no data.  Everything that holds pointers into a storage lives in a per-storage bundle;
+  * the controller state (hidden states, previous action / reward / incentives) lives in static tensors; the t == 0 history
+    features are zeros because the previous action is -1 (all-zero one-hot);
+  * with FastPolicy's fused kernels (default) a timestep is 4 launches: k_encode reads obs[:, t] where the env kernel wrote it,
+    k_head<env>, the fused env step + observe (writes obs[:, t + 1] of the storage), k_head<inc>; the heads file actions /
+    pose / rewards in slot t and carry the runner state.  Other configurations (non-shipped input flags, fast_policy=False)
+    take the generic torch timestep, captured the same way;
+  * epsilon is a device scalar; exploration uses the package's counter generator (no multinomial, no host sync).
+The first episode runs eagerly (warm-up of hipBLASLt plans and the allocator); graphs are captured from the second on.
+The returned EpisodeBatch is the persistent storage: consume it (buffer.insert_episode_batch) before the next run(), as the
+training loop does (run.py:184-185).
 """
 import ctypes as C
 
