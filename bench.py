@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--runner", default="hip_graph", choices=["hip_vec", "hip_graph"], help="e2e: rollout runner")
     ap.add_argument("--train-graph", type=int, default=1, help="e2e: capture the train step as hipGraphs")
     ap.add_argument("--steps-per-graph", type=int, default=10, help="e2e: timesteps captured per rollout hipGraph")
+    ap.add_argument("--warm", type=float, default=0.0,
+                    help="env workload: fraction of the waste cells turned into clean river after every reset (SURVEY.md 8d 'warm' variant: "
+                         "exercises apple spawning; 0 = start from the map's reset state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=500)
     args = ap.parse_args()
@@ -102,9 +105,16 @@ def main():
         acts = [avail[torch.randint(0, 6, (N, n), generator=g, device=dev)].contiguous() for _ in range(n_act)]
         bufs = env.obs_buffers(abi.OBS_F32)
 
+        def reset_env():
+            env.reset()
+            if args.warm > 0:      # pre-clean part of the waste through the state import (not a kernel of the path; outside the brackets)
+                grid = env.export_state()["grid"]
+                hit = (grid == 3) & (torch.rand(grid.shape, generator=g, device=dev) < args.warm)
+                env.import_state(grid=torch.where(hit, torch.full_like(grid, 4), grid))
+
         def one_step(t):
             if t % T == 0:
-                env.reset()
+                reset_env()
             env.step_observe(acts[t % n_act], out=bufs)
 
         for t in range(args.warmup):
@@ -122,7 +132,7 @@ def main():
             if (args.warmup + t) % T == 0:
                 if open_ev is not None:
                     e = torch.cuda.Event(enable_timing=True); e.record(); ev.append((open_ev, e)); open_ev = None
-                env.reset()
+                reset_env()
             if open_ev is None:
                 open_ev = torch.cuda.Event(enable_timing=True); open_ev.record(); run_len.append(0)
             env.step_observe(acts[t % n_act], out=bufs)
@@ -139,7 +149,7 @@ def main():
         kern_med_us = per_launch[len(per_launch) // 2]
         bytes_per_launch = algorithmic_bytes_per_env_step(env.H, env.W, n, env.V) * N
         result = dict(elapsed=elapsed, kern_avg_us=kern_avg_us, kern_med_us=kern_med_us, bytes_per_launch=bytes_per_launch,
-                      dtype="u8", workload="cleanup_default5_env_step_observe_fp32obs",
+                      dtype="u8", workload="cleanup_default5_env_step_observe_fp32obs" + ("_warm%d" % round(100 * args.warm) if args.warm > 0 else ""),
                       extra=dict(obs_format="f32[n_env,n,3,15,15]", kernel="ssd::k_env<MODE_STEP_OBS>"))
 
     elapsed = result["elapsed"]
