@@ -384,19 +384,31 @@ __global__ __launch_bounds__(256, 3) void k_encode(EncK a, const float* __restri
             if (a.slot_t_copy) *a.slot_t_copy = *a.slot_t;
             if (a.counter_inc) *a.counter_inc += 1;
         }
-        constexpr int PR = (L + 255) / 256;
+        // row r of the tile = (env b, agent i): walk (b, i) incrementally, one address per row (wave-uniform arithmetic)
+        constexpr int PR = (L + 255) / 256, FULLJ = L / 256;          // loads per thread and row; the first FULLJ need no bound test
         float tmp[16][PR];
+        const float* src[16];
+        {
+            int b = row0 / a.n, i = row0 - b * a.n;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + (r < nrows ? r : 0), b = row / a.n, i = row - b * a.n;
-            const float* src = a.obs + (long)b * a.env_stride + t_off + (long)i * L;
-#pragma unroll
-            for (int j = 0; j < PR; ++j) { const int e = tid + 256 * j; tmp[r][j] = (r < nrows && e < L) ? src[e] : 0.f; }
+            for (int r = 0; r < 16; ++r) {
+                src[r] = a.obs + (long)b * a.env_stride + t_off + (long)i * L;
+                if (r + 1 < nrows) { if (++i == a.n) { i = 0; ++b; } }      // rows past the end re-read the last valid one (discarded)
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int j = 0; j < PR; ++j) { const int e = tid + 256 * j; if (e < L) tile[r * L + e] = tmp[r][j]; }
+            for (int j = 0; j < FULLJ; ++j) tmp[r][j] = src[r][tid + 256 * j];
+        if (PR > FULLJ) {                                              // the ragged last load of every row under ONE predicate
+            const bool in = tid + 256 * FULLJ < L;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmp[r][FULLJ] = in ? src[r][tid + 256 * FULLJ] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int j = 0; j < PR; ++j) { const int e = tid + 256 * j; if (j < FULLJ || e < L) tile[r * L + e] = r < nrows ? tmp[r][j] : 0.f; }
     }
     __syncthreads();
     PSTAMP(1);
