@@ -32,26 +32,45 @@ def algorithmic_bytes_per_env_step(H, W, n, V, obs_bytes_per_elem=4):
 
 
 def cpu_baseline(n_env, steps):
-    """The CPU restatement (oracle/, kind "port") on ONE host core: same workload, bounded sample."""
+    """The CPU restatement (oracle/, kind "port") on the host cores: same workload, bounded sample.  The serial C port is run as
+    one env shard per thread (ctypes releases the GIL; envs never interact, so this is the CPU's own data-parallel form); the
+    single-thread rate of a shorter sample is reported in `sample`."""
+    import threading
     import numpy as np
     from homophily_marl_amd import abi
     from oracle.oracle_py import OracleEnv
     n = 5
-    env = OracleEnv("cleanup", map="default5", num_agents=n, n_env=n_env, view_size=7, episode_limit=100,
-                    rng_mode=abi.RNG_COUNTER, seed=1)
-    rng = np.random.default_rng(0x5D5D)
     avail = np.array([0, 1, 2, 3, 4, 8])
-    acts = [avail[rng.integers(0, 6, (n_env, n))].astype(np.int32) for _ in range(min(steps, 16))]
-    env.reset()
+
+    def run(shard_envs, env_id_base, nsteps, out, k):
+        env = OracleEnv("cleanup", map="default5", num_agents=n, n_env=shard_envs, view_size=7, episode_limit=100,
+                        rng_mode=abi.RNG_COUNTER, seed=1, env_id_base=env_id_base)
+        rng = np.random.default_rng(0x5D5D + k)
+        acts = [avail[rng.integers(0, 6, (shard_envs, n))].astype(np.int32) for _ in range(16)]
+        env.reset()
+        t0 = time.perf_counter()
+        for t in range(nsteps):
+            if t and t % 100 == 0:
+                env.reset()
+            env.step(acts[t % 16])
+            env.observe(abi.OBS_F32)
+        out[k] = time.perf_counter() - t0
+
+    one = [0.0]
+    s1 = max(100, steps // 4)
+    run(n_env, 0, s1, one, 0)                                  # single thread, all envs
+    cores = max(1, min(16, os.cpu_count() or 1, n_env))
+    shard = n_env // cores
+    dts = [0.0] * cores
     t0 = time.perf_counter()
-    for t in range(steps):
-        if t and t % 100 == 0:
-            env.reset()
-        env.step(acts[t % len(acts)])
-        env.observe(abi.OBS_F32)
-    dt = time.perf_counter() - t0
-    return dict(value=n_env * n * steps / dt, unit="agent-steps/s", cores=1, kind="port",
-                sample="%d envs x %d steps of step+observe(fp32), C oracle single thread, %.1f s" % (n_env, steps, dt))
+    th = [threading.Thread(target=run, args=(shard, k * shard, steps, dts, k)) for k in range(cores)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    wall = time.perf_counter() - t0
+    return dict(value=shard * cores * n * steps / max(dts), unit="agent-steps/s", cores=cores, kind="port",
+                sample="%d envs x %d steps of step+observe(fp32), C oracle, one shard of %d envs per thread, %.1f s; "
+                       "single thread: %.0f agent-steps/s (%d steps, %.1f s)" % (shard * cores, steps, shard, wall,
+                                                                                n_env * n * s1 / one[0], s1, one[0]))
 
 
 def main():
@@ -68,7 +87,7 @@ def main():
                     help="env workload: fraction of the waste cells turned into clean river after every reset (SURVEY.md 8d 'warm' variant: "
                          "exercises apple spawning; 0 = start from the map's reset state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-steps", type=int, default=500)
+    ap.add_argument("--cpu-sample-steps", type=int, default=2000)
     args = ap.parse_args()
 
     import torch
