@@ -26,9 +26,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
 
 
-def algorithmic_bytes_per_env_step(H, W, n, V, obs_bytes_per_elem=4):
-    """SURVEY.md section 8(d), format R: grid r+w, actions, agent state r+w, obs [n,3,V,V], 7 f32 scalars per agent."""
-    return 2 * H * W + 4 * n + 16 * n + 3 * obs_bytes_per_elem * n * V * V + 28 * n
+def algorithmic_bytes_per_env_step(H, W, n, V, obs_bytes_per_elem=4, planes=3):
+    """grid r+w, actions, agent state r+w, obs, 7 f32 scalars per agent.  Format R (default): obs f32
+    [n, 3, V, V]; format C: planes = 1, obs_bytes_per_elem = 1 (u8 class codes [n, V, V])."""
+    return 2 * H * W + 4 * n + 16 * n + planes * obs_bytes_per_elem * n * V * V + 28 * n
 
 
 def cpu_baseline(n_env, steps):
@@ -83,6 +84,9 @@ def main():
     ap.add_argument("--runner", default="hip_graph", choices=["hip_vec", "hip_graph"], help="e2e: rollout runner")
     ap.add_argument("--train-graph", type=int, default=1, help="e2e: capture the train step as hipGraphs")
     ap.add_argument("--steps-per-graph", type=int, default=10, help="e2e: timesteps captured per rollout hipGraph")
+    ap.add_argument("--obs-storage", default="f32", choices=["f32", "code"],
+                    help="e2e: observation format of the episode storage / replay buffer: f32 planes (format R, the reference's) or "
+                         "u8 class codes (format C: 12x fewer observation bytes; the roofline object then uses format C bytes)")
     ap.add_argument("--warm", type=float, default=0.0,
                     help="env workload: fraction of the waste cells turned into clean river after every reset (SURVEY.md 8d 'warm' variant: "
                          "exercises apple spawning; 0 = start from the map's reset state)")
@@ -183,7 +187,7 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             tr = json.load(open(tj))
-            if tr.get("kernel") == result["extra"]["kernel"] and tr.get("n_env") == N:
+            if tr.get("kernel") == result["extra"]["kernel"] and tr.get("n_env") == N and result["extra"]["obs_format"].startswith("f32"):
                 traffic = tr.get("hbm_bytes_per_launch")
         line = {
             "metric": "agent_steps_per_sec", "value": total_agent_steps / elapsed, "unit": "agent-steps/s",

@@ -25,7 +25,7 @@ def run_e2e(args, rank, world, local_rank):
     if spg < 1 or args.steps % spg or args.warmup % spg or T % spg:
         spg = 1
     cfg = load_config("cleanup", overrides=dict(
-        runner=args.runner, train_graph=args.train_graph, steps_per_graph=spg, batch_size_run=N, batch_size=16, buffer_size=buffer_size, buffer_cpu_only=False, store_state=False,
+        runner=args.runner, train_graph=args.train_graph, steps_per_graph=spg, batch_size_run=N, batch_size=16, buffer_size=buffer_size, obs_storage=getattr(args, "obs_storage", "f32"), buffer_cpu_only=False, store_state=False,
         env_args=dict(num_agents=n, map="default5", episode_limit=T, view_size=7, seed=1), use_cuda=True, save_model=False,
         device_index=local_rank, env_id_base=rank * N, runner_stats=False, learner_log_interval=10 ** 12))
     th.manual_seed(0)                     # fixed-seed random-init weights, identical on every rank
@@ -88,25 +88,28 @@ def run_e2e(args, rank, world, local_rank):
     env = runner.env
     avail = th.nonzero(env.avail_actions_batch[0, 0]).squeeze(-1).to(th.int32)
     acts = [avail[th.randint(0, avail.numel(), (N, n), device=env.device)].contiguous() for _ in range(8)]
+    code = getattr(args, "obs_storage", "f32") == "code"
+    kfmt = abi.OBS_CODE if code else abi.OBS_F32   # the format the loop's env launches emit
     env.reset_batch()
     for i in range(20):                           # un-timed: the eager launch path has been idle during the graph replays
-        env.step_batch(acts[i % 8], observe=True, fmt=abi.OBS_F32)
+        env.step_batch(acts[i % 8], observe=True, fmt=kfmt)
     ev, run_len = [], []
     for rep in range(3):                          # three whole episodes, like the env workload: reset, then T back-to-back launches
         env.reset_batch()
         s, e = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
         s.record()
         for i in range(T):                        # back-to-back launches of the dominant kernel, bracketed by two events
-            env.step_batch(acts[i % 8], observe=True, fmt=abi.OBS_F32)
+            env.step_batch(acts[i % 8], observe=True, fmt=kfmt)
         e.record()
         ev.append((s, e)); run_len.append(T)
     th.cuda.synchronize()
     ms = sorted(s.elapsed_time(e) / k for (s, e), k in zip(ev, run_len))
     from bench import algorithmic_bytes_per_env_step
     return dict(elapsed=elapsed, kern_avg_us=1e3 * sum(ms) / len(ms), kern_med_us=1e3 * ms[len(ms) // 2],
-                bytes_per_launch=algorithmic_bytes_per_env_step(25, 18, n, 15) * N, dtype="fp32",
+                bytes_per_launch=(algorithmic_bytes_per_env_step(25, 18, n, 15, 1, 1) if code else algorithmic_bytes_per_env_step(25, 18, n, 15)) * N,
+                dtype="fp32",
                 workload="cleanup_default5_rollout_plus_homophily_train",
-                extra=dict(obs_format="f32[n_env,n,3,15,15]", kernel="ssd::k_env<MODE_STEP_OBS>", qnet_dtype="fp32",
+                extra=dict(obs_format="u8 class codes [n_env,n,15,15] (format C)" if code else "f32[n_env,n,3,15,15]", kernel="ssd::k_env<MODE_STEP_OBS>", qnet_dtype="fp32",
                            train="1 learner.train(batch_size 16 x T 101) per 100-step rollout, double-Q + sim loss, 2x Adam",
                            buffer="device-resident ReplayBuffer, %d episodes, %s" % (buf.buffer_size, "written in place by the runner" if getattr(runner, "_replay", None) is not None else "copy insertion"),
                            runner=args.runner, train_graph=bool(args.train_graph), steps_per_rollout_graph=int(getattr(runner, "_graph_steps", 1)),

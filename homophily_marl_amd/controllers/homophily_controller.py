@@ -97,8 +97,18 @@ class HomophilyMAC(nn.Module):
         self.agent.load_state_dict(th.load("{}/agent.th".format(path), map_location=lambda storage, loc: storage, weights_only=True))
 
     # ---- inputs ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def expand_codes(codes):
+        """u8 class codes [..., V, V] of the simplified palette (0 nothing, 1 apple, 2 waste, 3 wall / agent; include/ssd_hip.h
+        SSD_OBS_CODE) -> f32 [..., 3, V, V]: waste = R, apple = G, wall / agent = B at 255/256 -- the observation the env emits in
+        f32 form (map_env.py:945, cleanup.py:96-105)."""
+        c = codes.unsqueeze(-3)
+        return th.cat([c == 2, c == 1, c == 3], dim=-3).float() * (255.0 / 256.0)
+
     def encode_obs(self, obs):
-        """obs [B, n, 3, V, V] (any float dtype) -> conv features [B * n, obs_dim_net]."""
+        """obs [B, n, 3, V, V] (any float dtype; or u8 class codes [B, n, V, V]) -> conv features [B * n, obs_dim_net]."""
+        if obs.dtype == th.uint8:
+            obs = self.expand_codes(obs)
         B = obs.shape[0]
         return self.agent.rgb_preprocess(obs.reshape(B * self.n_agents, 3, self.args.obs_dims[0], self.args.obs_dims[1]).float())
 
@@ -147,6 +157,8 @@ class HomophilyMAC(nn.Module):
         a = self.args
         B, T, n = batch.batch_size, batch.max_seq_length, self.n_agents
         obs = batch["obs"]
+        if obs.dtype == th.uint8:                                                      # compact storage (class codes)
+            obs = self.expand_codes(obs)
         if a.rgb_input:
             feat = self.agent.rgb_preprocess(obs.reshape(B * T * n, 3, a.obs_dims[0], a.obs_dims[1]).float())
         else:

@@ -403,9 +403,10 @@ int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const f
     return launched();
 }
 
-int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
+int ssd_policy_encode(const void* obs, int32_t obs_format, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
                       const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, int64_t obs_env_stride,
                       int64_t obs_slot_stride, const int64_t* slot_t, int64_t* slot_t_copy, int64_t* counter_inc, void* stream) {
+    if (obs_format != SSD_OBS_F32 && obs_format != SSD_OBS_CODE) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode reads f32 observations or class codes");
     if (!obs || !conv_w || !conv_b || !lin_w_packed || !lin_b || !out || rows < 1 || n_agents < 1 || rows % n_agents || out_stride < 32)
         return fail(SSD_ERR_INVALID, "bad argument");
     if (view_edge != 15) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode is instantiated for view_size 7 (15 x 15 windows); use ssd_conv_leaky + GEMM");
@@ -413,8 +414,9 @@ int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const f
     if (obs_env_stride < 0 || obs_slot_stride < 0 || (obs_slot_stride && (!obs_env_stride || !slot_t)))
         return fail(SSD_ERR_INVALID, "obs_env_stride / obs_slot_stride / slot_t");
     if (slot_t_copy && (!slot_t || slot_t_copy == slot_t)) return fail(SSD_ERR_INVALID, "slot_t_copy needs a distinct slot_t");
-    const int rc = launch_policy_encode(obs, rows, view_edge, conv_w, conv_b, lin_w_packed, lin_b, out, out_stride, n_agents, agent_major,
-                                        (long)obs_env_stride, (long)obs_slot_stride, slot_t, slot_t_copy, counter_inc, (hipStream_t)stream);
+    const int rc = launch_policy_encode(static_cast<const float*>(obs), rows, view_edge, conv_w, conv_b, lin_w_packed, lin_b, out, out_stride, n_agents, agent_major,
+                                        (long)obs_env_stride, (long)obs_slot_stride, slot_t, slot_t_copy, counter_inc, obs_format == SSD_OBS_CODE,
+                                        (hipStream_t)stream);
     if (rc) return fail(SSD_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS) failed");
     return launched();
 }

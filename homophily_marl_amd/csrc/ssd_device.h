@@ -124,7 +124,7 @@ void launch_gru_bwd(const float* dh, const float* rzn, const float* gh, const fl
                     int H, hipStream_t s);
 int launch_policy_encode(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lwp, const float* lb, float* out,
                          int out_stride, int n_agents, int agent_major, long env_stride, long slot_stride, const int64_t* slot_t,
-                         int64_t* slot_t_copy, int64_t* counter_inc, hipStream_t s);
+                         int64_t* slot_t_copy, int64_t* counter_inc, int code, hipStream_t s);
 void launch_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T, int G, int B, hipStream_t s);
 void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* d_wh_part,
                         float* d_bh_part, int T, int G, int B, hipStream_t s);

@@ -363,6 +363,7 @@ struct EncK {
     long env_stride, slot_stride; const int64_t* slot_t;   // row (b, i) = obs + b * env_stride + *slot_t * slot_stride + i * 3VV
     int64_t* slot_t_copy;
     int64_t* counter_inc;
+    int code;                           // obs holds u8 class codes [.., V, V] (SSD_OBS_CODE) instead of f32 [.., 3, V, V]
     PSTAMP_DECL
 };
 
@@ -384,6 +385,32 @@ __global__ __launch_bounds__(256, 3) void k_encode(EncK a, const float* __restri
             if (a.slot_t_copy) *a.slot_t_copy = *a.slot_t;
             if (a.counter_inc) *a.counter_inc += 1;
         }
+        if (a.code) {
+            // compact storage: one class code per cell (0 nothing, 1 apple, 2 waste, 3 wall-or-agent; simplified palette) is expanded
+            // to the three colour planes on the way into LDS -- waste = R, apple = G, wall / agent = B at 255/256 (map_env.py:945)
+            const uint8_t* codes = reinterpret_cast<const uint8_t*>(a.obs);
+            constexpr int CPT = (16 * VV + 255) / 256;
+            uint8_t cv[CPT];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int idx = tid + 256 * j, r = idx / VV, cell = idx - r * VV;
+                cv[j] = 0;
+                if (idx < 16 * VV && r < nrows) {
+                    const int row = row0 + r, b = row / a.n, i = row - b * a.n;
+                    cv[j] = codes[(long)b * a.env_stride + t_off + (long)i * VV + cell];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int idx = tid + 256 * j, r = idx / VV, cell = idx - r * VV;
+                if (idx < 16 * VV) {
+                    const float on = 255.0f / 256.0f;
+                    tile[r * L + cell] = cv[j] == 2 ? on : 0.f;
+                    tile[r * L + VV + cell] = cv[j] == 1 ? on : 0.f;
+                    tile[r * L + 2 * VV + cell] = cv[j] == 3 ? on : 0.f;
+                }
+            }
+        } else {
         // row r of the tile = (env b, agent i): walk (b, i) incrementally, one address per row (wave-uniform arithmetic)
         constexpr int PR = (L + 255) / 256, FULLJ = L / 256;          // loads per thread and row; the first FULLJ need no bound test
         float tmp[16][PR];
@@ -409,6 +436,7 @@ __global__ __launch_bounds__(256, 3) void k_encode(EncK a, const float* __restri
         for (int r = 0; r < 16; ++r)
 #pragma unroll
             for (int j = 0; j < PR; ++j) { const int e = tid + 256 * j; if (j < FULLJ || e < L) tile[r * L + e] = r < nrows ? tmp[r][j] : 0.f; }
+        }
     }
     __syncthreads();
     PSTAMP(1);
@@ -487,7 +515,7 @@ __global__ __launch_bounds__(256, 3) void k_encode(EncK a, const float* __restri
 
 int launch_policy_encode(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lwp, const float* lb, float* out,
                          int out_stride, int n_agents, int agent_major, long env_stride, long slot_stride, const int64_t* slot_t,
-                         int64_t* slot_t_copy, int64_t* counter_inc, hipStream_t s) {
+                         int64_t* slot_t_copy, int64_t* counter_inc, int code, hipStream_t s) {
     if (V != 15) return -2;
     constexpr int L = 3 * 15 * 15;
     const size_t lds = (size_t)(16 * L) * sizeof(float);
@@ -498,7 +526,7 @@ int launch_policy_encode(const float* obs, int rows, int V, const float* cw, con
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         attr_done_dev[dev] = true;
     }
-    EncK k{obs, rows, out, out_stride, n_agents, agent_major, env_stride ? env_stride : (long)n_agents * L, slot_stride, slot_t, slot_t_copy, counter_inc};
+    EncK k{obs, rows, out, out_stride, n_agents, agent_major, env_stride ? env_stride : (long)n_agents * (code ? L / 3 : L), slot_stride, slot_t, slot_t_copy, counter_inc, code};
     PSTAMP_SET(k);
     hipLaunchKernelGGL(k_encode<15>, dim3((rows + 15) / 16), dim3(256), lds, s, k, cw, cb, lwp, lb);
     return 0;

@@ -170,12 +170,14 @@ class FastPolicy:
         if self.fused and V == 15:      # conv + Linear in one launch (f32 MFMA), features straight into the input matrix
             enc = (p["cw"].data_ptr(), p["cb"].data_ptr(), p["lwp"].data_ptr(), p["lb"].data_ptr(), self.inputs.data_ptr(),
                    self.inputs.shape[-1], n, 1)
+            src = store_obs if obs_in_storage else obs
+            fmt = abi.OBS_CODE if src.dtype == th.uint8 else abi.OBS_F32       # u8 class codes [.., V, V]: compact storage
             if obs_in_storage:
-                abi.check(lib, lib.ssd_policy_encode(store_obs.data_ptr(), N * n, V, *enc, store_obs.stride(0), store_obs.stride(1), so[2],
+                abi.check(lib, lib.ssd_policy_encode(store_obs.data_ptr(), fmt, N * n, V, *enc, store_obs.stride(0), store_obs.stride(1), so[2],
                                                      None if t_copy is None else t_copy.data_ptr(),
                                                      None if counter_inc is None else counter_inc.data_ptr(), st))
             else:
-                abi.check(lib, lib.ssd_policy_encode(obs.data_ptr(), N * n, V, *enc, 0, 0, None, None, None if counter_inc is None else counter_inc.data_ptr(), st))
+                abi.check(lib, lib.ssd_policy_encode(obs.data_ptr(), fmt, N * n, V, *enc, 0, 0, None, None, None if counter_inc is None else counter_inc.data_ptr(), st))
                 if store_obs is not None:
                     store_obs.index_copy_(1, store_t, obs.unsqueeze(1))
         else:

@@ -47,6 +47,9 @@ def build_scheme(args, env_info):
         "agent_pos": {"vshape": (args.n_agents, 2)},
         "agent_orientation": {"vshape": (args.n_agents, 2)},
     }
+    if getattr(args, "obs_storage", "f32") == "code":      # compact storage: one u8 class code per window cell (include/ssd_hip.h)
+        # (the env rejects the code format under extra_args.obs_color: "full")
+        scheme["obs"] = {"vshape": tuple(env_info["obs_dims"]), "group": "agents", "dtype": th.uint8}
     if not getattr(args, "store_state", True):
         del scheme["state"]        # nothing downstream reads it; 22 MB/step at 4096 envs
     if "homophily" in args.name:

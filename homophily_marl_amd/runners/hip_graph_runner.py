@@ -95,8 +95,12 @@ class HipGraphRunner(HipVecRunner):
             self.actions_i32 = th.zeros(N, n, dtype=th.int32, device=dev)
             self.t_store = th.zeros(1, dtype=th.long, device=dev)     # the encoder's copy of t_dev, read by the store-step launch
             # fused encoder: the env kernel writes obs[:, t + 1] of the storage itself and the encoder reads it there (no obs copy)
-            self.direct_obs = self.fast.fused and self.env.native.V == 15 and self.obs_fmt == abi.OBS_F32
+            self.direct_obs = self.fast.fused and self.env.native.V == 15 and self.obs_fmt in (abi.OBS_F32, abi.OBS_CODE)
             self.fold_store = self.direct_obs and G == 1 and bool(getattr(a, "fold_store", True))
+            if self.obs_fmt == abi.OBS_CODE and not self.direct_obs:
+                # class-code storage is consumed by the fused encoder only; other window sizes take the generic timestep
+                # (the torch controller expands the codes itself)
+                self.fast, self.fasts, self.fold_store = None, [], False
         self._ready = True
 
     def _bind_store(self, store):

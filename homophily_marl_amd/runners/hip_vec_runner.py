@@ -35,7 +35,9 @@ class HipVecRunner:
         self.train_returns, self.test_returns = [], []
         self.train_stats, self.test_stats = {}, {}
         self.log_train_stats_t = -1000000
-        self.obs_fmt = abi.OBS_F32
+        # obs_storage: "code" keeps observations as u8 class codes (simplified palette; 12x fewer bytes in the storage and the
+        # replay buffer); the controller expands them where it consumes them
+        self.obs_fmt = abi.OBS_CODE if getattr(self.args, "obs_storage", "f32") == "code" else abi.OBS_F32
 
     def setup(self, scheme, groups, preprocess, mac):
         self.new_batch = partial(EpisodeBatch, scheme, groups, self.batch_size, self.episode_limit + 1, preprocess=preprocess,

@@ -322,13 +322,15 @@ int ssd_policy_head_inc(const ssd_policy_head* args, void* stream);
 /* ssd_policy_encode: rgb_preprocess (homophily_agent.py:20-27,213-214) for 15 x 15 windows with the Linear layer on f32-input
  * MFMA.  The Linear weight f32 [32, 6 * 169] is passed re-packed per conv channel and zero padded: lin_w_packed f32 [6][32][176],
  * lin_w_packed[c][f][p] = lin_w[f][c * 169 + p] for p < 169, else 0.  out / out_stride / agent_major as in ssd_encoder.
- * The observation of row (env b, agent i) is read at obs + b * obs_env_stride + (*slot_t) * obs_slot_stride + i * 3VV:
+ * obs_format: SSD_OBS_F32 (f32 [.., 3, V, V]) or SSD_OBS_CODE (u8 class codes [.., V, V] of the simplified palette, expanded to the
+ * three colour planes on the way into LDS: compact episode storage, 12x fewer observation bytes).
+ * The observation of row (env b, agent i) is read at obs + b * obs_env_stride + (*slot_t) * obs_slot_stride + i * 3VV (i * VV for codes):
  * obs_env_stride = 0 means dense [rows, 3, V, V]; with the strides of an episode storage [n_env, t_slots, n, 3, V, V] and the
  * device time index slot_t the encoder reads obs[:, t] where ssd_step_observe put it (ssd_obs_out.obs_env_stride).
  * slot_t_copy (nullable) receives *slot_t: a second copy of the time index for the kernels that file results and advance slot_t
  * (ssd_policy_head.t_index / next_t_out, ssd_store_step_launch).  counter_inc (nullable): *counter_inc += 1 (the exploration-draw
  * counter read by the heads that follow; this kernel does not read it). */
-int ssd_policy_encode(const float* obs, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
+int ssd_policy_encode(const void* obs, int32_t obs_format, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
                       const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, int64_t obs_env_stride,
                       int64_t obs_slot_stride, const int64_t* slot_t, int64_t* slot_t_copy, int64_t* counter_inc, void* stream);
 

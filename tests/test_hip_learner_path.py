@@ -274,9 +274,10 @@ def test_fast_policy_matches_torch_controller(fused, N, kind, n):
     env.close()
 
 
-@pytest.mark.parametrize("groups,kind,n,view", [(1, "cleanup", 5, 7), (2, "cleanup", 5, 7), (1, "harvest", 5, 7), (1, "cleanup", 10, 7),
-                                                  (1, "harvest", 5, 15)])
-def test_fast_graph_runner_stores_a_consistent_batch(groups, kind, n, view):
+@pytest.mark.parametrize("groups,kind,n,view,storage", [(1, "cleanup", 5, 7, "f32"), (2, "cleanup", 5, 7, "f32"), (1, "harvest", 5, 7, "f32"),
+                                                          (1, "cleanup", 10, 7, "f32"), (1, "harvest", 5, 15, "f32"),
+                                                          (1, "cleanup", 5, 7, "code"), (2, "harvest", 5, 15, "code")])
+def test_fast_graph_runner_stores_a_consistent_batch(groups, kind, n, view, storage):
     """hip_graph + FastPolicy (encoder-fused obs store, store-step kernel): the stored batch must be self-consistent
     with the env dynamics (replayed on the CPU oracle with the stored actions), exactly like the generic runner's."""
     from homophily_marl_amd.run import load_config, setup
@@ -287,25 +288,27 @@ def test_fast_graph_runner_stores_a_consistent_batch(groups, kind, n, view):
     cfg = load_config(kind, overrides=dict(
         runner="hip_graph", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False, store_state=False,
         env_args=dict(num_agents=n, map=mp, episode_limit=T, seed=21, view_size=view), use_cuda=True, save_model=False, runner_stats=False,
-        policy_groups=groups))
+        policy_groups=groups, obs_storage=storage))
     ctx = setup(cfg)
+    ofmt = abi.OBS_CODE if storage == "code" else abi.OBS_F32            # compact storage: u8 class codes instead of f32 planes
     assert ctx.runner.env.native.V == 2 * view + 1       # 31 x 31 windows: per-layer encoder + store-step launch instead of the fused path
     orc = OracleEnv(kind, map=mp, num_agents=n, n_env=N, view_size=view, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=21)
     ok_actions = th.nonzero(ctx.runner.env.avail_actions_batch[0, 0]).squeeze(-1).cpu().numpy()
     for ep in range(3):                                  # eager, captured, replayed
         batch = ctx.runner.run(test_mode=False)
-        assert ctx.runner.fast is not None and (ep == 0 or ctx.runner._graph is not None)
+        generic = storage == "code" and view != 7     # class codes without the fused 15 x 15 encoder: the torch controller expands them
+        assert (ctx.runner.fast is None) == generic and (ep == 0 or ctx.runner._graph is not None)
         orc.reset()
         acts = batch["actions"].squeeze(-1).cpu().numpy()
         for t in range(T):
-            ob = orc.observe()
+            ob = orc.observe(ofmt)
             assert (batch["obs"][:, t].cpu().numpy() == ob["obs"]).all(), (ep, t)
             assert (batch["agent_pos"][:, t].cpu().numpy() == ob["pos"]).all() and (batch["agent_orientation"][:, t].cpu().numpy() == ob["orient"]).all()
             o = orc.step(acts[:, t])
             for k in ("reward", "clean_num", "apple_den"):
                 assert (batch[k][:, t].cpu().numpy() == o[k]).all(), (ep, t, k)
             assert (batch["terminated"][:, t, 0].cpu().numpy() == o["terminated"]).all()
-        assert (batch["obs"][:, T].cpu().numpy() == orc.observe()["obs"]).all()
+        assert (batch["obs"][:, T].cpu().numpy() == orc.observe(ofmt)["obs"]).all()
         assert np.isin(acts, ok_actions).all()
         ai = batch["actions_inc"].squeeze(-1)
         assert (ai.diagonal(dim1=2, dim2=3) == 0).all() and int(ai.max()) <= 2 and int(ai.min()) >= 0
@@ -389,3 +392,37 @@ def test_graph_runner_with_non_shipped_input_flags():
         assert int(batch["filled"].sum()) == N * (T + 1)
     train_iteration(ctx, 0)
     ctx.runner.close_env()
+
+
+def test_encoder_on_class_codes_equals_encoder_on_f32_planes():
+    """ssd_policy_encode with SSD_OBS_CODE input (compact storage) expands the codes to exactly the f32 planes the env would have
+    written: identical features, bit for bit; also through an episode-storage layout with a device time index."""
+    from homophily_marl_amd.fast_policy import FastPolicy
+    from homophily_marl_amd.run import load_config, setup
+    N, n = 203, 5
+    th.manual_seed(2)
+    cfg = load_config("cleanup", overrides=dict(runner="hip_vec", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False,
+                                                 store_state=False, env_args=dict(num_agents=n, map="default5", episode_limit=20, seed=4),
+                                                 use_cuda=True, save_model=False, runner_stats=False))
+    ctx = setup(cfg)
+    env, fp = ctx.runner.env, FastPolicy(ctx.mac, N, ctx.runner.env.avail_actions_batch[0, 0], seed=1, fused=True)
+    env.reset_batch()
+    g = th.Generator(device="cuda").manual_seed(0)
+    for _ in range(7):
+        env.step_batch(th.randint(0, 5, (N, n), generator=g, device="cuda", dtype=th.int32), observe=False)
+    f32 = env.observe_batch(abi.OBS_F32)["obs"].clone()
+    codes = env.observe_batch(abi.OBS_CODE)["obs"].clone()
+    assert th.equal(ctx.mac.expand_codes(codes), f32)
+    lib, p, st = fp.lib, fp.p, th.cuda.current_stream().cuda_stream
+    enc = (p["cw"].data_ptr(), p["cb"].data_ptr(), p["lwp"].data_ptr(), p["lb"].data_ptr())
+    out = [th.zeros(n, N, 64, device="cuda") for _ in range(3)]
+    abi.check(lib, lib.ssd_policy_encode(f32.data_ptr(), abi.OBS_F32, N * n, 15, *enc, out[0].data_ptr(), 64, n, 1, 0, 0, None, None, None, st))
+    abi.check(lib, lib.ssd_policy_encode(codes.data_ptr(), abi.OBS_CODE, N * n, 15, *enc, out[1].data_ptr(), 64, n, 1, 0, 0, None, None, None, st))
+    storage = th.zeros(N, 4, n, 15, 15, dtype=th.uint8, device="cuda")
+    storage[:, 2] = codes
+    t = th.full((1,), 2, dtype=th.long, device="cuda")
+    abi.check(lib, lib.ssd_policy_encode(storage.data_ptr(), abi.OBS_CODE, N * n, 15, *enc, out[2].data_ptr(), 64, n, 1, storage.stride(0),
+                                         storage.stride(1), t.data_ptr(), None, None, st))
+    th.cuda.synchronize()
+    assert out[0][..., :32].abs().sum() > 0 and th.equal(out[0], out[1]) and th.equal(out[0], out[2])
+    env.close()

@@ -107,3 +107,21 @@ def test_build_inputs_non_shipped_flag_sets():
             for t in range(3):
                 qe, qi, _ = mac.forward(batch, t)
                 assert (qe - q_env[:, t]).abs().max() < 1e-5 and (qi - q_inc[:, t]).abs().max() < 1e-5
+
+
+def test_class_code_storage_expands_to_the_reference_observation():
+    """obs_storage: "code": HomophilyMAC.expand_codes on the class codes reproduces, bit for bit, the observations the reference
+    stored in the learner fixture (simplified palette), so the learner sees identical inputs from the compact storage."""
+    from homophily_marl_amd.controllers.homophily_controller import HomophilyMAC
+    z, meta = load_fixture("learner_cleanup5.npz")
+    o = z["batch_obs"]                                                   # u8 [B, T, n, 3, V, V], values k of k / 256
+    assert set(np.unique(o)) <= {0, 255} and (o.astype(np.int32).sum(axis=3) <= 255).all()    # at most one channel per cell
+    codes = np.where(o[:, :, :, 0] == 255, 2, np.where(o[:, :, :, 1] == 255, 1, np.where(o[:, :, :, 2] == 255, 3, 0))).astype(np.uint8)
+    got = HomophilyMAC.expand_codes(th.as_tensor(codes))
+    assert got.shape == o.shape and th.equal(got, th.as_tensor(o).float() / 256)
+    args, batch, mac, _ = build(z, meta)
+    with th.no_grad():
+        qe, qi = mac.unroll(batch)
+        batch.data.transition_data["obs"] = th.as_tensor(codes)          # the compact form of the same batch
+        qe2, qi2 = mac.unroll(batch)
+    assert th.equal(qe, qe2) and th.equal(qi, qi2)
