@@ -65,7 +65,7 @@ class FastPolicy:
         if self._pack_calls == 3 and self.dev.type == "cuda" and not th.cuda.is_current_stream_capturing():
             th.cuda.synchronize()
             g = th.cuda.CUDAGraph()
-            with th.cuda.graph(g):
+            with th.cuda.graph(g, capture_error_mode="thread_local"):
                 self._pack_eager()
             self._pack_graph = g
             g.replay()

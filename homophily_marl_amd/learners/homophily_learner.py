@@ -221,10 +221,11 @@ class HomophilyLearner:
                                               device=batch.device)
             self._static_dens = th.zeros(2, device=batch.device)
             th.cuda.synchronize()
+            # thread_local: with an initialised process group the RCCL watchdog thread keeps polling events while we capture
             g1, g2 = th.cuda.CUDAGraph(), th.cuda.CUDAGraph()
-            with th.cuda.graph(g1):
+            with th.cuda.graph(g1, capture_error_mode="thread_local"):
                 self._static_logs = self.forward_backward(self._static_batch, self._static_dens)
-            with th.cuda.graph(g2, pool=g1.pool()):
+            with th.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
                 self.clip_and_step()
             self._graph = (g1, g2)
         for k, v in batch.data.transition_data.items():

@@ -305,7 +305,7 @@ class HipGraphRunner(HipVecRunner):
             while self.episode_limit % K:
                 K -= 1
             self._graph_steps = K
-            with th.no_grad(), th.cuda.graph(g):
+            with th.no_grad(), th.cuda.graph(g, capture_error_mode="thread_local"):
                 for _ in range(K):
                     self._select(True)
             self._graph = self._bundle.graph = g
