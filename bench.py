@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- agent-steps/sec of the SSD hot path on N MI355X GPUs (one process per GPU), BASELINE.json metric.
 
-    python bench.py --gpus N --steps K --warmup W [--workload env|e2e] [--n-env 4096]
+    python bench.py --gpus N --steps K --warmup W [--config cleanup5|harvest5|cleanup10] [--workload e2e|env]
     (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): Cleanup `default5`, 5 agents, 4096 vectorised envs per GPU, episode_limit 100,
-default extra_args, COUNTER-mode env RNG (seed 1), synthetic actions.
-  --workload env : one "step" = one transition of all envs: the fused ssd_step_observe launch (moves, beams, respawn,
-                   rewards, egocentric fp32 obs of the new state) with actions i.i.d. uniform over the available set,
-                   pre-generated in HBM; ssd_reset at every episode boundary is inside the timed region.
-  --workload e2e : one "step" = one transition of all envs inside the full loop: Q-net action selection (env + incentive
-                   heads), ssd_step_observe, rollout storage, and one learner.train per 100-step rollout.
-Rank 0 prints ONE JSON line with the driver's fields plus `roofline` (dominant kernel k_env<STEP_OBS>, HIP-event timed
-on the launch stream) and `cpu_baseline` (the C oracle on the host cores, rank 0, N = 1 only).
+Configurations (BASELINE.json `configs`; episode_limit 100, default extra_args, COUNTER-mode env RNG seed 1):
+  cleanup5  (default, configs[1], the one the metric is quoted on): Cleanup `default5`, 5 agents, 4096 envs per GPU
+  harvest5  (configs[2]): Harvest `default10` map, view_size 15 (31 x 31 windows), 5 agents, 4096 envs per GPU
+  cleanup10 (configs[3]): Cleanup `default10`, 10 agents, 8192 envs per GPU
+Workloads:
+  e2e (default): ONE STEP = ONE WHOLE TRAINING ITERATION of the reference loop (run.py:181-210) on all envs of the rank:
+        reset, episode_limit timesteps (Q-net action selection of both heads, fused ssd_step_observe, storage), the slot-T
+        bootstrapping pass, replay insertion, sampling and learner.train (batch 16 x T 101, double-Q + similarity loss, 2x Adam).
+        value = n_env * n_agents * episode_limit * steps * world / elapsed.  Nothing is skipped in the timed region, whatever
+        --steps / --warmup are.
+  env: one step = one transition of all envs: the fused ssd_step_observe launch with pre-generated synthetic actions
+        (resets at the episode boundaries are inside the timed region).
+Rank 0 prints ONE JSON line with the driver's fields plus
+  `roofline`     : the kernel with the largest share of the timestep (measured live with HIP events on the launch stream),
+  `kernels`      : the same object for every kernel of the rollout timestep (e2e),
+  `cpu_baseline` : the C oracle on the host cores (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -23,7 +30,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_F32_PEAK_TF = 157.3    # f32-input MFMA = f32 vector peak
+
+CONFIGS = {
+    "cleanup5": dict(env="cleanup", map="default5", n_agents=5, view_size=7, n_env=4096, H=25, W=18, n_actions=9),
+    "harvest5": dict(env="harvest", map="default10", n_agents=5, view_size=15, n_env=4096, H=9, W=38, n_actions=8),
+    "cleanup10": dict(env="cleanup", map="default10", n_agents=10, view_size=7, n_env=8192, H=48, W=18, n_actions=9),
+}
 
 
 def algorithmic_bytes_per_env_step(H, W, n, V, obs_bytes_per_elem=4, planes=3):
@@ -32,7 +47,16 @@ def algorithmic_bytes_per_env_step(H, W, n, V, obs_bytes_per_elem=4, planes=3):
     return 2 * H * W + 4 * n + 16 * n + planes * obs_bytes_per_elem * n * V * V + 28 * n
 
 
-def cpu_baseline(n_env, steps):
+def host_threads():
+    """threads the CPU baseline may use: the scheduler affinity of this process (the GPU box gives a 1-GPU job 16), capped at 32."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(int(os.environ.get("SSD_CPU_THREADS", "32")), avail))
+
+
+def cpu_baseline(c, n_env, steps):
     """The CPU restatement (oracle/, kind "port") on the host cores: same workload, bounded sample.  The serial C port is run as
     one env shard per thread (ctypes releases the GIL; envs never interact, so this is the CPU's own data-parallel form); the
     single-thread rate of a shorter sample is reported in `sample`."""
@@ -40,14 +64,14 @@ def cpu_baseline(n_env, steps):
     import numpy as np
     from homophily_marl_amd import abi
     from oracle.oracle_py import OracleEnv
-    n = 5
-    avail = np.array([0, 1, 2, 3, 4, 8])
+    n = c["n_agents"]
+    avail = np.array([0, 1, 2, 3, 4, 8] if c["env"] == "cleanup" else [0, 1, 2, 3, 4])
 
     def run(shard_envs, env_id_base, nsteps, out, k):
-        env = OracleEnv("cleanup", map="default5", num_agents=n, n_env=shard_envs, view_size=7, episode_limit=100,
+        env = OracleEnv(c["env"], map=c["map"], num_agents=n, n_env=shard_envs, view_size=c["view_size"], episode_limit=100,
                         rng_mode=abi.RNG_COUNTER, seed=1, env_id_base=env_id_base)
         rng = np.random.default_rng(0x5D5D + k)
-        acts = [avail[rng.integers(0, 6, (shard_envs, n))].astype(np.int32) for _ in range(16)]
+        acts = [avail[rng.integers(0, len(avail), (shard_envs, n))].astype(np.int32) for _ in range(16)]
         env.reset()
         t0 = time.perf_counter()
         for t in range(nsteps):
@@ -58,9 +82,9 @@ def cpu_baseline(n_env, steps):
         out[k] = time.perf_counter() - t0
 
     one = [0.0]
-    s1 = max(100, steps // 4)
+    s1 = max(50, steps // 8)
     run(n_env, 0, s1, one, 0)                                  # single thread, all envs
-    cores = max(1, min(16, os.cpu_count() or 1, n_env))
+    cores = min(host_threads(), n_env)
     shard = n_env // cores
     dts = [0.0] * cores
     t0 = time.perf_counter()
@@ -68,22 +92,47 @@ def cpu_baseline(n_env, steps):
     [t.start() for t in th]
     [t.join() for t in th]
     wall = time.perf_counter() - t0
-    return dict(value=shard * cores * n * steps / max(dts), unit="agent-steps/s", cores=cores, kind="port",
+    return dict(value=shard * cores * n * steps / max(dts), unit="agent-steps/s", cores=cores, host_cpus=os.cpu_count(), kind="port",
                 sample="%d envs x %d steps of step+observe(fp32), C oracle, one shard of %d envs per thread, %.1f s; "
                        "single thread: %.0f agent-steps/s (%d steps, %.1f s)" % (shard * cores, steps, shard, wall,
                                                                                 n_env * n * s1 / one[0], s1, one[0]))
 
 
+def roofline_entry(k):
+    """k: dict(name, avg_us, median_us, bound, and bytes_per_launch | flops_per_launch [+ issued_flops_per_launch, peak_tf])."""
+    if k["bound"] == "hbm":
+        achieved = k["bytes_per_launch"] / (k["avg_us"] * 1e-6) / 1e9
+        e = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+             "traffic": k.get("traffic"), "algorithmic_bytes_per_launch": k["bytes_per_launch"]}
+    else:
+        achieved = k["flops_per_launch"] / (k["avg_us"] * 1e-6) / 1e12
+        peak = k.get("peak_tf", MFMA_F32_PEAK_TF)
+        e = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+             "traffic": k.get("traffic"), "algorithmic_flops_per_launch": k["flops_per_launch"]}
+        for key in ("mfma_dtype", "note"):
+            if key in k:
+                e[key] = k[key]
+    e.update(kernel=k["name"], kernel_avg_us=k["avg_us"], kernel_median_us=k.get("median_us", k["avg_us"]))
+    if "share_of_timestep" in k:
+        e["share_of_timestep"] = k["share_of_timestep"]
+    return e
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--n-env", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--steps", type=int, default=None, help="e2e: whole iterations (default 20); env: transitions (default 500)")
+    ap.add_argument("--warmup", type=int, default=None, help="e2e: whole iterations (default 5); env: transitions (default 100)")
+    ap.add_argument("--config", default=os.environ.get("SSD_BENCH_CONFIG", "cleanup5"), choices=sorted(CONFIGS))
+    ap.add_argument("--n-env", type=int, default=None, help="envs per GPU (default: the configuration's)")
     ap.add_argument("--workload", default=os.environ.get("SSD_BENCH_WORKLOAD", "e2e"), choices=["env", "e2e"])
     ap.add_argument("--runner", default="hip_graph", choices=["hip_vec", "hip_graph"], help="e2e: rollout runner")
     ap.add_argument("--train-graph", type=int, default=1, help="e2e: capture the train step as hipGraphs")
     ap.add_argument("--steps-per-graph", type=int, default=10, help="e2e: timesteps captured per rollout hipGraph")
+    ap.add_argument("--qnet-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="e2e: arithmetic of the ROLLOUT controller kernels: fp32 (split-bf16 MFMA products, f32-equivalent; the headline) "
+                         "or bf16 (single bf16 products; a second, labelled line -- the learner stays fp32)")
+    ap.add_argument("--train-steps-per-rollout", type=int, default=1, help="e2e: learner.train calls per rollout (reference cadence: 1)")
     ap.add_argument("--obs-storage", default="f32", choices=["f32", "code"],
                     help="e2e: observation format of the episode storage / replay buffer: f32 planes (format R, the reference's) or "
                          "u8 class codes (format C: 12x fewer observation bytes; the roofline object then uses format C bytes)")
@@ -91,8 +140,15 @@ def main():
                     help="env workload: fraction of the waste cells turned into clean river after every reset (SURVEY.md 8d 'warm' variant: "
                          "exercises apple spawning; 0 = start from the map's reset state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-steps", type=int, default=2000)
+    ap.add_argument("--cpu-sample-steps", type=int, default=None)
     args = ap.parse_args()
+    c = dict(CONFIGS[args.config])
+    if args.n_env:
+        c["n_env"] = args.n_env
+    if args.steps is None:
+        args.steps = 20 if args.workload == "e2e" else 500
+    if args.warmup is None:
+        args.warmup = 5 if args.workload == "e2e" else 100
 
     import torch
     import torch.distributed as dist
@@ -102,6 +158,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = "none"
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
         backend = os.environ.get("SSD_DIST_BACKEND", "nccl")     # "nccl" = RCCL; "gloo" only for rehearsing >1 rank on one GPU
@@ -114,18 +171,19 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    n, N, T = 5, args.n_env, 100
+    n, N, T, V = c["n_agents"], c["n_env"], 100, 2 * c["view_size"] + 1
     if args.workload == "e2e":
         from homophily_marl_amd.bench_e2e import run_e2e
-        result = run_e2e(args, rank, world, local_rank)
+        result = run_e2e(args, c, rank, world, local_rank)
+        units = N * n * T * args.steps * world
     else:
-        env = NativeEnv("cleanup", device=local_rank, map="default5", num_agents=n, n_env=N, view_size=7, episode_limit=T,
+        env = NativeEnv(c["env"], device=local_rank, map=c["map"], num_agents=n, n_env=N, view_size=c["view_size"], episode_limit=T,
                         rng_mode=abi.RNG_COUNTER, seed=1, env_id_base=rank * N)
-        # synthetic actions: i.i.d. uniform over the available set {0,1,2,3,4,8}, resident in HBM
+        # synthetic actions: i.i.d. uniform over the available set, resident in HBM
         g = torch.Generator(device=dev).manual_seed(0x5D5D + rank)
-        avail = torch.tensor([0, 1, 2, 3, 4, 8], dtype=torch.int32, device=dev)
+        avail = torch.tensor([0, 1, 2, 3, 4, 8] if c["env"] == "cleanup" else [0, 1, 2, 3, 4], dtype=torch.int32, device=dev)
         n_act = 64
-        acts = [avail[torch.randint(0, 6, (N, n), generator=g, device=dev)].contiguous() for _ in range(n_act)]
+        acts = [avail[torch.randint(0, avail.numel(), (N, n), generator=g, device=dev)].contiguous() for _ in range(n_act)]
         bufs = env.obs_buffers(abi.OBS_F32)
 
         def reset_env():
@@ -168,12 +226,12 @@ def main():
         elapsed = time.perf_counter() - t0
         assert env.poll_error() == 0
         per_launch = sorted(1e3 * a.elapsed_time(b) / k for (a, b), k in zip(ev, run_len))
-        kern_avg_us = sum(1e3 * a.elapsed_time(b) for a, b in ev) / sum(run_len)
-        kern_med_us = per_launch[len(per_launch) // 2]
-        bytes_per_launch = algorithmic_bytes_per_env_step(env.H, env.W, n, env.V) * N
-        result = dict(elapsed=elapsed, kern_avg_us=kern_avg_us, kern_med_us=kern_med_us, bytes_per_launch=bytes_per_launch,
-                      dtype="u8", workload="cleanup_default5_env_step_observe_fp32obs" + ("_warm%d" % round(100 * args.warm) if args.warm > 0 else ""),
-                      extra=dict(obs_format="f32[n_env,n,3,15,15]", kernel="ssd::k_env<MODE_STEP_OBS>"))
+        kern = dict(name="ssd::k_env<MODE_STEP_OBS>", bound="hbm", avg_us=sum(1e3 * a.elapsed_time(b) for a, b in ev) / sum(run_len),
+                    median_us=per_launch[len(per_launch) // 2], bytes_per_launch=algorithmic_bytes_per_env_step(env.H, env.W, n, env.V) * N)
+        result = dict(elapsed=elapsed, kernels=[kern], dtype="u8",
+                      workload="%s_env_step_observe_fp32obs" % args.config + ("_warm%d" % round(100 * args.warm) if args.warm > 0 else ""),
+                      extra=dict(obs_format="f32[n_env,n,3,%d,%d]" % (V, V)))
+        units = N * n * args.steps * world
 
     elapsed = result["elapsed"]
     if world > 1:
@@ -181,30 +239,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        total_agent_steps = N * n * args.steps * world
-        achieved = result["bytes_per_launch"] / (result["kern_avg_us"] * 1e-6) / 1e9
-        traffic = None
+        kernels = result["kernels"]
         tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
+        if os.path.exists(tj):      # PMC traffic of the committed rocprofv3 --pmc passes, per launch (same kernel, same sizes only)
             tr = json.load(open(tj))
-            if tr.get("kernel") == result["extra"]["kernel"] and tr.get("n_env") == N and result["extra"]["obs_format"].startswith("f32"):
-                traffic = tr.get("hbm_bytes_per_launch")
+            for k in kernels:
+                rec = tr.get("kernels", {}).get("%s@%s" % (k["name"], args.config))
+                if rec and rec.get("n_env") == N and rec.get("obs_format", "f32") == getattr(args, "obs_storage", "f32"):
+                    k["traffic"] = rec.get("hbm_bytes_per_launch")
+        entries = [roofline_entry(k) for k in kernels]
+        dominant = max(entries, key=lambda e: e["kernel_avg_us"])
         line = {
-            "metric": "agent_steps_per_sec", "value": total_agent_steps / elapsed, "unit": "agent-steps/s",
+            "metric": "agent_steps_per_sec", "value": units / elapsed, "unit": "agent-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": result["dtype"], "data": "synthetic",
-            "config": dict({"workload": result["workload"], "env": "cleanup", "map": "default5", "n_agents": n,
-                            "n_env_per_gpu": N, "episode_limit": T, "rng": "counter(philox4x32-10, seed 1)",
+            "config": dict({"workload": result["workload"], "name": args.config, "env": c["env"], "map": c["map"], "n_agents": n,
+                            "n_env_per_gpu": N, "episode_limit": T, "view_size": c["view_size"], "rng": "counter(philox4x32-10, seed 1)",
+                            "world_size": world, "backend": {"nccl": "nccl(RCCL)"}.get(backend, backend),
                             "parallelism": ("dp%d: env shards, no collective in the rollout" % world) +
                                            ("; 1 flat-gradient all-reduce + 2 scalars per train step" if args.workload == "e2e" else "")},
                            **result["extra"]),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_avg_us": result["kern_avg_us"], "kernel_median_us": result["kern_med_us"],
-                         "algorithmic_bytes_per_launch": result["bytes_per_launch"]},
+            "roofline": dominant,
         }
+        if len(entries) > 1:
+            line["kernels"] = entries
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(N, args.cpu_sample_steps)
+            per_step = {"cleanup5": 2000, "harvest5": 600, "cleanup10": 500}[args.config]
+            line["cpu_baseline"] = cpu_baseline(c, N, args.cpu_sample_steps or per_step)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,9 +1,10 @@
 """End-to-end workload of bench.py: the full homophily training loop on vectorised envs.
 
-One "step" = one transition of all N envs of this rank inside the real loop: observation storage, env-head and
-incentive-head action selection (Q-net forward), the fused ssd_step_observe launch, and -- at every episode end --
-slot-T bootstrapping, replay insertion, sampling and ONE learner.train (run.py:184-210 cadence, batch_size 16).
-Nothing is skipped inside the timed region.
+One bench "step" = ONE WHOLE ITERATION of the reference's training loop (run.py:181-210) on the N envs of this rank: reset,
+`episode_limit` timesteps (observation storage, env-head and incentive-head action selection = Q-net forward, the fused
+ssd_step_observe launch), the slot-T bootstrapping pass, replay insertion, sampling and `train_steps_per_rollout`
+learner.train calls (reference cadence: one; batch_size 16).  Nothing is skipped inside the timed region and the timed region
+holds exactly `steps` rollouts and `steps * train_steps_per_rollout` optimisation steps, whatever the arguments are.
 """
 import time
 
@@ -14,103 +15,167 @@ from . import abi
 from .run import load_config, setup
 
 
-def run_e2e(args, rank, world, local_rank):
-    N, n, T = args.n_env, 5, 100
+def _event_time(fn, reps, rounds=3):
+    """average / median microseconds of one call of fn, from HIP events (torch's current stream = the launch stream) bracketing
+    `rounds` runs of `reps` back-to-back launches."""
+    for _ in range(5):
+        fn()
+    per = []
+    for _ in range(rounds):
+        s, e = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        th.cuda.synchronize()
+        per.append(1e3 * s.elapsed_time(e) / reps)
+    per.sort()
+    return sum(per) / len(per), per[len(per) // 2]
+
+
+def controller_flops(c, inp):
+    """algorithmic FLOPs (2 x MAC of the reference's f32 layers, homophily_agent.py:20-27,154-208) per agent-step."""
+    n, A, V = c["n_agents"], c["n_actions"], 2 * c["view_size"] + 1
+    P = (V - 2) * (V - 2)
+    E = A + 7
+    return dict(encode=2 * (27 * 6 * P + 6 * P * 32),
+                head_env=2 * (inp * 64 + 6 * 64 * 64 + 64 * (A + 1)),
+                head_inc=2 * ((inp + A) * 64 + 6 * 64 * 64 + n * (64 + E) * 4))
+
+
+def run_e2e(args, c, rank, world, local_rank):
+    N, n, T = c["n_env"], c["n_agents"], 100
     # replay capacity: at least the reference's 5000 episodes (config/default.yaml), rounded up to a multiple of the env batch so
     # that the runner can write its episodes straight into the buffer's slots (ReplayBuffer.reserve: insertion moves no data)
     buffer_size = -(-5000 // N) * N
-    # timesteps per rollout-graph replay: only if the timed region and the warm-up are whole numbers of replays, so that
-    # EXACTLY `steps` timesteps of work are inside the timed region
-    spg = int(getattr(args, "steps_per_graph", 10))
-    if spg < 1 or args.steps % spg or args.warmup % spg or T % spg:
-        spg = 1
-    cfg = load_config("cleanup", overrides=dict(
-        runner=args.runner, train_graph=args.train_graph, steps_per_graph=spg, batch_size_run=N, batch_size=16, buffer_size=buffer_size, obs_storage=getattr(args, "obs_storage", "f32"), buffer_cpu_only=False, store_state=False,
-        env_args=dict(num_agents=n, map="default5", episode_limit=T, view_size=7, seed=1), use_cuda=True, save_model=False,
+    spg = max(1, int(getattr(args, "steps_per_graph", 10)))
+    while T % spg:
+        spg -= 1
+    qnet = getattr(args, "qnet_dtype", "fp32")
+    tspr = max(1, int(getattr(args, "train_steps_per_rollout", 1)))
+    cfg = load_config(c["env"], overrides=dict(
+        runner=args.runner, train_graph=args.train_graph, steps_per_graph=spg, batch_size_run=N, batch_size=16, buffer_size=buffer_size,
+        obs_storage=getattr(args, "obs_storage", "f32"), buffer_cpu_only=False, store_state=False, qnet_dtype=qnet,
+        train_steps_per_rollout=tspr,
+        env_args=dict(num_agents=n, map=c["map"], episode_limit=T, view_size=c["view_size"], seed=1), use_cuda=True, save_model=False,
         device_index=local_rank, env_id_base=rank * N, runner_stats=False, learner_log_interval=10 ** 12))
     th.manual_seed(0)                     # fixed-seed random-init weights (BASELINE.md section 3), identical on every rank
     ctx = setup(cfg)
     runner, learner, buf = ctx.runner, ctx.learner, ctx.buffer
     a = ctx.args
-    state = dict(episode=0, in_episode=False)
+    state = dict(episode=0, trains=0, timesteps=0)
 
-    def one_step():
-        if not state["in_episode"]:
-            runner.begin_episode(False)
-            state["in_episode"] = True
-        if runner.step_once():
-            batch = runner.finish_episode()
-            buf.insert_episode_batch(batch)
-            if buf.can_sample(a.batch_size):
-                sample = buf.sample(a.batch_size)
-                sample = sample[:, :T + 1]
-                learner.train(sample, runner.t_env, state["episode"])
-            state["episode"] += a.batch_size_run
-            state["in_episode"] = False
+    def iteration():
+        runner.begin_episode(False)
+        for _ in range(T):
+            runner.step_once()
+        state["timesteps"] += T
+        batch = runner.finish_episode()
+        buf.insert_episode_batch(batch)
+        if buf.can_sample(a.batch_size):
+            for _ in range(tspr):
+                sample = buf.sample(a.batch_size)[:, :T + 1]
+                learner.train(sample, runner.t_env, ctx.train_steps if a.schedule_unit == "rollouts" else state["episode"])
+                ctx.train_steps += 1
+                state["trains"] += 1
+        state["episode"] += a.batch_size_run
 
-    # Setup (not warm-up): build the hipGraphs.  The rollout graph is captured at the start of the 2nd episode and the two
-    # train-step graphs at the 3rd learner.train call, so at least 4 full iterations (every replay slab is visited) are run before the W warm-up steps; this is the
-    # analogue of compiling the step and is excluded from both the warm-up count and the timed region.
-    for _ in range(max(4, buffer_size // N + 2) * T):       # every replay slab gets its graph before the warm-up starts
-        one_step()
+    # Setup (not warm-up): build the hipGraphs.  The rollout graph of a replay slab is captured at the start of the 2nd episode
+    # that lands in it and the two train-step graphs at the 3rd learner.train call, so every slab is visited twice before the W
+    # warm-up iterations; this is the analogue of compiling the step and is excluded from the warm-up and the timed region.
+    for _ in range(max(4, 2 * (buffer_size // N) + 1)):
+        iteration()
     for _ in range(args.warmup):
-        one_step()
+        iteration()
     th.cuda.synchronize()
     if world > 1:
         dist.barrier()
     th.cuda.synchronize()
+    state["trains"] = state["timesteps"] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step()
+        iteration()
     th.cuda.synchronize()
     if world > 1:
         dist.barrier()
     th.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timed = dict(state)
     assert runner.env.native.poll_error() == 0
+    assert timed["trains"] == args.steps * tspr and timed["timesteps"] == args.steps * T
+
     # Steady-state breakdown of one more rollout + train iteration (synchronised between phases; NOT part of `elapsed`)
-    def timed(fn):
+    def timed_ms(fn):
         th.cuda.synchronize(); t = time.perf_counter(); r = fn(); th.cuda.synchronize()
         return r, 1e3 * (time.perf_counter() - t)
-    while state["in_episode"]:
-        one_step()
     bd = {}
-    _, bd["begin_episode_ms"] = timed(lambda: runner.begin_episode(False))
-    _, bd["rollout_100_steps_ms"] = timed(lambda: [runner.step_once() for _ in range(T)])
-    batch, bd["finish_episode_ms"] = timed(runner.finish_episode)
-    _, bd["replay_insert_ms"] = timed(lambda: buf.insert_episode_batch(batch))
-    sample, bd["sample_ms"] = timed(lambda: buf.sample(a.batch_size)[:, :T + 1])
-    _, bd["learner_train_ms"] = timed(lambda: learner.train(sample, runner.t_env, state["episode"]))
+    _, bd["begin_episode_ms"] = timed_ms(lambda: runner.begin_episode(False))
+    _, bd["rollout_100_steps_ms"] = timed_ms(lambda: [runner.step_once() for _ in range(T)])
+    batch, bd["finish_episode_ms"] = timed_ms(runner.finish_episode)
+    _, bd["replay_insert_ms"] = timed_ms(lambda: buf.insert_episode_batch(batch))
+    sample, bd["sample_ms"] = timed_ms(lambda: buf.sample(a.batch_size)[:, :T + 1])
+    _, bd["learner_train_ms"] = timed_ms(lambda: learner.train(sample, runner.t_env, ctx.train_steps if a.schedule_unit == "rollouts" else state["episode"]))
     bd = {k: round(v, 3) for k, v in bd.items()}
-    # Kernel timing for the roofline: inside a hipGraph replay there is no host call to bracket, so the SAME kernel on the
-    # SAME live env object is timed with HIP-event pairs (torch's current stream = the launch stream) right after the
-    # timed region, over three whole episodes with actions drawn like the policy's epsilon-random ones.
+
+    # Kernel timing for the roofline objects.  Inside a hipGraph replay there is no host call to bracket, so the SAME launches on
+    # the SAME live objects (runner.timestep_launches(): the closures the graph was captured from) are timed right after the timed
+    # region with HIP events around runs of back-to-back launches of one kernel (every launch is idempotent in its cost: the data it
+    # reads is whatever the rollout left).  The env kernel is timed over three whole episodes (reset, then T launches).
+    from bench import MFMA_BF16_PEAK_TF, algorithmic_bytes_per_env_step
+    code = getattr(args, "obs_storage", "f32") == "code"
+    V = 2 * c["view_size"] + 1
+    env_bytes = (algorithmic_bytes_per_env_step(c["H"], c["W"], n, V, 1, 1) if code else algorithmic_bytes_per_env_step(c["H"], c["W"], n, V)) * N
+    kernels = []
+    fl = controller_flops(c, ctx.mac.input_shape)
+    nprod = getattr(runner.fast, "n_products", None) if getattr(runner, "fast", None) is not None else None
+    if hasattr(runner, "timestep_launches"):
+        runner.begin_episode(False)
+        for _ in range(10):
+            runner.step_once()                      # a live mid-episode state
+        th.cuda.synchronize()
+        for name, key, fn in runner.timestep_launches():
+            if key == "env":
+                continue
+            avg, med = _event_time(fn, 50)
+            k = dict(name=name, avg_us=avg, median_us=med, bound="mfma", flops_per_launch=fl[key] * N * n)
+            if nprod:
+                # the products are evaluated as `nprod` bf16 MFMA products each (f32 = hi + mid + lo bf16 terms): count the bf16
+                # work the f32-equivalent result needs against the dense bf16 MFMA peak
+                k.update(flops_per_launch=fl[key] * N * n * nprod[key], peak_tf=MFMA_BF16_PEAK_TF,
+                         mfma_dtype="bf16 x%d split products, f32 accumulate (f32-equivalent)" % nprod[key] if nprod[key] > 1 else "bf16, f32 accumulate",
+                         note="algorithmic f32 FLOPs %d x %d bf16 products each" % (fl[key] * N * n, nprod[key]))
+            kernels.append(k)
     env = runner.env
     avail = th.nonzero(env.avail_actions_batch[0, 0]).squeeze(-1).to(th.int32)
     acts = [avail[th.randint(0, avail.numel(), (N, n), device=env.device)].contiguous() for _ in range(8)]
-    code = getattr(args, "obs_storage", "f32") == "code"
     kfmt = abi.OBS_CODE if code else abi.OBS_F32   # the format the loop's env launches emit
     env.reset_batch()
     for i in range(20):                           # un-timed: the eager launch path has been idle during the graph replays
         env.step_batch(acts[i % 8], observe=True, fmt=kfmt)
-    ev, run_len = [], []
+    per = []
     for rep in range(3):                          # three whole episodes, like the env workload: reset, then T back-to-back launches
         env.reset_batch()
         s, e = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
         s.record()
-        for i in range(T):                        # back-to-back launches of the dominant kernel, bracketed by two events
+        for i in range(T):
             env.step_batch(acts[i % 8], observe=True, fmt=kfmt)
         e.record()
-        ev.append((s, e)); run_len.append(T)
-    th.cuda.synchronize()
-    ms = sorted(s.elapsed_time(e) / k for (s, e), k in zip(ev, run_len))
-    from bench import algorithmic_bytes_per_env_step
-    return dict(elapsed=elapsed, kern_avg_us=1e3 * sum(ms) / len(ms), kern_med_us=1e3 * ms[len(ms) // 2],
-                bytes_per_launch=(algorithmic_bytes_per_env_step(25, 18, n, 15, 1, 1) if code else algorithmic_bytes_per_env_step(25, 18, n, 15)) * N,
-                dtype="fp32",
-                workload="cleanup_default5_rollout_plus_homophily_train",
-                extra=dict(obs_format="u8 class codes [n_env,n,15,15] (format C)" if code else "f32[n_env,n,3,15,15]", kernel="ssd::k_env<MODE_STEP_OBS>", qnet_dtype="fp32",
-                           train="1 learner.train(batch_size 16 x T 101) per 100-step rollout, double-Q + sim loss, 2x Adam",
+        th.cuda.synchronize()
+        per.append(1e3 * s.elapsed_time(e) / T)
+    per.sort()
+    kernels.append(dict(name="ssd::k_env<MODE_STEP_OBS>", avg_us=sum(per) / len(per), median_us=per[len(per) // 2], bound="hbm",
+                        bytes_per_launch=env_bytes))
+    tot = sum(k["avg_us"] for k in kernels)
+    for k in kernels:
+        k["share_of_timestep"] = round(k["avg_us"] / tot, 4)
+    return dict(elapsed=elapsed, kernels=kernels, dtype="fp32" if qnet == "fp32" else "bf16",
+                workload="%s_rollout_plus_homophily_train" % args.config,
+                extra=dict(obs_format=("u8 class codes [n_env,n,%d,%d] (format C)" % (V, V)) if code else "f32[n_env,n,3,%d,%d]" % (V, V),
+                           qnet_dtype=("fp32 (rollout: split-bf16 MFMA products, f32-equivalent; learner: fp32)" if qnet == "fp32"
+                                       else "bf16 rollout inference (single bf16 MFMA products), fp32 learner"),
+                           step="1 bench step = 1 iteration: reset + %d timesteps + slot-T pass + replay insert + sample + %d learner.train" % (T, tspr),
+                           timesteps_timed=timed["timesteps"], train_steps_timed=timed["trains"], rollouts_timed=args.steps,
+                           train="learner.train(batch_size 16 x T 101), double-Q + sim loss, 2x Adam; %d per rollout" % tspr,
                            buffer="device-resident ReplayBuffer, %d episodes, %s" % (buf.buffer_size, "written in place by the runner" if getattr(runner, "_replay", None) is not None else "copy insertion"),
                            runner=args.runner, train_graph=bool(args.train_graph), steps_per_rollout_graph=int(getattr(runner, "_graph_steps", 1)),
                            breakdown_ms=bd))

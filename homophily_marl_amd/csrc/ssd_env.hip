@@ -859,7 +859,8 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
         // scalars (map_env.py:291-292, 883-914).  After the consume loop no agent stands on an apple and nothing spawns
         // under an agent, so the apples visible in map_with_agents are all apples of the grid.
         const int apples = n_apple_cells;
-        const float den = S->tab_den[apples < SSD_MAX_SITES ? apples : SSD_MAX_SITES];   // host-tabulated fp64 quotient (apples live on apple sites only)
+        // host-tabulated fp64 quotient (apples live on apple sites only); an imported grid may hold more apples than sites
+        const float den = apples <= SSD_MAX_SITES ? S->tab_den[apples] : (float)((double)apples / (double)E.HW);
         ep_r += reward;
         const int step = ep_step0 + 1;
         const bool term = step >= h->episode_limit;

@@ -161,8 +161,16 @@ class FastPolicy:
         NativeEnv.storage_obs_buffers) and `obs` is ignored.
         Fused path only: actions_i32 also receives the actions as int32; pos_copy / orient_copy receive copies of pos / orient;
         counter_inc: device i64 incremented by the encoder launch; file: dict of ssd_policy_head storage fields (pointers as ints)
-        with which the head files its results into the episode storage itself (include/ssd_hip.h)."""
-        p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
+        with which the head files its results into the episode storage itself (include/ssd_hip.h).
+        = encode() followed by head_env()."""
+        self.encode(obs, store_obs=store_obs, store_t=store_t, obs_in_storage=obs_in_storage, t_copy=t_copy, counter_inc=counter_inc)
+        return self.head_env(prev_actions, prev_reward, prev_inc, pos, eps, step, q_out=q_out, orient=orient, actions_i32=actions_i32,
+                             pos_copy=pos_copy, orient_copy=orient_copy, file=file)
+
+    @th.no_grad()
+    def encode(self, obs, store_obs=None, store_t=None, obs_in_storage=False, t_copy=None, counter_inc=None):
+        """rgb_preprocess (homophily_agent.py:20-27,213-214) of the current observation into columns 0..31 of `inputs`."""
+        p, lib, n, N = self.p, self.lib, self.n, self.N
         V = (store_obs if obs_in_storage else obs).shape[-1]
         st = self._stream()
         so = (None if store_obs is None else store_obs.data_ptr(), 0 if store_obs is None else store_obs.stride(0),
@@ -190,6 +198,13 @@ class FastPolicy:
             feat = self.inputs.view(n * N, self.inputs.shape[-1])[:, :32]                    # Linear + LeakyReLU straight into the input matrix
             th.addmm(p["lb"], self._conv, p["lw_t"], out=feat)
             F.leaky_relu_(feat)
+
+    @th.no_grad()
+    def head_env(self, prev_actions, prev_reward, prev_inc, pos, eps, step, q_out=None, orient=None, actions_i32=None, pos_copy=None,
+                 orient_copy=None, file=None):
+        """input tail + fc1 + GRU + dueling + epsilon-greedy of the env head on the features encode() left in `inputs`."""
+        p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
+        st = self._stream()
         if self.fused:
             ha = self._head_args(False, eps, step, q_out)
             ha.avail = self.avail.data_ptr()

@@ -269,3 +269,15 @@ class HomophilyLearner:
         load = lambda f: th.load("{}/{}".format(path, f), map_location=lambda storage, loc: storage, weights_only=True)
         self.optimiser_env.load_state_dict(load("opt_env.th"))
         self.optimiser_inc.load_state_dict(load("opt_inc.th"))
+        # load_state_dict takes `capturable` from the SAVED param_groups (the reference's checkpoints, or ours saved with
+        # train_graph off, carry False) and leaves `step` where the file had it: restore what this learner's step needs and
+        # drop any captured graph (it baked the old optimiser state in)
+        for opt in (self.optimiser_env, self.optimiser_inc):
+            for group in opt.param_groups:
+                group["capturable"] = self.use_graph
+                for p in group["params"]:
+                    st = opt.state.get(p)
+                    if st and "step" in st:
+                        step = st["step"] if th.is_tensor(st["step"]) else th.tensor(float(st["step"]))
+                        st["step"] = step.to(device=p.device if self.use_graph else "cpu", dtype=th.float32)
+        self._graph, self._graph_calls = None, 0

@@ -65,6 +65,13 @@ def setup(config, logger=None):
     if args.use_cuda and not th.cuda.is_available():
         args.use_cuda = False
     args.device = ("cuda:%d" % getattr(args, "device_index", 0)) if args.use_cuda else "cpu"
+    # Units of the two schedules that the reference counts in env steps / episodes of its ONE env (epsilon_anneal_time,
+    # target_update_interval).  "env_steps": the reference's literal arithmetic (default at batch_size_run == 1).  "rollouts"
+    # (default for vectorised rollouts): one rollout of all envs advances the epsilon clock by episode_limit and the target-sync
+    # counter counts learner.train calls -- the same number of rollouts / optimisation steps per anneal and per sync as the reference.
+    if getattr(args, "schedule_unit", None) not in ("env_steps", "rollouts"):
+        args.schedule_unit = "env_steps" if args.batch_size_run == 1 else "rollouts"
+    args.train_steps_per_rollout = max(1, int(getattr(args, "train_steps_per_rollout", 1) or 1))
     logger = logger or Logger()
     runner = r_REGISTRY[args.runner](args=args, logger=logger)
     env_info = runner.get_env_info()
@@ -82,20 +89,24 @@ def setup(config, logger=None):
         learner.cuda()
     if getattr(args, "replay_in_place", True) and hasattr(runner, "set_replay_buffer"):
         runner.set_replay_buffer(buffer)        # hip_graph: rollouts land in the replay buffer's own slots when the sizes allow
-    return SimpleNamespace(args=args, logger=logger, runner=runner, buffer=buffer, mac=mac, learner=learner)
+    return SimpleNamespace(args=args, logger=logger, runner=runner, buffer=buffer, mac=mac, learner=learner, train_steps=0)
 
 
 def train_iteration(ctx, episode):
-    """One pass of the while-loop body of run.py:181-210: rollout, insert, sample, train."""
+    """One pass of the while-loop body of run.py:181-210: rollout, insert, sample, train (train_steps_per_rollout times; the
+    reference's cadence is one).  The learner's episode counter (target sync every target_update_interval, homophily_learner.py:255-257)
+    is the env-episode count under schedule_unit "env_steps" and the number of learner.train calls under "rollouts"."""
     a = ctx.args
     batch = ctx.runner.run(test_mode=False)
     ctx.buffer.insert_episode_batch(batch)
     if ctx.buffer.can_sample(a.batch_size):
-        sample = ctx.buffer.sample(a.batch_size)
-        sample = sample[:, :sample.max_t_filled()]
-        if str(sample.device) != str(a.device):
-            sample.to(a.device)
-        ctx.learner.train(sample, ctx.runner.t_env, episode)
+        for _ in range(a.train_steps_per_rollout):
+            sample = ctx.buffer.sample(a.batch_size)
+            sample = sample[:, :sample.max_t_filled()]
+            if str(sample.device) != str(a.device):
+                sample.to(a.device)
+            ctx.learner.train(sample, ctx.runner.t_env, ctx.train_steps if a.schedule_unit == "rollouts" else episode)
+            ctx.train_steps += 1
     return episode + a.batch_size_run
 
 

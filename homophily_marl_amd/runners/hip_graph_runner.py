@@ -157,44 +157,68 @@ class HipGraphRunner(HipVecRunner):
         for s in self.side_streams:
             main.wait_stream(s)
 
-    def _select_fast(self, store_env_step):
-        """_select with the FastPolicy kernels.  Fused path (default): k_encode reads obs[:, t] from the storage where the env
-        kernel put it, the two head kernels file actions / pose / rewards into slot t and carry the previous-step inputs, return
-        and counters themselves -- a timestep is 4 launches (encode, env head, env step+observe, inc head).  Otherwise one
-        store-step launch writes the nine small fields."""
+    def _fast_stages(self, store_env_step):
+        """The launches of one timestep with the FastPolicy kernels, in order, as (kernel name, key, closure).  Fused path
+        (default): k_encode reads obs[:, t] from the storage where the env kernel put it, the two head kernels file actions / pose /
+        rewards into slot t and carry the previous-step inputs, return and counters themselves -- a timestep is 4 launches
+        (encode, env head, env step+observe, inc head).  Otherwise one store-step launch writes the nine small fields."""
         st = self.store.data.transition_data
         td = self.t_dev
         obs, pos, orient = self.cur["obs"], self.cur["pos"], self.cur["orient"]
-
         fused = self.fast.fused
+        actions = self.actions_full
+        pos_t, orient_t = self.pos_t, self.orient_t                     # forward_inc sees the PRE-step pose (controller :78-82)
+        bundle = self._bundle
+
+        def encode(g):
+            sl = self.gslices[g]
+            self.fasts[g].encode(None if self.direct_obs else obs[sl], store_obs=st["obs"][sl], store_t=td, obs_in_storage=self.direct_obs,
+                                 t_copy=self.t_store if (self.direct_obs and g == 0) else None,
+                                 counter_inc=self.rng_ctr if self.fold_store else None)
 
         def env_head(g):
             sl = self.gslices[g]
-            extra = dict(orient=orient[sl], actions_i32=self.actions_i32[sl], pos_copy=self.pos_t[sl], orient_copy=self.orient_t[sl]) if fused else {}
-            self.fasts[g].act_env(None if self.direct_obs else obs[sl], self.prev_actions[sl], self.prev_reward[sl], self.prev_inc[sl],
-                                  pos[sl], self.eps, self.rng_ctr, store_obs=st["obs"][sl], store_t=td, obs_in_storage=self.direct_obs,
-                                  t_copy=self.t_store if (self.direct_obs and g == 0) else None,
-                                  counter_inc=self.rng_ctr if self.fold_store else None, file=self._bundle.file_env, **extra)
-        self._fork(env_head)
-        actions = self.actions_full
-        pos_t, orient_t = self.pos_t, self.orient_t                     # forward_inc sees the PRE-step pose (controller :78-82)
-        if not fused:
-            pos_t.copy_(pos); orient_t.copy_(orient)
-            self.actions_i32.copy_(actions)
-        ss = self._ss if store_env_step else self._ss_last
-        if store_env_step:
-            out = self.env.step_batch(self.actions_i32, observe=True, fmt=self.obs_fmt, out=self.cur if self.direct_obs else None)
-            reward, clean, den = out["reward"], out["clean_num"], out["apple_den"]
-        else:
-            reward = clean = den = self._zeros_nn
+            extra = dict(orient=orient[sl], actions_i32=self.actions_i32[sl], pos_copy=pos_t[sl], orient_copy=orient_t[sl]) if fused else {}
+            self.fasts[g].head_env(self.prev_actions[sl], self.prev_reward[sl], self.prev_inc[sl], pos[sl], self.eps, self.rng_ctr,
+                                   file=bundle.file_env, **extra)
+
+        def env_step():
+            if not fused:
+                pos_t.copy_(pos); orient_t.copy_(orient)
+                self.actions_i32.copy_(actions)
+            if store_env_step:
+                self.env.step_batch(self.actions_i32, observe=True, fmt=self.obs_fmt, out=self.cur if self.direct_obs else None)
 
         def inc_head(g):
             sl = self.gslices[g]
+            if store_env_step:
+                out = self.env.native.out
+                reward, clean, den = out["reward"], out["clean_num"], out["apple_den"]
+            else:
+                reward = clean = den = self._zeros_nn
             self.fasts[g].act_inc(actions[sl], pos_t[sl], orient_t[sl], reward[sl], clean[sl], den[sl], self.eps, self.rng_ctr,
-                                  file=self._bundle.file_inc if store_env_step else self._bundle.file_inc_last)
-        self._fork(inc_head)
+                                  file=bundle.file_inc if store_env_step else bundle.file_inc_last)
+
+        return [("ssd::k_encode", "encode", lambda: self._fork(encode)),
+                ("ssd::k_head<env>", "head_env", lambda: self._fork(env_head)),
+                ("ssd::k_env<MODE_STEP_OBS>", "env", env_step),
+                ("ssd::k_head<inc>", "head_inc", lambda: self._fork(inc_head))]
+
+    def timestep_launches(self):
+        """(kernel name, key, closure) of the launches of one rollout timestep on the live buffers -- what the rollout hipGraph was
+        captured from; bench.py times them one by one with HIP events (a graph replay has no host call to bracket)."""
+        if self.fast is None or not self.fast.fused or not self.fold_store:
+            return []
+        return self._fast_stages(True)
+
+    def _select_fast(self, store_env_step):
+        """_select with the FastPolicy kernels (see _fast_stages)."""
+        td = self.t_dev
+        for _, _, fn in self._fast_stages(store_env_step):
+            fn()
         if self.fold_store:
             return
+        ss = self._ss if store_env_step else self._ss_last
         # ONE launch: the nine small fields of slot t, the controller's "previous step" inputs, the episode return and the
         # time / exploration counters (incremented after every block has read t)
         abi.check(self.fast.lib, self.fast.lib.ssd_store_step_launch(C.byref(ss), th.cuda.current_stream(self.env.device).cuda_stream))
@@ -290,7 +314,7 @@ class HipGraphRunner(HipVecRunner):
                 fp.reset()
             self.fast.pack()          # the learner may have stepped the weights since the last episode (packs are shared)
         sel = self.mac.action_selector
-        sel.epsilon = 0.0 if test_mode else sel.schedule.eval(self.t_env)
+        sel.epsilon = 0.0 if test_mode else sel.schedule.eval(self.sched_t)
         zero_after = getattr(self.args, "epsilon_zero", None)
         if zero_after is not None and self.t_env > zero_after:
             sel.epsilon = 0.0

@@ -32,12 +32,24 @@ class HipVecRunner:
         self.episode_limit = self.env.episode_limit
         self.t = 0
         self.t_env = 0
+        self.rollouts = 0          # training rollouts finished (schedule_unit "rollouts": the epsilon clock, see sched_t)
         self.train_returns, self.test_returns = [], []
         self.train_stats, self.test_stats = {}, {}
         self.log_train_stats_t = -1000000
         # obs_storage: "code" keeps observations as u8 class codes (simplified palette; 12x fewer bytes in the storage and the
         # replay buffer); the controller expands them where it consumes them
         self.obs_fmt = abi.OBS_CODE if getattr(self.args, "obs_storage", "f32") == "code" else abi.OBS_F32
+
+    @property
+    def sched_t(self):
+        """The clock of the epsilon schedule (epsilon_schedules.py; reference: t_env, episode_runner.py:72).  The reference only
+        ever runs ONE env, where t_env advances by episode_limit per rollout and per learner.train.  schedule_unit "env_steps"
+        keeps that literally; "rollouts" (the default for batch_size_run > 1, run.py setup) advances the clock by episode_limit per
+        ROLLOUT, so that epsilon_anneal_time spans the same number of rollouts / optimisation steps as in the reference instead of
+        collapsing to the first rollout (4096 envs x 100 steps >> 50000)."""
+        if getattr(self.args, "schedule_unit", "env_steps") == "rollouts":
+            return self.rollouts * self.episode_limit
+        return self.t_env
 
     def setup(self, scheme, groups, preprocess, mac):
         self.new_batch = partial(EpisodeBatch, scheme, groups, self.batch_size, self.episode_limit + 1, preprocess=preprocess,
@@ -79,13 +91,13 @@ class HipVecRunner:
     def step_once(self):
         t, test_mode = self.t, self._test_mode
         self._store_observation(self._o, t)
-        actions = self.mac.select_actions_env(self.batch, t_ep=t, t_env=self.t_env, test_mode=test_mode)
+        actions = self.mac.select_actions_env(self.batch, t_ep=t, t_env=self.sched_t, test_mode=test_mode)
         out = self.env.step_batch((actions.squeeze(-1) % self.args.n_actions).to(th.int32), observe=True, fmt=self.obs_fmt)
         self._ep_return += out["reward"]
         # `terminated` is stored as the env flag: episode_limit never appears in info (episode_runner.py:83)
         self.batch.update({"actions": actions, "reward": out["reward"], "terminated": out["terminated"].unsqueeze(-1),
                            "clean_num": out["clean_num"], "apple_den": out["apple_den"]}, ts=t)
-        actions_inc = self.mac.select_actions_inc(actions, self.batch, t_ep=t, t_env=self.t_env, test_mode=test_mode)
+        actions_inc = self.mac.select_actions_inc(actions, self.batch, t_ep=t, t_env=self.sched_t, test_mode=test_mode)
         self.batch.update({"actions_inc": actions_inc}, ts=t)
         self._o = self._out = out
         self.t += 1
@@ -96,8 +108,8 @@ class HipVecRunner:
         """slot T: last observation and the bootstrapping actions (episode_runner.py:99-119), then stats."""
         test_mode = self._test_mode
         self._store_observation(self._o, self.t)
-        actions = self.mac.select_actions_env(self.batch, t_ep=self.t, t_env=self.t_env, test_mode=test_mode)
-        actions_inc = self.mac.select_actions_inc(actions, self.batch, t_ep=self.t, t_env=self.t_env, test_mode=test_mode)
+        actions = self.mac.select_actions_env(self.batch, t_ep=self.t, t_env=self.sched_t, test_mode=test_mode)
+        actions_inc = self.mac.select_actions_inc(actions, self.batch, t_ep=self.t, t_env=self.sched_t, test_mode=test_mode)
         self.batch.update({"actions_inc": actions_inc}, ts=self.t)
         self.batch.update({"actions": actions}, ts=self.t)
         return self._finish_stats()
@@ -118,6 +130,7 @@ class HipVecRunner:
             returns.extend(ep_return.cpu().numpy())
         if not test_mode:
             self.t_env += self.t * self.batch_size
+            self.rollouts += 1
         if getattr(self.args, "runner_stats", True):
             if test_mode and len(self.test_returns) >= self.args.test_nepisode:
                 self._log(returns, stats, prefix)

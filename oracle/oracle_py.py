@@ -79,11 +79,15 @@ class OracleEnv:
         self.n_actions = info.n_actions
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):          # the constructor may have failed before the handle existed
             self.lib.ssd_cpu_destroy(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _out(self):
         N, n = self.n_env, self.n

@@ -22,9 +22,11 @@ def load_fixture(name):
     return z, meta
 
 
-def build(z, meta, device="cpu", sl=slice(None)):
-    """Returns (args, batch, mac, learner) with the fixture's initial weights; `sl` selects episodes (DP shards)."""
-    cfg = load_config(meta["env"], overrides=dict(env_args=meta["env_args"], use_cuda=device != "cpu", batch_size=4))
+def build(z, meta, device="cpu", sl=slice(None), overrides=None):
+    """Returns (args, batch, mac, learner) with the fixture's initial weights (random-init when the fixture holds none); `sl`
+    selects episodes (DP shards); `overrides`: extra config keys."""
+    cfg = load_config(meta["env"], overrides=dict(dict(env_args=meta["env_args"], use_cuda=device != "cpu", batch_size=4),
+                                                  **dict(meta.get("overrides", {}), **(overrides or {}))))
     args = SimpleNamespace(**cfg)
     args.device = device
     obs = z["batch_obs"][sl]
@@ -32,7 +34,8 @@ def build(z, meta, device="cpu", sl=slice(None)):
     args.n_agents, args.n_actions = n, z["batch_avail_actions"].shape[-1]
     args.obs_shape = obs.shape[3:]
     args.obs_dims = obs.shape[4:]
-    H, W = {"cleanup": (25, 18), "harvest": (9, 38)}[meta["env"]]
+    H, W = {"default3": (10, 10), "default5": (25, 18), "default10": (48, 18)}[meta["env_args"].get("map", "default5")] \
+        if meta["env"] == "cleanup" else (9, 38)
     args.state_dims = (H, W)
     scheme = {
         "obs": {"vshape": tuple(obs.shape[3:]), "group": "agents"},
@@ -53,7 +56,8 @@ def build(z, meta, device="cpu", sl=slice(None)):
     assert (batch["filled"].cpu().numpy() == z["batch_filled"][sl]).all()
     mac = mac_REGISTRY[args.mac](batch.scheme, groups, args)
     sd = {k[2:]: th.as_tensor(z[k]) for k in z.files if k.startswith("w_")}
-    mac.agent.load_state_dict(sd)
+    if sd:
+        mac.agent.load_state_dict(sd)
     logger = SimpleNamespace(log_stat=lambda *a, **k: None, console_logger=None)
     if device != "cpu":
         mac.cuda()
