@@ -6,7 +6,7 @@ The native library is REQUIRED: there is no CPU fallback on the product path.  `
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_AGENTS = 10
 MAX_CELLS = 1024
 MAX_SITES = 256
@@ -51,6 +51,7 @@ class SsdObsOut(C.Structure):
     _fields_ = [
         ("obs", C.c_void_p), ("obs_format", C.c_int32), ("state", C.c_void_p), ("pos", C.c_void_p),
         ("orient", C.c_void_p), ("obs_env_stride", C.c_int64), ("obs_slot_stride", C.c_int64),
+        ("obs_t_slots", C.c_int32), ("obs_code", C.c_void_p),
     ]
 
 
@@ -123,16 +124,55 @@ class SsdPolicyHead(C.Structure):
                 ("dst_pos", C.c_void_p), ("dst_orient", C.c_void_p), ("dst_actions_onehot", C.c_void_p), ("dst_reward", C.c_void_p),
                 ("dst_clean_num", C.c_void_p), ("dst_apple_den", C.c_void_p), ("dst_terminated", C.c_void_p), ("terminated", C.c_void_p),
                 ("dst_actions", C.c_void_p), ("dst_actions_inc", C.c_void_p), ("prev_actions_out", C.c_void_p),
-                ("prev_actions_inc_out", C.c_void_p), ("prev_reward_out", C.c_void_p), ("ep_return", C.c_void_p), ("next_t_out", C.c_void_p)]
+                ("prev_actions_inc_out", C.c_void_p), ("prev_reward_out", C.c_void_p), ("ep_return", C.c_void_p), ("next_t_out", C.c_void_p),
+                ("precision", C.c_int32), ("env_id_base", C.c_uint32), ("feat_part", C.c_void_p), ("feat_bands", C.c_int32),
+                ("lin_b", C.c_void_p)]
 
 
-POLICY_IMAGE_FLOATS = 464 * 68 + 464 + 64
+class SsdPolicyHeadParams(C.Structure):
+    """include/ssd_hip.h: ssd_policy_head_params (the reference-shaped f32 parameters of one head)."""
+    _fields_ = [("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p), ("w_i", C.c_void_p * 3), ("w_h", C.c_void_p * 3), ("b_i", C.c_void_p * 3),
+                ("b_h", C.c_void_p * 3), ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p), ("fc2_v_w", C.c_void_p), ("fc2_v_b", C.c_void_p),
+                ("n_agents", C.c_int32), ("fc1_in", C.c_int32), ("fc2_in", C.c_int32), ("fc2_out", C.c_int32)]
+
+
+class SsdPolicyEncodeArgs(C.Structure):
+    """include/ssd_hip.h: ssd_policy_encode_args."""
+    _fields_ = [("codes", C.c_void_p), ("code_bytes", C.c_int64), ("env_stride", C.c_int64), ("slot_stride", C.c_int64),
+                ("agent_stride", C.c_int64), ("slot_t", C.c_void_p),
+                ("rows", C.c_int32), ("view_edge", C.c_int32), ("n_agents", C.c_int32), ("agent_major", C.c_int32), ("precision", C.c_int32),
+                ("conv_frags", C.c_void_p), ("lin_frags", C.c_void_p), ("conv_b", C.c_void_p), ("lin_b", C.c_void_p),
+                ("out", C.c_void_p), ("out_stride", C.c_int32), ("part", C.c_void_p), ("slot_t_copy", C.c_void_p), ("counter_inc", C.c_void_p)]
+
+
+POLICY_HEAD_FRAGS, POLICY_HEAD_TAIL_FLOATS = 58, 464 + 64
+
+
+def policy_image_bytes(precision):
+    return precision * POLICY_HEAD_FRAGS * 1024 + POLICY_HEAD_TAIL_FLOATS * 4
+
+
+def encode_bands(V):
+    return 6 if V == 31 else 1
+
+
+def encode_frag_bytes(V, precision):
+    """(conv fragment image, Linear fragment image) sizes in bytes (include/ssd_hip.h SSD_ENCODE_*)."""
+    ksteps, units = (7, 29 * 2 * 3) if V == 31 else (5, 13 * 3)
+    return precision * 6 * ksteps * 1024, units * 2 * precision * 1024
+
+
+def code_agent_stride(V):
+    return (V * V + 15) & ~15
+
+
 HIP_SIGNATURES["ssd_policy_head_env"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.c_void_p])
 HIP_SIGNATURES["ssd_policy_head_inc"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_fwd"] = (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_bwd"] = (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 3 + [C.c_void_p])
-HIP_SIGNATURES["ssd_policy_encode"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
+HIP_SIGNATURES["ssd_policy_encode"] = (C.c_int, [C.POINTER(SsdPolicyEncodeArgs), C.c_void_p])
+HIP_SIGNATURES["ssd_policy_pack_encoder"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])
+HIP_SIGNATURES["ssd_policy_pack_head"] = (C.c_int, [C.POINTER(SsdPolicyHeadParams), C.c_int32, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_conv_leaky"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_store_step_launch"] = (C.c_int, [C.POINTER(SsdStoreStep), C.c_void_p])
@@ -140,7 +180,7 @@ HIP_SIGNATURES["ssd_gru_gates"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p,
 HIP_SIGNATURES["ssd_gru_gates_fwd"] = (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_gru_gates_bwd"] = (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_dueling_pick"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32,
-                                               C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])
+                                               C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p])
 HIP_SIGNATURES["ssd_poll_error"] = (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)])
 CPU_SIGNATURES = _sigs("ssd_cpu_", False)
 

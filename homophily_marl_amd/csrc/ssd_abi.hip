@@ -46,7 +46,7 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
     if (cfg->view_size < 0 || cfg->view_size > 31) return fail(SSD_ERR_INVALID, "view_size out of range (0..31)");
     {   // LDS budget: 4 waves (envs) per workgroup must fit the 160 KiB of a CU
         const long V = 2L * cfg->view_size + 1, pm = (cfg->height + 2L * cfg->view_size) * (cfg->width + 2L * cfg->view_size);
-        const long per_wave = 2L * ((cfg->height * cfg->width + 15) & ~15) + pm + 16 + cfg->n_agents * 3L * V * V + 32 + 64;
+        const long per_wave = 2L * ((cfg->height * cfg->width + 15) & ~15) + pm + 16 + cfg->n_agents * 3L * V * V + 32 + 64 + SSD_CODE_AGENT_STRIDE(V) + 16;
         if (per_wave * 4 > 160 * 1024) return fail(SSD_ERR_INVALID, "map / view_size / n_agents exceed the LDS budget of one workgroup");
     }
     if (cfg->spawn_rotation > 3) return fail(SSD_ERR_INVALID, "spawn_rotation must be -1..3");
@@ -235,8 +235,15 @@ static int make_oo(const ssd_env* E, const ssd_obs_out* o, DevObsOut* d) {
     if (o->state && ((uintptr_t)o->state & 15) != 0) return fail(SSD_ERR_INVALID, "state must be 16-byte aligned");
     if (o->obs_env_stride < 0 || o->obs_slot_stride < 0 || (!o->obs_env_stride && o->obs_slot_stride))
         return fail(SSD_ERR_INVALID, "obs_env_stride / obs_slot_stride");
+    if (o->obs_t_slots < 0) return fail(SSD_ERR_INVALID, "obs_t_slots");
+    if (o->obs_code) {
+        if (!o->obs || o->obs_format == SSD_OBS_CODE) return fail(SSD_ERR_INVALID, "obs_code accompanies a f32 / bf16 / u8 obs output");
+        if (E->hs.obs_color != SSD_COLOR_SIMPLIFIED) return fail(SSD_ERR_INVALID, "obs_code needs simplified colours");
+        if (((uintptr_t)o->obs_code & 15) != 0) return fail(SSD_ERR_INVALID, "obs_code must be 16-byte aligned");
+    }
     d->obs = o->obs; d->fmt = o->obs_format; d->state = o->state; d->pos = o->pos; d->orient = o->orient;
     d->env_stride = (long)o->obs_env_stride; d->slot_stride = (long)o->obs_slot_stride;
+    d->t_slots = o->obs_t_slots; d->code = o->obs_code; d->code_agent_stride = SSD_CODE_AGENT_STRIDE(E->hs.V);
     d->stamps = E->st.stamps;
     return SSD_OK;
 }
@@ -282,7 +289,6 @@ int ssd_step_observe(ssd_env* E, const int32_t* actions, const ssd_tape* tape, s
 #ifdef SSD_STAMPS
 // diagnostic build only: device buffer [n_env, 16] of u64 receiving the phase stamps
 int ssd_debug_set_stamps(ssd_env* E, unsigned long long* buf) { E->st.stamps = buf; return SSD_OK; }
-int ssd_debug_set_policy_stamps(unsigned long long* buf) { ssd::set_policy_stamps(buf); return SSD_OK; }
 #endif
 
 int ssd_poll_error(ssd_env* E, int32_t* bits) {
@@ -380,10 +386,11 @@ int ssd_gru_gates_bwd(const float* dh_new, const float* rzn, const float* gh, co
 }
 
 int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uint8_t* avail, const float* epsilon, const int64_t* step,
-                     uint32_t seed, int32_t n_agents, int32_t batch, int32_t pairs, int64_t* actions, float* q_out, void* stream) {
+                     uint32_t seed, int32_t n_agents, int32_t batch, int32_t pairs, int64_t* actions, float* q_out, uint32_t env_id_base,
+                     void* stream) {
     if (!av || !epsilon || !step || !actions || rows < 1 || n_actions < 1 || n_agents < 1 || batch < 1) return fail(SSD_ERR_INVALID, "bad argument");
     if (rows != (pairs ? n_agents * batch * n_agents : n_agents * batch)) return fail(SSD_ERR_INVALID, "rows must be n*B (or n*B*n for pairs)");
-    launch_dueling_pick(av, rows, n_actions, avail, epsilon, step, seed, n_agents, batch, pairs, actions, q_out, (hipStream_t)stream);
+    launch_dueling_pick(av, rows, n_actions, avail, epsilon, step, seed, n_agents, batch, pairs, actions, q_out, env_id_base, (hipStream_t)stream);
     return launched();
 }
 
@@ -403,27 +410,54 @@ int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const f
     return launched();
 }
 
-int ssd_policy_encode(const void* obs, int32_t obs_format, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
-                      const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, int64_t obs_env_stride,
-                      int64_t obs_slot_stride, const int64_t* slot_t, int64_t* slot_t_copy, int64_t* counter_inc, void* stream) {
-    if (obs_format != SSD_OBS_F32 && obs_format != SSD_OBS_CODE) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode reads f32 observations or class codes");
-    if (!obs || !conv_w || !conv_b || !lin_w_packed || !lin_b || !out || rows < 1 || n_agents < 1 || rows % n_agents || out_stride < 32)
+int ssd_policy_encode(const ssd_policy_encode_args* a, void* stream) {
+    if (!a || !a->codes || !a->conv_frags || !a->lin_frags || !a->conv_b || !a->lin_b || a->rows < 1 || a->n_agents < 1 || a->rows % a->n_agents)
         return fail(SSD_ERR_INVALID, "bad argument");
-    if (view_edge != 15) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode is instantiated for view_size 7 (15 x 15 windows); use ssd_conv_leaky + GEMM");
-    if (reinterpret_cast<uintptr_t>(lin_w_packed) & 15) return fail(SSD_ERR_INVALID, "lin_w_packed must be 16-byte aligned");
-    if (obs_env_stride < 0 || obs_slot_stride < 0 || (obs_slot_stride && (!obs_env_stride || !slot_t)))
-        return fail(SSD_ERR_INVALID, "obs_env_stride / obs_slot_stride / slot_t");
-    if (slot_t_copy && (!slot_t || slot_t_copy == slot_t)) return fail(SSD_ERR_INVALID, "slot_t_copy needs a distinct slot_t");
-    const int rc = launch_policy_encode(static_cast<const float*>(obs), rows, view_edge, conv_w, conv_b, lin_w_packed, lin_b, out, out_stride, n_agents, agent_major,
-                                        (long)obs_env_stride, (long)obs_slot_stride, slot_t, slot_t_copy, counter_inc, obs_format == SSD_OBS_CODE,
-                                        (hipStream_t)stream);
+    if (a->view_edge != 15 && a->view_edge != 31)
+        return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode is instantiated for view_size 7 and 15 (15 x 15 / 31 x 31 windows); use ssd_conv_leaky + GEMM");
+    if (a->precision != 0 && a->precision != 1 && a->precision != 2) return fail(SSD_ERR_INVALID, "precision must be 1 (bf16) or 2 (f32-equivalent)");
+    const int bands = SSD_ENCODE_BANDS(a->view_edge);
+    if (bands == 1 ? (!a->out || a->part || a->out_stride < 32) : (!a->part || a->out)) return fail(SSD_ERR_INVALID, "one band writes `out`, several bands write `part`");
+    if ((reinterpret_cast<uintptr_t>(a->conv_frags) | reinterpret_cast<uintptr_t>(a->lin_frags) | reinterpret_cast<uintptr_t>(a->part)) & 15)
+        return fail(SSD_ERR_INVALID, "conv_frags / lin_frags / part must be 16-byte aligned");
+    const long VV = (long)a->view_edge * a->view_edge;
+    if (a->agent_stride < VV || a->env_stride < (long)a->n_agents * a->agent_stride || a->slot_stride < 0 || (a->slot_stride && !a->slot_t))
+        return fail(SSD_ERR_INVALID, "env_stride / slot_stride / agent_stride / slot_t");
+    if (a->code_bytes < (long)(a->rows / a->n_agents - 1) * a->env_stride + (long)(a->n_agents - 1) * a->agent_stride + VV)
+        return fail(SSD_ERR_INVALID, "code_bytes does not cover the rows");
+    if (a->slot_t_copy && (!a->slot_t || a->slot_t_copy == a->slot_t)) return fail(SSD_ERR_INVALID, "slot_t_copy needs a distinct slot_t");
+    const int rc = launch_policy_encode(a, (hipStream_t)stream);
     if (rc) return fail(SSD_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS) failed");
+    return launched();
+}
+
+int ssd_policy_pack_encoder(const float* conv_w, const float* lin_w, int32_t view_edge, int32_t precision, void* conv_frags,
+                            void* lin_frags, void* stream) {
+    if (!conv_w || !lin_w || !conv_frags || !lin_frags) return fail(SSD_ERR_INVALID, "null argument");
+    if (precision != 1 && precision != 2) return fail(SSD_ERR_INVALID, "precision must be 1 or 2");
+    if ((reinterpret_cast<uintptr_t>(conv_frags) | reinterpret_cast<uintptr_t>(lin_frags)) & 15) return fail(SSD_ERR_INVALID, "fragment images must be 16-byte aligned");
+    if (launch_pack_encoder(conv_w, lin_w, view_edge, precision, conv_frags, lin_frags, (hipStream_t)stream))
+        return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_pack_encoder: view_edge must be 15 or 31");
+    return launched();
+}
+
+int ssd_policy_pack_head(const ssd_policy_head_params* p, int32_t precision, void* image, void* stream) {
+    if (!p || !image || !p->fc1_w || !p->fc1_b || !p->fc2_w || !p->fc2_b || !p->fc2_v_w || !p->fc2_v_b) return fail(SSD_ERR_INVALID, "null argument");
+    for (int g = 0; g < 3; ++g) if (!p->w_i[g] || !p->w_h[g] || !p->b_i[g] || !p->b_h[g]) return fail(SSD_ERR_INVALID, "null GRU parameter");
+    if (precision != 1 && precision != 2) return fail(SSD_ERR_INVALID, "precision must be 1 or 2");
+    if (p->n_agents < 1 || p->fc1_in < 1 || p->fc1_in > 64 || p->fc2_in < 64 || p->fc2_in > 80 || p->fc2_out < 1 || p->fc2_out > 15)
+        return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_pack_head: fc1_in <= 64, 64 <= fc2_in <= 80, fc2_out <= 15");
+    if (reinterpret_cast<uintptr_t>(image) & 15) return fail(SSD_ERR_INVALID, "image must be 16-byte aligned");
+    launch_pack_head(p, precision, image, (hipStream_t)stream);
     return launched();
 }
 
 static int policy_head(const ssd_policy_head* a, int inc, void* stream) {
     if (!a || !a->inputs || !a->h || !a->weights || !a->epsilon || !a->step || !a->out_actions) return fail(SSD_ERR_INVALID, "bad argument");
     if (a->n_env < 1 || a->n_agents < 1 || a->n_actions < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if (a->precision != 0 && a->precision != 1 && a->precision != 2) return fail(SSD_ERR_INVALID, "precision must be 1 (bf16) or 2 (f32-equivalent)");
+    if (a->feat_part && (inc || a->feat_bands < 1 || !a->lin_b || (reinterpret_cast<uintptr_t>(a->feat_part) & 15)))
+        return fail(SSD_ERR_INVALID, "feat_part (env head only) needs feat_bands >= 1, lin_b and 16-byte alignment");
     if (!inc && (a->pos_copy || a->dst_pos) && (!a->orient || (a->pos_copy && !a->orient_copy) || (a->dst_pos && !a->dst_orient)))
         return fail(SSD_ERR_INVALID, "pos_copy / dst_pos need orient and their orient twin");
     const bool files = a->dst_pos || a->dst_actions || a->dst_actions_inc || a->dst_reward || a->next_t_out;

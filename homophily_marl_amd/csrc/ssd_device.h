@@ -84,18 +84,23 @@ struct DevObsOut {
     int32_t fmt;
     float *state, *pos, *orient;
     long env_stride, slot_stride;  // placement of obs inside an episode storage (elements); 0, 0 = dense
+    int32_t t_slots;               // slots of that storage (0 = unchecked): no observation is written at slot >= t_slots
+    uint8_t* code;                 // optional side output: u8 cell classes [N, n, code_agent_stride]
+    int32_t code_agent_stride;     // V * V rounded up to 16
     unsigned long long* stamps;  // diagnostic builds only
 };
 
-enum : int { ERR_BAD_ACTION = 1, ERR_BAD_TAPE = 2, ERR_KEYERROR = 4, ERR_TAPE_OVERRUN = 8 };
+enum : int { ERR_BAD_ACTION = 1, ERR_BAD_TAPE = 2, ERR_KEYERROR = 4, ERR_TAPE_OVERRUN = 8, ERR_SLOT_OVERRUN = 16 };
 
 // LDS bytes one wave needs: grid | agent overlay | padded class map | output planes (+16 alignment slack) | colour lut.
 // The class map + planes region doubles as scratch for the tape-mode waste ranks (2 * 256 bytes) during the step.
 __host__ __device__ inline int lds_planes_bytes(const DevHead& s) { return ((s.n * 3 * s.VV + 16) + 15) & ~15; }
+// (+ one agent's class-code window, V * V rounded up to 16, + 16 for the dump byte of idle lanes: the obs_code side output)
+__host__ __device__ inline int lds_code_bytes(const DevHead& s) { return SSD_CODE_AGENT_STRIDE(s.V) + 16; }
 __host__ __device__ inline int lds_per_wave(const DevHead& s) {
     int obs = s.PMS + lds_planes_bytes(s);
     if (obs < 512) obs = 512;
-    return 2 * s.GS + obs + 64;
+    return 2 * s.GS + obs + 64 + lds_code_bytes(s);
 }
 
 void launch_env(int mode, const DevSpec* spec, const DevSpec& host_spec, DevState st, const int32_t* actions,
@@ -122,17 +127,14 @@ void launch_gru_gates(const float* gi, const float* gh, float* h, int R, int H, 
 void launch_gru_fwd_train(const float* gi, const float* gh, const float* h, float* h_new, float* rzn, int R, int H, hipStream_t s);
 void launch_gru_bwd(const float* dh, const float* rzn, const float* gh, const float* h, float* d_gi, float* d_gh, float* dh_prev, int R,
                     int H, hipStream_t s);
-int launch_policy_encode(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lwp, const float* lb, float* out,
-                         int out_stride, int n_agents, int agent_major, long env_stride, long slot_stride, const int64_t* slot_t,
-                         int64_t* slot_t_copy, int64_t* counter_inc, int code, hipStream_t s);
+int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s);
+int launch_pack_encoder(const float* cw, const float* lw, int V, int prec, void* conv_frags, void* lin_frags, hipStream_t s);
+void launch_pack_head(const ssd_policy_head_params* p, int prec, void* image, hipStream_t s);
 void launch_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T, int G, int B, hipStream_t s);
 void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* d_wh_part,
                         float* d_bh_part, int T, int G, int B, hipStream_t s);
-#ifdef SSD_STAMPS
-void set_policy_stamps(unsigned long long* buf);
-#endif
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s);
 void launch_dueling_pick(const float* av, int R, int A, const uint8_t* avail, const float* eps, const int64_t* step, uint32_t seed,
-                         int n_agents, int B, int pairs, int64_t* actions, float* q_out, hipStream_t s);
+                         int n_agents, int B, int pairs, int64_t* actions, float* q_out, uint32_t env_id_base, hipStream_t s);
 
 }  // namespace ssd

@@ -101,8 +101,10 @@ struct Env {
     uint8_t* occ;   // LDS agent overlay [GS]: 0 or the agent char (1..9) of the highest id standing there
     uint8_t* pm;    // LDS padded class map [PMS] (observe) / scratch (step)
     uint8_t* pl;    // LDS output planes
+    uint8_t* cbuf;  // LDS class-code window of one agent (obs_code side output)
     int lane, n, W, HW, GS;
     int obs_slot;   // the env's step counter after this call (time slot of the observation in an episode storage)
+    int32_t* err;   // sticky error word
     bool ag;        // lane < n
     int P;          // my agent's cell (r * W + c); unique negative for non-agent lanes
     int O;          // orientation
@@ -522,7 +524,9 @@ __device__ __forceinline__ void expand_range(const uint8_t* src, T* out, int q0,
 }
 
 // FMT: SSD_OBS_F32 / BF16 / U8 (three byte planes per agent) or SSD_OBS_CODE (one class plane per agent)
-template <bool FULL, int FMT>
+// WC: also emit the window as class codes into the dense side buffer oo.code (simplified palette; what the rollout-time encoder
+// reads): one extra LDS byte per cell in the gather, one 16-byte store per lane and agent.
+template <bool FULL, int FMT, bool WC>
 __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut& oo, const uint8_t* lut) {
     typedef typename std::conditional<FMT == SSD_OBS_F32, float, typename std::conditional<FMT == SSD_OBS_BF16, uint16_t, uint8_t>::type>::type T;
     constexpr bool CODE = FMT == SSD_OBS_CODE;
@@ -549,6 +553,8 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
     }
     int q_done = 0;
     const int dump = (int)(lut - E.pl);
+    uint8_t* cbuf = E.cbuf;                                       // one agent's class codes [V * V] (+ pad, + dump byte)
+    const int cstride = oo.code_agent_stride, cdump = cstride;
     for (int a = 0; a < n; ++a) {
         const int pa = rl(E.P, a), oa = rl(E.O, a);
         const int pr = (int)udiv((uint32_t)pa, h->magic_W), pc = pa - pr * W;
@@ -563,8 +569,9 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
         const int sstep = rpi * ci, dstep = rpi * V;
         int sidx = pr * Wp + pc + c0 + il * ci + j * cj;
         int d = a * A + delta + il * V + j;
+        int cd = il * V + j;
         // 4 row groups per batch: the 4 class reads are in flight together, then the plane bytes are written
-        for (int i = il; i < V; i += 4 * rpi, sidx += 4 * sstep, d += 4 * dstep) {
+        for (int i = il; i < V; i += 4 * rpi, sidx += 4 * sstep, d += 4 * dstep, cd += 4 * dstep) {
             int cls[4];
             bool ok[4];
 #pragma unroll
@@ -581,9 +588,17 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
                     // their 255 into a dump byte behind the planes (the lut slot, unused with the simplified palette)
                     E.pl[(ok[u] && c) ? du + __mul24(c >> 1, VV) : dump] = 255;
                 }
+                if (WC) {   // class bits 1 (waste) / 2 (apple) / 4 (wall, agent) -> codes 2 / 1 / 3 (SSD_OBS_CODE alphabet)
+                    const int c3 = c - (c >> 2);
+                    cbuf[ok[u] ? cd + u * dstep : cdump] = (uint8_t)((0x03010200u >> (8 * c3)) & 0xFFu);
+                }
             }
         }
         wsync();
+        if (WC) {   // this agent's code window: 16-byte stores (the side buffer's agent stride is a multiple of 16)
+            uint8_t* cdst = oo.code + ((size_t)env * n + a) * cstride;
+            for (int v16 = lane * 16; v16 < cstride; v16 += kWave * 16) *(uint4*)(cdst + v16) = *(const uint4*)(cbuf + v16);
+        }
         // expand and store every vector that is complete by now, so the store stream overlaps the next agent's gather
         const int q_end = a == n - 1 ? nvec : ((a + 1) * A - head) / EPV;
         if (q_end > q_done) { expand_range<T>(src, dst + head, q_done, q_end, lane); q_done = q_end; }
@@ -646,12 +661,20 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
     }
     wsync();
     STAMP_OBS(8);
-    if (oo.obs) {
+    // an env stepped past its episode storage writes no observation (it would land in the next env's block)
+    const bool slot_ok = !(oo.env_stride && oo.t_slots > 0 && E.obs_slot >= oo.t_slots);
+    if (!slot_ok && lane == 0) atomicOr(E.err, ERR_SLOT_OVERRUN);
+    if (oo.obs && slot_ok) {
         // gather windows into LDS in output order, expand to the output dtype (value / 256, CHW; map_env.py:945)
-        if (oo.fmt == SSD_OBS_F32) observe_windows<FULL, SSD_OBS_F32>(E, env, oo, lut);
-        else if (oo.fmt == SSD_OBS_BF16) observe_windows<FULL, SSD_OBS_BF16>(E, env, oo, lut);
-        else if (oo.fmt == SSD_OBS_U8) observe_windows<FULL, SSD_OBS_U8>(E, env, oo, lut);
-        else observe_windows<false, SSD_OBS_CODE>(E, env, oo, lut);
+        if (oo.code && !FULL) {
+            if (oo.fmt == SSD_OBS_F32) observe_windows<FULL, SSD_OBS_F32, true>(E, env, oo, lut);
+            else if (oo.fmt == SSD_OBS_BF16) observe_windows<FULL, SSD_OBS_BF16, true>(E, env, oo, lut);
+            else if (oo.fmt == SSD_OBS_U8) observe_windows<FULL, SSD_OBS_U8, true>(E, env, oo, lut);
+            else observe_windows<false, SSD_OBS_CODE, false>(E, env, oo, lut);
+        } else if (oo.fmt == SSD_OBS_F32) observe_windows<FULL, SSD_OBS_F32, false>(E, env, oo, lut);
+        else if (oo.fmt == SSD_OBS_BF16) observe_windows<FULL, SSD_OBS_BF16, false>(E, env, oo, lut);
+        else if (oo.fmt == SSD_OBS_U8) observe_windows<FULL, SSD_OBS_U8, false>(E, env, oo, lut);
+        else observe_windows<false, SSD_OBS_CODE, false>(E, env, oo, lut);
     }
     STAMP_OBS(9);
     if (oo.state) {  // get_state (map_env.py:950-957): [3, H, W] / 256
@@ -708,7 +731,9 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
     E.occ = E.g + E.GS;
     E.pm = E.occ + E.GS;
     E.pl = E.pm + h->PMS;
+    E.cbuf = E.g + lds_stride - lds_code_bytes(*h);
     E.ag = lane < E.n;
+    E.err = st.err;
     const int n = E.n, GS = E.GS;
     STAMP(0);
 

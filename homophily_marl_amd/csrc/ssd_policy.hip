@@ -7,8 +7,8 @@
 //                                                                                         action_selectors.py:44-68)
 //   k_store_step    the small per-step fields of the episode storage in one launch       (episode_runner.py:59-93)
 // In this per-layer composition the per-agent matrix products stay in hipBLASLt.  It is the second implementation of the
-// rollout-time controller (window sizes without a fused encoder, FastPolicy(fused=False)) and the cross-check of the fused
-// kernels in ssd_policy_fused.hip, which replace it on the hot path.
+// rollout-time controller (window sizes / palettes without a fused encoder, FastPolicy(fused=False)) and the cross-check of the
+// fused matrix-core kernels in ssd_policy_mfma.hip, which replace it on the hot path.
 #include "ssd_policy_common.h"
 
 namespace ssd {
@@ -265,16 +265,23 @@ __global__ void k_gru_bwd(const float* __restrict__ dh, const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void k_dueling_pick(const float* __restrict__ av, int R, int A, const uint8_t* __restrict__ avail,
                                const float* __restrict__ eps_p, const int64_t* __restrict__ step_p, uint32_t seed, int n_agents, int B,
-                               int pairs /*0: rows (i,b); 1: rows (i,b,j)*/, int64_t* __restrict__ actions, float* __restrict__ q_out) {
+                               int pairs /*0: rows (i,b); 1: rows (i,b,j)*/, int64_t* __restrict__ actions, float* __restrict__ q_out,
+                               uint32_t env_id_base) {
     const float eps = *eps_p;
     const uint32_t step = (uint32_t)*step_p;
+    const uint32_t n = (uint32_t)n_agents;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
         const float* a = av + (size_t)r * (A + 1);
-        int act = dueling_pick_row(a, a[A], A, avail, eps, step, seed, (uint32_t)r, q_out ? q_out + (size_t)r * A : nullptr);
+        // the exploration key is the GLOBAL env id (env_id_base + b), agent (and receiver): shards draw what the whole job draws
         size_t o;
-        if (!pairs) { const int i = r / B, b = r - i * B; o = (size_t)b * n_agents + i; }
+        uint32_t key;
+        bool diag = false;
+        if (!pairs) { const int i = r / B, b = r - i * B; o = (size_t)b * n_agents + i; key = (env_id_base + (uint32_t)b) * n + (uint32_t)i; }
         else { const int i = r / (B * n_agents), rem = r - i * B * n_agents, b = rem / n_agents, j = rem - b * n_agents;
-               o = ((size_t)b * n_agents + i) * n_agents + j; if (i == j) act = 0; }
+               o = ((size_t)b * n_agents + i) * n_agents + j; diag = i == j;
+               key = ((env_id_base + (uint32_t)b) * n + (uint32_t)i) * n + (uint32_t)j; }
+        int act = dueling_pick_row(a, a[A], A, avail, eps, step, seed, key, q_out ? q_out + (size_t)r * A : nullptr);
+        if (diag) act = 0;
         actions[o] = act;
     }
 }
@@ -322,9 +329,9 @@ void launch_gru_bwd(const float* dh, const float* rzn, const float* gh, const fl
     hipLaunchKernelGGL(k_gru_bwd, dim3(blocks), dim3(256), 0, s, dh, rzn, gh, h, d_gi, d_gh, dh_prev, R, H);
 }
 void launch_dueling_pick(const float* av, int R, int A, const uint8_t* avail, const float* eps, const int64_t* step, uint32_t seed,
-                         int n_agents, int B, int pairs, int64_t* actions, float* q_out, hipStream_t s) {
+                         int n_agents, int B, int pairs, int64_t* actions, float* q_out, uint32_t env_id_base, hipStream_t s) {
     int blocks = (R + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_dueling_pick, dim3(blocks), dim3(256), 0, s, av, R, A, avail, eps, step, seed, n_agents, B, pairs, actions, q_out);
+    hipLaunchKernelGGL(k_dueling_pick, dim3(blocks), dim3(256), 0, s, av, R, A, avail, eps, step, seed, n_agents, B, pairs, actions, q_out, env_id_base);
 }
 
 }  // namespace ssd

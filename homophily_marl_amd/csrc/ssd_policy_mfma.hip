@@ -1,0 +1,702 @@
+// ssd_policy_mfma.hip -- the rollout-time controller on the 16-bit matrix cores (include/ssd_hip.h: ssd_policy_encode,
+// ssd_policy_head_env / _inc, ssd_policy_pack_*).
+//
+// What is evaluated (reference): HomophilyAgent.rgb_preprocess (homophily_agent.py:20-27,213-214), the _build_inputs tail
+// (homophily_controller.py:137-184), forward_env / forward_inc (homophily_agent.py:154-208: fc1 -> LeakyReLU -> hand-written GRU
+// cell -> dueling Q) and the epsilon-greedy selector (action_selectors.py:44-68).
+//
+// Arithmetic.  The reference computes in f32.  gfx950's f32-input MFMA runs at the VALU rate (1/16 of the f16 / bf16 rate), so
+// every f32 product is evaluated on v_mfma_f32_16x16x32_f16 from two-term splits x = hi + lo (hi = f16(x), lo = f16(x - hi): 22
+// significand bits) as lo_w*hi_x + hi_w*lo_x + hi_w*hi_x with f32 accumulation: three MFMAs at 16x the f32 rate.  Exact powers of
+// two scale weights and activations so that the lo terms stay in f16's normal range; they are divided out of the f32 result.
+// PREC = 1 is the reduced-precision variant: single bf16 terms, one MFMA per product.
+//
+// Layout.  Every product is computed transposed, D^T = W^T X^T: the weight fragment is the A operand (lane (q, m): output
+// feature m of a 16-feature tile, 8 reduction indices of quarter q), 16 activation rows are the B operand (lane (q, m): row m),
+// and D puts the activation ROW on the lane (m) and 4 consecutive OUTPUT features (4 q + r) in the lane's registers.  With the
+// reduction index of K-step s, quarter q, element j chosen as k = 32 s + 16 (j >> 2) + 4 q + (j & 3), the result tiles 2 s and
+// 2 s + 1 of one product are, element for element, the B operand of K-step s of the next product: fc1 -> GRU -> dueling (and
+// conv -> Linear in the encoder) chain in registers without LDS round trips or lane shuffles, and the GRU gate arithmetic is
+// lane-local.  Weight fragments are pre-swizzled by the pack kernels below so that one ds_read_b128 / global_load_dwordx4 per
+// lane fetches a whole A operand.
+#include "ssd_policy_common.h"
+
+namespace ssd {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using b8 = __attribute__((ext_vector_type(8))) __bf16;
+
+template <int PREC>
+__device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (PREC == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+}
+
+// 8 f32 values -> the 16-bit fragment(s): hi (and, PREC 2, lo = v - hi; the subtraction is exact)
+template <int PREC>
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+    if constexpr (PREC == 2) {
+        h8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { h[j] = (_Float16)v[j]; l[j] = (_Float16)(v[j] - (float)h[j]); }
+        hi = __builtin_bit_cast(u32x4, h); lo = __builtin_bit_cast(u32x4, l);
+    } else {
+        b8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (__bf16)v[j];
+        hi = __builtin_bit_cast(u32x4, h); lo = hi;
+    }
+}
+template <int PREC> __device__ __forceinline__ void store_term(uint8_t* dst, float v, size_t term_stride) {
+    if constexpr (PREC == 2) {
+        const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+        *reinterpret_cast<_Float16*>(dst) = h; *reinterpret_cast<_Float16*>(dst + term_stride) = l;
+    } else {
+        *reinterpret_cast<__bf16*>(dst) = (__bf16)v;
+    }
+}
+
+// exact power-of-two scales (PREC 2; PREC 1 needs none: bf16 has the f32 exponent range)
+constexpr float HEAD_WSCALE = 64.f, HEAD_XSCALE = 16.f;                  // head weights / activations
+constexpr float ENC_CSCALE = 256.f, ENC_LSCALE = 256.f;                  // conv weights (= conv activations' scale) / Linear weights
+
+// ===========================================================================================================================
+// heads
+// ===========================================================================================================================
+constexpr int HF_FC1 = 0, HF_WI = 8, HF_WH = 32, HF_FC2 = 56, HF_TOT = SSD_POLICY_HEAD_FRAGS;
+constexpr int HT_B1 = 0, HT_BI = 64, HT_BH = 256, HT_B2 = 448, HT_W2O = 464, HT_TOT = SSD_POLICY_HEAD_TAIL_FLOATS;
+constexpr int HEAD_WAVES = 8;
+constexpr int SCRATCH = 16 * 16;               // per wave: fc2 output tile [row 16][out 16]
+
+struct HeadK {
+    int N, n, A, inp, bpa;
+    float pos_scale;
+    uint32_t seed, env_id_base;
+    float* inputs;
+    float* h;
+    const uint8_t* weights;
+    const uint8_t* avail;
+    const float* eps;
+    const int64_t* step;
+    const int64_t* prev_actions;
+    const float* prev_reward;
+    const int64_t* prev_inc;
+    const float* pos;
+    const int64_t* actions;
+    const float *pos_pre, *orient_pre, *reward, *clean, *den;
+    int64_t* out_actions;
+    float* q_out;
+    const float* orient;
+    int32_t* out_actions_i32;
+    float *pos_copy, *orient_copy;
+    const int64_t* t_index; int slots;
+    float *d_pos, *d_orient, *d_onehot, *d_reward, *d_clean, *d_den;
+    uint8_t* d_term; const uint8_t* term;
+    int64_t *d_actions, *d_actions_inc, *p_act, *p_inc;
+    float *p_rew, *ep_ret;
+    int64_t* next_t;
+    const float* feat_part; int feat_bands; const float* lin_b;
+};
+
+// acc[ot] += (W^T tile ot of the block starting at fragment F0) x B for OT output tiles, both K-steps; small terms first
+template <int PREC, int OT>
+__device__ __forceinline__ void gemm_t(const uint8_t* img, int F0, const u32x4 (&bh)[2], const u32x4 (&bl)[2], f32x4* acc, int lane) {
+    constexpr size_t TERM = (size_t)HF_TOT * 1024;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4 ah[OT], al[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+            const uint8_t* p = img + ((size_t)(F0 + 2 * ot + s) * 64 + lane) * 16;
+            ah[ot] = *reinterpret_cast<const u32x4*>(p);
+            if (PREC == 2) al[ot] = *reinterpret_cast<const u32x4*>(p + TERM);
+        }
+        if (PREC == 2) {
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) acc[ot] = mma<PREC>(al[ot], bh[s], acc[ot]);
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) acc[ot] = mma<PREC>(ah[ot], bl[s], acc[ot]);
+        }
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = mma<PREC>(ah[ot], bh[s], acc[ot]);
+    }
+}
+
+// the B operand of a product from 4 x 4 features per lane (x[ct][r] = feature 16 ct + 4 q + r), scaled
+template <int PREC>
+__device__ __forceinline__ void operand(const f32x4 (&x)[4], float scale, u32x4 (&bh)[2], u32x4 (&bl)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = x[2 * s + (j >> 2)][j & 3] * scale;
+        split8<PREC>(v, bh[s], bl[s]);
+    }
+}
+
+// sigmoid / tanh on v_exp_f32 + v_rcp_f32 (1 ulp each)
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float ax = fminf(fabsf(x), 15.f);                            // 1 - 2 / (e^{2|x|} + 1), saturated
+    const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * ax) + 1.f);
+    return copysignf(t, x);
+}
+
+template <int INC, int PREC>
+__global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    constexpr int FRAG_BYTES = PREC * HF_TOT * 1024, IMAGE_BYTES = FRAG_BYTES + HT_TOT * 4;
+    constexpr float XS = PREC == 2 ? HEAD_XSCALE : 1.f, INV = PREC == 2 ? 1.f / (HEAD_WSCALE * HEAD_XSCALE) : 1.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int agent = blockIdx.x / a.bpa, bia = blockIdx.x - agent * a.bpa;
+    const int m = lane & 15, q = lane >> 4;
+    const int N = a.N, n = a.n, A = a.A;
+    {   // stage this agent's image (already in LDS layout): every load in flight before the first LDS write
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.weights + (size_t)agent * IMAGE_BYTES);
+        u32x4* dst = reinterpret_cast<u32x4*>(lds_raw);
+        constexpr int NV = IMAGE_BYTES / 16, PER = (NV + HEAD_WAVES * 64 - 1) / (HEAD_WAVES * 64);
+        u32x4 tmp[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { const int e = tid + j * HEAD_WAVES * 64; if (e < NV) tmp[j] = src[e]; }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { const int e = tid + j * HEAD_WAVES * 64; if (e < NV) dst[e] = tmp[j]; }
+    }
+    __syncthreads();
+    const uint8_t* img = lds_raw;
+    const float* tail = reinterpret_cast<const float*>(lds_raw + FRAG_BYTES);
+    float* scratch = reinterpret_cast<float*>(lds_raw + IMAGE_BYTES) + wave * SCRATCH;
+    const float eps = *a.eps;
+    const uint32_t step = (uint32_t)*a.step;
+    const long slot_t = a.t_index ? (long)*a.t_index : 0;
+    const bool file = slot_t < (long)a.slots;                          // never file past the episode storage
+    if (INC && a.next_t && blockIdx.x == 0 && tid == 0) *a.next_t = slot_t + 1;   // not read by this kernel (t_index is a copy)
+    const int tiles = (N + 15) >> 4;
+    for (int tile = wave * a.bpa + bia; tile < tiles; tile += a.bpa * HEAD_WAVES) {   // consecutive tiles go to different CUs
+        const int b = tile * 16 + m;
+        const bool valid = b < N;
+        const int bc = valid ? b : N - 1;
+        const size_t arow = (size_t)agent * N + bc;                    // agent-major row
+        float* in_row = a.inputs + arow * 64;
+        // ---- the 64 (zero padded) input features of row m, 4 per (ct, lane) ---------------------------------------------------
+        f32x4 x[4];
+        if (!INC) {
+            if (a.feat_part) {      // the encoder left per-band partial sums: features = LeakyReLU(lin_b + sum), band order
+                const size_t rows = (size_t)n * N;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    f32x4 s = *reinterpret_cast<const f32x4*>(a.lin_b + 16 * ct + 4 * q);
+                    for (int bd = 0; bd < a.feat_bands; ++bd) s += *reinterpret_cast<const f32x4*>(a.feat_part + ((size_t)bd * rows + arow) * 32 + 16 * ct + 4 * q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r] = leaky(s[r]);
+                    x[ct] = s;
+                    if (valid) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = s;
+                }
+            } else {
+                x[0] = *reinterpret_cast<const f32x4*>(in_row + 4 * q);
+                x[1] = *reinterpret_cast<const f32x4*>(in_row + 16 + 4 * q);
+            }
+            const size_t er = (size_t)bc * n + agent;                  // env-major row
+            const int pa = (int)a.prev_actions[er];
+            const float pr = a.prev_reward[er];
+            int recv = 0;
+            for (int g = 0; g < n; ++g) {
+                if (g == agent) continue;                              // inc_mask_actions: no self incentive
+                const int64_t v = a.prev_inc[((size_t)bc * n + g) * n + agent];
+                recv += (v == 1) - (v == 2);
+            }
+            const float px = a.pos[er * 2] / a.pos_scale, py = a.pos[er * 2 + 1] / a.pos_scale;
+            if (valid && q == 0 && (a.pos_copy || a.d_pos)) {          // the pose BEFORE the env step (inc head input, storage slot t)
+                const float p0 = a.pos[er * 2], p1 = a.pos[er * 2 + 1], o0 = a.orient[er * 2], o1 = a.orient[er * 2 + 1];
+                if (a.pos_copy) { a.pos_copy[er * 2] = p0; a.pos_copy[er * 2 + 1] = p1; a.orient_copy[er * 2] = o0; a.orient_copy[er * 2 + 1] = o1; }
+                if (a.d_pos && file) {
+                    const size_t sr = (((size_t)bc * a.slots + slot_t) * n + agent) * 2;
+                    a.d_pos[sr] = p0; a.d_pos[sr + 1] = p1; a.d_orient[sr] = o0; a.d_orient[sr + 1] = o1;
+                }
+            }
+#pragma unroll
+            for (int ct = 2; ct < 4; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * ct + 4 * q + r - 32;            // tail column (controller :137-184)
+                    float v = 0.f;
+                    if (j < A) v = pa == j ? 1.f : 0.f;
+                    else if (j < A + n) v = j - A == agent ? 1.f : 0.f;
+                    else if (j == A + n) v = (float)((pr > 0.f) - (pr < 0.f));
+                    else if (j == A + n + 1) v = (float)((recv > 0) - (recv < 0));
+                    else if (j == A + n + 2) v = px;
+                    else if (j == A + n + 3) v = py;
+                    x[ct][r] = v;
+                }
+                if (valid) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = x[ct];   // the inc head reads the full row
+            }
+        } else {
+            const int act = (int)a.actions[(size_t)bc * n + agent];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                x[ct] = *reinterpret_cast<const f32x4*>(in_row + 16 * ct + 4 * q);
+                if (ct >= 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 16 * ct + 4 * q + r - a.inp;     // [inputs | one-hot(action)] (homophily_agent.py:181)
+                        if (k >= 0 && k < A) x[ct][r] = act == k ? 1.f : 0.f;
+                    }
+                }
+            }
+        }
+        u32x4 bh[2], bl[2];
+        // ---- fc1 + LeakyReLU -----------------------------------------------------------------------------------------------
+        f32x4 x1[4];
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) x1[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+        operand<PREC>(x, XS, bh, bl);
+        gemm_t<PREC, 4>(img, HF_FC1, bh, bl, x1, lane);
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(tail + HT_B1 + 16 * ot + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x1[ot][r] = leaky(fmaf(x1[ot][r], INV, bias[r]));
+        }
+        // ---- GRU cell: r, z share one accumulator for the input and the hidden side; n needs both separately -------------------
+        float* h_row = a.h + arow * 64;
+        f32x4 hp[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) hp[ct] = *reinterpret_cast<const f32x4*>(h_row + 16 * ct + 4 * q);
+        f32x4 g[16];                                                   // 0-3 r, 4-7 z, 8-11 i_n, 12-15 h_n
+#pragma unroll
+        for (int ot = 0; ot < 16; ++ot) g[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+        operand<PREC>(x1, XS, bh, bl);
+        gemm_t<PREC, 8>(img, HF_WI, bh, bl, g, lane);
+        gemm_t<PREC, 4>(img, HF_WI + 16, bh, bl, g + 8, lane);
+        operand<PREC>(hp, XS, bh, bl);
+        gemm_t<PREC, 8>(img, HF_WH, bh, bl, g, lane);
+        gemm_t<PREC, 4>(img, HF_WH + 16, bh, bl, g + 12, lane);
+        f32x4 hn[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const f32x4 bir = *reinterpret_cast<const f32x4*>(tail + HT_BI + 16 * ft + 4 * q), bhr = *reinterpret_cast<const f32x4*>(tail + HT_BH + 16 * ft + 4 * q);
+            const f32x4 biz = *reinterpret_cast<const f32x4*>(tail + HT_BI + 64 + 16 * ft + 4 * q), bhz = *reinterpret_cast<const f32x4*>(tail + HT_BH + 64 + 16 * ft + 4 * q);
+            const f32x4 bin = *reinterpret_cast<const f32x4*>(tail + HT_BI + 128 + 16 * ft + 4 * q), bhn = *reinterpret_cast<const f32x4*>(tail + HT_BH + 128 + 16 * ft + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rg = sigmoid_fast(fmaf(g[ft][r], INV, bir[r] + bhr[r]));
+                const float zg = sigmoid_fast(fmaf(g[4 + ft][r], INV, biz[r] + bhz[r]));
+                const float ng = tanh_fast(fmaf(g[8 + ft][r], INV, bin[r]) + rg * fmaf(g[12 + ft][r], INV, bhn[r]));
+                hn[ft][r] = (1.f - zg) * ng + zg * hp[ft][r];
+            }
+            if (valid) *reinterpret_cast<f32x4*>(h_row + 16 * ft + 4 * q) = hn[ft];
+        }
+        // ---- fc2 (advantages + value, padded to 16 outputs) ---------------------------------------------------------------
+        f32x4 o2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        operand<PREC>(hn, XS, bh, bl);
+        gemm_t<PREC, 1>(img, HF_FC2, bh, bl, &o2, lane);
+        {
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(tail + HT_B2 + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o2[r] = fmaf(o2[r], INV, b2[r]);
+        }
+        *reinterpret_cast<f32x4*>(scratch + m * 16 + 4 * q) = o2;      // scratch[row][out]
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!INC) {
+            const int bb = tile * 16 + lane;
+            if (lane < 16 && bb < N) {
+                float av[16];
+                for (int k = 0; k <= A; ++k) av[k] = scratch[lane * 16 + k];
+                const uint32_t rq = (uint32_t)(agent * N + bb);                                  // q_out row (agent-major)
+                const uint32_t rk = (a.env_id_base + (uint32_t)bb) * (uint32_t)n + (uint32_t)agent;   // exploration key: global env id
+                const int act = dueling_pick_row(av, av[A], A, a.avail, eps, step, a.seed, rk,
+                                                 a.q_out ? a.q_out + (size_t)rq * A : nullptr);
+                a.out_actions[(size_t)bb * n + agent] = act;
+                if (a.out_actions_i32) a.out_actions_i32[(size_t)bb * n + agent] = act;
+                if (a.p_act) a.p_act[(size_t)bb * n + agent] = act;
+                if (a.d_actions && file) {
+                    const size_t sr = ((size_t)bb * a.slots + slot_t) * n + agent;
+                    a.d_actions[sr] = act;
+                    for (int k = 0; k < A; ++k) a.d_onehot[sr * A + k] = k == act ? 1.f : 0.f;
+                }
+            }
+        } else {
+            const float* w2o = tail + HT_W2O;                          // [E][4]: 3 advantages + value per extra feature
+            for (int it = lane; it < 16 * n; it += 64) {
+                const int row = it / n, j = it - row * n, bb = tile * 16 + row;
+                if (bb >= N) continue;
+                const size_t ej = (size_t)bb * n + j;
+                // other_j = [one-hot(a_j), pos_j / scale, orient_j, r_j, clean_j, apple_den_j] (homophily_agent.py:194-201)
+                const int aj = (int)a.actions[ej];
+                float f[7];
+                f[0] = a.pos_pre[ej * 2] / a.pos_scale; f[1] = a.pos_pre[ej * 2 + 1] / a.pos_scale;
+                f[2] = a.orient_pre[ej * 2]; f[3] = a.orient_pre[ej * 2 + 1];
+                f[4] = a.reward[ej]; f[5] = a.clean[ej]; f[6] = a.den[ej];
+                float av[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float s = scratch[row * 16 + o] + w2o[aj * 4 + o];
+#pragma unroll
+                    for (int e = 0; e < 7; ++e) s = fmaf(f[e], w2o[(A + e) * 4 + o], s);
+                    av[o] = s;
+                }
+                const uint32_t rq = (uint32_t)((agent * N + bb) * n + j);
+                const uint32_t rk = ((a.env_id_base + (uint32_t)bb) * (uint32_t)n + (uint32_t)agent) * (uint32_t)n + (uint32_t)j;
+                int act = dueling_pick_row(av, av[3], 3, nullptr, eps, step, a.seed, rk, a.q_out ? a.q_out + (size_t)rq * 3 : nullptr);
+                if (j == agent) act = 0;                               // no self incentive (homophily_controller.py:44-46)
+                a.out_actions[((size_t)bb * n + agent) * n + j] = act;
+                if (a.p_inc) a.p_inc[((size_t)bb * n + agent) * n + j] = act;
+                const size_t sr = ((size_t)bb * a.slots + slot_t) * n + agent;
+                if (a.d_actions_inc && file) a.d_actions_inc[sr * n + j] = act;
+                if (j == 0 && a.d_reward) {                            // once per (env, agent): this step's outcome
+                    const size_t ea = (size_t)bb * n + agent;
+                    const float rw = a.reward[ea];
+                    if (file) { a.d_reward[sr] = rw; a.d_clean[sr] = a.clean[ea]; a.d_den[sr] = a.den[ea]; }
+                    if (a.p_rew) a.p_rew[ea] = rw;
+                    if (a.ep_ret) a.ep_ret[ea] += rw;
+                    if (agent == 0 && a.d_term && file) a.d_term[(size_t)bb * a.slots + slot_t] = a.term[bb];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                               // scratch is reused by the next tile
+    }
+}
+
+int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
+    HeadK k;
+    k.N = p->n_env; k.n = p->n_agents; k.A = p->n_actions; k.inp = p->input_shape;
+    k.pos_scale = p->pos_scale; k.seed = p->seed; k.env_id_base = p->env_id_base;
+    k.inputs = p->inputs; k.h = p->h; k.weights = static_cast<const uint8_t*>(p->weights); k.avail = p->avail; k.eps = p->epsilon; k.step = p->step;
+    k.prev_actions = p->prev_actions; k.prev_reward = p->prev_reward; k.prev_inc = p->prev_actions_inc; k.pos = p->pos;
+    k.actions = p->actions; k.pos_pre = p->pos_pre; k.orient_pre = p->orient_pre; k.reward = p->reward; k.clean = p->clean_num;
+    k.den = p->apple_den; k.out_actions = p->out_actions; k.q_out = p->q_out;
+    k.t_index = p->t_index; k.slots = p->t_index ? p->t_slots : 1;
+    k.d_pos = p->dst_pos; k.d_orient = p->dst_orient; k.d_onehot = p->dst_actions_onehot; k.d_reward = p->dst_reward;
+    k.d_clean = p->dst_clean_num; k.d_den = p->dst_apple_den; k.d_term = p->dst_terminated; k.term = p->terminated;
+    k.d_actions = p->dst_actions; k.d_actions_inc = p->dst_actions_inc; k.p_act = p->prev_actions_out; k.p_inc = p->prev_actions_inc_out;
+    k.p_rew = p->prev_reward_out; k.ep_ret = p->ep_return; k.next_t = p->next_t_out;
+    k.orient = p->orient; k.out_actions_i32 = p->out_actions_i32; k.pos_copy = p->pos_copy; k.orient_copy = p->orient_copy;
+    k.feat_part = p->feat_part; k.feat_bands = p->feat_bands; k.lin_b = p->lin_b;
+    const int prec = p->precision == 1 ? 1 : 2;
+    const int tiles = (k.N + 15) / 16;
+    int bpa = 256 / k.n;                                               // one workgroup per CU (the image fills most of the LDS)
+    if (bpa > tiles) bpa = tiles;
+    if (bpa < 1) bpa = 1;
+    k.bpa = bpa;
+    const size_t lds = (size_t)SSD_POLICY_IMAGE_BYTES(prec) + HEAD_WAVES * SCRATCH * sizeof(float);
+    static bool attr_done_dev[64] = {};                               // the attribute is per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    if (!attr_done_dev[dev]) {
+        const size_t l2 = (size_t)SSD_POLICY_IMAGE_BYTES(2) + HEAD_WAVES * SCRATCH * sizeof(float);
+        const void* fns[4] = {reinterpret_cast<const void*>(&k_head<0, 2>), reinterpret_cast<const void*>(&k_head<1, 2>),
+                              reinterpret_cast<const void*>(&k_head<0, 1>), reinterpret_cast<const void*>(&k_head<1, 1>)};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess) return -1;
+        attr_done_dev[dev] = true;
+    }
+    const dim3 grid(k.n * bpa), block(HEAD_WAVES * 64);
+    if (prec == 2) {
+        if (inc) hipLaunchKernelGGL((k_head<1, 2>), grid, block, lds, s, k); else hipLaunchKernelGGL((k_head<0, 2>), grid, block, lds, s, k);
+    } else {
+        if (inc) hipLaunchKernelGGL((k_head<1, 1>), grid, block, lds, s, k); else hipLaunchKernelGGL((k_head<0, 1>), grid, block, lds, s, k);
+    }
+    return 0;
+}
+
+// ---- pack: reference-shaped f32 parameters -> the per-agent head image --------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(256) void k_pack_head(ssd_policy_head_params p, uint8_t* image) {
+    constexpr size_t TERM = (size_t)HF_TOT * 1024, IMAGE_BYTES = PREC * TERM + HT_TOT * 4;
+    constexpr float WS = PREC == 2 ? HEAD_WSCALE : 1.f;
+    const int agent = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    uint8_t* img = image + (size_t)agent * IMAGE_BYTES;
+    if (e < HF_TOT * 512) {
+        const int F = e >> 9, lane = (e >> 3) & 63, j = e & 7, q = lane >> 4, m = lane & 15;
+        float w = 0.f;
+        if (F < HF_WI) {
+            const int ot = F >> 1, s = F & 1, out = 16 * ot + m, k = 32 * s + 16 * (j >> 2) + 4 * q + (j & 3);
+            if (k < p.fc1_in) w = p.fc1_w[((size_t)agent * p.fc1_in + k) * 64 + out];
+        } else if (F < HF_FC2) {
+            const bool hid = F >= HF_WH;
+            const int G = F - (hid ? HF_WH : HF_WI), ot = G >> 1, s = G & 1, out = 16 * ot + m, k = 32 * s + 16 * (j >> 2) + 4 * q + (j & 3);
+            const float* W = (hid ? p.w_h : p.w_i)[out >> 6];
+            w = W[((size_t)agent * 64 + k) * 64 + (out & 63)];
+        } else {
+            const int s = F - HF_FC2, k = 32 * s + 16 * (j >> 2) + 4 * q + (j & 3);   // the h part of fc2: rows 0..63 of [fc2_in, out]
+            if (m < p.fc2_out) w = p.fc2_w[((size_t)agent * p.fc2_in + k) * p.fc2_out + m];
+            else if (m == p.fc2_out) w = p.fc2_v_w[(size_t)agent * p.fc2_in + k];
+        }
+        store_term<PREC>(img + ((size_t)F * 64 + lane) * 16 + 2 * j, w * WS, TERM);
+    }
+    if (e < HT_TOT) {
+        float v = 0.f;
+        if (e < HT_BI) v = p.fc1_b[(size_t)agent * 64 + e];
+        else if (e < HT_BH) { const int i = e - HT_BI; v = p.b_i[i >> 6][(size_t)agent * 64 + (i & 63)]; }
+        else if (e < HT_B2) { const int i = e - HT_BH; v = p.b_h[i >> 6][(size_t)agent * 64 + (i & 63)]; }
+        else if (e < HT_W2O) {
+            const int o = e - HT_B2;
+            if (o < p.fc2_out) v = p.fc2_b[(size_t)agent * p.fc2_out + o]; else if (o == p.fc2_out) v = p.fc2_v_b[agent];
+        } else {
+            const int i = e - HT_W2O, ee = i >> 2, o = i & 3;          // pair part of fc2 (inc): rows 64.. of [fc2_in, out]
+            if (64 + ee < p.fc2_in) {
+                if (o < p.fc2_out) v = p.fc2_w[((size_t)agent * p.fc2_in + 64 + ee) * p.fc2_out + o];
+                else if (o == p.fc2_out) v = p.fc2_v_w[(size_t)agent * p.fc2_in + 64 + ee];
+            }
+        }
+        reinterpret_cast<float*>(img + PREC * TERM)[e] = v;
+    }
+}
+
+void launch_pack_head(const ssd_policy_head_params* p, int prec, void* image, hipStream_t s) {
+    const dim3 grid((HF_TOT * 512 + 255) / 256, p->n_agents);
+    if (prec == 2) hipLaunchKernelGGL(k_pack_head<2>, grid, dim3(256), 0, s, *p, static_cast<uint8_t*>(image));
+    else hipLaunchKernelGGL(k_pack_head<1>, grid, dim3(256), 0, s, *p, static_cast<uint8_t*>(image));
+}
+
+// ===========================================================================================================================
+// encoder
+// ===========================================================================================================================
+// Geometry of one window size.  O output positions per row; a plane row is padded to CP cells; a position tile is 16 positions
+// fed by NF fragments of 8 cells; XT tiles per output row; the output rows are cut into bands of R rows (one workgroup each).
+template <int V> struct Geo;
+template <> struct Geo<15> { static constexpr int O = 13, CP = 16, NF = 2, XT = 1, R = 13, NB = 1; };
+template <> struct Geo<31> { static constexpr int O = 29, CP = 40, NF = 3, XT = 2, R = 5, NB = 6; };
+constexpr int ENC_BT = 5;                      // batch tiles (16 rows each) per workgroup: Linear weights are fetched once per 80 rows
+constexpr int ENC_WAVES = 4;
+
+struct EncK {
+    const uint8_t* codes; long code_bytes, env_stride, slot_stride, agent_stride; const int64_t* slot_t;
+    int rows, n, agent_major;
+    const uint8_t *conv_frags, *lin_frags;
+    const float *conv_b, *lin_b;
+    float* out; int out_stride;
+    float* part;
+    int64_t* slot_t_copy; int64_t* counter_inc;
+};
+
+template <int V, int PREC>
+__global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
+    using G = Geo<V>;
+    constexpr int O = G::O, CP = G::CP, NF = G::NF, XT = G::XT, R = G::R, BT = ENC_BT;
+    constexpr int KS = SSD_ENCODE_KSTEPS(V), NFR = 9 * NF;             // K-steps; real fragments of a position tile
+    constexpr int PR = 3 * (R + 2) * CP;                               // plane bytes per batch row (this band)
+    constexpr int PLANES = BT * 16 * PR, CONV_BYTES = PREC * 6 * KS * 1024;
+    constexpr uint32_t ON = PREC == 2 ? 0x3Cu : 0x3Fu;                 // f16 0x3C00 = 1.0;  bf16 0x3F00 = 0.5 (the conv weights carry the 2)
+    constexpr float CS = PREC == 2 ? ENC_CSCALE : 1.f, INV = PREC == 2 ? 1.f / (ENC_CSCALE * ENC_LSCALE) : 1.f;
+    static_assert(ENC_WAVES * BT * 2 * 1024 <= PLANES, "the reduction scratch aliases the planes");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint8_t* planes = lds_raw;                                         // [BT * 16 rows][3 ch][R + 2][CP] one-hot bytes
+    uint8_t* cfr = lds_raw + PLANES;                                   // conv fragments [term][oc][ks][lane][16 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * (BT * 16);
+    const int band = blockIdx.y, y0 = band * R;
+    const int Rb = O - y0 < R ? O - y0 : R;                            // output rows of this band
+    const long t_off = a.slot_t ? (long)(*a.slot_t) * a.slot_stride : 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        if (a.slot_t_copy) *a.slot_t_copy = *a.slot_t;
+        if (a.counter_inc) *a.counter_inc += 1;
+    }
+    // ---- stage: conv fragments (global -> LDS), class codes -> one-hot plane bytes ---------------------------------------
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.conv_frags);
+        u32x4* dst = reinterpret_cast<u32x4*>(cfr);
+        constexpr int NV = CONV_BYTES / 16, PER = (NV + ENC_WAVES * 64 - 1) / (ENC_WAVES * 64);
+        u32x4 tmp[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { const int e = tid + j * ENC_WAVES * 64; if (e < NV) tmp[j] = src[e]; }
+        // plane bytes: items = (batch row, band input row, group of 4 cells); 4 codes come from two aligned dwords
+        constexpr int GPR = CP / 4, ITEMS = BT * 16 * (R + 2) * GPR;
+        for (int it = tid; it < ITEMS; it += ENC_WAVES * 64) {
+            const int g4 = it % GPR, yy = (it / GPR) % (R + 2), r = it / (GPR * (R + 2));
+            const int row = row0 + r, y = y0 + yy, x = 4 * g4;
+            uint32_t c4 = 0;
+            if (row < a.rows && y < V && x < V) {
+                const int b = row / a.n, i = row - b * a.n;
+                // 4 codes from the two aligned dwords that hold them (rows of 225 / 961 bytes are not dword aligned); only dwords that
+                // contain readable codes are touched
+                const uintptr_t ptr = reinterpret_cast<uintptr_t>(a.codes) + (uintptr_t)((long)b * a.env_stride + t_off + (long)i * a.agent_stride + y * V + x);
+                const uintptr_t al = ptr & ~(uintptr_t)3, end = (reinterpret_cast<uintptr_t>(a.codes) + (uintptr_t)a.code_bytes + 3) & ~(uintptr_t)3;
+                const uint32_t w0 = *reinterpret_cast<const uint32_t*>(al);
+                const uint32_t w1 = al + 8 <= end ? *reinterpret_cast<const uint32_t*>(al + 4) : 0u;
+                c4 = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)(ptr & 3));
+                const int left = V - x;                               // cells of this group inside the window row
+                if (left < 4) c4 &= (1u << (8 * left)) - 1u;
+            }
+            uint8_t* d = planes + (size_t)r * PR + yy * CP + x;
+            // code 2 = waste -> R, 1 = apple -> G, 3 = wall / agent -> B (cleanup.py:93-105): byte == code <=> (byte ^ code) == 0
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const uint32_t t = c4 ^ ((ch == 0 ? 2u : ch == 1 ? 1u : 3u) * 0x01010101u);
+                const uint32_t hit = ~(t | (t >> 1) | (t >> 2) | (t >> 3) | (t >> 4) | (t >> 5) | (t >> 6) | (t >> 7)) & 0x01010101u;
+                *reinterpret_cast<uint32_t*>(d + ch * (R + 2) * CP) = hit * ON;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { const int e = tid + j * ENC_WAVES * 64; if (e < NV) dst[e] = tmp[j]; }
+    }
+    __syncthreads();
+    // ---- units (output row y, position tile xt, output-channel pair s) of this band, a contiguous range per wave ---------------
+    f32x4 accl[BT][2];
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) { accl[bt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[bt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int U = Rb * XT * 3;
+    const int u_begin = (wave * U) / ENC_WAVES, u_end = ((wave + 1) * U) / ENC_WAVES;
+    const uint8_t* my_planes = planes + (size_t)m * PR;
+#pragma unroll 1
+    for (int u = u_begin; u < u_end; ++u) {
+        const int s = u % 3, xt = (u / 3) % XT, yl = u / (3 * XT);    // yl: output row inside the band
+        // Linear A fragments of this unit (global, L2-resident): requested now, used after the conv
+        const size_t gu = (size_t)((y0 + yl) * XT + xt) * 3 + s;
+        u32x4 la[2][PREC];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < PREC; ++t)
+                la[mt][t] = *reinterpret_cast<const u32x4*>(a.lin_frags + (((gu * 2 + mt) * PREC + t) * 64 + lane) * 16);
+        f32x4 accc[2][BT];
+        {
+            const float b0 = a.conv_b[2 * s] * CS, b1 = a.conv_b[2 * s + 1] * CS;
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) { accc[0][bt] = f32x4{b0, b0, b0, b0}; accc[1][bt] = f32x4{b1, b1, b1, b1}; }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int F = 4 * ks + q;                                  // fragment of this lane's quarter: (dy, ch, f)
+            const bool real = F < NFR;
+            const int Fc = real ? F : 0, dy = Fc / (3 * NF), ch = (Fc / NF) % 3, f = Fc % NF;
+            const int boff = (ch * (R + 2) + yl + dy) * CP + 16 * xt + 8 * f;
+            u32x4 bfr[BT];
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                const u32x2 w = *reinterpret_cast<const u32x2*>(my_planes + (size_t)bt * 16 * PR + boff);
+                u32x4 e;
+                e[0] = __builtin_amdgcn_perm(0u, w[0], 0x010C000Cu); e[1] = __builtin_amdgcn_perm(0u, w[0], 0x030C020Cu);
+                e[2] = __builtin_amdgcn_perm(0u, w[1], 0x010C000Cu); e[3] = __builtin_amdgcn_perm(0u, w[1], 0x030C020Cu);
+                bfr[bt] = real ? e : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int o2 = 0; o2 < 2; ++o2)
+#pragma unroll
+                for (int t = PREC - 1; t >= 0; --t) {
+                    const u32x4 af = *reinterpret_cast<const u32x4*>(cfr + ((size_t)((t * 6 + 2 * s + o2) * KS + ks) * 64 + lane) * 16);
+#pragma unroll
+                    for (int bt = 0; bt < BT; ++bt) accc[o2][bt] = mma<PREC>(af, bfr[bt], accc[o2][bt]);
+                }
+        }
+        // LeakyReLU (positively homogeneous: the scale CS rides through), split, Linear K-step of this unit
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = leaky(accc[j >> 2][bt][j & 3]);
+            u32x4 xh, xl;
+            split8<PREC>(v, xh, xl);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                if (PREC == 2) {
+                    accl[bt][mt] = mma<PREC>(la[mt][PREC - 1], xh, accl[bt][mt]);
+                    accl[bt][mt] = mma<PREC>(la[mt][0], xl, accl[bt][mt]);
+                }
+                accl[bt][mt] = mma<PREC>(la[mt][0], xh, accl[bt][mt]);
+            }
+        }
+    }
+    // ---- add the four waves' partial sums in a fixed order (deterministic), finish ------------------------------------------------
+    __syncthreads();                                                   // every wave is done with the planes: reuse them
+    f32x4* red = reinterpret_cast<f32x4*>(lds_raw);                    // [wave][bt][mt][lane]
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) red[((wave * BT + bt) * 2 + mt) * 64 + lane] = accl[bt][mt];
+    __syncthreads();
+    for (int it = tid; it < BT * 2 * 64; it += ENC_WAVES * 64) {
+        const int l = it & 63, mt = (it >> 6) & 1, bt = it >> 7;
+        f32x4 sum = red[((0 * BT + bt) * 2 + mt) * 64 + l];
+#pragma unroll
+        for (int w = 1; w < ENC_WAVES; ++w) sum += red[((w * BT + bt) * 2 + mt) * 64 + l];
+        const int row = row0 + bt * 16 + (l & 15), f0 = 16 * mt + 4 * (l >> 4);
+        if (row < a.rows) {
+            const int b = row / a.n, i = row - b * a.n;
+            const size_t orow = a.agent_major ? (size_t)i * (a.rows / a.n) + b : (size_t)row;
+            if (a.part) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = sum[r] * INV;
+                *reinterpret_cast<f32x4*>(a.part + ((size_t)band * a.rows + orow) * 32 + f0) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.out[orow * a.out_stride + f0 + r] = leaky(fmaf(sum[r], INV, a.lin_b[f0 + r]));
+            }
+        }
+    }
+}
+
+template <int V, int PREC>
+static int launch_encode_t(const EncK& k, hipStream_t s) {
+    using G = Geo<V>;
+    constexpr size_t lds = (size_t)ENC_BT * 16 * 3 * (G::R + 2) * G::CP + (size_t)PREC * 6 * SSD_ENCODE_KSTEPS(V) * 1024;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    if (!done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode<V, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        done[dev] = true;
+    }
+    const int groups = (k.rows + ENC_BT * 16 - 1) / (ENC_BT * 16);
+    hipLaunchKernelGGL((k_encode<V, PREC>), dim3(groups, G::NB), dim3(ENC_WAVES * 64), lds, s, k);
+    return 0;
+}
+
+int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s) {
+    EncK k;
+    k.codes = p->codes; k.code_bytes = (long)p->code_bytes; k.env_stride = (long)p->env_stride; k.slot_stride = (long)p->slot_stride;
+    k.agent_stride = (long)p->agent_stride; k.slot_t = p->slot_t; k.rows = p->rows; k.n = p->n_agents; k.agent_major = p->agent_major;
+    k.conv_frags = static_cast<const uint8_t*>(p->conv_frags); k.lin_frags = static_cast<const uint8_t*>(p->lin_frags);
+    k.conv_b = p->conv_b; k.lin_b = p->lin_b; k.out = p->out; k.out_stride = p->out_stride; k.part = p->part;
+    k.slot_t_copy = p->slot_t_copy; k.counter_inc = p->counter_inc;
+    const int prec = p->precision == 1 ? 1 : 2;
+    if (p->view_edge == 15) return prec == 2 ? launch_encode_t<15, 2>(k, s) : launch_encode_t<15, 1>(k, s);
+    if (p->view_edge == 31) return prec == 2 ? launch_encode_t<31, 2>(k, s) : launch_encode_t<31, 1>(k, s);
+    return -2;
+}
+
+// ---- pack: conv_w f32 [6, 3, 3, 3], lin_w f32 [32, 6 P] -> fragment images ------------------------------------------------------
+template <int V, int PREC>
+__global__ __launch_bounds__(256) void k_pack_encoder(const float* __restrict__ cw, const float* __restrict__ lw, uint8_t* conv_frags, uint8_t* lin_frags) {
+    using G = Geo<V>;
+    constexpr int O = G::O, NF = G::NF, XT = G::XT, KS = SSD_ENCODE_KSTEPS(V), P = O * O, UNITS = SSD_ENCODE_UNITS(V);
+    constexpr int NCONV = 6 * KS * 512, NLIN = UNITS * 2 * 512;
+    constexpr float CS = PREC == 2 ? ENC_CSCALE : 2.f, LS = PREC == 2 ? ENC_LSCALE : 1.f;   // PREC 1: the plane value is 0.5
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < NCONV) {
+        const int oc = e / (KS * 512), ks = (e >> 9) % KS, lane = (e >> 3) & 63, j = e & 7, q = lane >> 4, m = lane & 15;
+        const int F = 4 * ks + q;
+        float w = 0.f;
+        if (F < 9 * NF) {
+            const int dy = F / (3 * NF), ch = (F / NF) % 3, f = F % NF, d = 8 * f + j - m;
+            if (d >= 0 && d <= 2) w = (float)((double)cw[((oc * 3 + ch) * 3 + dy) * 3 + d] * (255.0 / 256.0) * (double)CS);
+        }
+        store_term<PREC>(conv_frags + ((size_t)(oc * KS + ks) * 64 + lane) * 16 + 2 * j, w, (size_t)6 * KS * 1024);
+    } else if (e < NCONV + NLIN) {
+        const int i = e - NCONV, mt = (i >> 9) & 1, u = i >> 10, lane = (i >> 3) & 63, j = i & 7, q = lane >> 4, m = lane & 15;
+        const int s = u % 3, xt = (u / 3) % XT, y = u / (3 * XT);
+        const int oc = 2 * s + (j >> 2), x = 16 * xt + 4 * q + (j & 3);
+        const float w = x < O ? lw[(size_t)(16 * mt + m) * (6 * P) + oc * P + y * O + x] * LS : 0.f;
+        store_term<PREC>(lin_frags + (((size_t)(u * 2 + mt) * PREC) * 64 + lane) * 16 + 2 * j, w, (size_t)64 * 16);
+    }
+}
+
+int launch_pack_encoder(const float* cw, const float* lw, int V, int prec, void* conv_frags, void* lin_frags, hipStream_t s) {
+    uint8_t *c = static_cast<uint8_t*>(conv_frags), *l = static_cast<uint8_t*>(lin_frags);
+#define SSD_PACK(V_, P_)                                                                                                     \
+    do {                                                                                                                     \
+        const int total = 6 * SSD_ENCODE_KSTEPS(V_) * 512 + SSD_ENCODE_UNITS(V_) * 2 * 512;                                  \
+        hipLaunchKernelGGL((k_pack_encoder<V_, P_>), dim3((total + 255) / 256), dim3(256), 0, s, cw, lw, c, l);              \
+    } while (0)
+    if (V == 15) { if (prec == 2) SSD_PACK(15, 2); else SSD_PACK(15, 1); return 0; }
+    if (V == 31) { if (prec == 2) SSD_PACK(31, 2); else SSD_PACK(31, 1); return 0; }
+#undef SSD_PACK
+    return -2;
+}
+
+}  // namespace ssd

@@ -86,8 +86,10 @@ class NativeEnv:
         t._keep = keep
         return t
 
-    def obs_buffers(self, fmt=abi.OBS_F32, want_state=False):
-        key = (fmt, want_state)
+    def obs_buffers(self, fmt=abi.OBS_F32, want_state=False, want_code=False):
+        """Persistent output buffers of an observation pass.  want_code (simplified colours, fmt != OBS_CODE): also the window as u8
+        class codes [n_env, n, V * V rounded up to 16] (ssd_obs_out.obs_code: what the rollout-time encoder reads)."""
+        key = (fmt, want_state, want_code)
         if key not in self._obs_bufs:
             N, n, V = self.n_env, self.n, self.V
             shape = (N, n, V, V) if fmt == abi.OBS_CODE else (N, n, 3, V, V)
@@ -96,6 +98,9 @@ class NativeEnv:
                      orient=torch.empty(N, n, 2, dtype=torch.float32, device=self.device))
             if want_state:
                 b["state"] = torch.empty(N, 3, self.H, self.W, dtype=torch.float32, device=self.device)
+            if want_code:
+                assert fmt != abi.OBS_CODE
+                b["code"] = torch.zeros(N, n, abi.code_agent_stride(V), dtype=torch.uint8, device=self.device)
             self._obs_bufs[key] = b
         return self._obs_bufs[key]
 
@@ -105,16 +110,24 @@ class NativeEnv:
         o.state, o.pos, o.orient = _ptr(bufs.get("state")), _ptr(bufs.get("pos")), _ptr(bufs.get("orient"))
         # obs placed inside an episode storage [n_env, t_slots, n, ...]: the env writes slot ep_step itself
         o.obs_env_stride, o.obs_slot_stride = int(bufs.get("obs_env_stride", 0)), int(bufs.get("obs_slot_stride", 0))
+        o.obs_t_slots = int(bufs.get("obs_t_slots", 0))
+        o.obs_code = _ptr(bufs.get("code"))
         return o
 
-    def storage_obs_buffers(self, storage, fmt=abi.OBS_F32):
+    def storage_obs_buffers(self, storage, fmt=abi.OBS_F32, want_code=False):
         """Output buffers whose `obs` is an episode storage [n_env, t_slots, n, 3, V, V] (dense inner dims): every observe /
-        step_observe writes the env's block at time slot ep_step (include/ssd_hip.h: ssd_obs_out.obs_env_stride)."""
+        step_observe writes the env's block at time slot ep_step (include/ssd_hip.h: ssd_obs_out.obs_env_stride); a call that would
+        land past the last slot writes nothing and raises error bit 16 (obs_t_slots).  want_code: plus the dense class-code side
+        buffer of obs_buffers."""
         N, n, V = self.n_env, self.n, self.V
         assert storage.shape[0] == N and tuple(storage.shape[2:]) == ((n, V, V) if fmt == abi.OBS_CODE else (n, 3, V, V))
         assert storage[0, 0].is_contiguous() and storage.dtype == _OBS_DTYPE[fmt] and storage.device == self.device
-        dense = self.obs_buffers(fmt)
-        return dict(obs=storage, pos=dense["pos"], orient=dense["orient"], obs_env_stride=storage.stride(0), obs_slot_stride=storage.stride(1))
+        dense = self.obs_buffers(fmt, want_code=want_code)
+        b = dict(obs=storage, pos=dense["pos"], orient=dense["orient"], obs_env_stride=storage.stride(0), obs_slot_stride=storage.stride(1),
+                 obs_t_slots=storage.shape[1])
+        if want_code:
+            b["code"] = dense["code"]
+        return b
 
     # ------------------------------------------------------------------------------------------------------
     def reset(self, tape=None, env_mask=None):

@@ -2,14 +2,17 @@
 
 Computes what HomophilyMAC.select_actions_env / select_actions_inc compute (homophily_controller.py:30-65 on top of
 homophily_agent.py:154-208) with agent-major activations [n, N, 64] and the weights re-packed once per episode:
-  * fused path (default; csrc/ssd_policy_fused.hip): k_encode (conv + Linear encoder, f32 MFMA, reads the observation where
-    the env kernel wrote it) and ONE launch per head -- k_head<env> (input tail + fc1 + GRU + dueling + epsilon-greedy) and
-    k_head<inc> (the same plus the per-pair term) -- which also file their results in the episode storage;
-  * per-layer path (fused=False, or window sizes without a fused encoder): every per-agent layer as one batched GEMM
+  * fused path (default; csrc/ssd_policy_mfma.hip): k_encode (conv + Linear encoder as banded GEMMs on the 16-bit matrix cores,
+    reading the u8 class codes the env kernel emits) and ONE launch per head -- k_head<env> (input tail + fc1 + GRU + dueling +
+    epsilon-greedy) and k_head<inc> (the same plus the per-pair term) -- which also file their results in the episode storage.
+    `precision` 2 (default): every f32 product as three f16 MFMA products of two-term splits (f32-equivalent, the reference's dtype);
+    1: single bf16 products (BASELINE.json's "bf16 Q-net" variant; rollout inference only, the learner stays fp32);
+  * per-layer path (fused=False, or window sizes / palettes without a fused encoder): every per-agent layer as one batched GEMM
     (hipBLASLt) between the small kernels of csrc/ssd_policy.hip; the incentive head's pairwise layer [h_i | other_j] @ W is
     split into h_i @ W_h + other_j @ W_o, so the [n, N * n, H + E] concatenation is never materialised.
 Both implement the shipped _build_inputs flag set (config/default.yaml:45-51).
-Action RNG: the package's counter generator (not torch's Philox); exploration draws are not parity-pinned.
+Action RNG: the package's counter generator (not torch's Philox) keyed by the GLOBAL env id (env_id_base + local env), so env
+shards draw what the unsharded job draws; exploration draws are not parity-pinned against torch.
 """
 import ctypes as C
 
@@ -20,20 +23,31 @@ from . import abi
 
 
 class FastPolicy:
-    def __init__(self, mac, n_env, avail_mask_u8, seed=0, actions_out=None, actions_inc_out=None, share_packs_from=None, fused=True):
+    def __init__(self, mac, n_env, avail_mask_u8, seed=0, actions_out=None, actions_inc_out=None, share_packs_from=None, fused=True,
+                 precision=2, env_id_base=0):
         self.mac, self.agent, self.a = mac, mac.agent, mac.args
         a = self.a
         assert a.rgb_input and a.conv_out == 6 and a.obs_dim_net == 32 and a.conv_kernel == 3 and a.conv_stride == 1
+        assert precision in (1, 2)
         self.lib = abi.load_library()
         self.N, self.n, self.H, self.A = n_env, mac.n_agents, a.rnn_hidden_dim, a.n_actions
         self.dev = next(self.agent.parameters()).device
         self.inp = mac.input_shape
+        self.V = int(a.obs_dims[0])
+        self.precision, self.env_id_base = int(precision), int(env_id_base) & 0xFFFFFFFF
         n, N, H = self.n, self.N, self.H
         f32 = dict(dtype=th.float32, device=self.dev)
-        # fused: one launch per head (csrc/ssd_policy_fused.hip), inputs padded to 64 columns; otherwise the per-layer
+        # fused: one launch per head (csrc/ssd_policy_mfma.hip), inputs padded to 64 columns; otherwise the per-layer
         # composition below (batched hipBLASLt GEMMs + the small kernels of csrc/ssd_policy.hip)
         self.fused = bool(fused) and H == 64 and self.inp + self.A <= 64 and self.A + 7 <= 16
+        # the fused encoder exists for 15 x 15 and 31 x 31 windows (view_size 7 / 15: the shipped configurations)
+        self.fused_enc = self.fused and self.V in (15, 31) and tuple(a.obs_dims) == (self.V, self.V)
+        self.bands = abi.encode_bands(self.V) if self.fused_enc else 1
+        # bf16 MFMA products an f32-equivalent product costs (bench.py's roofline accounting); conv: the planes are exact, 2
+        self.n_products = dict(encode_conv=2, encode_lin=3, head_env=3, head_inc=3) if precision == 2 else \
+            dict(encode_conv=1, encode_lin=1, head_env=1, head_inc=1)
         self.inputs = th.zeros(n, N, 64 if self.fused else self.inp, **f32)          # [feat | tail (| 0)], agent-major
+        self.feat_part = th.zeros(self.bands, n * N, 32, **f32) if self.bands > 1 else None
         self.h_env = th.zeros(n, N, H, **f32)
         self.h_inc = th.zeros(n, N, H, **f32)
         # outputs may be slices of a caller-owned full-batch buffer (env groups evaluated on separate streams)
@@ -53,10 +67,11 @@ class FastPolicy:
 
     @th.no_grad()
     def pack(self):
-        """Snapshot the (possibly just trained) weights into kernel-ready contiguous packs; values are copied in place so
-        that a captured graph keeps seeing the same addresses.  Fused path: the encoder weights and one LDS-layout weight
-        image per agent and head; per-layer path: GEMM-ready operands.  The ~30 small copies are themselves replayed as one
-        hipGraph from the third call on (parameters and packs live at fixed addresses; optimisers update in place)."""
+        """Snapshot the (possibly just trained) weights into kernel-ready packs; values are written in place so that a captured
+        graph keeps seeing the same addresses.  Fused path: the fragment images of the encoder and one image per agent and head,
+        built on the device by ssd_policy_pack_encoder / ssd_policy_pack_head (3 launches); per-layer path: GEMM-ready operands.
+        The launches are themselves replayed as one hipGraph from the third call on (parameters and packs live at fixed addresses;
+        the optimisers update in place)."""
         self._pack_calls = getattr(self, "_pack_calls", 0) + 1
         g = getattr(self, "_pack_graph", None)
         if g is not None:
@@ -77,11 +92,9 @@ class FastPolicy:
         ag, H, A = self.agent, self.H, self.A
         w, b = ag._w, ag._b
         lin = ag.conv_to_fc[3].weight
-        packs = dict(
-            cw=ag.conv_to_fc[0].weight, cb=ag.conv_to_fc[0].bias, lb=ag.conv_to_fc[3].bias, lw_t=lin.t(),
-            # Linear weight per conv channel, K zero-padded 169 -> 176 (ssd_policy_encode; include/ssd_hip.h)
-            lwp=F.pad(lin.reshape(32, 6, -1).permute(1, 0, 2), (0, (-lin.shape[1] // 6) % 16)),
-        )
+        packs = dict(cw=ag.conv_to_fc[0].weight, cb=ag.conv_to_fc[0].bias, lb=ag.conv_to_fc[3].bias)
+        if not self.fused_enc:
+            packs["lw_t"] = lin.t()
         if not self.fused:
             packs.update(
                 w1e=w("fc1_env_w"), b1e=b("fc1_env_b"),
@@ -95,44 +108,41 @@ class FastPolicy:
             packs["b2i"] = th.cat([b("fc2_inc_b"), b("fc2_inc_v_b")], dim=2).unsqueeze(2)  # [n, 1, 1, 4]
         if not hasattr(self, "p"):
             self.p = {k: v.detach().clone().contiguous() for k, v in packs.items()}
+            u8 = dict(dtype=th.uint8, device=self.dev)
             if self.fused:
-                for head in ("env", "inc"):      # zero once: the K / row padding of the image is never written again
-                    self.p["img_" + head] = th.zeros(self.n, abi.POLICY_IMAGE_FLOATS, dtype=th.float32, device=self.dev)
+                for head in ("env", "inc"):
+                    self.p["img_" + head] = th.zeros(self.n, abi.policy_image_bytes(self.precision), **u8)
+            if self.fused_enc:
+                cbytes, lbytes = abi.encode_frag_bytes(self.V, self.precision)
+                self.p["conv_frags"], self.p["lin_frags"] = th.zeros(cbytes, **u8), th.zeros(lbytes, **u8)
         else:
             for k, v in packs.items():
                 self.p[k].copy_(v)
+        st = self._stream()
         if self.fused:
-            self._image("env", self.p["img_env"])
-            self._image("inc", self.p["img_inc"])
+            for head in ("env", "inc"):
+                hp = self._head_params(head)
+                abi.check(self.lib, self.lib.ssd_policy_pack_head(C.byref(hp), self.precision, self.p["img_" + head].data_ptr(), st))
+        if self.fused_enc:
+            abi.check(self.lib, self.lib.ssd_policy_pack_encoder(ag.conv_to_fc[0].weight.data_ptr(), lin.data_ptr(), self.V, self.precision,
+                                                                 self.p["conv_frags"].data_ptr(), self.p["lin_frags"].data_ptr(), st))
 
-    def _image(self, head, img):
-        """Fill the per-agent weight image of the fused head kernel in place (layout: include/ssd_hip.h, ssd_policy_head)."""
-        ag, n, H = self.agent, self.n, self.H
-        w, b = ag._w, ag._b
-        W = img[:, :464 * 68].view(n, 464, 68)
-        w1 = w("fc1_%s_w" % head)                                                      # [n, in, 64]
-        W[:, 0:64, :w1.shape[1]] = w1.transpose(1, 2)
-        p = "rnn_%s_" % head
-        for gi_, gate in enumerate("rzn"):
-            W[:, 64 + 64 * gi_:128 + 64 * gi_, :H] = w(p + "i%s_w" % gate).transpose(1, 2)
-            W[:, 256 + 64 * gi_:320 + 64 * gi_, :H] = w(p + "h%s_w" % gate).transpose(1, 2)
-        B = img[:, 464 * 68:]
-        B[:, 0:64] = b("fc1_%s_b" % head)[:, 0]
-        for gi_, gate in enumerate("rzn"):
-            B[:, 64 + 64 * gi_:128 + 64 * gi_] = b(p + "i%s_b" % gate)[:, 0]
-            B[:, 256 + 64 * gi_:320 + 64 * gi_] = b(p + "h%s_b" % gate)[:, 0]
-        wa, wv = w("fc2_%s_w" % head), w("fc2_%s_v_w" % head)                          # env [n, 64, A], [n, 64, 1]; inc [n, 64 + E, 3], [.., 1]
-        k = wa.shape[2]
-        W[:, 448:448 + k, :H] = wa[:, :H].transpose(1, 2)
-        W[:, 448 + k, :H] = wv[:, :H, 0]
-        B[:, 448:448 + k] = b("fc2_%s_b" % head)[:, 0]
-        B[:, 448 + k] = b("fc2_%s_v_b" % head)[:, 0, 0]
-        if head == "inc":
-            E = wa.shape[1] - H
-            O = B[:, 464:464 + E * 4].view(n, E, 4)
-            O[:, :, :k] = wa[:, H:]
-            O[:, :, k] = wv[:, H:, 0]
-        return img
+    def _head_params(self, head):
+        """ssd_policy_head_params of one head: pointers to the reference-shaped parameters (homophily_agent.py:37-125)."""
+        ag = self.agent
+        g = lambda name: getattr(ag, name)
+        for t in (g("fc1_%s_w" % head), g("fc2_%s_w" % head)):
+            assert t.is_contiguous() and t.dtype == th.float32
+        hp = abi.SsdPolicyHeadParams()
+        hp.fc1_w, hp.fc1_b = g("fc1_%s_w" % head).data_ptr(), g("fc1_%s_b" % head).data_ptr()
+        for k, gate in enumerate("rzn"):
+            hp.w_i[k], hp.w_h[k] = g("rnn_%s_i%s_w" % (head, gate)).data_ptr(), g("rnn_%s_h%s_w" % (head, gate)).data_ptr()
+            hp.b_i[k], hp.b_h[k] = g("rnn_%s_i%s_b" % (head, gate)).data_ptr(), g("rnn_%s_h%s_b" % (head, gate)).data_ptr()
+        hp.fc2_w, hp.fc2_b = g("fc2_%s_w" % head).data_ptr(), g("fc2_%s_b" % head).data_ptr()
+        hp.fc2_v_w, hp.fc2_v_b = g("fc2_%s_v_w" % head).data_ptr(), g("fc2_%s_v_b" % head).data_ptr()
+        hp.n_agents, hp.fc1_in = self.n, g("fc1_%s_w" % head).shape[2]
+        hp.fc2_in, hp.fc2_out = g("fc2_%s_w" % head).shape[2], g("fc2_%s_w" % head).shape[3]
+        return hp
 
     def _head_args(self, inc, eps, step, q_out=None):
         a = abi.SsdPolicyHead()
@@ -144,6 +154,7 @@ class FastPolicy:
         a.weights = self.p["img_inc" if inc else "img_env"].data_ptr()
         a.epsilon, a.step = eps.data_ptr(), step.data_ptr()
         a.q_out = None if q_out is None else q_out.data_ptr()
+        a.precision, a.env_id_base = self.precision, self.env_id_base
         return a
 
     def reset(self):
@@ -151,53 +162,72 @@ class FastPolicy:
 
     # ---- env head -----------------------------------------------------------------------------------------------
     @th.no_grad()
-    def act_env(self, obs, prev_actions, prev_reward, prev_inc, pos, eps, step, store_obs=None, store_t=None, q_out=None,
-                orient=None, actions_i32=None, pos_copy=None, orient_copy=None, obs_in_storage=False, t_copy=None, counter_inc=None,
-                file=None):
-        """obs f32 [N, n, 3, V, V]; prev_* of the previous timestep (prev_actions = -1 at t = 0); pos f32 [N, n, 2];
-        eps f32 scalar tensor, step i64 [1] tensor.  Returns actions i64 [N, n] (static buffer).
-        store_obs / store_t: episode storage obs f32 [N, T+1, n, 3, V, V] and the device time index; the observation is copied
-        to store_obs[:, t] on the way -- or, with obs_in_storage (fused encoder only), it already IS there (the env wrote it,
-        NativeEnv.storage_obs_buffers) and `obs` is ignored.
-        Fused path only: actions_i32 also receives the actions as int32; pos_copy / orient_copy receive copies of pos / orient;
-        counter_inc: device i64 incremented by the encoder launch; file: dict of ssd_policy_head storage fields (pointers as ints)
-        with which the head files its results into the episode storage itself (include/ssd_hip.h).
-        = encode() followed by head_env()."""
-        self.encode(obs, store_obs=store_obs, store_t=store_t, obs_in_storage=obs_in_storage, t_copy=t_copy, counter_inc=counter_inc)
+    def act_env(self, obs, prev_actions, prev_reward, prev_inc, pos, eps, step, codes=None, slot_t=None, store_obs=None, store_t=None,
+                q_out=None, orient=None, actions_i32=None, pos_copy=None, orient_copy=None, t_copy=None, counter_inc=None, file=None):
+        """encode() followed by head_env(); returns actions i64 [N, n] (static buffer).  See the two methods for the arguments."""
+        self.encode(obs, codes=codes, slot_t=slot_t, store_obs=store_obs, store_t=store_t, t_copy=t_copy, counter_inc=counter_inc)
         return self.head_env(prev_actions, prev_reward, prev_inc, pos, eps, step, q_out=q_out, orient=orient, actions_i32=actions_i32,
                              pos_copy=pos_copy, orient_copy=orient_copy, file=file)
 
+    @staticmethod
+    def codes_from_obs(obs):
+        """u8 class codes [N, n, stride] (SSD_OBS_CODE alphabet; stride = V * V rounded up to 16) of a simplified-palette observation
+        f32 [N, n, 3, V, V]: waste = R -> 2, apple = G -> 1, wall / agent = B -> 3 (cleanup.py:93-105).  For callers that hold no
+        code buffer (tests); the runner takes the codes the env kernel emits (ssd_obs_out.obs_code)."""
+        N, n, _, V, _ = obs.shape
+        c = ((obs[:, :, 0] > 0) * 2 + (obs[:, :, 1] > 0) * 1 + (obs[:, :, 2] > 0) * 3).to(th.uint8).reshape(N, n, V * V)
+        return F.pad(c, (0, abi.code_agent_stride(V) - V * V)).contiguous()
+
     @th.no_grad()
-    def encode(self, obs, store_obs=None, store_t=None, obs_in_storage=False, t_copy=None, counter_inc=None):
-        """rgb_preprocess (homophily_agent.py:20-27,213-214) of the current observation into columns 0..31 of `inputs`."""
+    def encode(self, obs, codes=None, slot_t=None, store_obs=None, store_t=None, t_copy=None, counter_inc=None):
+        """rgb_preprocess (homophily_agent.py:20-27,213-214) of the current observation into columns 0..31 of `inputs` (31 x 31
+        windows: into the per-band partial sums that head_env finishes).
+        Fused encoder: reads u8 class codes -- `codes` [N, n, stride] (the env's obs_code side buffer) or, with slot_t (device time
+        index), an episode storage of codes u8 [N, T+1, n, V, V]; with codes = None they are derived from obs f32 [N, n, 3, V, V].
+        Per-layer path: obs f32.  store_obs / store_t: copy obs into store_obs[:, t] (callers whose env does not write the storage
+        itself).  t_copy receives *slot_t; counter_inc is incremented (device scalars for the kernels that follow)."""
         p, lib, n, N = self.p, self.lib, self.n, self.N
-        V = (store_obs if obs_in_storage else obs).shape[-1]
         st = self._stream()
+        if self.fused_enc:
+            V = self.V
+            if codes is None:
+                codes = self.codes_from_obs(obs)
+            assert codes.dtype == th.uint8 and codes.shape[0] == N
+            ea = abi.SsdPolicyEncodeArgs()
+            ea.codes = codes.data_ptr()
+            ea.code_bytes = codes.untyped_storage().nbytes() - codes.storage_offset()
+            if codes.dim() == 5:        # an episode storage [N, T+1, n, V, V], time slot *slot_t
+                assert slot_t is not None and codes[0, 0].is_contiguous()
+                ea.env_stride, ea.slot_stride, ea.agent_stride = codes.stride(0), codes.stride(1), V * V
+            else:                       # the dense side buffer [N, n, stride]
+                assert codes.dim() == 3 and codes[0].is_contiguous()
+                ea.env_stride, ea.slot_stride, ea.agent_stride = codes.stride(0), 0, codes.stride(1)
+            ea.slot_t = None if slot_t is None else slot_t.data_ptr()
+            ea.rows, ea.view_edge, ea.n_agents, ea.agent_major, ea.precision = N * n, V, n, 1, self.precision
+            ea.conv_frags, ea.lin_frags = p["conv_frags"].data_ptr(), p["lin_frags"].data_ptr()
+            ea.conv_b, ea.lin_b = p["cb"].data_ptr(), p["lb"].data_ptr()
+            if self.bands > 1:
+                ea.part = self.feat_part.data_ptr()
+            else:
+                ea.out, ea.out_stride = self.inputs.data_ptr(), self.inputs.shape[-1]
+            ea.slot_t_copy = None if t_copy is None else t_copy.data_ptr()
+            ea.counter_inc = None if counter_inc is None else counter_inc.data_ptr()
+            abi.check(lib, lib.ssd_policy_encode(C.byref(ea), st))
+            self._keep_codes = codes
+            if store_obs is not None and obs is not None:
+                store_obs.index_copy_(1, store_t, obs.unsqueeze(1))
+            return
+        V = obs.shape[-1]
         so = (None if store_obs is None else store_obs.data_ptr(), 0 if store_obs is None else store_obs.stride(0),
               None if store_t is None else store_t.data_ptr())
-        if self.fused and V == 15:      # conv + Linear in one launch (f32 MFMA), features straight into the input matrix
-            enc = (p["cw"].data_ptr(), p["cb"].data_ptr(), p["lwp"].data_ptr(), p["lb"].data_ptr(), self.inputs.data_ptr(),
-                   self.inputs.shape[-1], n, 1)
-            src = store_obs if obs_in_storage else obs
-            fmt = abi.OBS_CODE if src.dtype == th.uint8 else abi.OBS_F32       # u8 class codes [.., V, V]: compact storage
-            if obs_in_storage:
-                abi.check(lib, lib.ssd_policy_encode(store_obs.data_ptr(), fmt, N * n, V, *enc, store_obs.stride(0), store_obs.stride(1), so[2],
-                                                     None if t_copy is None else t_copy.data_ptr(),
-                                                     None if counter_inc is None else counter_inc.data_ptr(), st))
-            else:
-                abi.check(lib, lib.ssd_policy_encode(obs.data_ptr(), fmt, N * n, V, *enc, 0, 0, None, None, None if counter_inc is None else counter_inc.data_ptr(), st))
-                if store_obs is not None:
-                    store_obs.index_copy_(1, store_t, obs.unsqueeze(1))
-        else:
-            assert not obs_in_storage, "obs_in_storage needs the fused encoder (15 x 15 windows)"
-            K = 6 * (V - 2) * (V - 2)
-            if getattr(self, "_conv", None) is None or self._conv.shape[1] != K:
-                self._conv = th.empty(n * N, K, dtype=th.float32, device=self.dev)           # agent-major rows
-            abi.check(lib, lib.ssd_conv_leaky(obs.data_ptr(), N * n, V, 6, p["cw"].data_ptr(), p["cb"].data_ptr(), self._conv.data_ptr(), n, 1,
-                                              so[0], so[1], so[2], st))
-            feat = self.inputs.view(n * N, self.inputs.shape[-1])[:, :32]                    # Linear + LeakyReLU straight into the input matrix
-            th.addmm(p["lb"], self._conv, p["lw_t"], out=feat)
-            F.leaky_relu_(feat)
+        K = 6 * (V - 2) * (V - 2)
+        if getattr(self, "_conv", None) is None or self._conv.shape[1] != K:
+            self._conv = th.empty(n * N, K, dtype=th.float32, device=self.dev)           # agent-major rows
+        abi.check(lib, lib.ssd_conv_leaky(obs.data_ptr(), N * n, V, 6, p["cw"].data_ptr(), p["cb"].data_ptr(), self._conv.data_ptr(), n, 1,
+                                          so[0], so[1], so[2], st))
+        feat = self.inputs.view(n * N, self.inputs.shape[-1])[:, :32]                    # Linear + LeakyReLU straight into the input matrix
+        th.addmm(p["lb"], self._conv, p["lw_t"], out=feat)
+        F.leaky_relu_(feat)
 
     @th.no_grad()
     def head_env(self, prev_actions, prev_reward, prev_inc, pos, eps, step, q_out=None, orient=None, actions_i32=None, pos_copy=None,
@@ -215,6 +245,8 @@ class FastPolicy:
                 ha.out_actions_i32 = actions_i32.data_ptr()
             if pos_copy is not None:
                 ha.orient, ha.pos_copy, ha.orient_copy = orient.data_ptr(), pos_copy.data_ptr(), orient_copy.data_ptr()
+            if self.fused_enc and self.bands > 1:      # the encoder left per-band partial sums: the head finishes the features
+                ha.feat_part, ha.feat_bands, ha.lin_b = self.feat_part.data_ptr(), self.bands, p["lb"].data_ptr()
             for k, v in (file or {}).items():
                 setattr(ha, k, v)
             abi.check(lib, lib.ssd_policy_head_env(C.byref(ha), st))
@@ -227,7 +259,8 @@ class FastPolicy:
         abi.check(lib, lib.ssd_gru_gates(gi.data_ptr(), gh.data_ptr(), self.h_env.data_ptr(), n * N, H, st))
         av = th.baddbmm(p["b2e"], self.h_env, p["w2e"])                                # [n, N, A + 1]
         abi.check(lib, lib.ssd_dueling_pick(av.data_ptr(), n * N, self.A, self.avail.data_ptr(), eps.data_ptr(), step.data_ptr(),
-                                            self.seed, n, N, 0, self.actions.data_ptr(), None if q_out is None else q_out.data_ptr(), st))
+                                            self.seed, n, N, 0, self.actions.data_ptr(), None if q_out is None else q_out.data_ptr(),
+                                            self.env_id_base, st))
         self._keep = (x, gi, gh, av)
         return self.actions
 
@@ -258,7 +291,8 @@ class FastPolicy:
         opart = (other.reshape(N * n, -1) @ p["w2i_o"]).reshape(N, n, n, 4).permute(2, 0, 1, 3)   # [n(i), N, n(j), 4]
         av = (hpart.unsqueeze(2) + opart + p["b2i"]).contiguous()                        # [n(i), N, n(j), 4]
         abi.check(lib, lib.ssd_dueling_pick(av.data_ptr(), n * N * n, self.a.n_inc_actions, None, eps.data_ptr(), step.data_ptr(),
-                                            self.seed ^ 0x5bd1e995, n, N, 1, self.actions_inc.data_ptr(), None if q_out is None else q_out.data_ptr(), st))
+                                            self.seed ^ 0x5bd1e995, n, N, 1, self.actions_inc.data_ptr(), None if q_out is None else q_out.data_ptr(),
+                                            self.env_id_base, st))
         self._keep2 = (x, gi, gh, av)
         return self.actions_inc
 

@@ -50,7 +50,12 @@ class HipGraphRunner(HipVecRunner):
     def _allocate(self):
         a, N, n, T = self.args, self.batch_size, self.args.n_agents, self.episode_limit
         dev = self.env.device
-        self._dense_cur = self.env.native.obs_buffers(self.obs_fmt)     # obs / pos / orient written by the env kernel
+        simplified = self.env.native.cfg.obs_color == abi.COLOR_SIMPLIFIED
+        # the fused encoder reads u8 class codes: the env kernel emits them next to the f32 observation (format R storage) or the
+        # storage itself holds them (format C)
+        self._want_code = bool(getattr(a, "fast_policy", True) and getattr(a, "fused_policy", True) and simplified
+                               and self.obs_fmt != abi.OBS_CODE and self.env.native.V in (15, 31))
+        self._dense_cur = self.env.native.obs_buffers(self.obs_fmt, want_code=self._want_code)   # obs / pos / orient written by the env kernel
         self.cur = self._dense_cur
         self.t_dev = th.zeros(1, dtype=th.long, device=dev)
         self.rng_ctr = th.zeros(1, dtype=th.long, device=dev)          # never reset: exploration draws differ between episodes
@@ -80,13 +85,17 @@ class HipGraphRunner(HipVecRunner):
             self.actions_full = th.zeros(N, n, dtype=th.long, device=dev)
             self.actions_inc_full = th.zeros(N, n, n, dtype=th.long, device=dev)
             seed = int(self.env.native.cfg.seed) * 2654435761 + 12345
+            prec = 1 if str(getattr(a, "qnet_dtype", "fp32")).lower() in ("bf16", "bfloat16") else 2
+            base = int(self.env.native.cfg.env_id_base)
             self.fasts = []
             for g in range(G):
                 sl = slice(g * hsz, (g + 1) * hsz)
-                self.fasts.append(FastPolicy(self.mac, hsz, avail, seed=seed + 0x9E3779B1 * g, actions_out=self.actions_full[sl],
+                # one exploration seed for every group and rank: the draws are keyed by the GLOBAL env id (env_id_base + local env)
+                self.fasts.append(FastPolicy(self.mac, hsz, avail, seed=seed, actions_out=self.actions_full[sl],
                                              actions_inc_out=self.actions_inc_full[sl],
                                              share_packs_from=self.fasts[0] if g else None,
-                                             fused=bool(getattr(a, "fused_policy", True))))
+                                             fused=bool(getattr(a, "fused_policy", True)) and simplified, precision=prec,
+                                             env_id_base=base + g * hsz))
             self.fast = self.fasts[0]
             self.gslices = [slice(g * hsz, (g + 1) * hsz) for g in range(G)]
             self.side_streams = [th.cuda.Stream(device=dev) for _ in range(G)] if G > 1 else []
@@ -94,8 +103,8 @@ class HipGraphRunner(HipVecRunner):
             self.pos_t, self.orient_t = th.zeros(N, n, 2, device=dev), th.zeros(N, n, 2, device=dev)   # pose before the env step
             self.actions_i32 = th.zeros(N, n, dtype=th.int32, device=dev)
             self.t_store = th.zeros(1, dtype=th.long, device=dev)     # the encoder's copy of t_dev, read by the store-step launch
-            # fused encoder: the env kernel writes obs[:, t + 1] of the storage itself and the encoder reads it there (no obs copy)
-            self.direct_obs = self.fast.fused and self.env.native.V == 15 and self.obs_fmt in (abi.OBS_F32, abi.OBS_CODE)
+            # fused encoder: the env kernel writes obs[:, t + 1] of the storage itself (and the class codes the encoder reads)
+            self.direct_obs = self.fast.fused_enc and self.obs_fmt in (abi.OBS_F32, abi.OBS_CODE)
             self.fold_store = self.direct_obs and G == 1 and bool(getattr(a, "fold_store", True))
             if self.obs_fmt == abi.OBS_CODE and not self.direct_obs:
                 # class-code storage is consumed by the fused encoder only; other window sizes take the generic timestep
@@ -117,7 +126,7 @@ class HipGraphRunner(HipVecRunner):
             b = SimpleNamespace(graph=None, cur=self._dense_cur, ss=None, ss_last=None, file_env=None, file_inc=None, file_inc_last=None)
             if self.fast is not None:
                 if self.direct_obs:
-                    b.cur = self.env.native.storage_obs_buffers(st["obs"], self.obs_fmt)
+                    b.cur = self.env.native.storage_obs_buffers(st["obs"], self.obs_fmt, want_code=self._want_code)
                 b.ss, b.ss_last = self._make_store_args(True), self._make_store_args(False)
                 if self.fold_store:     # the two heads file their results in the storage themselves: no store-step launch
                     out, slots = self.env.native.out, self.episode_limit + 1
@@ -172,9 +181,12 @@ class HipGraphRunner(HipVecRunner):
 
         def encode(g):
             sl = self.gslices[g]
-            self.fasts[g].encode(None if self.direct_obs else obs[sl], store_obs=st["obs"][sl], store_t=td, obs_in_storage=self.direct_obs,
-                                 t_copy=self.t_store if (self.direct_obs and g == 0) else None,
-                                 counter_inc=self.rng_ctr if self.fold_store else None)
+            if self.direct_obs:     # the observation is already in the storage; the encoder reads its class codes
+                code_store = self.obs_fmt == abi.OBS_CODE
+                self.fasts[g].encode(None, codes=(st["obs"] if code_store else self.cur["code"])[sl], slot_t=td,
+                                     t_copy=self.t_store if g == 0 else None, counter_inc=self.rng_ctr if self.fold_store else None)
+            else:
+                self.fasts[g].encode(obs[sl], codes=self.cur["code"][sl] if "code" in self.cur else None, store_obs=st["obs"][sl], store_t=td)
 
         def env_head(g):
             sl = self.gslices[g]
@@ -338,6 +350,8 @@ class HipGraphRunner(HipVecRunner):
 
     @th.no_grad()
     def step_once(self):
+        if self.t >= self.episode_limit:
+            raise RuntimeError("step_once() past episode_limit: the episode storage has no slot left (finish_episode / begin_episode first)")
         if self._graph is not None:
             if self.t % self._graph_steps == 0:       # one replay advances _graph_steps timesteps
                 self._graph.replay()

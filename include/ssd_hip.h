@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSD_ABI_VERSION 1
+#define SSD_ABI_VERSION 2
 
 #define SSD_MAX_AGENTS 10   /* maps hold at most 10 spawn points; agent ids >= 10 break the reference (map_env.py:370) */
 #define SSD_MAX_CELLS 1024  /* H*W upper bound (largest reference map is 48x18 = 864) */
@@ -120,7 +120,16 @@ typedef struct ssd_obs_out {
      * b * obs_env_stride + ep_step * obs_slot_stride, ep_step being the env's step counter AFTER the call (0 after a reset).
      * Both 0 (default): dense [n_env, n, ...].  GPU library only. */
     int64_t obs_env_stride, obs_slot_stride;
+    /* obs_t_slots (0 = unchecked): number of time slots of that storage.  A call whose slot would be >= obs_t_slots (stepping an
+     * env past its episode storage) writes NO observation and raises the sticky bit 16 of ssd_poll_error. */
+    int32_t obs_t_slots;
+    /* obs_code (nullable; simplified colours; together with a f32 / bf16 / u8 `obs`): additionally emit the window as u8 cell
+     * classes (0 nothing, 1 apple, 2 waste, 3 wall-or-agent -- the SSD_OBS_CODE alphabet) into a dense side buffer
+     * u8 [n_env, n, obs_code_agent_stride], obs_code_agent_stride = V * V rounded up to 16, 16-byte aligned.  This is what the
+     * rollout-time encoder (ssd_policy_encode) consumes: 225 B instead of 2 700 B per agent-step at V = 15. */
+    uint8_t* obs_code;
 } ssd_obs_out;
+#define SSD_CODE_AGENT_STRIDE(V) ((((V) * (V)) + 15) & ~15)
 
 /* Raw env state for parity tests and KATs (Agent.set_pos etc. in the reference). */
 typedef struct ssd_state {
@@ -153,7 +162,8 @@ int ssd_step_observe(ssd_env* env, const int32_t* actions, const ssd_tape* tape,
                      ssd_obs_out* obs, void* stream);
 
 /* Sticky device-side error bits (1 action out of range = KeyError in action_map, agent.py:174-176,235-237;
- * 2 malformed tape; 4 agent_by_pos KeyError; 8 tape overrun).  Synchronises the device; clears the bits. */
+ * 2 malformed tape; 4 agent_by_pos KeyError; 8 tape overrun; 16 observation slot >= obs_t_slots).  Synchronises the device;
+ * clears the bits. */
 int ssd_poll_error(ssd_env* env, int32_t* bits);
 
 int ssd_export_state(ssd_env* env, ssd_state* dst, void* stream);
@@ -196,7 +206,8 @@ int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int
  *   value) followed by the epsilon-greedy choice of EpsilonGreedyActionSelector (action_selectors.py:44-68) with the available
  *   mask avail u8[n_actions] (NULL = all).  epsilon f32 and step i64 are device scalars; rows are agent-major (i, b) or, with
  *   pairs = 1, (i, b, j) with the diagonal i == j forced to 0 (homophily_controller.py:44-46); actions are written env-major
- *   [batch, n] / [batch, n, n].  q_out (nullable) receives q [rows, n_actions]. */
+ *   [batch, n] / [batch, n, n].  q_out (nullable) receives q [rows, n_actions].  The exploration draw of a row is keyed by
+ *   (seed, *step, (env_id_base + b) * n + i [, * n + j]): the GLOBAL env id, so env shards draw what the unsharded job draws. */
 int ssd_encoder(const float* obs, int32_t rows, int32_t view_edge, int32_t conv_out, int32_t feat_out, const float* conv_w,
                 const float* conv_b, const float* lin_w, const float* lin_b, float* out, int32_t out_stride, int32_t n_agents,
                 int32_t agent_major, float* store_obs, int64_t store_env_stride, const int64_t* store_t, void* stream);
@@ -242,7 +253,8 @@ int ssd_gru_gates_fwd(const float* gi, const float* gh, const float* h, float* h
 int ssd_gru_gates_bwd(const float* dh_new, const float* rzn, const float* gh, const float* h, float* d_gi, float* d_gh, float* dh_prev,
                       int32_t rows, int32_t hidden, void* stream);
 int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uint8_t* avail, const float* epsilon, const int64_t* step,
-                     uint32_t seed, int32_t n_agents, int32_t batch, int32_t pairs, int64_t* actions, float* q_out, void* stream);
+                     uint32_t seed, int32_t n_agents, int32_t batch, int32_t pairs, int64_t* actions, float* q_out, uint32_t env_id_base,
+                     void* stream);
 
 /* ---- the learner's recurrence over all T timesteps in one launch per direction (csrc/ssd_gru_seq.hip) -----------------------
  * The GRU cell of HomophilyAgent (homophily_agent.py:162-165,188-191) unrolled from a zero state as the learner does
@@ -256,32 +268,48 @@ int ssd_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs
 int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* d_wh_part,
                     float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream);
 
-/* ---- fused rollout-time controller step (csrc/ssd_policy_fused.hip) ------------------------------------------------------
- * One launch per head and timestep for what HomophilyMAC.select_actions_env / select_actions_inc evaluate
- * (homophily_controller.py:30-65, 127-184 on top of homophily_agent.py:154-208 and action_selectors.py:44-68):
- *   env head: input tail (one-hot last action, agent id, sign of last reward, sign of received incentives, pos / scale)
- *             -> fc1_env + LeakyReLU -> GRU cell -> dueling Q -> epsilon-greedy over the available actions
- *   inc head: [inputs | one-hot(action)] -> fc1_inc + LeakyReLU -> GRU cell -> per ordered pair (i -> j)
- *             [h_i | one-hot(a_j), pos_j / scale, orient_j, r_j, clean_j, apple_den_j] -> dueling Q -> epsilon-greedy, diagonal 0
- * The per-agent (unshared) matrices are applied with f32-input MFMA (exact f32); hidden = 64 and n_feat = 32 are fixed.
- * Activations are agent-major: inputs f32 [n, n_env, 64] (columns 0..31 = encoder output, written by ssd_policy_encode /
- * the caller; the env head fills columns 32..63: tail then zeros), h f32 [n, n_env, 64] updated in place.
- * weights: per agent one f32 image of SSD_POLICY_IMAGE_FLOATS floats (row stride 68, K padded to 64 with zeros):
- *   rows   0.. 63  fc1 weight transposed  [out 64][in]            (in = input_shape, or input_shape + n_actions for inc)
- *   rows  64..255  GRU input-side  weight transposed [3*64 (r, z, n)][64]
- *   rows 256..447  GRU hidden-side weight transposed [3*64 (r, z, n)][64]
- *   rows 448..463  fc2 transposed [16][64]: env: n_actions advantage rows then the value row; inc: the h part, 3 + 1 rows
- *   then biases fc1[64], gru_i[192], gru_h[192], fc2[16], then (inc) the pair part of fc2 [16 (extra features)][4].
- * Random numbers and the pick are those of ssd_dueling_pick (same seed / step / row indexing). q_out (nullable):
- * env f32 [n, n_env, n_actions]; inc f32 [n, n_env, n, 3]. */
-#define SSD_POLICY_IMAGE_FLOATS (464 * 68 + 464 + 64)
+/* ---- fused rollout-time controller step (csrc/ssd_policy_mfma.hip) -------------------------------------------------------
+ * What HomophilyMAC.select_actions_env / select_actions_inc evaluate (homophily_controller.py:30-65, 127-184 on top of
+ * homophily_agent.py:20-27,154-214 and action_selectors.py:44-68) as THREE launches per timestep:
+ *   ssd_policy_encode   rgb_preprocess: Conv2d(3, 6, 3) + LeakyReLU + Flatten + Linear(6 (V-2)^2, 32) [+ LeakyReLU]
+ *   ssd_policy_head_env input tail (one-hot last action, agent id, sign of last reward, sign of received incentives, pos / scale)
+ *                       -> fc1_env + LeakyReLU -> GRU cell -> dueling Q -> epsilon-greedy over the available actions
+ *   ssd_policy_head_inc [inputs | one-hot(action)] -> fc1_inc + LeakyReLU -> GRU cell -> per ordered pair (i -> j)
+ *                       [h_i | one-hot(a_j), pos_j / scale, orient_j, r_j, clean_j, apple_den_j] -> dueling Q -> epsilon-greedy, diagonal 0
+ * All matrix products run on the 16-bit matrix cores (v_mfma_f32_16x16x32_{f16,bf16}, f32 accumulate).  `precision`:
+ *   2  f32-equivalent (the default, the reference's dtype): every f32 operand is split into two f16 terms x = hi + lo (22
+ *      significand bits) and a product is evaluated as hi*hi + hi*lo + lo*hi -- three MFMAs; the one-hot observation planes are exact
+ *      in f16, so the conv needs two.  Weights and activations carry exact power-of-two scales that keep the lo terms in the normal
+ *      f16 range; measured deviation from the reference's f32 Q-values < 1e-5 (tests/test_policy_mfma.py).
+ *   1  bf16: single bf16 terms, one MFMA per product (the "bf16 Q-net" of BASELINE.json configs[1]; rollout inference only).
+ * hidden = 64, n_feat = 32, conv_out = 6 are fixed (config/default.yaml:44,59-63).
+ *
+ * Weights are passed as kernel-ready FRAGMENT IMAGES built on the device by ssd_policy_pack_* from the reference-shaped f32
+ * parameters (names and shapes of homophily_agent.py:37-125, [1, n, in, out] contiguous).  A fragment is the A operand of one
+ * MFMA: 64 lanes x 8 values, lane l = (q = l >> 4, m = l & 15) holding row m of a 16-row output tile at the 8 reduction indices of
+ * its quarter q -- 1 KiB, read by one ds_read_b128 / global_load_dwordx4 per lane.  All products are computed TRANSPOSED
+ * (D^T = W^T X^T: the weight is the A operand, 16 activation rows are the B operand), and the reduction index of step s, quarter q,
+ * element j is k = 32 s + 16 (j >> 2) + 4 q + (j & 3), which makes an MFMA result tile the B operand of the next product without
+ * any lane movement (fc1 -> GRU -> dueling chain in registers).
+ *
+ * Head image (per agent, SSD_POLICY_IMAGE_BYTES(precision) bytes, 16-byte aligned):
+ *   [term t < precision][fragment F < 58][lane][8 x 16 bit], then f32 biases fc1[64] gru_i[192] gru_h[192] fc2[16], then (inc) the
+ *   pair part of fc2 f32 [16 extra features][4].  Fragments: F = 2 ot + s: fc1 (4 output tiles); 8 + 2 ot + s: GRU input side
+ *   (12 tiles: r, z, n); 32 + 2 ot + s: GRU hidden side; 56 + s: fc2 (advantage rows, then the value row; inc: the h part).
+ * Activations are agent-major: inputs f32 [n, n_env, 64] (columns 0..31 = encoder output; the env head fills 32..63: tail then
+ * zeros), h f32 [n, n_env, 64] updated in place. q_out (nullable): env f32 [n, n_env, n_actions]; inc f32 [n, n_env, n, 3].
+ * Exploration draws: the package's counter generator keyed by (seed, *step, GLOBAL env id = env_id_base + env, agent[, j]) --
+ * a shard of a larger job draws what the unsharded job draws for the same envs (ssd_dueling_pick uses the same key). */
+#define SSD_POLICY_HEAD_FRAGS 58
+#define SSD_POLICY_HEAD_TAIL_FLOATS (464 + 64)
+#define SSD_POLICY_IMAGE_BYTES(precision) ((precision) * SSD_POLICY_HEAD_FRAGS * 1024 + SSD_POLICY_HEAD_TAIL_FLOATS * 4)
 typedef struct ssd_policy_head {
     int32_t n_env, n_agents, n_actions, input_shape;
     float pos_scale;
     uint32_t seed;
     float* inputs;                 /* [n, n_env, 64] */
     float* h;                      /* [n, n_env, 64] */
-    const float* weights;          /* [n, SSD_POLICY_IMAGE_FLOATS] */
+    const void* weights;           /* [n, SSD_POLICY_IMAGE_BYTES(precision)] from ssd_policy_pack_head */
     const uint8_t* avail;          /* env: u8 [n_actions] or NULL */
     const float* epsilon;          /* device scalar */
     const int64_t* step;           /* device scalar */
@@ -302,7 +330,8 @@ typedef struct ssd_policy_head {
     int32_t* out_actions_i32;
     float *pos_copy, *orient_copy;
     /* Optional: the head also files its results in the episode storage [n_env, t_slots, ...] at time slot *t_index (what
-     * ssd_store_step_launch does as a separate launch; every pointer nullable = skipped), and carries the runner state:
+     * ssd_store_step_launch does as a separate launch; every pointer nullable = skipped; nothing is filed when *t_index >= t_slots),
+     * and carries the runner state:
      *   env head: dst_actions, dst_actions_onehot, dst_pos, dst_orient (the current pose), prev_actions_out <- actions
      *   inc head: dst_actions_inc, prev_actions_inc_out <- actions_inc; dst_reward / dst_clean_num / dst_apple_den /
      *             dst_terminated <- this step's reward, clean_num, apple_den, terminated; prev_reward_out <- reward;
@@ -316,23 +345,73 @@ typedef struct ssd_policy_head {
     int64_t *prev_actions_out, *prev_actions_inc_out;
     float *prev_reward_out, *ep_return;
     int64_t* next_t_out;
+    /* ---- ABI 2 ---- */
+    int32_t precision;             /* 2 (f32-equivalent, default when 0) or 1 (bf16) -- must match the image */
+    uint32_t env_id_base;          /* global id of env 0 of this shard (exploration key) */
+    /* env head: the encoder's unfinished output (ssd_policy_encode with bands > 1): features = LeakyReLU(lin_b + sum over bands
+     * of feat_part[band][agent-major row][32]); written to inputs[:, 0..31] by this launch.  NULL: inputs[:, 0..31] are final. */
+    const float* feat_part;
+    int32_t feat_bands;
+    const float* lin_b;            /* [32] */
 } ssd_policy_head;
 int ssd_policy_head_env(const ssd_policy_head* args, void* stream);
 int ssd_policy_head_inc(const ssd_policy_head* args, void* stream);
-/* ssd_policy_encode: rgb_preprocess (homophily_agent.py:20-27,213-214) for 15 x 15 windows with the Linear layer on f32-input
- * MFMA.  The Linear weight f32 [32, 6 * 169] is passed re-packed per conv channel and zero padded: lin_w_packed f32 [6][32][176],
- * lin_w_packed[c][f][p] = lin_w[f][c * 169 + p] for p < 169, else 0.  out / out_stride / agent_major as in ssd_encoder.
- * obs_format: SSD_OBS_F32 (f32 [.., 3, V, V]) or SSD_OBS_CODE (u8 class codes [.., V, V] of the simplified palette, expanded to the
- * three colour planes on the way into LDS: compact episode storage, 12x fewer observation bytes).
- * The observation of row (env b, agent i) is read at obs + b * obs_env_stride + (*slot_t) * obs_slot_stride + i * 3VV (i * VV for codes):
- * obs_env_stride = 0 means dense [rows, 3, V, V]; with the strides of an episode storage [n_env, t_slots, n, 3, V, V] and the
- * device time index slot_t the encoder reads obs[:, t] where ssd_step_observe put it (ssd_obs_out.obs_env_stride).
+
+/* The reference-shaped parameters of one head (homophily_agent.py:37-125; every tensor [1, n, in, out] / [1, n, 1, out] f32,
+ * contiguous, device memory).  w_i / w_h / b_i / b_h in (r, z, n) order.  env: fc1_in = input_shape, fc2_in = 64, fc2_out = n_actions;
+ * inc: fc1_in = input_shape + n_actions, fc2_in = 64 + n_actions + 7, fc2_out = 3. */
+typedef struct ssd_policy_head_params {
+    const float *fc1_w, *fc1_b;
+    const float *w_i[3], *w_h[3], *b_i[3], *b_h[3];
+    const float *fc2_w, *fc2_b, *fc2_v_w, *fc2_v_b;
+    int32_t n_agents, fc1_in, fc2_in, fc2_out;
+} ssd_policy_head_params;
+/* image: [n, SSD_POLICY_IMAGE_BYTES(precision)] */
+int ssd_policy_pack_head(const ssd_policy_head_params* params, int32_t precision, void* image, void* stream);
+
+/* ssd_policy_encode: rgb_preprocess for 15 x 15 (view_size 7) and 31 x 31 (view_size 15) windows of the SIMPLIFIED palette.
+ * Input: u8 cell classes (SSD_OBS_CODE alphabet); the three colour planes are rebuilt in LDS as one-hot f16 bytes (exact), so the
+ * conv is a banded (Toeplitz) GEMM over 16 batch rows per MFMA and the whole encoder runs on the matrix cores:
+ *   conv   D[16 positions of an output row][16 batch rows] += A[positions][(dy, ch, 8 cells)] x B[(dy, ch, 8 cells)][batch rows]
+ *          A = Toeplitz image of the 3 x 3 taps (ssd_policy_pack_encoder), B = plane bytes read from LDS (ds_read_b64 + 4 v_perm)
+ *   Linear the conv result tiles of an output-channel pair ARE the B operand of the Linear product (no transposition, no LDS)
+ * The class of row (env b, agent i) cell c is read at codes[b * env_stride + (*slot_t) * slot_stride + i * agent_stride + c]
+ * (slot_t NULL: slot 0): the dense side buffer of ssd_obs_out.obs_code (env_stride = n * agent_stride, slot_stride = 0) or an
+ * episode storage of class codes u8 [n_env, t_slots, n, V, V] (agent_stride = V * V).  code_bytes = readable bytes behind `codes`;
+ * the kernel reads whole aligned 4-byte words, never one that holds no byte of [codes, codes + code_bytes).
+ * Output rows are agent-major (i * n_env + b) when agent_major, else (b * n + i).
+ *   V = 15: one launch computes the whole Linear sum; out[row * out_stride + 0..31] = LeakyReLU(. + lin_b)   (part = NULL)
+ *   V = 31: the 29 output rows are cut into SSD_ENCODE_BANDS(31) = 6 bands evaluated by different workgroups; band k writes its
+ *           partial Linear sum to part[k][row][32] and the consumer (ssd_policy_head_env: feat_part / feat_bands / lin_b) adds
+ *           them in band order, adds the bias and applies the LeakyReLU (out = NULL).
  * slot_t_copy (nullable) receives *slot_t: a second copy of the time index for the kernels that file results and advance slot_t
  * (ssd_policy_head.t_index / next_t_out, ssd_store_step_launch).  counter_inc (nullable): *counter_inc += 1 (the exploration-draw
- * counter read by the heads that follow; this kernel does not read it). */
-int ssd_policy_encode(const void* obs, int32_t obs_format, int32_t rows, int32_t view_edge, const float* conv_w, const float* conv_b, const float* lin_w_packed,
-                      const float* lin_b, float* out, int32_t out_stride, int32_t n_agents, int32_t agent_major, int64_t obs_env_stride,
-                      int64_t obs_slot_stride, const int64_t* slot_t, int64_t* slot_t_copy, int64_t* counter_inc, void* stream);
+ * counter read by the heads that follow; this kernel does not read it).
+ * Fragment images (ssd_policy_pack_encoder from conv_w f32 [6, 3, 3, 3] and lin_w f32 [32, 6 (V-2)^2]):
+ *   conv_frags [term][oc 6][K-step][lane][8]: element (q, m, j) of K-step ks = tap weight w[oc][ch][dy][d] * 255/256 for fragment
+ *              F = 4 ks + q = (dy * 3 + ch) * NF + f, cell 8 f + j, d = cell - m in 0..2, else 0   (NF = 2 / 3 fragments per plane row)
+ *   lin_frags  [unit = ((y * XT + xt) * 3 + s)][output tile 2][term][lane][8]: element (q, m, j) = lin_w[16 Mt + m][oc * P + y * O + x],
+ *              oc = 2 s + (j >> 2), x = 16 xt + 4 q + (j & 3), 0 where x >= O   (XT = 1 / 2 position tiles per output row) */
+#define SSD_ENCODE_BANDS(V) ((V) == 31 ? 6 : 1)
+#define SSD_ENCODE_KSTEPS(V) ((V) == 31 ? 7 : 5)
+#define SSD_ENCODE_UNITS(V) ((V) == 31 ? 29 * 2 * 3 : 13 * 1 * 3)
+#define SSD_ENCODE_CONV_FRAG_BYTES(V, precision) ((precision) * 6 * SSD_ENCODE_KSTEPS(V) * 1024)
+#define SSD_ENCODE_LIN_FRAG_BYTES(V, precision) (SSD_ENCODE_UNITS(V) * 2 * (precision) * 1024)
+typedef struct ssd_policy_encode_args {
+    const uint8_t* codes;
+    int64_t code_bytes, env_stride, slot_stride, agent_stride;
+    const int64_t* slot_t;
+    int32_t rows, view_edge, n_agents, agent_major, precision;
+    const void *conv_frags, *lin_frags;
+    const float *conv_b, *lin_b;
+    float* out; int32_t out_stride;
+    float* part;
+    int64_t* slot_t_copy;
+    int64_t* counter_inc;
+} ssd_policy_encode_args;
+int ssd_policy_encode(const ssd_policy_encode_args* args, void* stream);
+int ssd_policy_pack_encoder(const float* conv_w, const float* lin_w, int32_t view_edge, int32_t precision, void* conv_frags,
+                            void* lin_frags, void* stream);
 
 /* ---- COUNTER-mode generator (shared definition) ---------------------------------------------
  * Two levels, so that the expensive part is computed once per EPISODE (by the reset call) and kept in the env state:

@@ -202,78 +202,6 @@ def test_stepwise_forward_equals_time_batched_unroll():
             assert (a - q_env[:, t]).abs().max() < 1e-5 and (b - q_inc[:, t]).abs().max() < 1e-5, t
 
 
-@pytest.mark.parametrize("fused,N,kind,n", [(False, 192, "cleanup", 5), (True, 192, "cleanup", 5), (True, 203, "cleanup", 5), (True, 9, "cleanup", 5),
-                                             (True, 4096, "cleanup", 5), (True, 3300, "cleanup", 5), (True, 203, "harvest", 5),
-                                             (True, 203, "cleanup", 10), (False, 64, "harvest", 10)])
-def test_fast_policy_matches_torch_controller(fused, N, kind, n):
-    """FastPolicy against the torch controller on the same inputs: features, hidden states, Q values and greedy actions.
-    fused = one MFMA launch per head (ssd_policy_head_env / _inc), else HIP encoder / GRU gates / dueling-pick kernels around
-    agent-major GEMMs.  N = 203, 9: ragged last 16-row tile; N = 4096, 3300: workgroups that walk 4-6 tiles (more tiles than
-    CUs per agent), 3300 ragged.  Harvest has 8 actions, n = 10 fills the 64 input columns of the inc head exactly."""
-    from homophily_marl_amd.fast_policy import FastPolicy
-    from homophily_marl_amd.run import load_config, setup
-    th.manual_seed(1)
-    cfg = load_config(kind, overrides=dict(runner="hip_vec", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False,
-                                            store_state=False,
-                                            env_args=dict(num_agents=n, map="default10" if (kind == "harvest" or n == 10) else "default5",
-                                                          episode_limit=20, seed=3),
-                                            use_cuda=True, save_model=False, runner_stats=False))
-    ctx = setup(cfg)
-    mac, env = ctx.mac, ctx.runner.env
-    A = mac.args.n_actions
-    env.reset_batch()
-    g = th.Generator(device="cuda").manual_seed(0)
-    ok_actions = th.nonzero(env.avail_actions_batch[0, 0]).squeeze(-1).to(th.int32)
-    for _ in range(6):      # a few random steps so the observations are not the reset image
-        env.step_batch(ok_actions[th.randint(0, ok_actions.numel(), (N, n), generator=g, device="cuda")].contiguous(), observe=False)
-    o = env.observe_batch()
-    obs, pos, orient = o["obs"].clone(), o["pos"].clone(), o["orient"].clone()
-    prev_a = th.randint(-1, A, (N, n), generator=g, device="cuda")
-    prev_r = th.randint(-1, 2, (N, n), generator=g, device="cuda").float()
-    prev_i = th.randint(0, 3, (N, n, n), generator=g, device="cuda")
-    h0e = th.randn(N, n, 1, 64, generator=g, device="cuda") * 0.3
-    h0i = th.randn(N, n, 1, 64, generator=g, device="cuda") * 0.3
-    avail = env.avail_actions_batch[0, 0]
-    fp = FastPolicy(mac, N, avail, seed=7, fused=fused)
-    assert fp.fused == fused
-    qe, qi = th.zeros(n, N, A, device="cuda"), th.zeros(n, N, n, 3, device="cuda")
-    fp.h_env.copy_(h0e.squeeze(2).transpose(0, 1)); fp.h_inc.copy_(h0i.squeeze(2).transpose(0, 1))
-    eps, step = th.zeros((), device="cuda"), th.zeros(1, dtype=th.long, device="cuda")
-    with th.no_grad():
-        feat = mac.encode_obs(obs)
-        safe_prev = prev_a.clamp(min=0)
-        inputs = mac.assemble_inputs(feat, prev_a, prev_r, prev_i, pos, False)
-        q_env, h_env, _ = mac.agent.forward_env(inputs, h0e)
-        act = fp.act_env(obs, prev_a, prev_r, prev_i, pos, eps, step, q_out=qe).clone()
-        assert (fp.inputs[..., :mac.input_shape].transpose(0, 1).reshape(N * n, -1) - inputs).abs().max() < 2e-5
-        assert (fp.inputs[..., mac.input_shape:] == 0).all()
-        assert (qe.transpose(0, 1) - q_env).abs().max() < 5e-5
-        assert (fp.h_env.transpose(0, 1) - h_env.squeeze(2)).abs().max() < 2e-5
-        ref_act = q_env.masked_fill(avail.view(1, 1, -1) == 0, -float("inf")).argmax(-1)
-        assert (act == ref_act).float().mean() > 0.999
-        reward = th.randint(-1, 2, (N, n), generator=g, device="cuda").float()
-        clean = th.randint(0, 3, (N, n), generator=g, device="cuda").float()
-        den = th.rand(N, n, generator=g, device="cuda")
-        q_inc, h_inc, _ = mac.agent.forward_inc(inputs, h0i, th.nn.functional.one_hot(ref_act, A), pos / mac.pos_scale, orient,
-                                                reward.unsqueeze(-1), clean.unsqueeze(-1), den.unsqueeze(-1))
-        ainc = fp.act_inc(ref_act, pos, orient, reward, clean, den, eps, step, q_out=qi).clone()
-        assert (qi.transpose(0, 1) - q_inc).abs().max() < 5e-5
-        assert (fp.h_inc.transpose(0, 1) - h_inc.squeeze(2)).abs().max() < 2e-5
-        ref_inc = q_inc.argmax(-1) * (1 - th.eye(n, device="cuda", dtype=th.long))
-        assert (ainc == ref_inc).float().mean() > 0.999
-        assert (ainc.diagonal(dim1=1, dim2=2) == 0).all()
-        # exploration: with eps = 1 every action is random, available, and the inc diagonal stays 0
-        eps.fill_(1.0)
-        cnt = th.zeros(A, device="cuda")
-        for s in range(20):
-            step.fill_(s)
-            a = fp.act_env(obs, prev_a, prev_r, prev_i, pos, eps, step)
-            cnt += th.bincount(a.reshape(-1), minlength=A).float()
-        on = avail.bool()
-        assert cnt[~on].sum() == 0 and (cnt[on] / cnt.sum() - 1 / on.sum()).abs().max() < (0.02 if N >= 192 else 0.06)
-    env.close()
-
-
 @pytest.mark.parametrize("groups,kind,n,view,storage", [(1, "cleanup", 5, 7, "f32"), (2, "cleanup", 5, 7, "f32"), (1, "harvest", 5, 7, "f32"),
                                                           (1, "cleanup", 10, 7, "f32"), (1, "harvest", 5, 15, "f32"),
                                                           (1, "cleanup", 5, 7, "code"), (2, "harvest", 5, 15, "code")])
@@ -291,13 +219,15 @@ def test_fast_graph_runner_stores_a_consistent_batch(groups, kind, n, view, stor
         policy_groups=groups, obs_storage=storage))
     ctx = setup(cfg)
     ofmt = abi.OBS_CODE if storage == "code" else abi.OBS_F32            # compact storage: u8 class codes instead of f32 planes
-    assert ctx.runner.env.native.V == 2 * view + 1       # 31 x 31 windows: per-layer encoder + store-step launch instead of the fused path
+    assert ctx.runner.env.native.V == 2 * view + 1
     orc = OracleEnv(kind, map=mp, num_agents=n, n_env=N, view_size=view, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=21)
     ok_actions = th.nonzero(ctx.runner.env.avail_actions_batch[0, 0]).squeeze(-1).cpu().numpy()
     for ep in range(3):                                  # eager, captured, replayed
         batch = ctx.runner.run(test_mode=False)
-        generic = storage == "code" and view != 7     # class codes without the fused 15 x 15 encoder: the torch controller expands them
-        assert (ctx.runner.fast is None) == generic and (ep == 0 or ctx.runner._graph is not None)
+        # 15 x 15 and 31 x 31 windows both take the fused matrix-core encoder (it reads class codes: the env's side buffer under
+        # f32 storage, the storage itself under code storage) and the heads file the small fields: 4 launches per timestep
+        assert ctx.runner.fast is not None and ctx.runner.fast.fused_enc and ctx.runner.fold_store == (groups == 1)
+        assert ep == 0 or ctx.runner._graph is not None
         orc.reset()
         acts = batch["actions"].squeeze(-1).cpu().numpy()
         for t in range(T):
@@ -392,37 +322,3 @@ def test_graph_runner_with_non_shipped_input_flags():
         assert int(batch["filled"].sum()) == N * (T + 1)
     train_iteration(ctx, 0)
     ctx.runner.close_env()
-
-
-def test_encoder_on_class_codes_equals_encoder_on_f32_planes():
-    """ssd_policy_encode with SSD_OBS_CODE input (compact storage) expands the codes to exactly the f32 planes the env would have
-    written: identical features, bit for bit; also through an episode-storage layout with a device time index."""
-    from homophily_marl_amd.fast_policy import FastPolicy
-    from homophily_marl_amd.run import load_config, setup
-    N, n = 203, 5
-    th.manual_seed(2)
-    cfg = load_config("cleanup", overrides=dict(runner="hip_vec", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False,
-                                                 store_state=False, env_args=dict(num_agents=n, map="default5", episode_limit=20, seed=4),
-                                                 use_cuda=True, save_model=False, runner_stats=False))
-    ctx = setup(cfg)
-    env, fp = ctx.runner.env, FastPolicy(ctx.mac, N, ctx.runner.env.avail_actions_batch[0, 0], seed=1, fused=True)
-    env.reset_batch()
-    g = th.Generator(device="cuda").manual_seed(0)
-    for _ in range(7):
-        env.step_batch(th.randint(0, 5, (N, n), generator=g, device="cuda", dtype=th.int32), observe=False)
-    f32 = env.observe_batch(abi.OBS_F32)["obs"].clone()
-    codes = env.observe_batch(abi.OBS_CODE)["obs"].clone()
-    assert th.equal(ctx.mac.expand_codes(codes), f32)
-    lib, p, st = fp.lib, fp.p, th.cuda.current_stream().cuda_stream
-    enc = (p["cw"].data_ptr(), p["cb"].data_ptr(), p["lwp"].data_ptr(), p["lb"].data_ptr())
-    out = [th.zeros(n, N, 64, device="cuda") for _ in range(3)]
-    abi.check(lib, lib.ssd_policy_encode(f32.data_ptr(), abi.OBS_F32, N * n, 15, *enc, out[0].data_ptr(), 64, n, 1, 0, 0, None, None, None, st))
-    abi.check(lib, lib.ssd_policy_encode(codes.data_ptr(), abi.OBS_CODE, N * n, 15, *enc, out[1].data_ptr(), 64, n, 1, 0, 0, None, None, None, st))
-    storage = th.zeros(N, 4, n, 15, 15, dtype=th.uint8, device="cuda")
-    storage[:, 2] = codes
-    t = th.full((1,), 2, dtype=th.long, device="cuda")
-    abi.check(lib, lib.ssd_policy_encode(storage.data_ptr(), abi.OBS_CODE, N * n, 15, *enc, out[2].data_ptr(), 64, n, 1, storage.stride(0),
-                                         storage.stride(1), t.data_ptr(), None, None, st))
-    th.cuda.synchronize()
-    assert out[0][..., :32].abs().sum() > 0 and th.equal(out[0], out[1]) and th.equal(out[0], out[2])
-    env.close()
