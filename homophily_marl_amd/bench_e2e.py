@@ -38,7 +38,7 @@ def controller_flops(c, inp):
     n, A, V = c["n_agents"], c["n_actions"], 2 * c["view_size"] + 1
     P = (V - 2) * (V - 2)
     E = A + 7
-    return dict(encode=2 * (27 * 6 * P + 6 * P * 32),
+    return dict(encode_conv=2 * 27 * 6 * P, encode_lin=2 * 6 * P * 32,
                 head_env=2 * (inp * 64 + 6 * 64 * 64 + 64 * (A + 1)),
                 head_inc=2 * ((inp + A) * 64 + 6 * 64 * 64 + n * (64 + E) * 4))
 
@@ -137,13 +137,16 @@ def run_e2e(args, c, rank, world, local_rank):
             if key == "env":
                 continue
             avg, med = _event_time(fn, 50)
-            k = dict(name=name, avg_us=avg, median_us=med, bound="mfma", flops_per_launch=fl[key] * N * n)
+            parts = ["encode_conv", "encode_lin"] if key == "encode" else [key]
+            alg = sum(fl[p] for p in parts) * N * n
+            k = dict(name=name, avg_us=avg, median_us=med, bound="mfma", flops_per_launch=alg)
             if nprod:
-                # the products are evaluated as `nprod` bf16 MFMA products each (f32 = hi + mid + lo bf16 terms): count the bf16
-                # work the f32-equivalent result needs against the dense bf16 MFMA peak
-                k.update(flops_per_launch=fl[key] * N * n * nprod[key], peak_tf=MFMA_BF16_PEAK_TF,
-                         mfma_dtype="bf16 x%d split products, f32 accumulate (f32-equivalent)" % nprod[key] if nprod[key] > 1 else "bf16, f32 accumulate",
-                         note="algorithmic f32 FLOPs %d x %d bf16 products each" % (fl[key] * N * n, nprod[key]))
+                # precision 2: an f32 product is evaluated as 3 f16 MFMA products of two-term splits (the one-hot conv planes are
+                # exact: 2) -- count the 16-bit MFMA work the f32-equivalent result needs against the dense 16-bit MFMA peak
+                issued = sum(fl[p] * nprod[p] for p in parts) * N * n
+                k.update(flops_per_launch=issued, peak_tf=MFMA_BF16_PEAK_TF,
+                         mfma_dtype=("f16 two-term splits, f32 accumulate (f32-equivalent)" if max(nprod.values()) > 1 else "bf16, f32 accumulate"),
+                         note="algorithmic f32 FLOPs %d; 16-bit MFMA products per f32 product: %s" % (alg, {p: nprod[p] for p in parts}))
             kernels.append(k)
     env = runner.env
     avail = th.nonzero(env.avail_actions_batch[0, 0]).squeeze(-1).to(th.int32)

@@ -289,6 +289,7 @@ int ssd_step_observe(ssd_env* E, const int32_t* actions, const ssd_tape* tape, s
 #ifdef SSD_STAMPS
 // diagnostic build only: device buffer [n_env, 16] of u64 receiving the phase stamps
 int ssd_debug_set_stamps(ssd_env* E, unsigned long long* buf) { E->st.stamps = buf; return SSD_OK; }
+int ssd_debug_set_policy_stamps(unsigned long long* buf) { ssd::set_policy_stamps(buf); return SSD_OK; }
 #endif
 
 int ssd_poll_error(ssd_env* E, int32_t* bits) {
@@ -474,7 +475,8 @@ static int policy_head(const ssd_policy_head* a, int inc, void* stream) {
     if ((reinterpret_cast<uintptr_t>(a->inputs) | reinterpret_cast<uintptr_t>(a->h) | reinterpret_cast<uintptr_t>(a->weights)) & 15)
         return fail(SSD_ERR_INVALID, "inputs / h / weights must be 16-byte aligned");
     const int rc = launch_policy_head(a, inc, (hipStream_t)stream);
-    if (rc) return fail(SSD_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS) failed");
+    if (rc == -3) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_head is instantiated for n_actions 9 (Cleanup) and 8 (Harvest)");
+    if (rc) return fail(SSD_ERR_DEVICE, "ssd_policy_head: launch / hipFuncSetAttribute(max dynamic LDS) failed");
     return launched();
 }
 int ssd_policy_head_env(const ssd_policy_head* a, void* stream) { return policy_head(a, 0, stream); }

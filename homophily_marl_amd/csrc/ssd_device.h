@@ -134,6 +134,9 @@ void launch_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float
 void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* d_wh_part,
                         float* d_bh_part, int T, int G, int B, hipStream_t s);
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s);
+#ifdef SSD_STAMPS
+void set_policy_stamps(unsigned long long* buf);
+#endif
 void launch_dueling_pick(const float* av, int R, int A, const uint8_t* avail, const float* eps, const int64_t* step, uint32_t seed,
                          int n_agents, int B, int pairs, int64_t* actions, float* q_out, uint32_t env_id_base, hipStream_t s);
 

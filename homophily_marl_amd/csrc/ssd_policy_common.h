@@ -13,28 +13,52 @@ __device__ __forceinline__ uint32_t mix32p(uint32_t x) {
 
 // Dueling head + epsilon-greedy on one row: a[0..A) advantages, v the state value (homophily_agent.py:168-170;
 // action_selectors.py:44-68).  The exploration draws are keyed by (seed, step, r).  Returns the action; q (nullable) gets Q.
-__device__ __forceinline__ int dueling_pick_row(const float* a, float v, int A, const uint8_t* avail, float eps, uint32_t step,
-                                                uint32_t seed, uint32_t r, float* q_out) {
+// avail_bits: bit k set = action k available (all ones: no mask).  AT > 0: compile-time action count (the loops unroll and `a`
+// stays in registers); AT = 0: runtime A.
+template <int AT = 0>
+__device__ __forceinline__ int dueling_pick_bits(const float* a, float v, int A_rt, uint32_t avail_bits, float eps, uint32_t step,
+                                                 uint32_t seed, uint32_t r, float* q_out) {
+    const int A = AT ? AT : A_rt;
     float mean = 0.f;
+#pragma unroll
     for (int k = 0; k < A; ++k) mean += a[k];
     mean /= (float)A;
-    int best = 0, navail = 0;
+    int best = 0;
     float bq = -INFINITY;
+#pragma unroll
     for (int k = 0; k < A; ++k) {
         const float q = v + a[k] - mean;
         if (q_out) q_out[k] = q;
-        const bool ok = !avail || avail[k];
-        navail += ok;
+        const bool ok = (avail_bits >> k) & 1u;
         if (ok && q > bq) { bq = q; best = k; }          // first maximum, like torch.max / argmax
     }
+    const uint32_t live = avail_bits & (A >= 32 ? 0xFFFFFFFFu : (1u << A) - 1u);
     const uint32_t x0 = mix32p(seed ^ mix32p(step * 0x9E3779B9u + r));
     const uint32_t x1 = mix32p(x0 ^ 0x85EBCA6Bu);
     int act = best;
     if ((float)(x0 >> 8) * (1.0f / 16777216.0f) < eps) {
-        int pick = (int)(((uint64_t)x1 * (uint32_t)navail) >> 32);   // uniform over the available actions
-        for (int k = 0; k < A; ++k) { const bool ok = !avail || avail[k]; if (ok) { if (pick == 0) { act = k; break; } --pick; } }
+        int pick = (int)(((uint64_t)x1 * (uint32_t)__builtin_popcount(live)) >> 32);   // uniform over the available actions
+        uint32_t mset = live;
+        for (; pick > 0; --pick) mset &= mset - 1u;      // drop the `pick` lowest available actions
+        act = mset ? __builtin_ctz(mset) : best;
     }
     return act;
+}
+__device__ __forceinline__ uint32_t avail_to_bits(const uint8_t* avail, int A) {
+    uint32_t bits = 0xFFFFFFFFu;
+    if (avail) {   // 16 independent byte loads (clamped index: no branch, nothing read past the array), one wait
+        uint8_t v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = avail[k < A ? k : A - 1];
+        bits = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bits |= ((k < A && v[k]) ? 1u : 0u) << k;
+    }
+    return bits;
+}
+__device__ __forceinline__ int dueling_pick_row(const float* a, float v, int A, const uint8_t* avail, float eps, uint32_t step,
+                                                uint32_t seed, uint32_t r, float* q_out) {
+    return dueling_pick_bits<0>(a, v, A, avail_to_bits(avail, A), eps, step, seed, r, q_out);
 }
 
 }  // namespace ssd

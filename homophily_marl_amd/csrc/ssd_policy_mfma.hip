@@ -59,6 +59,20 @@ template <int PREC> __device__ __forceinline__ void store_term(uint8_t* dst, flo
     }
 }
 
+// Diagnostic build (-DSSD_STAMPS, tools/pstamps.py): per-wave s_memtime stamps of the kernel phases, [workgroup * waves + wave][16]
+// u64, into a buffer registered with ssd_debug_set_policy_stamps.  In the product build the macros are empty: no stamp executes.
+#ifdef SSD_STAMPS
+static unsigned long long* g_policy_stamps = nullptr;
+void set_policy_stamps(unsigned long long* buf) { g_policy_stamps = buf; }
+#define PSTAMP_DECL unsigned long long* stamps;
+#define PSTAMP_SET(k) (k).stamps = g_policy_stamps
+#define PSTAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PSTAMP_DECL
+#define PSTAMP_SET(k)
+#define PSTAMP(i)
+#endif
+
 // exact power-of-two scales (PREC 2; PREC 1 needs none: bf16 has the f32 exponent range)
 constexpr float HEAD_WSCALE = 64.f, HEAD_XSCALE = 16.f;                  // head weights / activations
 constexpr float ENC_CSCALE = 256.f, ENC_LSCALE = 256.f;                  // conv weights (= conv activations' scale) / Linear weights
@@ -71,8 +85,12 @@ constexpr int HT_B1 = 0, HT_BI = 64, HT_BH = 256, HT_B2 = 448, HT_W2O = 464, HT_
 constexpr int HEAD_WAVES = 8;
 constexpr int SCRATCH = 16 * 16;               // per wave: fc2 output tile [row 16][out 16]
 
+// Kernel arguments.  HeadK is what the main path reads; HeadCold holds the ~20 pointers only the epilogue touches (results, filing
+// into the episode storage, runner state).  hipcc loads every by-value kernel argument into SGPRs at kernel entry -- 100+ SGPRs
+// here, most of them then spilled to VGPR lanes for the whole kernel -- so the cold ones are fetched from the kernarg segment
+// where they are used (cold_ptr below: one s_load_dwordx2 each).
 struct HeadK {
-    int N, n, A, inp, bpa;
+    int N, n, A, inp, bpa, slots, feat_bands;
     float pos_scale;
     uint32_t seed, env_id_base;
     float* inputs;
@@ -84,22 +102,33 @@ struct HeadK {
     const int64_t* prev_actions;
     const float* prev_reward;
     const int64_t* prev_inc;
-    const float* pos;
+    const float *pos, *orient;
     const int64_t* actions;
     const float *pos_pre, *orient_pre, *reward, *clean, *den;
+    const int64_t* t_index;
+    const float *feat_part, *lin_b;
+    PSTAMP_DECL
+};
+struct HeadCold {
     int64_t* out_actions;
     float* q_out;
-    const float* orient;
     int32_t* out_actions_i32;
     float *pos_copy, *orient_copy;
-    const int64_t* t_index; int slots;
     float *d_pos, *d_orient, *d_onehot, *d_reward, *d_clean, *d_den;
     uint8_t* d_term; const uint8_t* term;
     int64_t *d_actions, *d_actions_inc, *p_act, *p_inc;
     float *p_rew, *ep_ret;
     int64_t* next_t;
-    const float* feat_part; int feat_bands; const float* lin_b;
 };
+constexpr int HEAD_COLD_OFFSET = (int)((sizeof(HeadK) + alignof(HeadCold) - 1) / alignof(HeadCold) * alignof(HeadCold));   // second kernel argument
+template <typename T>
+__device__ __forceinline__ T* cold_ptr(int field_offset) {
+    auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    uint64_t v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "s"(HEAD_COLD_OFFSET + field_offset) : "memory");
+    return reinterpret_cast<T*>(v);
+}
+#define COLD(T, field) cold_ptr<T>((int)offsetof(HeadCold, field))
 
 // acc[ot] += (W^T tile ot of the block starting at fragment F0) x B for OT output tiles, both K-steps; small terms first
 template <int PREC, int OT>
@@ -145,15 +174,168 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return copysignf(t, x);
 }
 
-template <int INC, int PREC>
-__global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
+// Everything a 16-row tile needs from global memory, requested in ONE batch of independent loads: the first tile's batch is
+// issued before the weight image is staged (its latency hides under the staging), later ones right after the previous tile.
+template <int INC>
+struct TileIn {
+    f32x4 x[4];                    // env: x[0..1] = encoder features (final, or lin_b + the band sums); inc: the 64 stored inputs
+    f32x4 hp[4];                   // previous hidden state
+    int pa, recv, act;             // env: last action, #recv+ - #recv-; inc: the env action just taken
+    float pr, p0, p1, o0, o1;      // env: last reward, pose
+    int aj[3];                     // inc epilogue items (row, j) = lane + 64 k: action of j and its 7 features
+    float f[3][7];
+};
+
+template <int INC>
+__device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, int lane, TileIn<INC>& in) {
+    const int m = lane & 15, q = lane >> 4, N = a.N, n = a.n;
+    const int b = tile * 16 + m, bc = b < N ? b : N - 1;
+    const size_t arow = (size_t)agent * N + bc;
+    const float* in_row = a.inputs + arow * 64;
+    const float* h_row = a.h + arow * 64;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) in.hp[ct] = *reinterpret_cast<const f32x4*>(h_row + 16 * ct + 4 * q);
+    if (!INC) {
+        if (a.feat_part) {          // the encoder left per-band partial sums: lin_b + sum over the bands, band order
+            const size_t rows = (size_t)n * N;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                f32x4 part[6];
+#pragma unroll
+                for (int bd = 0; bd < 6; ++bd) {   // branch-free: bands past the last re-read the last one and are masked out
+                    const int bdc = bd < a.feat_bands ? bd : a.feat_bands - 1;
+                    part[bd] = *reinterpret_cast<const f32x4*>(a.feat_part + ((size_t)bdc * rows + arow) * 32 + 16 * ct + 4 * q);
+                }
+                f32x4 s = *reinterpret_cast<const f32x4*>(a.lin_b + 16 * ct + 4 * q);
+#pragma unroll
+                for (int bd = 0; bd < 6; ++bd) { const float on = bd < a.feat_bands ? 1.f : 0.f; s += part[bd] * on; }
+                in.x[ct] = s;
+            }
+        } else {
+            in.x[0] = *reinterpret_cast<const f32x4*>(in_row + 4 * q);
+            in.x[1] = *reinterpret_cast<const f32x4*>(in_row + 16 + 4 * q);
+        }
+        const size_t er = (size_t)bc * n + agent;                      // env-major row
+        in.pa = (int)a.prev_actions[er];
+        in.pr = a.prev_reward[er];
+        int64_t v[SSD_MAX_AGENTS];
+#pragma unroll
+        for (int g = 0; g < SSD_MAX_AGENTS; ++g) v[g] = a.prev_inc[((size_t)bc * n + (g < n ? g : agent)) * n + agent];   // branch-free: clamped index
+        int recv = 0;
+#pragma unroll
+        for (int g = 0; g < SSD_MAX_AGENTS; ++g) recv += (g < n && g != agent) ? (v[g] == 1) - (v[g] == 2) : 0;   // inc_mask_actions: no self incentive
+        in.recv = recv;
+        in.p0 = a.pos[er * 2]; in.p1 = a.pos[er * 2 + 1];
+        in.o0 = in.o1 = 0.f;
+        if (a.orient) { in.o0 = a.orient[er * 2]; in.o1 = a.orient[er * 2 + 1]; }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) in.x[ct] = *reinterpret_cast<const f32x4*>(in_row + 16 * ct + 4 * q);
+        in.act = (int)a.actions[(size_t)bc * n + agent];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int it = lane + 64 * k, row = it / n, j = it - row * n, bb = tile * 16 + row;
+            in.aj[k] = 0;
+#pragma unroll
+            for (int e = 0; e < 7; ++e) in.f[k][e] = 0.f;
+            if (it < 16 * n && bb < N) {
+                // other_j = [one-hot(a_j), pos_j / scale, orient_j, r_j, clean_j, apple_den_j] (homophily_agent.py:194-201)
+                const size_t ej = (size_t)bb * n + j;
+                in.aj[k] = (int)a.actions[ej];
+                in.f[k][0] = a.pos_pre[ej * 2]; in.f[k][1] = a.pos_pre[ej * 2 + 1];
+                in.f[k][2] = a.orient_pre[ej * 2]; in.f[k][3] = a.orient_pre[ej * 2 + 1];
+                in.f[k][4] = a.reward[ej]; in.f[k][5] = a.clean[ej]; in.f[k][6] = a.den[ej];
+            }
+        }
+    }
+}
+
+// AT: the env's action count (9 Cleanup, 8 Harvest) at compile time: the one-hot / dueling loops unroll
+template <int INC, int PREC, int AT>
+__global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold_unused) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     constexpr int FRAG_BYTES = PREC * HF_TOT * 1024, IMAGE_BYTES = FRAG_BYTES + HT_TOT * 4;
     constexpr float XS = PREC == 2 ? HEAD_XSCALE : 1.f, INV = PREC == 2 ? 1.f / (HEAD_WSCALE * HEAD_XSCALE) : 1.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int agent = blockIdx.x / a.bpa, bia = blockIdx.x - agent * a.bpa;
     const int m = lane & 15, q = lane >> 4;
-    const int N = a.N, n = a.n, A = a.A;
+    const int N = a.N, n = a.n;
+    constexpr int A = AT;
+    PSTAMP(0);
+    const int tiles = (N + 15) >> 4, tstep = a.bpa * HEAD_WAVES;
+    int tile = wave * a.bpa + bia;                                     // consecutive tiles go to different CUs
+    TileIn<INC> in;
+    if (tile < tiles) load_tile<INC>(a, tile, agent, lane, in);        // in flight while the image is staged
+    const float eps = *a.eps;
+    const uint32_t step = (uint32_t)*a.step;
+    const long slot_t = a.t_index ? (long)*a.t_index : 0;
+    const bool file = slot_t < (long)a.slots;                          // never file past the episode storage
+    const uint32_t avail_bits = INC ? 0xFFFFFFFFu : avail_to_bits(a.avail, A);
+    u32x4 bh[2], bl[2];                                                // the fc1 operand of the current tile
+    // Everything of a tile that only needs its inputs -- the input tail (controller :137-184), the by-product stores, the split
+    // of the fc1 operand -- is done as soon as the loads land: for the first tile while the weight image is still in flight.
+    auto prepare = [&](int tl) {
+        const int b = tl * 16 + m;
+        const bool valid = b < N;
+        const int bc = valid ? b : N - 1;
+        float* in_row = a.inputs + ((size_t)agent * N + bc) * 64;
+        f32x4 x[4];
+        if (!INC) {
+            x[0] = in.x[0]; x[1] = in.x[1];
+            if (a.feat_part) {      // finish the encoder: LeakyReLU of (lin_b + band sums); the inc head reads them from `inputs`
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[ct][r] = leaky(x[ct][r]);
+                    if (valid) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = x[ct];
+                }
+            }
+            const size_t er = (size_t)bc * n + agent;                  // env-major row
+            {   // the pose BEFORE the env step (inc head input, storage slot t)
+                float *pos_copy = COLD(float, pos_copy), *d_pos = COLD(float, d_pos);
+                if (valid && q == 0 && pos_copy) {
+                    float* orient_copy = COLD(float, orient_copy);
+                    pos_copy[er * 2] = in.p0; pos_copy[er * 2 + 1] = in.p1; orient_copy[er * 2] = in.o0; orient_copy[er * 2 + 1] = in.o1;
+                }
+                if (valid && q == 0 && d_pos && file) {
+                    float* d_orient = COLD(float, d_orient);
+                    const size_t sr = (((size_t)bc * a.slots + slot_t) * n + agent) * 2;
+                    d_pos[sr] = in.p0; d_pos[sr + 1] = in.p1; d_orient[sr] = in.o0; d_orient[sr + 1] = in.o1;
+                }
+            }
+            // tail columns: one-hot(last action) | one-hot(agent id) | sign(r) | sign(received incentives) | pos / scale
+            const float px = in.p0 / a.pos_scale, py = in.p1 / a.pos_scale;
+            const float sg_r = (float)((in.pr > 0.f) - (in.pr < 0.f)), sg_i = (float)((in.recv > 0) - (in.recv < 0));
+            const int c_id = A + agent, c0 = A + n;
+#pragma unroll
+            for (int ct = 2; ct < 4; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * ct + 4 * q + r - 32;
+                    float v = (j == in.pa || j == c_id) ? 1.f : 0.f;   // pa in [-1, A): a hit is a one-hot column
+                    v = j == c0 ? sg_r : v;
+                    v = j == c0 + 1 ? sg_i : v;
+                    v = j == c0 + 2 ? px : v;
+                    v = j == c0 + 3 ? py : v;
+                    x[ct][r] = v;
+                }
+                if (valid) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = x[ct];   // the inc head reads the full row
+            }
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                x[ct] = in.x[ct];
+                if (ct >= 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 16 * ct + 4 * q + r - a.inp;     // [inputs | one-hot(action)] (homophily_agent.py:181)
+                        if (k >= 0 && k < A) x[ct][r] = in.act == k ? 1.f : 0.f;
+                    }
+                }
+            }
+        }
+        operand<PREC>(x, XS, bh, bl);
+    };
     {   // stage this agent's image (already in LDS layout): every load in flight before the first LDS write
         const u32x4* src = reinterpret_cast<const u32x4*>(a.weights + (size_t)agent * IMAGE_BYTES);
         u32x4* dst = reinterpret_cast<u32x4*>(lds_raw);
@@ -161,97 +343,30 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
         u32x4 tmp[PER];
 #pragma unroll
         for (int j = 0; j < PER; ++j) { const int e = tid + j * HEAD_WAVES * 64; if (e < NV) tmp[j] = src[e]; }
+        if (tile < tiles) prepare(tile);
 #pragma unroll
         for (int j = 0; j < PER; ++j) { const int e = tid + j * HEAD_WAVES * 64; if (e < NV) dst[e] = tmp[j]; }
     }
     __syncthreads();
+    PSTAMP(1);
+    bool first = true;
     const uint8_t* img = lds_raw;
     const float* tail = reinterpret_cast<const float*>(lds_raw + FRAG_BYTES);
     float* scratch = reinterpret_cast<float*>(lds_raw + IMAGE_BYTES) + wave * SCRATCH;
-    const float eps = *a.eps;
-    const uint32_t step = (uint32_t)*a.step;
-    const long slot_t = a.t_index ? (long)*a.t_index : 0;
-    const bool file = slot_t < (long)a.slots;                          // never file past the episode storage
-    if (INC && a.next_t && blockIdx.x == 0 && tid == 0) *a.next_t = slot_t + 1;   // not read by this kernel (t_index is a copy)
-    const int tiles = (N + 15) >> 4;
-    for (int tile = wave * a.bpa + bia; tile < tiles; tile += a.bpa * HEAD_WAVES) {   // consecutive tiles go to different CUs
+    if (INC && blockIdx.x == 0 && tid == 0) {                          // not read by this kernel (t_index is a copy)
+        int64_t* next_t = COLD(int64_t, next_t);
+        if (next_t) *next_t = slot_t + 1;
+    }
+    while (tile < tiles) {
         const int b = tile * 16 + m;
         const bool valid = b < N;
         const int bc = valid ? b : N - 1;
         const size_t arow = (size_t)agent * N + bc;                    // agent-major row
-        float* in_row = a.inputs + arow * 64;
-        // ---- the 64 (zero padded) input features of row m, 4 per (ct, lane) ---------------------------------------------------
-        f32x4 x[4];
-        if (!INC) {
-            if (a.feat_part) {      // the encoder left per-band partial sums: features = LeakyReLU(lin_b + sum), band order
-                const size_t rows = (size_t)n * N;
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    f32x4 s = *reinterpret_cast<const f32x4*>(a.lin_b + 16 * ct + 4 * q);
-                    for (int bd = 0; bd < a.feat_bands; ++bd) s += *reinterpret_cast<const f32x4*>(a.feat_part + ((size_t)bd * rows + arow) * 32 + 16 * ct + 4 * q);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[r] = leaky(s[r]);
-                    x[ct] = s;
-                    if (valid) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = s;
-                }
-            } else {
-                x[0] = *reinterpret_cast<const f32x4*>(in_row + 4 * q);
-                x[1] = *reinterpret_cast<const f32x4*>(in_row + 16 + 4 * q);
-            }
-            const size_t er = (size_t)bc * n + agent;                  // env-major row
-            const int pa = (int)a.prev_actions[er];
-            const float pr = a.prev_reward[er];
-            int recv = 0;
-            for (int g = 0; g < n; ++g) {
-                if (g == agent) continue;                              // inc_mask_actions: no self incentive
-                const int64_t v = a.prev_inc[((size_t)bc * n + g) * n + agent];
-                recv += (v == 1) - (v == 2);
-            }
-            const float px = a.pos[er * 2] / a.pos_scale, py = a.pos[er * 2 + 1] / a.pos_scale;
-            if (valid && q == 0 && (a.pos_copy || a.d_pos)) {          // the pose BEFORE the env step (inc head input, storage slot t)
-                const float p0 = a.pos[er * 2], p1 = a.pos[er * 2 + 1], o0 = a.orient[er * 2], o1 = a.orient[er * 2 + 1];
-                if (a.pos_copy) { a.pos_copy[er * 2] = p0; a.pos_copy[er * 2 + 1] = p1; a.orient_copy[er * 2] = o0; a.orient_copy[er * 2 + 1] = o1; }
-                if (a.d_pos && file) {
-                    const size_t sr = (((size_t)bc * a.slots + slot_t) * n + agent) * 2;
-                    a.d_pos[sr] = p0; a.d_pos[sr + 1] = p1; a.d_orient[sr] = o0; a.d_orient[sr + 1] = o1;
-                }
-            }
-#pragma unroll
-            for (int ct = 2; ct < 4; ++ct) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * ct + 4 * q + r - 32;            // tail column (controller :137-184)
-                    float v = 0.f;
-                    if (j < A) v = pa == j ? 1.f : 0.f;
-                    else if (j < A + n) v = j - A == agent ? 1.f : 0.f;
-                    else if (j == A + n) v = (float)((pr > 0.f) - (pr < 0.f));
-                    else if (j == A + n + 1) v = (float)((recv > 0) - (recv < 0));
-                    else if (j == A + n + 2) v = px;
-                    else if (j == A + n + 3) v = py;
-                    x[ct][r] = v;
-                }
-                if (valid) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = x[ct];   // the inc head reads the full row
-            }
-        } else {
-            const int act = (int)a.actions[(size_t)bc * n + agent];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                x[ct] = *reinterpret_cast<const f32x4*>(in_row + 16 * ct + 4 * q);
-                if (ct >= 2) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int k = 16 * ct + 4 * q + r - a.inp;     // [inputs | one-hot(action)] (homophily_agent.py:181)
-                        if (k >= 0 && k < A) x[ct][r] = act == k ? 1.f : 0.f;
-                    }
-                }
-            }
-        }
-        u32x4 bh[2], bl[2];
+        if (first) PSTAMP(2);
         // ---- fc1 + LeakyReLU -----------------------------------------------------------------------------------------------
         f32x4 x1[4];
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) x1[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
-        operand<PREC>(x, XS, bh, bl);
         gemm_t<PREC, 4>(img, HF_FC1, bh, bl, x1, lane);
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
@@ -259,20 +374,24 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) x1[ot][r] = leaky(fmaf(x1[ot][r], INV, bias[r]));
         }
+        if (first) PSTAMP(3);
         // ---- GRU cell: r, z share one accumulator for the input and the hidden side; n needs both separately -------------------
         float* h_row = a.h + arow * 64;
         f32x4 hp[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) hp[ct] = *reinterpret_cast<const f32x4*>(h_row + 16 * ct + 4 * q);
+        for (int ct = 0; ct < 4; ++ct) hp[ct] = in.hp[ct];
         f32x4 g[16];                                                   // 0-3 r, 4-7 z, 8-11 i_n, 12-15 h_n
 #pragma unroll
         for (int ot = 0; ot < 16; ++ot) g[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
         operand<PREC>(x1, XS, bh, bl);
-        gemm_t<PREC, 8>(img, HF_WI, bh, bl, g, lane);
+        gemm_t<PREC, 4>(img, HF_WI, bh, bl, g, lane);
+        gemm_t<PREC, 4>(img, HF_WI + 8, bh, bl, g + 4, lane);
         gemm_t<PREC, 4>(img, HF_WI + 16, bh, bl, g + 8, lane);
         operand<PREC>(hp, XS, bh, bl);
-        gemm_t<PREC, 8>(img, HF_WH, bh, bl, g, lane);
+        gemm_t<PREC, 4>(img, HF_WH, bh, bl, g, lane);
+        gemm_t<PREC, 4>(img, HF_WH + 8, bh, bl, g + 4, lane);
         gemm_t<PREC, 4>(img, HF_WH + 16, bh, bl, g + 12, lane);
+        if (first) PSTAMP(4);
         f32x4 hn[4];
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) {
@@ -288,6 +407,7 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
             }
             if (valid) *reinterpret_cast<f32x4*>(h_row + 16 * ft + 4 * q) = hn[ft];
         }
+        if (first) PSTAMP(5);
         // ---- fc2 (advantages + value, padded to 16 outputs) ---------------------------------------------------------------
         f32x4 o2 = f32x4{0.f, 0.f, 0.f, 0.f};
         operand<PREC>(hn, XS, bh, bl);
@@ -302,79 +422,100 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a) {
         __builtin_amdgcn_wave_barrier();
         if (!INC) {
             const int bb = tile * 16 + lane;
+            int64_t *out_actions = COLD(int64_t, out_actions), *p_act = COLD(int64_t, p_act), *d_actions = COLD(int64_t, d_actions);
+            int32_t* out_i32 = COLD(int32_t, out_actions_i32);
+            float *q_out = COLD(float, q_out), *d_onehot = COLD(float, d_onehot);
             if (lane < 16 && bb < N) {
                 float av[16];
-                for (int k = 0; k <= A; ++k) av[k] = scratch[lane * 16 + k];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(scratch + lane * 16 + 4 * k4);
+                    av[4 * k4] = t4[0]; av[4 * k4 + 1] = t4[1]; av[4 * k4 + 2] = t4[2]; av[4 * k4 + 3] = t4[3];
+                }
+                const float val = av[A];
                 const uint32_t rq = (uint32_t)(agent * N + bb);                                  // q_out row (agent-major)
                 const uint32_t rk = (a.env_id_base + (uint32_t)bb) * (uint32_t)n + (uint32_t)agent;   // exploration key: global env id
-                const int act = dueling_pick_row(av, av[A], A, a.avail, eps, step, a.seed, rk,
-                                                 a.q_out ? a.q_out + (size_t)rq * A : nullptr);
-                a.out_actions[(size_t)bb * n + agent] = act;
-                if (a.out_actions_i32) a.out_actions_i32[(size_t)bb * n + agent] = act;
-                if (a.p_act) a.p_act[(size_t)bb * n + agent] = act;
-                if (a.d_actions && file) {
+                const int act = dueling_pick_bits<AT>(av, val, A, avail_bits, eps, step, a.seed, rk, q_out ? q_out + (size_t)rq * A : nullptr);
+                out_actions[(size_t)bb * n + agent] = act;
+                if (out_i32) out_i32[(size_t)bb * n + agent] = act;
+                if (p_act) p_act[(size_t)bb * n + agent] = act;
+                if (d_actions && file) {
                     const size_t sr = ((size_t)bb * a.slots + slot_t) * n + agent;
-                    a.d_actions[sr] = act;
-                    for (int k = 0; k < A; ++k) a.d_onehot[sr * A + k] = k == act ? 1.f : 0.f;
+                    d_actions[sr] = act;
+#pragma unroll
+                    for (int k = 0; k < A; ++k) d_onehot[sr * A + k] = k == act ? 1.f : 0.f;
                 }
             }
         } else {
             const float* w2o = tail + HT_W2O;                          // [E][4]: 3 advantages + value per extra feature
-            for (int it = lane; it < 16 * n; it += 64) {
+            int64_t *out_actions = COLD(int64_t, out_actions), *p_inc = COLD(int64_t, p_inc), *d_actions_inc = COLD(int64_t, d_actions_inc);
+            float *q_out = COLD(float, q_out), *d_reward = COLD(float, d_reward), *p_rew = COLD(float, p_rew), *ep_ret = COLD(float, ep_ret);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int it = lane + 64 * k;
                 const int row = it / n, j = it - row * n, bb = tile * 16 + row;
-                if (bb >= N) continue;
-                const size_t ej = (size_t)bb * n + j;
-                // other_j = [one-hot(a_j), pos_j / scale, orient_j, r_j, clean_j, apple_den_j] (homophily_agent.py:194-201)
-                const int aj = (int)a.actions[ej];
+                if (it >= 16 * n || bb >= N) continue;
+                const int aj = in.aj[k];
                 float f[7];
-                f[0] = a.pos_pre[ej * 2] / a.pos_scale; f[1] = a.pos_pre[ej * 2 + 1] / a.pos_scale;
-                f[2] = a.orient_pre[ej * 2]; f[3] = a.orient_pre[ej * 2 + 1];
-                f[4] = a.reward[ej]; f[5] = a.clean[ej]; f[6] = a.den[ej];
+                f[0] = in.f[k][0] / a.pos_scale; f[1] = in.f[k][1] / a.pos_scale;
+#pragma unroll
+                for (int e = 2; e < 7; ++e) f[e] = in.f[k][e];
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(scratch + row * 16);
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(w2o + aj * 4);
                 float av[4];
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    float s = scratch[row * 16 + o] + w2o[aj * 4 + o];
+                for (int o = 0; o < 4; ++o) av[o] = sc[o] + wa[o];
 #pragma unroll
-                    for (int e = 0; e < 7; ++e) s = fmaf(f[e], w2o[(A + e) * 4 + o], s);
-                    av[o] = s;
+                for (int e = 0; e < 7; ++e) {
+                    const f32x4 we = *reinterpret_cast<const f32x4*>(w2o + (A + e) * 4);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) av[o] = fmaf(f[e], we[o], av[o]);
                 }
                 const uint32_t rq = (uint32_t)((agent * N + bb) * n + j);
                 const uint32_t rk = ((a.env_id_base + (uint32_t)bb) * (uint32_t)n + (uint32_t)agent) * (uint32_t)n + (uint32_t)j;
-                int act = dueling_pick_row(av, av[3], 3, nullptr, eps, step, a.seed, rk, a.q_out ? a.q_out + (size_t)rq * 3 : nullptr);
+                int act = dueling_pick_bits<3>(av, av[3], 3, 0xFFFFFFFFu, eps, step, a.seed, rk, q_out ? q_out + (size_t)rq * 3 : nullptr);
                 if (j == agent) act = 0;                               // no self incentive (homophily_controller.py:44-46)
-                a.out_actions[((size_t)bb * n + agent) * n + j] = act;
-                if (a.p_inc) a.p_inc[((size_t)bb * n + agent) * n + j] = act;
+                out_actions[((size_t)bb * n + agent) * n + j] = act;
+                if (p_inc) p_inc[((size_t)bb * n + agent) * n + j] = act;
                 const size_t sr = ((size_t)bb * a.slots + slot_t) * n + agent;
-                if (a.d_actions_inc && file) a.d_actions_inc[sr * n + j] = act;
-                if (j == 0 && a.d_reward) {                            // once per (env, agent): this step's outcome
+                if (d_actions_inc && file) d_actions_inc[sr * n + j] = act;
+                if (j == agent && d_reward) {                          // once per (env, agent): this step's outcome (f[4..6] are agent's own)
                     const size_t ea = (size_t)bb * n + agent;
-                    const float rw = a.reward[ea];
-                    if (file) { a.d_reward[sr] = rw; a.d_clean[sr] = a.clean[ea]; a.d_den[sr] = a.den[ea]; }
-                    if (a.p_rew) a.p_rew[ea] = rw;
-                    if (a.ep_ret) a.ep_ret[ea] += rw;
-                    if (agent == 0 && a.d_term && file) a.d_term[(size_t)bb * a.slots + slot_t] = a.term[bb];
+                    const float rw = f[4];
+                    if (file) { d_reward[sr] = rw; COLD(float, d_clean)[sr] = f[5]; COLD(float, d_den)[sr] = f[6]; }
+                    if (p_rew) p_rew[ea] = rw;
+                    if (ep_ret) ep_ret[ea] += rw;
+                    uint8_t* d_term = COLD(uint8_t, d_term);
+                    if (agent == 0 && d_term && file) d_term[(size_t)bb * a.slots + slot_t] = COLD(const uint8_t, term)[bb];
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();                               // scratch is reused by the next tile
+        if (first) PSTAMP(6);
+        first = false;
+        tile += tstep;
+        if (tile < tiles) { load_tile<INC>(a, tile, agent, lane, in); prepare(tile); }
     }
+    PSTAMP(7);
 }
 
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     HeadK k;
+    HeadCold c;
     k.N = p->n_env; k.n = p->n_agents; k.A = p->n_actions; k.inp = p->input_shape;
     k.pos_scale = p->pos_scale; k.seed = p->seed; k.env_id_base = p->env_id_base;
     k.inputs = p->inputs; k.h = p->h; k.weights = static_cast<const uint8_t*>(p->weights); k.avail = p->avail; k.eps = p->epsilon; k.step = p->step;
-    k.prev_actions = p->prev_actions; k.prev_reward = p->prev_reward; k.prev_inc = p->prev_actions_inc; k.pos = p->pos;
+    k.prev_actions = p->prev_actions; k.prev_reward = p->prev_reward; k.prev_inc = p->prev_actions_inc; k.pos = p->pos; k.orient = p->orient;
     k.actions = p->actions; k.pos_pre = p->pos_pre; k.orient_pre = p->orient_pre; k.reward = p->reward; k.clean = p->clean_num;
-    k.den = p->apple_den; k.out_actions = p->out_actions; k.q_out = p->q_out;
+    k.den = p->apple_den;
     k.t_index = p->t_index; k.slots = p->t_index ? p->t_slots : 1;
-    k.d_pos = p->dst_pos; k.d_orient = p->dst_orient; k.d_onehot = p->dst_actions_onehot; k.d_reward = p->dst_reward;
-    k.d_clean = p->dst_clean_num; k.d_den = p->dst_apple_den; k.d_term = p->dst_terminated; k.term = p->terminated;
-    k.d_actions = p->dst_actions; k.d_actions_inc = p->dst_actions_inc; k.p_act = p->prev_actions_out; k.p_inc = p->prev_actions_inc_out;
-    k.p_rew = p->prev_reward_out; k.ep_ret = p->ep_return; k.next_t = p->next_t_out;
-    k.orient = p->orient; k.out_actions_i32 = p->out_actions_i32; k.pos_copy = p->pos_copy; k.orient_copy = p->orient_copy;
     k.feat_part = p->feat_part; k.feat_bands = p->feat_bands; k.lin_b = p->lin_b;
+    c.out_actions = p->out_actions; c.q_out = p->q_out; c.out_actions_i32 = p->out_actions_i32; c.pos_copy = p->pos_copy; c.orient_copy = p->orient_copy;
+    c.d_pos = p->dst_pos; c.d_orient = p->dst_orient; c.d_onehot = p->dst_actions_onehot; c.d_reward = p->dst_reward;
+    c.d_clean = p->dst_clean_num; c.d_den = p->dst_apple_den; c.d_term = p->dst_terminated; c.term = p->terminated;
+    c.d_actions = p->dst_actions; c.d_actions_inc = p->dst_actions_inc; c.p_act = p->prev_actions_out; c.p_inc = p->prev_actions_inc_out;
+    c.p_rew = p->prev_reward_out; c.ep_ret = p->ep_return; c.next_t = p->next_t_out;
+    PSTAMP_SET(k);
     const int prec = p->precision == 1 ? 1 : 2;
     const int tiles = (k.N + 15) / 16;
     int bpa = 256 / k.n;                                               // one workgroup per CU (the image fills most of the LDS)
@@ -382,23 +523,23 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     if (bpa < 1) bpa = 1;
     k.bpa = bpa;
     const size_t lds = (size_t)SSD_POLICY_IMAGE_BYTES(prec) + HEAD_WAVES * SCRATCH * sizeof(float);
+    if (k.A != 9 && k.A != 8) return -3;                               // instantiated for Cleanup (9 actions) and Harvest (8)
     static bool attr_done_dev[64] = {};                               // the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    const void* fns[8] = {reinterpret_cast<const void*>(&k_head<0, 2, 9>), reinterpret_cast<const void*>(&k_head<1, 2, 9>),
+                          reinterpret_cast<const void*>(&k_head<0, 1, 9>), reinterpret_cast<const void*>(&k_head<1, 1, 9>),
+                          reinterpret_cast<const void*>(&k_head<0, 2, 8>), reinterpret_cast<const void*>(&k_head<1, 2, 8>),
+                          reinterpret_cast<const void*>(&k_head<0, 1, 8>), reinterpret_cast<const void*>(&k_head<1, 1, 8>)};
     if (!attr_done_dev[dev]) {
         const size_t l2 = (size_t)SSD_POLICY_IMAGE_BYTES(2) + HEAD_WAVES * SCRATCH * sizeof(float);
-        const void* fns[4] = {reinterpret_cast<const void*>(&k_head<0, 2>), reinterpret_cast<const void*>(&k_head<1, 2>),
-                              reinterpret_cast<const void*>(&k_head<0, 1>), reinterpret_cast<const void*>(&k_head<1, 1>)};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess) return -1;
         attr_done_dev[dev] = true;
     }
-    const dim3 grid(k.n * bpa), block(HEAD_WAVES * 64);
-    if (prec == 2) {
-        if (inc) hipLaunchKernelGGL((k_head<1, 2>), grid, block, lds, s, k); else hipLaunchKernelGGL((k_head<0, 2>), grid, block, lds, s, k);
-    } else {
-        if (inc) hipLaunchKernelGGL((k_head<1, 1>), grid, block, lds, s, k); else hipLaunchKernelGGL((k_head<0, 1>), grid, block, lds, s, k);
-    }
+    void* args[2] = {&k, &c};
+    const void* fn = fns[(k.A == 8 ? 4 : 0) + (prec == 1 ? 2 : 0) + (inc ? 1 : 0)];
+    if (hipLaunchKernel(fn, dim3(k.n * bpa), dim3(HEAD_WAVES * 64), args, lds, s) != hipSuccess) return -1;
     return 0;
 }
 
@@ -461,7 +602,7 @@ template <int V> struct Geo;
 template <> struct Geo<15> { static constexpr int O = 13, CP = 16, NF = 2, XT = 1, R = 13, NB = 1; };
 template <> struct Geo<31> { static constexpr int O = 29, CP = 40, NF = 3, XT = 2, R = 5, NB = 6; };
 constexpr int ENC_BT = 5;                      // batch tiles (16 rows each) per workgroup: Linear weights are fetched once per 80 rows
-constexpr int ENC_WAVES = 4;
+constexpr int ENC_WAVES = 8;                     // 2 per SIMD: one wave's LDS / VALU work overlaps its partner's MFMAs
 
 struct EncK {
     const uint8_t* codes; long code_bytes, env_stride, slot_stride, agent_stride; const int64_t* slot_t;
@@ -471,6 +612,7 @@ struct EncK {
     float* out; int out_stride;
     float* part;
     int64_t* slot_t_copy; int64_t* counter_inc;
+    PSTAMP_DECL
 };
 
 template <int V, int PREC>
@@ -482,16 +624,19 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
     constexpr int PLANES = BT * 16 * PR, CONV_BYTES = PREC * 6 * KS * 1024;
     constexpr uint32_t ON = PREC == 2 ? 0x3Cu : 0x3Fu;                 // f16 0x3C00 = 1.0;  bf16 0x3F00 = 0.5 (the conv weights carry the 2)
     constexpr float CS = PREC == 2 ? ENC_CSCALE : 1.f, INV = PREC == 2 ? 1.f / (ENC_CSCALE * ENC_LSCALE) : 1.f;
-    static_assert(ENC_WAVES * BT * 2 * 1024 <= PLANES, "the reduction scratch aliases the planes");
+    constexpr int ZPAD = 64;                                           // zeros: the B operand of the padding fragments of the last K-step
+    static_assert(ENC_WAVES * BT * 2 * 1024 <= PLANES + ZPAD + CONV_BYTES, "the reduction scratch aliases planes + fragments");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint8_t* planes = lds_raw;                                         // [BT * 16 rows][3 ch][R + 2][CP] one-hot bytes
-    uint8_t* cfr = lds_raw + PLANES;                                   // conv fragments [term][oc][ks][lane][16 B]
+    uint8_t* zeros = lds_raw + PLANES;
+    uint8_t* cfr = lds_raw + PLANES + ZPAD;                            // conv fragments [term][oc][ks][lane][16 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int row0 = blockIdx.x * (BT * 16);
     const int band = blockIdx.y, y0 = band * R;
     const int Rb = O - y0 < R ? O - y0 : R;                            // output rows of this band
     const long t_off = a.slot_t ? (long)(*a.slot_t) * a.slot_stride : 0;
+    PSTAMP(0);
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
         if (a.slot_t_copy) *a.slot_t_copy = *a.slot_t;
         if (a.counter_inc) *a.counter_inc += 1;
@@ -504,21 +649,38 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
         u32x4 tmp[PER];
 #pragma unroll
         for (int j = 0; j < PER; ++j) { const int e = tid + j * ENC_WAVES * 64; if (e < NV) tmp[j] = src[e]; }
-        // plane bytes: items = (batch row, band input row, group of 4 cells); 4 codes come from two aligned dwords
-        constexpr int GPR = CP / 4, ITEMS = BT * 16 * (R + 2) * GPR;
-        for (int it = tid; it < ITEMS; it += ENC_WAVES * 64) {
+        // plane bytes: items = (batch row, band input row, group of 4 cells).  The 4 codes of an item come from the two aligned
+        // dwords that hold them (window rows of 15 / 31 bytes are not dword aligned; only dwords that contain readable codes are
+        // touched).  Every load of the workgroup is in flight before the first plane byte is written.
+        constexpr int GPR = CP / 4, ITEMS = BT * 16 * (R + 2) * GPR, NT = ENC_WAVES * 64, IPT = (ITEMS + NT - 1) / NT;
+        uint32_t w0[IPT], w1[IPT];
+        const uintptr_t cbase = reinterpret_cast<uintptr_t>(a.codes), cend = (cbase + (uintptr_t)a.code_bytes + 3) & ~(uintptr_t)3;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int it = tid + k * NT;
+            const int g4 = it % GPR, yy = (it / GPR) % (R + 2), r = it / (GPR * (R + 2));
+            const int row = row0 + r, y = y0 + yy, x = 4 * g4;
+            w0[k] = w1[k] = 0u;
+            if (it < ITEMS && row < a.rows && y < V && x < V) {
+                const int b = row / a.n, i = row - b * a.n;
+                const uintptr_t ptr = cbase + (uintptr_t)((long)b * a.env_stride + t_off + (long)i * a.agent_stride + y * V + x);
+                const uintptr_t al = ptr & ~(uintptr_t)3;
+                w0[k] = *reinterpret_cast<const uint32_t*>(al);
+                if (al + 8 <= cend) w1[k] = *reinterpret_cast<const uint32_t*>(al + 4);
+            }
+        }
+        if (tid < ZPAD / 4) reinterpret_cast<uint32_t*>(zeros)[tid] = 0u;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int it = tid + k * NT;
+            if (it >= ITEMS) continue;
             const int g4 = it % GPR, yy = (it / GPR) % (R + 2), r = it / (GPR * (R + 2));
             const int row = row0 + r, y = y0 + yy, x = 4 * g4;
             uint32_t c4 = 0;
             if (row < a.rows && y < V && x < V) {
                 const int b = row / a.n, i = row - b * a.n;
-                // 4 codes from the two aligned dwords that hold them (rows of 225 / 961 bytes are not dword aligned); only dwords that
-                // contain readable codes are touched
-                const uintptr_t ptr = reinterpret_cast<uintptr_t>(a.codes) + (uintptr_t)((long)b * a.env_stride + t_off + (long)i * a.agent_stride + y * V + x);
-                const uintptr_t al = ptr & ~(uintptr_t)3, end = (reinterpret_cast<uintptr_t>(a.codes) + (uintptr_t)a.code_bytes + 3) & ~(uintptr_t)3;
-                const uint32_t w0 = *reinterpret_cast<const uint32_t*>(al);
-                const uint32_t w1 = al + 8 <= end ? *reinterpret_cast<const uint32_t*>(al + 4) : 0u;
-                c4 = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)(ptr & 3));
+                const uintptr_t ptr = cbase + (uintptr_t)((long)b * a.env_stride + t_off + (long)i * a.agent_stride + y * V + x);
+                c4 = __builtin_amdgcn_alignbyte(w1[k], w0[k], (uint32_t)(ptr & 3));
                 const int left = V - x;                               // cells of this group inside the window row
                 if (left < 4) c4 &= (1u << (8 * left)) - 1u;
             }
@@ -527,7 +689,8 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 const uint32_t t = c4 ^ ((ch == 0 ? 2u : ch == 1 ? 1u : 3u) * 0x01010101u);
-                const uint32_t hit = ~(t | (t >> 1) | (t >> 2) | (t >> 3) | (t >> 4) | (t >> 5) | (t >> 6) | (t >> 7)) & 0x01010101u;
+                const uint32_t u = t | (t >> 4), w = u | (u >> 2);                 // bit 0 of every byte = OR of the byte's bits
+                const uint32_t hit = ~(w | (w >> 1)) & 0x01010101u;
                 *reinterpret_cast<uint32_t*>(d + ch * (R + 2) * CP) = hit * ON;
             }
         }
@@ -535,6 +698,7 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
         for (int j = 0; j < PER; ++j) { const int e = tid + j * ENC_WAVES * 64; if (e < NV) dst[e] = tmp[j]; }
     }
     __syncthreads();
+    PSTAMP(1);
     // ---- units (output row y, position tile xt, output-channel pair s) of this band, a contiguous range per wave ---------------
     f32x4 accl[BT][2];
 #pragma unroll
@@ -562,17 +726,16 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int F = 4 * ks + q;                                  // fragment of this lane's quarter: (dy, ch, f)
-            const bool real = F < NFR;
+            const bool real = (4 * ks + 3 < NFR) || F < NFR;           // only the last K-step holds padding fragments: they read zeros
             const int Fc = real ? F : 0, dy = Fc / (3 * NF), ch = (Fc / NF) % 3, f = Fc % NF;
-            const int boff = (ch * (R + 2) + yl + dy) * CP + 16 * xt + 8 * f;
+            const uint8_t* bp = real ? my_planes + (ch * (R + 2) + yl + dy) * CP + 16 * xt + 8 * f : zeros;
+            const int bstride = real ? 16 * PR : 0;
             u32x4 bfr[BT];
 #pragma unroll
             for (int bt = 0; bt < BT; ++bt) {
-                const u32x2 w = *reinterpret_cast<const u32x2*>(my_planes + (size_t)bt * 16 * PR + boff);
-                u32x4 e;
-                e[0] = __builtin_amdgcn_perm(0u, w[0], 0x010C000Cu); e[1] = __builtin_amdgcn_perm(0u, w[0], 0x030C020Cu);
-                e[2] = __builtin_amdgcn_perm(0u, w[1], 0x010C000Cu); e[3] = __builtin_amdgcn_perm(0u, w[1], 0x030C020Cu);
-                bfr[bt] = real ? e : u32x4{0u, 0u, 0u, 0u};
+                const u32x2 w = *reinterpret_cast<const u32x2*>(bp + bt * bstride);
+                bfr[bt][0] = __builtin_amdgcn_perm(0u, w[0], 0x010C000Cu); bfr[bt][1] = __builtin_amdgcn_perm(0u, w[0], 0x030C020Cu);
+                bfr[bt][2] = __builtin_amdgcn_perm(0u, w[1], 0x010C000Cu); bfr[bt][3] = __builtin_amdgcn_perm(0u, w[1], 0x030C020Cu);
             }
 #pragma unroll
             for (int o2 = 0; o2 < 2; ++o2)
@@ -601,7 +764,8 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
             }
         }
     }
-    // ---- add the four waves' partial sums in a fixed order (deterministic), finish ------------------------------------------------
+    PSTAMP(2);
+    // ---- add the waves' partial sums in a fixed order (deterministic), finish ------------------------------------------------------
     __syncthreads();                                                   // every wave is done with the planes: reuse them
     f32x4* red = reinterpret_cast<f32x4*>(lds_raw);                    // [wave][bt][mt][lane]
 #pragma unroll
@@ -629,12 +793,13 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
             }
         }
     }
+    PSTAMP(3);
 }
 
 template <int V, int PREC>
 static int launch_encode_t(const EncK& k, hipStream_t s) {
     using G = Geo<V>;
-    constexpr size_t lds = (size_t)ENC_BT * 16 * 3 * (G::R + 2) * G::CP + (size_t)PREC * 6 * SSD_ENCODE_KSTEPS(V) * 1024;
+    constexpr size_t lds = (size_t)ENC_BT * 16 * 3 * (G::R + 2) * G::CP + 64 + (size_t)PREC * 6 * SSD_ENCODE_KSTEPS(V) * 1024;
     static bool done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
@@ -654,6 +819,7 @@ int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s) {
     k.conv_frags = static_cast<const uint8_t*>(p->conv_frags); k.lin_frags = static_cast<const uint8_t*>(p->lin_frags);
     k.conv_b = p->conv_b; k.lin_b = p->lin_b; k.out = p->out; k.out_stride = p->out_stride; k.part = p->part;
     k.slot_t_copy = p->slot_t_copy; k.counter_inc = p->counter_inc;
+    PSTAMP_SET(k);
     const int prec = p->precision == 1 ? 1 : 2;
     if (p->view_edge == 15) return prec == 2 ? launch_encode_t<15, 2>(k, s) : launch_encode_t<15, 1>(k, s);
     if (p->view_edge == 31) return prec == 2 ? launch_encode_t<31, 2>(k, s) : launch_encode_t<31, 1>(k, s);

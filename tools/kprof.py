@@ -1,0 +1,52 @@
+"""Run the four kernels of a rollout timestep in back-to-back runs on live data (diagnostic; driven by tools/kprof.sh under
+rocprofv3: per-kernel time from --kernel-trace --stats, SQ / TCC counters from separate --pmc passes).
+
+    python3 tools/kprof.py [--config cleanup5|harvest5|cleanup10] [--reps 40] [--only encode,head_env,head_inc,env] [--qnet-dtype fp32|bf16]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch as th  # noqa: E402
+
+from bench import CONFIGS  # noqa: E402
+from homophily_marl_amd.run import load_config, setup  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="cleanup5", choices=sorted(CONFIGS))
+ap.add_argument("--reps", type=int, default=40)
+ap.add_argument("--only", default="encode,head_env,head_inc,env")
+ap.add_argument("--qnet-dtype", default="fp32")
+ap.add_argument("--n-env", type=int, default=None)
+args = ap.parse_args()
+c = CONFIGS[args.config]
+N, n, T = args.n_env or c["n_env"], c["n_agents"], 100
+cfg = load_config(c["env"], overrides=dict(
+    runner="hip_graph", rollout_graph=False, batch_size_run=N, batch_size=16, buffer_size=N, buffer_cpu_only=False, store_state=False,
+    qnet_dtype=args.qnet_dtype, env_args=dict(num_agents=n, map=c["map"], episode_limit=T, view_size=c["view_size"], seed=1),
+    use_cuda=True, save_model=False, runner_stats=False, learner_log_interval=10 ** 12))
+th.manual_seed(0)
+ctx = setup(cfg)
+r = ctx.runner
+r.begin_episode(False)
+for _ in range(12):
+    r.step_once()                     # eager steps: a live mid-episode state (epsilon = 1: random actions)
+th.cuda.synchronize()
+only = set(args.only.split(","))
+for name, key, fn in r.timestep_launches():
+    if key not in only:
+        continue
+    for _ in range(3):
+        fn()
+    th.cuda.synchronize()
+    a, b = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+    a.record()
+    reps = min(args.reps, 60) if key == "env" else args.reps   # the env steps its episode: stay inside the storage
+    for _ in range(reps):
+        fn()
+    b.record()
+    th.cuda.synchronize()
+    print("%-28s %8.2f us / launch (%d back-to-back launches, HIP events)" % (name, 1e3 * a.elapsed_time(b) / reps, reps), flush=True)
+    if key == "env":
+        r.env.native.poll_error()
