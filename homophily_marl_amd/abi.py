@@ -145,6 +145,20 @@ class SsdPolicyEncodeArgs(C.Structure):
                 ("out", C.c_void_p), ("out_stride", C.c_int32), ("part", C.c_void_p), ("slot_t_copy", C.c_void_p), ("counter_inc", C.c_void_p)]
 
 
+class SsdTdLossArgs(C.Structure):
+    """include/ssd_hip.h: ssd_td_loss_args."""
+    _fields_ = [("batch", C.c_int32), ("t_slots", C.c_int32), ("n_agents", C.c_int32), ("n_actions", C.c_int32), ("sim_horizon", C.c_int32),
+                ("double_q", C.c_int32),
+                ("gamma_env", C.c_float), ("gamma_inc", C.c_float), ("reward_scale", C.c_float), ("incentive_ratio", C.c_float),
+                ("incentive_cost", C.c_float), ("incentive", C.c_float), ("seq_len", C.c_float), ("sim_threshold", C.c_float),
+                ("sim_loss_weight", C.c_float),
+                ("q_env", C.c_void_p), ("q_inc", C.c_void_p), ("tq_env", C.c_void_p), ("tq_inc", C.c_void_p),
+                ("actions", C.c_void_p), ("actions_inc", C.c_void_p), ("avail", C.c_void_p), ("reward", C.c_void_p), ("clean_num", C.c_void_p),
+                ("terminated", C.c_void_p), ("filled", C.c_void_p), ("dens", C.c_void_p),
+                ("dq_env", C.c_void_p), ("dq_inc", C.c_void_p), ("partials", C.c_void_p)]
+
+
+TD_LOSS_PARTIALS = 16
 POLICY_HEAD_FRAGS, POLICY_HEAD_TAIL_FLOATS = 58, 464 + 64
 
 
@@ -172,6 +186,7 @@ HIP_SIGNATURES["ssd_gru_seq_fwd"] = (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3
 HIP_SIGNATURES["ssd_gru_seq_bwd"] = (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 3 + [C.c_void_p])
 HIP_SIGNATURES["ssd_policy_encode"] = (C.c_int, [C.POINTER(SsdPolicyEncodeArgs), C.c_void_p])
 HIP_SIGNATURES["ssd_policy_pack_encoder"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])
+HIP_SIGNATURES["ssd_td_sim_loss"] = (C.c_int, [C.POINTER(SsdTdLossArgs), C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_policy_pack_head"] = (C.c_int, [C.POINTER(SsdPolicyHeadParams), C.c_int32, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_conv_leaky"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p])

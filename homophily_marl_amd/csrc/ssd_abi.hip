@@ -335,6 +335,17 @@ int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int
     return launched();
 }
 
+int ssd_td_sim_loss(const ssd_td_loss_args* a, int32_t mode, void* stream) {
+    if (!a || a->batch < 1 || a->t_slots < 2 || a->n_agents < 2 || a->n_agents > SSD_MAX_AGENTS || a->n_actions < 1 || a->sim_horizon < 1)
+        return fail(SSD_ERR_INVALID, "bad argument");
+    if (!a->reward || !a->clean_num || !a->terminated || !a->filled || !a->partials) return fail(SSD_ERR_INVALID, "null argument");
+    if (mode && (!a->q_env || !a->q_inc || !a->tq_env || !a->tq_inc || !a->actions || !a->actions_inc || !a->avail || !a->dens || !a->dq_env || !a->dq_inc))
+        return fail(SSD_ERR_INVALID, "null argument");
+    if (!(a->seq_len > 0.f) || !(a->reward_scale != 0.f)) return fail(SSD_ERR_INVALID, "seq_len / reward_scale");
+    launch_td_sim_loss(a, mode ? 1 : 0, (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_encoder(const float* obs, int32_t rows, int32_t view_edge, int32_t conv_out, int32_t feat_out, const float* conv_w,
                 const float* conv_b, const float* lin_w, const float* lin_b, float* out, int32_t out_stride, int32_t n_agents,
                 int32_t agent_major, float* store_obs, int64_t store_env_stride, const int64_t* store_t, void* stream) {

@@ -1,7 +1,9 @@
 // ssd_learner.hip -- the two integer/elementwise pieces of the homophily learner that sit on the data path.
 //   k_build_inputs        HomophilyMAC._build_inputs tail   (controllers/homophily_controller.py:137-184)
 //   k_incentive_transfer  incentive reward transfer         (learners/homophily_learner.py:94-115)
-// Both are HBM-bound elementwise kernels over [B(*T)*n] rows; one thread per output element / row.
+//   k_td_sim_loss         double-Q TD losses of both heads + similarity loss, forward AND the gradient w.r.t. the Q-values in one
+//                         launch (learners/homophily_learner.py:94-217)
+// All are elementwise / row kernels over [B(*T)*n] rows; one thread per output element / row.
 #include "ssd_device.h"
 
 namespace ssd {
@@ -67,6 +69,139 @@ __global__ void k_incentive_transfer(int32_t B, int32_t T, int32_t n, const int6
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_td_sim_loss: what homophily_learner.py:94-217 builds out of ~100 tensor ops (and autograd differentiates with ~200 more), per
+// (episode b, transition t, agent i) in one thread:
+//   incentive transfer (:94-115)   give_i, recv+-_i -> rewards_for_env / rewards_for_inc = (r +- ...) / max_seq_length
+//   env head TD (:118-177)         double-Q: a* = argmax of the LIVE q_env[t+1] over the available actions, value from the TARGET net;
+//                                  td = q_env[t, a_t] - (r_env + gamma_env (1 - terminated) tq_env[t+1, a*])
+//   inc head TD                    per receiver j != i: a*_j = argmax_c q_inc[t+1, i, j, c];
+//                                  td = sum_j q_inc[t, i, j, a_inc_ij] - (r_inc + gamma_inc (1 - terminated) sum_j tq_inc[t+1, i, j, a*_j])
+//   similarity loss (:184-217)     window (sim_horizon) activity flags -> cluster = 2 rw + cn (the exact-value rule standing in for x-means,
+//                                  SURVEY.md 8c), idle = cn + rw; for every ordered triple i != k != j != i with equal clusters:
+//                                  clamp_min(-log softmax(q_inc[t, i, j])[a_inc_kj], threshold) * idle_i * idle_k
+//   L = (sum (td_env mask)^2 + sum (td_inc mask)^2) / den0 + w_sim * sum_sim / (1 + den1),   den = the GLOBAL denominators (data parallel)
+// Outputs: per-thread partial sums (the caller adds them in a fixed order) and, MODE 1, dL/dq_env and dL/dq_inc -- each thread owns
+// the gradient rows of its (b, t, i), so nothing is accumulated across threads (deterministic).  MODE 0: the two denominators only.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr float kNeg = -9999999.f;            // the reference's masked_fill value (homophily_learner.py:137,150)
+template <int MODE>
+__global__ __launch_bounds__(128) void k_td_sim_loss(ssd_td_loss_args a) {
+    const int B = a.batch, T1 = a.t_slots, T = T1 - 1, n = a.n_agents, A = a.n_actions;
+    const int total = B * T1 * n;
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= total) return;
+    const int i = it % n, bt = it / n, t = bt % T1, b = bt / T1;
+    float* dqe = MODE ? a.dq_env + (size_t)it * A : nullptr;
+    float* dqi = MODE ? a.dq_inc + (size_t)it * n * 3 : nullptr;
+    if (t == T) {                              // the bootstrap slot: its Q-values enter the targets only (no gradient)
+        if (MODE) { for (int k = 0; k < A; ++k) dqe[k] = 0.f; for (int k = 0; k < n * 3; ++k) dqi[k] = 0.f; }
+        return;
+    }
+    float* out = a.partials + ((size_t)(b * T + t) * n + i) * SSD_TD_LOSS_PARTIALS;
+    const size_t row = (size_t)bt * n;                                          // (b, t, agent 0)
+    const float mask = (float)a.filled[bt] * (t ? 1.f - (float)a.terminated[bt - 1] : 1.f);   // :62-64
+    // ---- similarity mask: window flags of every agent (:184-191), cluster / idle (:194-206) ------------------------------------
+    uint32_t cn_bits = 0, rw_bits = 0;
+    const int t_lo = t - a.sim_horizon + 1 > 0 ? t - a.sim_horizon + 1 : 0;
+    for (int k = 0; k < n; ++k) {
+        float cn = 0.f, rw = 0.f;
+        for (int tau = t_lo; tau <= t; ++tau) {
+            const size_t e = ((size_t)b * T1 + tau) * n + k;
+            cn += a.clean_num[e] > 0.f ? 1.f : 0.f;
+            rw += a.reward[e] / a.reward_scale;
+        }
+        cn_bits |= (cn > 0.f ? 1u : 0u) << k; rw_bits |= (rw > 0.f ? 1u : 0u) << k;
+    }
+    const int cn_i = (cn_bits >> i) & 1, rw_i = (rw_bits >> i) & 1, cl_i = 2 * rw_i + cn_i, idle_i = cn_i + rw_i;
+    // sim(i, k) = [cluster_i == cluster_k] idle_i idle_k  (0, 1, 2 or 4)
+    auto sim_ik = [&](int k) -> float {
+        const int cn_k = (cn_bits >> k) & 1, rw_k = (rw_bits >> k) & 1;
+        return (2 * rw_k + cn_k == cl_i) ? (float)(idle_i * (cn_k + rw_k)) : 0.f;
+    };
+    float sim_sum = 0.f;
+    for (int k = 0; k < n; ++k) { if (k != i) sim_sum += sim_ik(k) * (float)(n - 2); }   // receivers j != i, j != k
+    out[0] = mask; out[1] = sim_sum;
+    if (!MODE) return;
+    // ---- incentive transfer (:94-115) ----------------------------------------------------------------------------------------------
+    const int64_t* ainc = a.actions_inc + row * n;                              // [giver][receiver] at (b, t)
+    int give = 0, rp = 0, rn = 0;
+    for (int j = 0; j < n; ++j) {
+        if (j == i) continue;
+        give += ainc[(size_t)i * n + j] != 0;
+        const int64_t x = ainc[(size_t)j * n + i];
+        rp += x == 1; rn += x == 2;
+    }
+    const float r = a.reward[row + i] / a.reward_scale;
+    const float clean = a.clean_num[row + i] > 0.f ? 1.f : 0.f;
+    const float rv = (float)(rp - rn);
+    const float r_env = (r + rv * a.incentive_ratio * a.incentive) / a.seq_len;
+    const float r_inc = (r - (float)give * a.incentive_cost * a.incentive) / a.seq_len;
+    const float live = 1.f - (float)a.terminated[bt];
+    const float den0 = a.dens[0], den1 = 1.f + a.dens[1];
+    // ---- env head (:118-177) ---------------------------------------------------------------------------------------------------
+    const size_t qe = (size_t)it * A, qe1 = qe + (size_t)n * A;                 // (b, t, i) and (b, t + 1, i)
+    const int a_t = (int)a.actions[row + i];
+    const float chosen_env = a.q_env[qe + a_t];
+    float tmax_env;
+    {
+        int best = 0; float bq = -INFINITY, btq = kNeg;
+        for (int k = 0; k < A; ++k) {
+            const bool ok = a.avail[qe1 + k] != 0;
+            const float q = a.double_q ? (ok ? a.q_env[qe1 + k] : kNeg) : (ok ? a.tq_env[qe1 + k] : kNeg);
+            if (q > bq) { bq = q; best = k; btq = ok ? a.tq_env[qe1 + k] : kNeg; }   // first maximum
+        }
+        (void)best;
+        tmax_env = btq;
+    }
+    const float td_env = chosen_env - (r_env + a.gamma_env * live * tmax_env);
+    const float g_env = 2.f * td_env * mask * mask / den0;
+    for (int k = 0; k < A; ++k) dqe[k] = k == a_t ? g_env : 0.f;
+    // ---- inc head: TD over the receivers j != i ---------------------------------------------------------------------------------
+    const size_t qi = (size_t)it * n * 3, qi1 = qi + (size_t)n * n * 3;
+    float sum_chosen = 0.f, sum_tmax = 0.f, q_inc_taken = 0.f;
+    for (int j = 0; j < n; ++j) {
+        const int c = (int)ainc[(size_t)i * n + j];
+        const float qc = a.q_inc[qi + j * 3 + c];
+        q_inc_taken += qc;
+        if (j == i) continue;
+        sum_chosen += qc;
+        const float* sel = (a.double_q ? a.q_inc : a.tq_inc) + qi1 + j * 3;
+        const int best = sel[1] > sel[0] ? (sel[2] > sel[1] ? 2 : 1) : (sel[2] > sel[0] ? 2 : 0);   // first maximum
+        sum_tmax += a.tq_inc[qi1 + j * 3 + best];
+    }
+    const float td_inc = sum_chosen - (r_inc + a.gamma_inc * live * sum_tmax);
+    const float g_inc = 2.f * td_inc * mask * mask / den0;
+    // ---- similarity loss (:208-217) and the inc gradient rows ------------------------------------------------------------------------
+    float sim_num = 0.f;
+    const float wsim = a.sim_loss_weight / den1;
+    for (int j = 0; j < n; ++j) {
+        const float q0 = a.q_inc[qi + j * 3], q1 = a.q_inc[qi + j * 3 + 1], q2 = a.q_inc[qi + j * 3 + 2];
+        const float mx = fmaxf(q0, fmaxf(q1, q2));
+        const float e0 = expf(q0 - mx), e1 = expf(q1 - mx), e2 = expf(q2 - mx), es = e0 + e1 + e2;
+        const float p[3] = {e0 / es, e1 / es, e2 / es};
+        float g[3] = {0.f, 0.f, 0.f};
+        if (j != i) {
+            for (int k = 0; k < n; ++k) {
+                if (k == i || k == j) continue;
+                const float sm = sim_ik(k);
+                if (sm == 0.f) continue;
+                const int c = (int)ainc[(size_t)k * n + j];                     // the incentive action k actually gave j
+                const float nl = -logf(c == 0 ? p[0] : c == 1 ? p[1] : p[2]);
+                sim_num += fmaxf(nl, a.sim_threshold) * sm;
+                if (nl >= a.sim_threshold) {                                    // clamp_min passes the gradient where input >= min
+                    g[0] += sm * (p[0] - (c == 0 ? 1.f : 0.f)); g[1] += sm * (p[1] - (c == 1 ? 1.f : 0.f)); g[2] += sm * (p[2] - (c == 2 ? 1.f : 0.f));
+                }
+            }
+        }
+        const int cij = (int)ainc[(size_t)i * n + j];
+        for (int x = 0; x < 3; ++x) dqi[j * 3 + x] = wsim * g[x] + ((j != i && x == cij) ? g_inc : 0.f);
+    }
+    out[2] = (td_env * mask) * (td_env * mask); out[3] = (td_inc * mask) * (td_inc * mask); out[4] = sim_num;
+    out[5] = chosen_env; out[6] = q_inc_taken; out[7] = (float)give; out[8] = rv;
+    out[9] = clean * rv; out[10] = clean; out[11] = r * rv; out[12] = r;
+}
+
 static int grid_for(size_t total) {
     size_t b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : b > 4096 ? 4096 : b);
@@ -87,6 +222,13 @@ void launch_incentive_transfer(int32_t B, int32_t T, int32_t n, const int64_t* a
     const size_t total = (size_t)B * T * n;
     hipLaunchKernelGGL(k_incentive_transfer, dim3(grid_for(total)), dim3(256), 0, stream, B, T, n, a_inc, rewards,
                        effect_ratio, cost_ratio, incentive, seq_len, give, recv_pos, recv_neg, recv_zero, r_env, r_inc);
+}
+
+void launch_td_sim_loss(const ssd_td_loss_args* a, int mode, hipStream_t stream) {
+    const int total = a->batch * a->t_slots * a->n_agents;
+    const dim3 grid((total + 127) / 128), block(128);
+    if (mode) hipLaunchKernelGGL(k_td_sim_loss<1>, grid, block, 0, stream, *a);
+    else hipLaunchKernelGGL(k_td_sim_loss<0>, grid, block, 0, stream, *a);
 }
 
 }  // namespace ssd

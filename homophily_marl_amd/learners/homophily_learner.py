@@ -96,9 +96,19 @@ class HomophilyLearner:
         mask[:, 1:] = mask[:, 1:] * (1 - terminated[:, :-1])                   # [bs, t-1, 1]
         return mask.expand(-1, -1, self.n_agents)
 
+    def _fused(self, batch):
+        """The loss and its gradient w.r.t. the Q-values as ONE HIP launch (ssd_td_sim_loss) instead of ~100 tensor ops + autograd:
+        device batches with the shipped loss flags; everything else (CPU tensors of the CPU suite / gloo rehearsal,
+        consider_others_inc) keeps the tensor-op statement below, which is also what the GPU tests check the kernel against."""
+        return (bool(getattr(self.args, "fused_loss", True)) and batch["reward"].is_cuda and not self.args.consider_others_inc
+                and self.n_agents >= 2)
+
     def denominators(self, batch):
         """[mask.sum(), sim_mask.sum()] of the GLOBAL batch (all-reduced over the data-parallel group)."""
-        d = th.stack([self._td_mask(batch).sum(), self._sim_inputs(batch).sum()])
+        if self._fused(batch):
+            d = ops.loss_denominators(batch, self.args, self.n_actions)
+        else:
+            d = th.stack([self._td_mask(batch).sum(), self._sim_inputs(batch).sum()])
         if self.distributed:
             dist.all_reduce(d, op=dist.ReduceOp.SUM)
         return d
@@ -114,6 +124,29 @@ class HomophilyLearner:
                 off += p.numel()
 
     def forward_backward(self, batch, dens):
+        if self._fused(batch):
+            return self._forward_backward_fused(batch, dens)
+        return self._forward_backward_ops(batch, dens)
+
+    def _forward_backward_fused(self, batch, dens):
+        a, n = self.args, self.n_agents
+        q_env, q_inc = self.unroll(self.mac, batch)
+        with th.no_grad():
+            tq_env, tq_inc = self.unroll(self.target_mac, batch)
+        loss, sums = ops.td_sim_loss(q_env, q_inc, tq_env, tq_inc, dens, batch, a)
+        self._bind_flat_grad()
+        self._flat_grad.zero_()                                                # optimiser_{inc,env}.zero_grad() (:220-221)
+        loss.backward()
+        with th.no_grad():
+            rows = float(batch.batch_size * (batch.max_seq_length - 1) * n)
+            return {
+                "incentives_to_cleanup_per": sums[9] / (sums[10] + 1e-6), "incentives_to_harvest_per": sums[11] / (sums[12] + 1e-6),
+                "value_give_mean": sums[7] / rows, "value_receive_mean": sums[8] / rows,
+                "q_env_taken_mean": sums[5] / rows, "q_inc_taken_mean": sums[6] / (rows * n),
+                "loss_value_env": sums[2] / dens[0], "loss_value_inc": sums[3] / dens[0], "loss_sim": sums[4] / (1 + dens[1]),
+            }
+
+    def _forward_backward_ops(self, batch, dens):
         a = self.args
         n = self.n_agents
         logs = {}

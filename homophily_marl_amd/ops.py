@@ -4,6 +4,8 @@ Device tensors always go through libssd_hip.so (load_library() raises if it is m
 box).  For CPU tensors -- the CPU test-suite and the gloo rehearsal of the data-parallel path, where no HIP device
 exists -- the same arithmetic is evaluated with torch expressions; that branch is never taken by a GPU run.
 """
+import ctypes as C
+
 import torch as th
 
 from . import abi
@@ -73,6 +75,68 @@ def incentive_transfer(actions_inc, rewards, effect_ratio, cost_ratio, incentive
     re = (rewards + rv * effect_ratio * incentive) / seq_len
     ri = (rewards - give * cost_ratio * incentive) / seq_len
     return give, rp, rn, rz, re, ri
+
+
+def _td_loss_args(batch, a, n_actions, partials):
+    """ssd_td_loss_args over the batch's tensors (contiguous copies where a view is not); returns (args, keep-alive list)."""
+    c = lambda x: x.contiguous()
+    B, T1, n = batch.batch_size, batch.max_seq_length, batch["reward"].shape[-1]
+    keep = dict(actions=c(batch["actions"].squeeze(-1)), actions_inc=c(batch["actions_inc"].squeeze(-1)), avail=c(batch["avail_actions"]),
+                reward=c(batch["reward"].float()), clean_num=c(batch["clean_num"].float()),
+                terminated=c(batch["terminated"].squeeze(-1)), filled=c(batch["filled"].squeeze(-1)))
+    assert keep["avail"].dtype == th.int32 and keep["terminated"].dtype == th.uint8 and keep["filled"].dtype == th.int64
+    t = abi.SsdTdLossArgs()
+    t.batch, t.t_slots, t.n_agents, t.n_actions, t.sim_horizon, t.double_q = B, T1, n, n_actions, int(a.sim_horizon), int(bool(a.double_q))
+    t.gamma_env, t.gamma_inc, t.reward_scale = float(a.gamma_env), float(a.gamma_inc), float(a.reward_scale)
+    t.incentive_ratio, t.incentive_cost, t.incentive = float(a.incentive_ratio), float(a.incentive_cost), float(a.incentive)
+    t.seq_len, t.sim_threshold, t.sim_loss_weight = float(T1), float(a.sim_threshold), float(a.sim_loss_weight)
+    for k, v in keep.items():
+        setattr(t, k, v.data_ptr())
+    t.partials = partials.data_ptr()
+    return t, keep
+
+
+def loss_denominators(batch, a, n_actions):
+    """[mask.sum(), sim_loss_mask.sum()] of this batch (homophily_learner.py:62-64,184-206,214) from ONE launch of ssd_td_sim_loss
+    (mode 0) instead of ~30 tensor ops; device tensors only."""
+    lib = abi.load_library()
+    B, T, n = batch.batch_size, batch.max_seq_length - 1, batch["reward"].shape[-1]
+    partials = th.zeros(B * T * n, abi.TD_LOSS_PARTIALS, dtype=th.float32, device=batch["reward"].device)
+    t, keep = _td_loss_args(batch, a, n_actions, partials)
+    abi.check(lib, lib.ssd_td_sim_loss(C.byref(t), 0, _stream(partials)))
+    return partials[:, :2].sum(0)
+
+
+class _TdSimLoss(th.autograd.Function):
+    """loss = (sum (td_env mask)^2 + sum (td_inc mask)^2) / dens[0] + sim_loss_weight * sum_sim / (1 + dens[1]) and its gradient w.r.t.
+    q_env / q_inc from one launch (csrc/ssd_learner.hip: k_td_sim_loss); returns (loss, column sums of the per-row partials)."""
+
+    @staticmethod
+    def forward(ctx, q_env, q_inc, tq_env, tq_inc, dens, batch, a):
+        lib = abi.load_library()
+        B, T, n = batch.batch_size, batch.max_seq_length - 1, q_env.shape[2]
+        q_env, q_inc, tq_env, tq_inc = q_env.contiguous(), q_inc.contiguous(), tq_env.contiguous(), tq_inc.contiguous()
+        partials = th.zeros(B * T * n, abi.TD_LOSS_PARTIALS, dtype=th.float32, device=q_env.device)
+        dq_env, dq_inc = th.empty_like(q_env), th.empty_like(q_inc)
+        t, keep = _td_loss_args(batch, a, q_env.shape[-1], partials)
+        t.q_env, t.q_inc, t.tq_env, t.tq_inc = q_env.data_ptr(), q_inc.data_ptr(), tq_env.data_ptr(), tq_inc.data_ptr()
+        dens = dens.contiguous().float()
+        t.dens, t.dq_env, t.dq_inc = dens.data_ptr(), dq_env.data_ptr(), dq_inc.data_ptr()
+        abi.check(lib, lib.ssd_td_sim_loss(C.byref(t), 1, _stream(q_env)))
+        sums = partials.sum(0)
+        loss = (sums[2] + sums[3]) / dens[0] + a.sim_loss_weight * sums[4] / (1 + dens[1])
+        ctx.save_for_backward(dq_env, dq_inc)
+        ctx.mark_non_differentiable(sums)
+        return loss, sums
+
+    @staticmethod
+    def backward(ctx, g_loss, g_sums):
+        dq_env, dq_inc = ctx.saved_tensors
+        return dq_env * g_loss, dq_inc * g_loss, None, None, None, None, None
+
+
+def td_sim_loss(q_env, q_inc, tq_env, tq_inc, dens, batch, a):
+    return _TdSimLoss.apply(q_env, q_inc, tq_env, tq_inc, dens, batch, a)
 
 
 class _GruGates(th.autograd.Function):

@@ -196,6 +196,36 @@ int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int
                            float seq_len, float* give, float* recv_pos, float* recv_neg, float* recv_zero,
                            float* rewards_for_env, float* rewards_for_inc, void* stream);
 
+/* ssd_td_sim_loss: the loss of HomophilyLearner.cal_loss_and_step (learners/homophily_learner.py:94-217) -- incentive reward
+ * transfer, double-Q TD losses of the env head and the incentive head, the similarity loss with the exact-value clustering rule --
+ * AND its gradient w.r.t. the live Q-values in one launch (the reference builds it from ~100 tensor ops that autograd differentiates).
+ * All tensors are over the batch's T+1 time slots (t_slots = batch.max_seq_length), contiguous:
+ *   q_env, tq_env f32 [B, T+1, n, A] (live / target net, masked by avail as the reference does); q_inc, tq_inc f32 [B, T+1, n, n, 3];
+ *   actions i64 [B, T+1, n]; actions_inc i64 [B, T+1, n(giver), n(receiver)]; avail i32 [B, T+1, n, A]; reward, clean_num f32 [B, T+1, n];
+ *   terminated u8 [B, T+1]; filled i64 [B, T+1].
+ * mode 0: only the per-row denominators: partials[:, 0] = mask, partials[:, 1] = sum of sim_loss_mask (their sums are
+ *         mask.sum() and sim_loss_mask.sum(); data parallel: all-reduce them before mode 1).
+ * mode 1: dens f32 [2] = the GLOBAL (mask.sum(), sim_loss_mask.sum()); writes dq_env / dq_inc (shapes of q_env / q_inc, every element)
+ *         = d loss / d q with loss = (sum (td_env mask)^2 + sum (td_inc mask)^2) / dens[0] + sim_loss_weight sum_sim / (1 + dens[1]),
+ *         and partials f32 [B * T * n, SSD_TD_LOSS_PARTIALS] per (b, t, i): 0 mask, 1 sim mask sum, 2 (td_env mask)^2,
+ *         3 (td_inc mask)^2, 4 similarity terms, 5 q_env taken, 6 sum_j q_inc taken, 7 give, 8 recv+ - recv-, 9 clean (recv+ - recv-),
+ *         10 clean flag, 11 r (recv+ - recv-), 12 r  -- the caller adds the rows in a fixed order (losses and the learner's log values).
+ * consider_others_inc (config/algs/homophily.yaml, default False) is not covered: the caller keeps its tensor-op path for it. */
+#define SSD_TD_LOSS_PARTIALS 16
+typedef struct ssd_td_loss_args {
+    int32_t batch, t_slots, n_agents, n_actions, sim_horizon, double_q;
+    float gamma_env, gamma_inc, reward_scale, incentive_ratio, incentive_cost, incentive, seq_len, sim_threshold, sim_loss_weight;
+    const float *q_env, *q_inc, *tq_env, *tq_inc;
+    const int64_t *actions, *actions_inc;
+    const int32_t* avail;
+    const float *reward, *clean_num;
+    const uint8_t* terminated;
+    const int64_t* filled;
+    const float* dens;
+    float *dq_env, *dq_inc, *partials;
+} ssd_td_loss_args;
+int ssd_td_sim_loss(const ssd_td_loss_args* args, int32_t mode, void* stream);
+
 /* ---- rollout-time (inference) controller pieces that are not GEMMs (csrc/ssd_policy.hip) -----------------------------
  * ssd_encoder: HomophilyAgent.rgb_preprocess (homophily_agent.py:20-27,213-214) = Conv2d(3, conv_out, 3, 1) + LeakyReLU +
  *   Flatten + Linear(conv_out * (V-2)^2, feat_out) + LeakyReLU on obs f32 [rows, 3, V, V] -> out[row * out_stride + 0..feat_out).

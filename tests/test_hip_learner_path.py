@@ -51,13 +51,22 @@ def test_incentive_transfer_kernel_vs_oracle_and_torch():
             assert (cpu[i].numpy() == outs[i]).all(), (B, T, n, i)
 
 
+LOG_KEYS = ("loss_value_env", "loss_value_inc", "loss_sim", "value_give_mean", "value_receive_mean", "q_env_taken_mean", "q_inc_taken_mean",
+            "incentives_to_cleanup_per", "incentives_to_harvest_per")
+
+
+@pytest.mark.parametrize("train_graph", [False, True])
 @pytest.mark.parametrize("name", ["learner_cleanup5.npz", "learner_harvest5.npz"])
-def test_learner_on_device_matches_reference_fixture(name):
-    """Same fixtures as the CPU suite, network + HIP kernels on the GPU: Q-loss within 1e-5 (fp32)."""
-    from tests.learner_util import build, load_fixture
+def test_learner_on_device_matches_reference_fixture(name, train_graph):
+    """Same fixtures as the CPU suite, network + HIP kernels on the GPU (fused loss kernel, sequence GRU kernels): inputs, Q-values,
+    every logged value of two optimisation steps within 1e-5 (fp32) and every parameter after each step (pins the two-Adam /
+    double-clip order on the device) -- eagerly and with the train step captured as hipGraphs (the captured step is compared with
+    the REFERENCE's numbers, not only with the eager step)."""
+    from tests.learner_util import build, load_fixture, param_checksums
     th.backends.cuda.matmul.allow_tf32 = False
     z, meta = load_fixture(name)
-    args, batch, mac, learner = build(z, meta, device="cuda:0")
+    args, batch, mac, learner = build(z, meta, device="cuda:0", overrides=dict(train_graph=train_graph))
+    assert learner._fused(batch) and learner.use_graph == train_graph
     with th.no_grad():
         got = mac._build_inputs(batch, 3).cpu().numpy()
         nf = args.obs_dim_net
@@ -65,10 +74,101 @@ def test_learner_on_device_matches_reference_fixture(name):
         q_env, q_inc = learner.unroll(mac, batch)
         assert np.abs(q_env.cpu().numpy() - z["q_env"]).max() < 1e-5
         assert np.abs(q_inc.cpu().numpy() - z["q_inc"]).max() < 1e-5
+    if train_graph:
+        # the graph path runs its first two calls eagerly and captures at the third: bring a SECOND learner past its capture on a
+        # scratch copy of the weights, then rewind weights / optimiser state and replay the two fixture steps through the graphs
+        sd0 = {k: v.clone() for k, v in mac.agent.state_dict().items()}
+        for _ in range(3):
+            learner.train(batch, 0, 0)
+        assert learner._graph is not None
+        mac.agent.load_state_dict(sd0); learner.target_mac.load_state(mac)
+        for opt in (learner.optimiser_env, learner.optimiser_inc):
+            for st in opt.state.values():
+                st["step"].zero_(); st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
     for step in range(2):
-        logs = learner.cal_loss_and_step(batch)
-        for k in ("loss_value_env", "loss_value_inc", "loss_sim"):
-            assert abs(float(logs[k]) - float(z["step%d_%s" % (step, k)])) < 1e-5, (step, k, float(logs[k]))
+        if train_graph:
+            learner.train(batch, 0, 0)
+            logs = learner._static_logs
+        else:
+            logs = learner.cal_loss_and_step(batch)
+        for k in LOG_KEYS:
+            assert abs(float(logs[k]) - float(z["step%d_%s" % (step, k)])) < 1e-5, (step, k, float(logs[k]), float(z["step%d_%s" % (step, k)]))
+        sums, sqs, heads = param_checksums(mac)
+        assert np.abs(heads - z["step%d_param_head" % step]).max() < 2e-5, step
+        assert np.abs(sqs - z["step%d_param_sq" % step]).max() / np.abs(z["step%d_param_sq" % step]).max() < 1e-5, step
+
+
+def _random_learner_batch(B, T, n, kind, seed):
+    """A synthetic sampled batch with everything the loss reads switched on: rewards of both signs, cleaning, incentives of all three
+    kinds, early termination (mask), random availability."""
+    from types import SimpleNamespace
+    from homophily_marl_amd.components.episode_buffer import EpisodeBatch
+    from homophily_marl_amd.components.transforms import OneHot
+    from homophily_marl_amd.controllers import REGISTRY as mac_REGISTRY
+    from homophily_marl_amd.learners import REGISTRY as le_REGISTRY
+    from homophily_marl_amd.run import load_config
+    g = th.Generator().manual_seed(seed)
+    A = 9 if kind == "cleanup" else 8
+    mp = "default10" if (kind == "harvest" or n == 10) else "default5"
+    cfg = load_config(kind, overrides=dict(env_args=dict(num_agents=n, map=mp, episode_limit=T, view_size=7), use_cuda=True, batch_size=B))
+    args = SimpleNamespace(**cfg)
+    args.device, args.n_agents, args.n_actions = "cuda:0", n, A
+    args.obs_shape, args.obs_dims = (3, 15, 15), (15, 15)
+    args.state_dims = {"default5": (25, 18), "default10": (48, 18) if kind == "cleanup" else (9, 38)}[mp]
+    scheme = {"obs": {"vshape": (3, 15, 15), "group": "agents"}, "actions": {"vshape": (1,), "group": "agents", "dtype": th.long},
+              "avail_actions": {"vshape": (A,), "group": "agents", "dtype": th.int}, "reward": {"vshape": (n,)},
+              "terminated": {"vshape": (1,), "dtype": th.uint8}, "clean_num": {"vshape": (n,)}, "apple_den": {"vshape": (n,)},
+              "agent_pos": {"vshape": (n, 2)}, "agent_orientation": {"vshape": (n, 2)},
+              "actions_inc": {"vshape": (n, 1), "group": "agents", "dtype": th.long}}
+    groups = {"agents": n}
+    batch = EpisodeBatch(scheme, groups, B, T + 1, preprocess={"actions": ("actions_onehot", [OneHot(out_dim=A)])}, device="cuda:0")
+    avail = (th.rand(B, T + 1, n, A, generator=g) < 0.7).int()
+    avail[..., 4] = 1                                                       # STAY is always available
+    acts = th.multinomial(avail.reshape(-1, A).float(), 1).reshape(B, T + 1, n, 1)
+    ainc = th.randint(0, 3, (B, T + 1, n, n), generator=g) * (1 - th.eye(n, dtype=th.long))
+    term = th.zeros(B, T + 1, 1, dtype=th.uint8)
+    for b in range(B):
+        term[b, T - 1 - (b % 3) * 2] = 1                                    # some episodes end early: the TD mask is not all ones
+    obs = th.zeros(B, T + 1, n, 3, 15, 15)
+    cls = th.randint(0, 4, (B, T + 1, n, 15, 15), generator=g)
+    for ch, c in ((0, 2), (1, 1), (2, 3)):
+        obs[:, :, :, ch] = (cls == c).float() * (255.0 / 256.0)
+    batch.update(dict(obs=obs, actions=acts, avail_actions=avail, actions_inc=ainc.unsqueeze(-1), terminated=term,
+                      reward=th.randint(-1, 3, (B, T + 1, n), generator=g).float() * (th.rand(B, T + 1, n, generator=g) < 0.3),
+                      clean_num=th.randint(0, 3, (B, T + 1, n), generator=g).float() * (th.rand(B, T + 1, n, generator=g) < 0.3),
+                      apple_den=th.rand(B, T + 1, n, generator=g), agent_pos=th.randint(1, 17, (B, T + 1, n, 2), generator=g).float(),
+                      agent_orientation=th.tensor([-1.0, 0.0]).expand(B, T + 1, n, 2)))
+    logger = SimpleNamespace(log_stat=lambda *a, **k: None, console_logger=None)
+    out = []
+    for fused in (True, False):
+        th.manual_seed(seed)
+        a2 = SimpleNamespace(**vars(args))
+        a2.fused_loss = fused
+        mac = mac_REGISTRY[a2.mac](batch.scheme, groups, a2).cuda()
+        learner = le_REGISTRY[a2.learner](mac, batch.scheme, logger, a2)
+        learner.cuda()
+        for p in learner.target_mac.parameters():                           # a target net that differs from the live net
+            p.data.add_(0.05 * th.randn(p.shape, generator=th.Generator().manual_seed(seed + p.numel())).cuda())
+        out.append(learner)
+    return batch, out[0], out[1]
+
+
+@pytest.mark.parametrize("B,T,n,kind", [(16, 100, 5, "cleanup"), (5, 23, 10, "cleanup"), (7, 31, 5, "harvest")])
+def test_fused_loss_kernel_matches_the_tensor_op_loss(B, T, n, kind):
+    """ssd_td_sim_loss (one launch: incentive transfer, both double-Q TD losses, the similarity loss and the gradient w.r.t. the
+    Q-values) against the tensor-op statement of homophily_learner.py:94-217 + autograd on the same batch and weights: denominators,
+    every logged value, and the whole flat parameter gradient."""
+    batch, fused, plain = _random_learner_batch(B, T, n, kind, seed=B + T)
+    assert fused._fused(batch) and not plain._fused(batch)
+    d1, d2 = fused.denominators(batch), plain.denominators(batch)
+    assert d1[0] == d2[0] and d1[1] == d2[1] and float(d1[1]) > 0 and float(d1[0]) < B * T * n       # sim mask active, TD mask not all ones
+    l1 = fused.forward_backward(batch, d1)
+    l2 = plain.forward_backward(batch, d2)
+    for k in LOG_KEYS:
+        assert abs(float(l1[k]) - float(l2[k])) < 1e-5 * max(1.0, abs(float(l2[k]))), (k, float(l1[k]), float(l2[k]))
+    g1, g2 = fused._flat_grad, plain._flat_grad
+    assert float(g2.abs().max()) > 1e-4
+    assert float((g1 - g2).abs().max()) < 2e-6 * max(1.0, float(g2.abs().max())), (float((g1 - g2).abs().max()), float(g2.abs().max()))
 
 
 def test_env_class_drop_in_surface_single_env():
