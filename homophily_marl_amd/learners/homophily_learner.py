@@ -41,9 +41,13 @@ class HomophilyLearner:
         self.last_target_update_episode = 0
         # train_graph: capture the step as hipGraphs (torch.cuda.CUDAGraph); needs capturable Adam (same arithmetic,
         # the step counter lives on the device)
-        self.use_graph = bool(getattr(args, "train_graph", False)) and str(self.device).startswith("cuda")
-        self.optimiser_env = Adam(params=self.params_env, lr=args.lr_env, capturable=self.use_graph)
-        self.optimiser_inc = Adam(params=self.params_inc, lr=args.lr_inc, capturable=self.use_graph)
+        on_gpu = str(self.device).startswith("cuda")
+        self.use_graph = bool(getattr(args, "train_graph", False)) and on_gpu
+        # fused: ONE multi-tensor kernel per optimiser step instead of ~90 small launches (same Adam arithmetic; the step counters
+        # then live on the device, as with capturable)
+        self.fused_adam = on_gpu and bool(getattr(args, "fused_adam", True))
+        self.optimiser_env = Adam(params=self.params_env, lr=args.lr_env, capturable=self.use_graph, fused=self.fused_adam or None)
+        self.optimiser_inc = Adam(params=self.params_inc, lr=args.lr_inc, capturable=self.use_graph, fused=self.fused_adam or None)
         self._flat_grad = None
         self._graph = None
         self._graph_calls = 0
@@ -114,14 +118,21 @@ class HomophilyLearner:
         return d
 
     def _bind_flat_grad(self):
-        """All gradients are views into ONE persistent flat fp32 buffer: zeroing is one memset, the data-parallel
-        all-reduce is one collective on the buffer itself, and graph replays see stable addresses."""
+        """All gradients are views into ONE persistent flat fp32 buffer: the data-parallel all-reduce is one collective on the
+        buffer itself, and graph replays see stable addresses."""
         if self._flat_grad is None:
             self._flat_grad = th.zeros(sum(p.numel() for p in self.params), dtype=th.float32, device=self.params[0].device)
             off = 0
             for p in self.params:
                 p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
                 off += p.numel()
+
+    def _backward(self, loss):
+        """optimiser_{inc,env}.zero_grad() + loss.backward() (homophily_learner.py:220-222): the gradients come back as fresh tensors
+        and ONE concatenation writes them into the flat buffer (accumulating into 44 pre-zeroed .grad views costs a launch each)."""
+        self._bind_flat_grad()
+        grads = th.autograd.grad(loss, self.params)
+        th.cat([g.reshape(-1) for g in grads], out=self._flat_grad)
 
     def forward_backward(self, batch, dens):
         if self._fused(batch):
@@ -134,9 +145,7 @@ class HomophilyLearner:
         with th.no_grad():
             tq_env, tq_inc = self.unroll(self.target_mac, batch)
         loss, sums = ops.td_sim_loss(q_env, q_inc, tq_env, tq_inc, dens, batch, a)
-        self._bind_flat_grad()
-        self._flat_grad.zero_()                                                # optimiser_{inc,env}.zero_grad() (:220-221)
-        loss.backward()
+        self._backward(loss)
         with th.no_grad():
             rows = float(batch.batch_size * (batch.max_seq_length - 1) * n)
             return {
@@ -207,9 +216,7 @@ class HomophilyLearner:
         p_ikj = th.gather(p_inc.unsqueeze(3).expand(-1, -1, -1, n, -1, -1), dim=-1, index=idx.unsqueeze(-1)).squeeze(-1)
         sim_loss = (th.clamp_min(-th.log(p_ikj), a.sim_threshold) * sim_mask).sum() / (1 + dens[1])
 
-        self._bind_flat_grad()
-        self._flat_grad.zero_()                                                # optimiser_{inc,env}.zero_grad() (:220-221)
-        (value_loss_inc + value_loss_env + sim_loss * a.sim_loss_weight).backward()
+        self._backward(value_loss_inc + value_loss_env + sim_loss * a.sim_loss_weight)
 
         with th.no_grad():
             q_inc_taken = th.gather(q_inc[:, :-1], dim=-1, index=actions_inc).squeeze(-1)
@@ -307,10 +314,12 @@ class HomophilyLearner:
         # drop any captured graph (it baked the old optimiser state in)
         for opt in (self.optimiser_env, self.optimiser_inc):
             for group in opt.param_groups:
-                group["capturable"] = self.use_graph
+                group["capturable"], group["fused"] = self.use_graph, (self.fused_adam or None)
+                if self.fused_adam:
+                    group["foreach"] = None
                 for p in group["params"]:
                     st = opt.state.get(p)
                     if st and "step" in st:
                         step = st["step"] if th.is_tensor(st["step"]) else th.tensor(float(st["step"]))
-                        st["step"] = step.to(device=p.device if self.use_graph else "cpu", dtype=th.float32)
+                        st["step"] = step.to(device=p.device if (self.use_graph or self.fused_adam) else "cpu", dtype=th.float32)
         self._graph, self._graph_calls = None, 0

@@ -72,11 +72,12 @@ class HomophilyAgent(nn.Module):
         return self.conv_to_fc(x)
 
     # ---- building blocks ----------------------------------------------------------------------------------------
+    # squeeze, not [0]: the backward of a select materialises a zero tensor + copy per parameter (36 of them per step)
     def _w(self, name):
-        return getattr(self, name)[0]            # [n, in, out]
+        return getattr(self, name).squeeze(0)    # [n, in, out]
 
     def _b(self, name):
-        return getattr(self, name)[0]            # [n, 1, out]
+        return getattr(self, name).squeeze(0)    # [n, 1, out]
 
     def _gru(self, head, x, h):
         """x, h: [n, B, H].  r, z, n gates exactly as homophily_agent.py:162-165 / 188-191."""

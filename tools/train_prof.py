@@ -19,3 +19,14 @@ for i in range(int(os.environ.get("TRAIN_CALLS", 40))):
     ctx.learner.train(sample, 100 * N, i * N)
 th.cuda.synchronize()
 print("train: %.2f ms/call" % (1e3 * (time.perf_counter() - t0) / (int(os.environ.get("TRAIN_CALLS", 40)) - 10)), flush=True)
+
+if os.environ.get("TORCH_PROFILE"):
+    # op-level view of ONE eager step: which aten ops the ~500 launches of a train step come from
+    from torch.profiler import profile, ProfilerActivity
+    ctx.learner.use_graph = False
+    ctx.learner.cal_loss_and_step(sample)
+    th.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        ctx.learner.cal_loss_and_step(sample)
+        th.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=60, max_name_column_width=60))
