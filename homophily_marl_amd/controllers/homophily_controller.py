@@ -154,24 +154,48 @@ class HomophilyMAC(nn.Module):
         """q_env [B, T, n, A], q_inc [B, T, n, n, 3] for every timestep of `batch` -- what calling forward(batch, t) for
         t = 0..T-1 from fresh hidden states returns (the learner's loops, homophily_learner.py:68-91) -- with the encoder,
         the input assembly and all non-recurrent layers evaluated once over all T."""
+        shared = self.unroll_shared(batch)
+        gi, wh, bh = self.unroll_pre(batch, shared)
+        return self.agent.unroll_post(ops.gru_sequence(gi, wh, bh), shared["other"])
+
+    def unroll_shared(self, batch):
+        """Everything of an unroll that does not depend on the weights (the learner evaluates the live and the target net on the
+        same batch): the observation as float planes, the history-shifted controller inputs, one-hot actions, the incentive
+        head's per-receiver features."""
         a = self.args
         B, T, n = batch.batch_size, batch.max_seq_length, self.n_agents
         obs = batch["obs"]
         if obs.dtype == th.uint8:                                                      # compact storage (class codes)
             obs = self.expand_codes(obs)
-        if a.rgb_input:
-            feat = self.agent.rgb_preprocess(obs.reshape(B * T * n, 3, a.obs_dims[0], a.obs_dims[1]).float())
-        else:
-            feat = obs.reshape(B * T * n, -1)
         acts = batch["actions"].squeeze(-1)                                            # [B, T, n]
         # history features of step t come from t - 1; at t = 0 they are zero: action -1 has an all-zero one-hot
         prev = lambda x, fill: th.cat([th.full_like(x[:, :1], fill), x[:, :-1]], dim=1)
-        inputs = self.assemble_inputs(feat, prev(acts, -1).reshape(B * T, n), prev(batch["reward"], 0).reshape(B * T, n),
-                                      prev(batch["actions_inc"].squeeze(-1), 0).reshape(B * T, n, n),
-                                      batch["agent_pos"].reshape(B * T, n, 2), False).reshape(B, T, n, -1)
+        hist = (prev(acts, -1).reshape(B * T, n), prev(batch["reward"], 0).reshape(B * T, n),
+                prev(batch["actions_inc"].squeeze(-1), 0).reshape(B * T, n, n), batch["agent_pos"].reshape(B * T, n, 2))
         onehot = F.one_hot(acts, num_classes=a.n_actions)
-        return self.agent.unroll(inputs, onehot, batch["agent_pos"] / self.pos_scale, batch["agent_orientation"],
-                                 batch["reward"], batch["clean_num"], batch["apple_den"])
+        sh = dict(obs=obs.float() if a.rgb_input else obs, hist=hist, onehot=onehot, tail=None,
+                  other=self.agent.unroll_other(onehot, batch["agent_pos"] / self.pos_scale, batch["agent_orientation"], batch["reward"],
+                                                batch["clean_num"], batch["apple_den"], th.float32))
+        if self.shipped_flags and a.rgb_input:      # the non-visual input columns do not depend on the weights either
+            tail = th.empty(B * T * n, self.input_shape - a.obs_dim_net, dtype=th.float32, device=obs.device)
+            ops.build_inputs_tail(tail, 0, hist[0], hist[1], hist[2], hist[3], self.pos_scale, a.n_actions, False)
+            sh["tail"] = tail
+        return sh
+
+    def unroll_pre(self, batch, shared):
+        """Encoder, input assembly, fc1 and the input-side GRU projections of this net: gi [T, 2n, B, 3H], wh, bh."""
+        a = self.args
+        B, T, n = batch.batch_size, batch.max_seq_length, self.n_agents
+        obs = shared["obs"]
+        if a.rgb_input:
+            feat = self.agent.rgb_preprocess(obs.reshape(B * T * n, 3, a.obs_dims[0], a.obs_dims[1]))
+        else:
+            feat = obs.reshape(B * T * n, -1)
+        if shared["tail"] is not None:
+            inputs = th.cat([feat, shared["tail"]], dim=1).reshape(B, T, n, -1)
+        else:
+            inputs = self.assemble_inputs(feat, *shared["hist"], False).reshape(B, T, n, -1)
+        return self.agent.unroll_pre(inputs, shared["onehot"])
 
     def _build_inputs(self, batch, t):
         if self.args.rgb_input:

@@ -65,6 +65,21 @@ class HomophilyLearner:
         """q_env [B, T, n, A], q_inc [B, T, n, n, 3] for t = 0..T-1 (the loops of homophily_learner.py:68-91)."""
         return mac.unroll(batch)
 
+    def unroll_pair(self, batch):
+        """(q_env, q_inc) of the live net and (tq_env, tq_inc) of the target net (no grad) on the same batch: the weight-independent
+        preparation is shared and both recurrences (4n weight sets) run in ONE sequence launch per direction."""
+        mac, tgt = self.mac, self.target_mac
+        shared = mac.unroll_shared(batch)
+        gi, wh, bh = mac.unroll_pre(batch, shared)
+        with th.no_grad():
+            gi_t, wh_t, bh_t = tgt.unroll_pre(batch, shared)
+        G = gi.shape[1]
+        hs = ops.gru_sequence(th.cat([gi, gi_t], dim=1), th.cat([wh, wh_t], dim=0), th.cat([bh, bh_t], dim=0))
+        q_env, q_inc = mac.agent.unroll_post(hs[:G], shared["other"])
+        with th.no_grad():
+            tq_env, tq_inc = tgt.agent.unroll_post(hs[G:].detach(), shared["other"])
+        return q_env, q_inc, tq_env, tq_inc
+
     def _global(self, x):
         """sum of a scalar tensor over the data-parallel group (loss denominators)."""
         if self.distributed:
@@ -141,9 +156,7 @@ class HomophilyLearner:
 
     def _forward_backward_fused(self, batch, dens):
         a, n = self.args, self.n_agents
-        q_env, q_inc = self.unroll(self.mac, batch)
-        with th.no_grad():
-            tq_env, tq_inc = self.unroll(self.target_mac, batch)
+        q_env, q_inc, tq_env, tq_inc = self.unroll_pair(batch)
         loss, sums = ops.td_sim_loss(q_env, q_inc, tq_env, tq_inc, dens, batch, a)
         self._backward(loss)
         with th.no_grad():
@@ -169,9 +182,8 @@ class HomophilyLearner:
         mask = self._td_mask(batch)
         sim_mask = self._sim_inputs(batch)
 
-        q_env, q_inc = self.unroll(self.mac, batch)
+        q_env, q_inc, tq_env, tq_inc = self.unroll_pair(batch)
         with th.no_grad():
-            tq_env, tq_inc = self.unroll(self.target_mac, batch)
             target_q_env, target_q_inc = tq_env[:, 1:].clone(), tq_inc[:, 1:].clone()
 
         # incentive reward transfer (:94-115): HIP kernel

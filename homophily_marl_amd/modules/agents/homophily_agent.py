@@ -109,9 +109,17 @@ class HomophilyAgent(nn.Module):
         Returns q_env [B, T, n, A], q_inc [B, T, n, n, 3] -- the values forward_env / forward_inc produce step by step
         (homophily_agent.py:154-208) from zero hidden states.  Everything that does not depend on the recurrence (fc1,
         the input-side GRU projections, both dueling heads) runs ONCE over all T; the recurrence itself (h @ W_h and the gate
-        arithmetic, env and inc head together as 2n weight sets) is one sequence kernel per direction on the GPU."""
+        arithmetic, env and inc head together as 2n weight sets) is one sequence kernel per direction on the GPU.
+        = unroll_pre -> ops.gru_sequence -> unroll_post (the learner runs the live and the target net through ONE sequence launch)."""
+        gi, wh, bh = self.unroll_pre(inputs, act_onehot)
+        hs = ops.gru_sequence(gi, wh, bh)                                              # [2n, T, B, H]: one launch for the T steps
+        return self.unroll_post(hs, self.unroll_other(act_onehot, agent_pos, agent_orientation, reward, clean_num, apple_den, inputs.dtype))
+
+    def unroll_pre(self, inputs, act_onehot):
+        """fc1 + the input-side GRU projections of both heads over all T: gi [T, 2n, B, 3H], and the recurrence weights
+        wh [2n, H, 3H], bh [2n, 1, 3H] (env sets first)."""
         B, T, n = inputs.shape[0], inputs.shape[1], self.n_agents
-        H, A = self.hidden, self.n_actions
+        H = self.hidden
         tm = lambda x: x.permute(2, 1, 0, 3).reshape(n, T * B, x.shape[-1])          # time-major rows [n, T*B, f]
         x, act = tm(inputs), tm(act_onehot.to(inputs.dtype))
         xe = F.leaky_relu(th.baddbmm(self._b("fc1_env_b"), x, self._w("fc1_env_w")))
@@ -120,15 +128,26 @@ class HomophilyAgent(nn.Module):
         wii, whi, bii, bhi = self._gru_weights("inc")
         gi = th.cat([th.baddbmm(bie, xe, wie), th.baddbmm(bii, xi, wii)], dim=0).reshape(2 * n, T, B, 3 * H)
         gi = gi.transpose(0, 1).contiguous()                                           # [T, 2n, B, 3H]: gi[t] is one contiguous block
-        wh, bh = th.cat([whe, whi], dim=0), th.cat([bhe, bhi], dim=0)                 # [2n, H, 3H], [2n, 1, 3H]
-        hs = ops.gru_sequence(gi, wh, bh)                                              # [2n, T, B, H]: one launch for the T steps
+        return gi, th.cat([whe, whi], dim=0), th.cat([bhe, bhi], dim=0)
+
+    @staticmethod
+    def unroll_other(act_onehot, agent_pos, agent_orientation, reward, clean_num, apple_den, dtype):
+        """other_j = [onehot(a_j), pos_j, orient_j, r_j, clean_j, apple_den_j] (homophily_agent.py:194-201) as [T*B, n(j), E];
+        independent of the weights (the learner shares it between the live and the target net)."""
+        T, B, n = act_onehot.shape[1], act_onehot.shape[0], act_onehot.shape[2]
+        return th.cat([act_onehot.to(dtype), agent_pos, agent_orientation, reward.unsqueeze(-1), clean_num.unsqueeze(-1),
+                       apple_den.unsqueeze(-1)], dim=-1).permute(1, 0, 2, 3).reshape(T * B, n, -1)
+
+    def unroll_post(self, hs, other):
+        """Both dueling heads on the recurrence states hs [2n, T, B, H] (env sets first) and other [T*B, n(j), E]:
+        q_env [B, T, n, A], q_inc [B, T, n, n, 3]."""
+        n, H, A = self.n_agents, self.hidden, self.n_actions
+        T, B = hs.shape[1], hs.shape[2]
         he, hi = hs[:n].reshape(n, T * B, H), hs[n:].reshape(n, T * B, H)
         a = th.baddbmm(self._b("fc2_env_b"), he, self._w("fc2_env_w"))
         v = th.baddbmm(self._b("fc2_env_v_b"), he, self._w("fc2_env_v_w"))
         q_env = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, T, B, A).permute(2, 1, 0, 3)
-        # inc head: per ordered pair (i -> j) [h_i | onehot(a_j), pos_j, orient_j, r_j, clean_j, apple_den_j]
-        other = th.cat([act_onehot.to(inputs.dtype), agent_pos, agent_orientation, reward.unsqueeze(-1), clean_num.unsqueeze(-1),
-                        apple_den.unsqueeze(-1)], dim=-1).permute(1, 0, 2, 3).reshape(T * B, n, -1)     # [T*B, n(j), E]
+        # inc head: per ordered pair (i -> j) [h_i | other_j]
         E = other.shape[-1]
         cat = th.cat([hi.unsqueeze(2).expand(n, T * B, n, H), other.unsqueeze(0).expand(n, T * B, n, E)], dim=-1)
         cat = cat.reshape(n, T * B * n, H + E)
