@@ -9,6 +9,7 @@ Differences in HOW, not WHAT:
     documented exact-value rule cluster = 2 * rewards_t + clean_num_t, which also removes the GPU->CPU sync of :194;
   * data parallel: loss denominators and gradients are all-reduced over the process group (RCCL) before clipping.
 """
+import os
 from types import SimpleNamespace
 
 import torch as th
@@ -146,8 +147,12 @@ class HomophilyLearner:
         """optimiser_{inc,env}.zero_grad() + loss.backward() (homophily_learner.py:220-222): the gradients come back as fresh tensors
         and ONE concatenation writes them into the flat buffer (accumulating into 44 pre-zeroed .grad views costs a launch each)."""
         self._bind_flat_grad()
-        grads = th.autograd.grad(loss, self.params)
-        th.cat([g.reshape(-1) for g in grads], out=self._flat_grad)
+        if getattr(self.args, "grad_by_cat", False):
+            grads = th.autograd.grad(loss, self.params)
+            th.cat([g.reshape(-1) for g in grads], out=self._flat_grad)
+        else:
+            self._flat_grad.zero_()
+            loss.backward()
 
     def forward_backward(self, batch, dens):
         if self._fused(batch):
@@ -284,6 +289,22 @@ class HomophilyLearner:
             self._static_data[k].copy_(v)
         self._static_dens.copy_(self.denominators(self._static_batch))
         self._graph[0].replay()
+        if os.environ.get("SSD_GRAPH_CHECK"):      # diagnostic: the replayed gradient against an eager evaluation of the same step
+            got = self._flat_grad.clone()
+            self.forward_backward(self._static_batch, self._static_dens)
+            ref = self._flat_grad.clone()
+            err = float((got - ref).abs().max())
+            self._check_n = getattr(self, "_check_n", 0) + 1
+            if err > 1e-4 * max(1.0, float(ref.abs().max())) or not bool(th.isfinite(got).all()):
+                print("GRAPH != EAGER at replay %d: max |diff| %.3e (|ref| max %.3e)" % (self._check_n, err, float(ref.abs().max())), flush=True)
+                off = 0
+                for name, prm in self.mac.agent.named_parameters():
+                    a_, b_ = got[off:off + prm.numel()], ref[off:off + prm.numel()]; off += prm.numel()
+                    dd = float((a_ - b_).abs().max())
+                    if dd > 1e-5 or not bool(th.isfinite(a_).all()):
+                        print("      %-22s max diff %.3e  |graph| %.3e |eager| %.3e" % (name, dd, float(a_.abs().max()), float(b_.abs().max())), flush=True)
+                raise SystemExit(3)
+            self._flat_grad.copy_(got)
         if self.distributed:
             dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
         self._graph[1].replay()

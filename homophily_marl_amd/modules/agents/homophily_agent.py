@@ -69,6 +69,13 @@ class HomophilyAgent(nn.Module):
         return z.detach(), z.clone().detach()
 
     def rgb_preprocess(self, x):
+        """Conv2d + LeakyReLU + Flatten + Linear + LeakyReLU (homophily_agent.py:20-27,213-214).  With gradients on the device the
+        two bias gradients are
+        evaluated as GEMMs (ops.column_sums: ATen's multi-block reductions are not safe inside a replayed hipGraph here)."""
+        if x.is_cuda and th.is_grad_enabled():
+            c = self.conv_to_fc
+            y = ops.channel_bias(F.conv2d(x, c[0].weight, None, c[0].stride), c[0].bias)
+            return c[4](ops.bias_linear(c[2](c[1](y)), c[3].weight, c[3].bias))
         return self.conv_to_fc(x)
 
     # ---- building blocks ----------------------------------------------------------------------------------------
@@ -122,11 +129,11 @@ class HomophilyAgent(nn.Module):
         H = self.hidden
         tm = lambda x: x.permute(2, 1, 0, 3).reshape(n, T * B, x.shape[-1])          # time-major rows [n, T*B, f]
         x, act = tm(inputs), tm(act_onehot.to(inputs.dtype))
-        xe = F.leaky_relu(th.baddbmm(self._b("fc1_env_b"), x, self._w("fc1_env_w")))
-        xi = F.leaky_relu(th.baddbmm(self._b("fc1_inc_b"), th.cat([x, act], dim=-1), self._w("fc1_inc_w")))
+        xe = F.leaky_relu(ops.bias_bmm(x, self._w("fc1_env_w"), self._b("fc1_env_b")))
+        xi = F.leaky_relu(ops.bias_bmm(th.cat([x, act], dim=-1), self._w("fc1_inc_w"), self._b("fc1_inc_b")))
         wie, whe, bie, bhe = self._gru_weights("env")
         wii, whi, bii, bhi = self._gru_weights("inc")
-        gi = th.cat([th.baddbmm(bie, xe, wie), th.baddbmm(bii, xi, wii)], dim=0).reshape(2 * n, T, B, 3 * H)
+        gi = th.cat([ops.bias_bmm(xe, wie, bie), ops.bias_bmm(xi, wii, bii)], dim=0).reshape(2 * n, T, B, 3 * H)
         gi = gi.transpose(0, 1).contiguous()                                           # [T, 2n, B, 3H]: gi[t] is one contiguous block
         return gi, th.cat([whe, whi], dim=0), th.cat([bhe, bhi], dim=0)
 
@@ -144,15 +151,15 @@ class HomophilyAgent(nn.Module):
         n, H, A = self.n_agents, self.hidden, self.n_actions
         T, B = hs.shape[1], hs.shape[2]
         he, hi = hs[:n].reshape(n, T * B, H), hs[n:].reshape(n, T * B, H)
-        a = th.baddbmm(self._b("fc2_env_b"), he, self._w("fc2_env_w"))
-        v = th.baddbmm(self._b("fc2_env_v_b"), he, self._w("fc2_env_v_w"))
+        a = ops.bias_bmm(he, self._w("fc2_env_w"), self._b("fc2_env_b"))
+        v = ops.bias_bmm(he, self._w("fc2_env_v_w"), self._b("fc2_env_v_b"))
         q_env = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, T, B, A).permute(2, 1, 0, 3)
         # inc head: per ordered pair (i -> j) [h_i | other_j]
         E = other.shape[-1]
         cat = th.cat([hi.unsqueeze(2).expand(n, T * B, n, H), other.unsqueeze(0).expand(n, T * B, n, E)], dim=-1)
         cat = cat.reshape(n, T * B * n, H + E)
-        a = th.baddbmm(self._b("fc2_inc_b"), cat, self._w("fc2_inc_w"))
-        v = th.baddbmm(self._b("fc2_inc_v_b"), cat, self._w("fc2_inc_v_w"))
+        a = ops.bias_bmm(cat, self._w("fc2_inc_w"), self._b("fc2_inc_b"))
+        v = ops.bias_bmm(cat, self._w("fc2_inc_v_w"), self._b("fc2_inc_v_b"))
         q_inc = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, T, B, n, -1).permute(2, 1, 0, 3, 4)
         return q_env, q_inc
 

@@ -104,7 +104,7 @@ def loss_denominators(batch, a, n_actions):
     partials = th.zeros(B * T * n, abi.TD_LOSS_PARTIALS, dtype=th.float32, device=batch["reward"].device)
     t, keep = _td_loss_args(batch, a, n_actions, partials)
     abi.check(lib, lib.ssd_td_sim_loss(C.byref(t), 0, _stream(partials)))
-    return partials[:, :2].sum(0)
+    return column_sums(partials)[:2]
 
 
 class _TdSimLoss(th.autograd.Function):
@@ -123,7 +123,7 @@ class _TdSimLoss(th.autograd.Function):
         dens = dens.contiguous().float()
         t.dens, t.dq_env, t.dq_inc = dens.data_ptr(), dq_env.data_ptr(), dq_inc.data_ptr()
         abi.check(lib, lib.ssd_td_sim_loss(C.byref(t), 1, _stream(q_env)))
-        sums = partials.sum(0)
+        sums = column_sums(partials)
         loss = (sums[2] + sums[3]) / dens[0] + a.sim_loss_weight * sums[4] / (1 + dens[1])
         ctx.save_for_backward(dq_env, dq_inc)
         ctx.mark_non_differentiable(sums)
@@ -137,6 +137,92 @@ class _TdSimLoss(th.autograd.Function):
 
 def td_sim_loss(q_env, q_inc, tq_env, tq_inc, dens, batch, a):
     return _TdSimLoss.apply(q_env, q_inc, tq_env, tq_inc, dens, batch, a)
+
+
+_ONES = {}
+
+
+def _ones_row(rows, like):
+    key = (rows, like.device, like.dtype)
+    if key not in _ONES:
+        _ONES[key] = th.ones(1, rows, dtype=like.dtype, device=like.device)
+    return _ONES[key]
+
+
+def column_sums(x):
+    """x [R, C] -> [C] as a GEMM with a row of ones.  Inside a captured hipGraph the multi-block reduction kernels of ATen (their
+    block-arrival semaphores are cleared by a memset node) were observed to return another reduction's partial sums on MI355X /
+    ROCm 7.2 once other work ran between two replays; a GEMM has no such cross-block hand-off."""
+    if not x.is_cuda:
+        return x.sum(0)
+    return (_ones_row(x.shape[0], x) @ x).squeeze(0)
+
+
+class _BiasBmm(th.autograd.Function):
+    """baddbmm(b [n, 1, O], x [n, R, I], w [n, I, O]) whose bias gradient is a GEMM (ones [n, 1, R] @ dY) instead of ATen's
+    multi-block row reduction (see column_sums)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return th.baddbmm(b, x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        dx = th.bmm(g, w.transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        dw = th.bmm(x.transpose(1, 2), g) if ctx.needs_input_grad[1] else None
+        db = th.bmm(_ones_row(g.shape[1], g).expand(g.shape[0], 1, g.shape[1]), g) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def bias_bmm(x, w, b):
+    """x @ w + b for per-agent weights: x [n, R, I], w [n, I, O], b [n, 1, O]."""
+    if x.is_cuda and (w.requires_grad or b.requires_grad or x.requires_grad):
+        return _BiasBmm.apply(x, w, b)
+    return th.baddbmm(b, x, w)
+
+
+class _BiasLinear(th.autograd.Function):
+    """F.linear(x [R, I], w [O, I], b [O]) with the bias gradient as a GEMM (see column_sums)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return th.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        return (g @ w if ctx.needs_input_grad[0] else None, g.t() @ x if ctx.needs_input_grad[1] else None,
+                column_sums(g) if ctx.needs_input_grad[2] else None)
+
+
+class _ChannelBias(th.autograd.Function):
+    """y [R, C, H, W] + b [C] (the bias of a convolution) with the bias gradient as a GEMM over the R rows followed by a short
+    per-channel sum (see column_sums)."""
+
+    @staticmethod
+    def forward(ctx, y, b):
+        return y + b.view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        R, C = g.shape[0], g.shape[1]
+        db = column_sums(g.reshape(R, -1)).view(C, -1).sum(1) if ctx.needs_input_grad[1] else None
+        return g, db
+
+
+def channel_bias(y, b):
+    return _ChannelBias.apply(y, b)
+
+
+def bias_linear(x, w, b):
+    if x.is_cuda and (w.requires_grad or b.requires_grad or x.requires_grad):
+        return _BiasLinear.apply(x, w, b)
+    return th.nn.functional.linear(x, w, b)
 
 
 class _GruGates(th.autograd.Function):
