@@ -15,6 +15,7 @@ ENV_CLEANUP, ENV_HARVEST = 0, 1
 RNG_TAPE, RNG_COUNTER = 0, 1
 OBS_F32, OBS_BF16, OBS_U8, OBS_CODE = 0, 1, 2, 3
 COLOR_SIMPLIFIED, COLOR_FULL = 0, 1
+CODE_CLASS, CODE_CHANNEL_MASK = 0, 1
 STREAM_UNIFORM, STREAM_MOVE, STREAM_WASTE, STREAM_SPAWN_ROT = 0, 1, 2, 3
 
 SSD_OK, SSD_ERR_INVALID, SSD_ERR_DEVICE, SSD_ERR_NOMEM, SSD_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
@@ -142,7 +143,8 @@ class SsdPolicyEncodeArgs(C.Structure):
                 ("agent_stride", C.c_int64), ("slot_t", C.c_void_p),
                 ("rows", C.c_int32), ("view_edge", C.c_int32), ("n_agents", C.c_int32), ("agent_major", C.c_int32), ("precision", C.c_int32),
                 ("conv_frags", C.c_void_p), ("lin_frags", C.c_void_p), ("conv_b", C.c_void_p), ("lin_b", C.c_void_p),
-                ("out", C.c_void_p), ("out_stride", C.c_int32), ("part", C.c_void_p), ("slot_t_copy", C.c_void_p), ("counter_inc", C.c_void_p)]
+                ("out", C.c_void_p), ("out_stride", C.c_int32), ("part", C.c_void_p), ("slot_t_copy", C.c_void_p), ("counter_inc", C.c_void_p),
+                ("alphabet", C.c_int32)]
 
 
 class SsdTdLossArgs(C.Structure):

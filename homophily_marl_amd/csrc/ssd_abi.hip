@@ -46,7 +46,7 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
     if (cfg->view_size < 0 || cfg->view_size > 31) return fail(SSD_ERR_INVALID, "view_size out of range (0..31)");
     {   // LDS budget: 4 waves (envs) per workgroup must fit the 160 KiB of a CU
         const long V = 2L * cfg->view_size + 1, pm = (cfg->height + 2L * cfg->view_size) * (cfg->width + 2L * cfg->view_size);
-        const long per_wave = 2L * ((cfg->height * cfg->width + 15) & ~15) + pm + 16 + cfg->n_agents * 3L * V * V + 32 + 64 + SSD_CODE_AGENT_STRIDE(V) + 16;
+        const long per_wave = 2L * ((cfg->height * cfg->width + 15) & ~15) + pm + 16 + cfg->n_agents * 3L * V * V + 32 + 64 + (cfg->n_agents * SSD_CODE_AGENT_STRIDE(V) <= 2560 ? cfg->n_agents : 1) * SSD_CODE_AGENT_STRIDE(V) + 16;
         if (per_wave * 4 > 160 * 1024) return fail(SSD_ERR_INVALID, "map / view_size / n_agents exceed the LDS budget of one workgroup");
     }
     if (cfg->spawn_rotation > 3) return fail(SSD_ERR_INVALID, "spawn_rotation must be -1..3");
@@ -109,7 +109,7 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
         }
         S.tab_p_apple[current] = pa; S.tab_p_waste[current] = pw;
     }
-    for (int a = 0; a <= SSD_MAX_SITES; ++a) S.tab_den[a] = (float)((double)a / (double)S.HW);
+    for (int a = 0; a <= SSD_MAX_CELLS; ++a) S.tab_den[a] = (float)((double)a / (double)S.HW);
     E->n_spawn = (int)spawn.size();
     S.random_spawn = cfg->random_spawn_point ? 1 : 0; S.n_spawn = (int)spawn.size();
     S.spawn_len = (S.kind == SSD_ENV_CLEANUP ? 2 : 1) * S.n_spawn;   // Cleanup's constructor appends every point again (cleanup.py:79-80)
@@ -428,6 +428,7 @@ int ssd_policy_encode(const ssd_policy_encode_args* a, void* stream) {
     if (a->view_edge != 15 && a->view_edge != 31)
         return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode is instantiated for view_size 7 and 15 (15 x 15 / 31 x 31 windows); use ssd_conv_leaky + GEMM");
     if (a->precision != 0 && a->precision != 1 && a->precision != 2) return fail(SSD_ERR_INVALID, "precision must be 1 (bf16) or 2 (f32-equivalent)");
+    if (a->alphabet != SSD_CODE_CLASS && a->alphabet != SSD_CODE_CHANNEL_MASK) return fail(SSD_ERR_INVALID, "alphabet");
     const int bands = SSD_ENCODE_BANDS(a->view_edge);
     if (bands == 1 ? (!a->out || a->part || a->out_stride < 32) : (!a->part || a->out)) return fail(SSD_ERR_INVALID, "one band writes `out`, several bands write `part`");
     if ((reinterpret_cast<uintptr_t>(a->conv_frags) | reinterpret_cast<uintptr_t>(a->lin_frags) | reinterpret_cast<uintptr_t>(a->part)) & 15)

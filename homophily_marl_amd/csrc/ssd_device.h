@@ -41,7 +41,7 @@ struct DevSpec : DevHead {
     // same fp64 expression evaluated once per possible count (-ffp-contract=off), so the kernel needs no fp64 division
     double tab_p_apple[SSD_MAX_SITES + 1];
     double tab_p_waste[SSD_MAX_SITES + 1];
-    float tab_den[SSD_MAX_SITES + 1];    // apple_den = (float)(apples / (H * W)) in fp64 (map_env.py:291-292) by the apple count
+    float tab_den[SSD_MAX_CELLS + 1];    // apple_den = (float)(apples / (H * W)) in fp64 (map_env.py:291-292) by the apple count (0..H*W)
     uint16_t apple[SSD_MAX_SITES];       // cell index of each apple site, row-major scan order
     uint16_t waste[SSD_MAX_SITES];
     uint16_t spawn_cell[SSD_MAX_AGENTS]; // spawn cell of agent a under random_spawn_point = False
@@ -96,11 +96,12 @@ enum : int { ERR_BAD_ACTION = 1, ERR_BAD_TAPE = 2, ERR_KEYERROR = 4, ERR_TAPE_OV
 // The class map + planes region doubles as scratch for the tape-mode waste ranks (2 * 256 bytes) during the step.
 __host__ __device__ inline int lds_planes_bytes(const DevHead& s) { return ((s.n * 3 * s.VV + 16) + 15) & ~15; }
 // (+ one agent's class-code window, V * V rounded up to 16, + 16 for the dump byte of idle lanes: the obs_code side output)
-__host__ __device__ inline int lds_code_bytes(const DevHead& s) { return SSD_CODE_AGENT_STRIDE(s.V) + 16; }
+__host__ __device__ inline bool lds_code_all(const DevHead& s) { return s.n * SSD_CODE_AGENT_STRIDE(s.V) <= 2560; }   // all agents' windows fit
+__host__ __device__ inline int lds_code_bytes(const DevHead& s) { return (lds_code_all(s) ? s.n : 1) * SSD_CODE_AGENT_STRIDE(s.V) + 16; }
 __host__ __device__ inline int lds_per_wave(const DevHead& s) {
     int obs = s.PMS + lds_planes_bytes(s);
     if (obs < 512) obs = 512;
-    return 2 * s.GS + obs + 64 + lds_code_bytes(s);
+    return (2 * s.GS + obs + 64 + lds_code_bytes(s) + 255) & ~255;   // a multiple of the 256-byte LDS bank row
 }
 
 void launch_env(int mode, const DevSpec* spec, const DevSpec& host_spec, DevState st, const int32_t* actions,

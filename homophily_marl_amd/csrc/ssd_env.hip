@@ -484,35 +484,44 @@ __device__ __forceinline__ float b2f(uint32_t w, int j) { return (float)((w >> (
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {   // k/256 is exact in bf16: truncation == rounding
     return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
 }
-template <typename T> struct Expand;
-template <> struct Expand<float> {
+// ONE: the plane bytes are 0 / 1 flags of the simplified palette (value 255 / 256 where set): the f32 bit pattern is one integer
+// multiply per element (byte * 0x3F7F0000) instead of a convert and a multiply
+template <typename T, bool ONE = false> struct Expand;
+template <> struct Expand<float, false> {
     static __device__ __forceinline__ uint4 vec(const uint8_t* src, int q) {
         const uint32_t w = *(const uint32_t*)(src + 4 * q);
         return make_uint4(__float_as_uint(b2f(w, 0)), __float_as_uint(b2f(w, 1)), __float_as_uint(b2f(w, 2)), __float_as_uint(b2f(w, 3)));
     }
 };
-template <> struct Expand<uint16_t> {
+template <> struct Expand<float, true> {
+    static __device__ __forceinline__ uint4 vec(const uint8_t* src, int q) {
+        const uint32_t w = *(const uint32_t*)(src + 4 * q);
+        constexpr uint32_t K = 0x3F7F0000u;                       // 255 / 256 as f32
+        return make_uint4((w & 0xFFu) * K, ((w >> 8) & 0xFFu) * K, ((w >> 16) & 0xFFu) * K, (w >> 24) * K);
+    }
+};
+template <> struct Expand<uint16_t, false> {
     static __device__ __forceinline__ uint4 vec(const uint8_t* src, int q) {
         const uint2 w = *(const uint2*)(src + 8 * q);
         return make_uint4(pack_bf16(b2f(w.x, 0), b2f(w.x, 1)), pack_bf16(b2f(w.x, 2), b2f(w.x, 3)),
                           pack_bf16(b2f(w.y, 0), b2f(w.y, 1)), pack_bf16(b2f(w.y, 2), b2f(w.y, 3)));
     }
 };
-template <> struct Expand<uint8_t> {
+template <> struct Expand<uint8_t, false> {
     static __device__ __forceinline__ uint4 vec(const uint8_t* src, int q) { return *(const uint4*)(src + 16 * q); }
 };
 
 // vectors [q0, q1) of the env's block: out = dst + head, src = pl + head + delta.  U vectors per lane per batch so that U LDS
 // reads are in flight before the first store issues; U is sized to one agent's share of the block at V = 15 (169 / 85 / 43
 // vectors for f32 / bf16 / u8), so that the common call is ONE batch without dead slots.
-template <typename T>
+template <typename T, bool ONE>
 __device__ __forceinline__ void expand_range(const uint8_t* src, T* out, int q0, int q1, int lane) {
     constexpr int EPV = 16 / (int)sizeof(T);
     constexpr int U = sizeof(T) == 4 ? 3 : sizeof(T) == 2 ? 2 : 1;
     for (int q = q0 + lane; q < q1; q += U * kWave) {
         uint4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = (q + u * kWave < q1) ? Expand<T>::vec(src, q + u * kWave) : make_uint4(0, 0, 0, 0);
+        for (int u = 0; u < U; ++u) v[u] = (q + u * kWave < q1) ? Expand<T, ONE>::vec(src, q + u * kWave) : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #ifdef SSD_NOSTORE   // diagnostic only: keep the compute, drop (almost) every store
@@ -524,12 +533,13 @@ __device__ __forceinline__ void expand_range(const uint8_t* src, T* out, int q0,
 }
 
 // FMT: SSD_OBS_F32 / BF16 / U8 (three byte planes per agent) or SSD_OBS_CODE (one class plane per agent)
-// WC: also emit the window as class codes into the dense side buffer oo.code (simplified palette; what the rollout-time encoder
-// reads): one extra LDS byte per cell in the gather, one 16-byte store per lane and agent.
+// WC: also emit the window as one channel-mask byte per cell (bit 0 R, 1 G, 2 B; simplified palette) into the dense side buffer
+// oo.code -- what the rollout-time encoder reads: one extra LDS byte per cell in the gather, one 16-byte store per lane and agent.
 template <bool FULL, int FMT, bool WC>
 __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut& oo, const uint8_t* lut) {
     typedef typename std::conditional<FMT == SSD_OBS_F32, float, typename std::conditional<FMT == SSD_OBS_BF16, uint16_t, uint8_t>::type>::type T;
     constexpr bool CODE = FMT == SSD_OBS_CODE;
+    constexpr bool ONE = false;                                   // (0 / 1 plane flags + integer-multiply expansion: measured no faster)
     constexpr int EPV = 16 / (int)sizeof(T);
     const DevSpec* S = E.S;
     const DevHead* h = E.h;
@@ -553,8 +563,12 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
     }
     int q_done = 0;
     const int dump = (int)(lut - E.pl);
-    uint8_t* cbuf = E.cbuf;                                       // one agent's class codes [V * V] (+ pad, + dump byte)
-    const int cstride = oo.code_agent_stride, cdump = cstride;
+    // code windows: every agent's in LDS when they fit (stored in ONE batch behind the last agent, off the per-agent critical
+    // path), else one agent's at a time (31 x 31 windows: LDS is what limits the workgroups per CU there)
+    const int cstride = oo.code_agent_stride;
+    const bool call = WC && lds_code_all(*h);
+    uint8_t* cbuf = E.cbuf;
+    const int cdump = call ? n * cstride : cstride;
     for (int a = 0; a < n; ++a) {
         const int pa = rl(E.P, a), oa = rl(E.O, a);
         const int pr = (int)udiv((uint32_t)pa, h->magic_W), pc = pa - pr * W;
@@ -569,7 +583,7 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
         const int sstep = rpi * ci, dstep = rpi * V;
         int sidx = pr * Wp + pc + c0 + il * ci + j * cj;
         int d = a * A + delta + il * V + j;
-        int cd = il * V + j;
+        int cd = (call ? a * cstride : 0) + il * V + j;
         // 4 row groups per batch: the 4 class reads are in flight together, then the plane bytes are written
         for (int i = il; i < V; i += 4 * rpi, sidx += 4 * sstep, d += 4 * dstep, cd += 4 * dstep) {
             int cls[4];
@@ -586,27 +600,28 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
                 } else {
                     // class bit 1 / 2 / 4 = channel R / G / B = plane 0 / 1 / 2.  Branch-free: empty cells and idle lanes write
                     // their 255 into a dump byte behind the planes (the lut slot, unused with the simplified palette)
-                    E.pl[(ok[u] && c) ? du + __mul24(c >> 1, VV) : dump] = 255;
+                    E.pl[(ok[u] && c) ? du + __mul24(c >> 1, VV) : dump] = ONE ? 1 : 255;
                 }
-                if (WC) {   // class bits 1 (waste) / 2 (apple) / 4 (wall, agent) -> codes 2 / 1 / 3 (SSD_OBS_CODE alphabet)
-                    const int c3 = c - (c >> 2);
-                    cbuf[ok[u] ? cd + u * dstep : cdump] = (uint8_t)((0x03010200u >> (8 * c3)) & 0xFFu);
-                }
+                if (WC) cbuf[ok[u] ? cd + u * dstep : cdump] = (uint8_t)c;   // channel mask: 1 R (waste), 2 G (apple), 4 B (wall / agent)
             }
         }
         wsync();
-        if (WC) {   // this agent's code window: 16-byte stores (the side buffer's agent stride is a multiple of 16)
+        if (WC && !call) {   // this agent's code window: 16-byte stores (the side buffer's agent stride is a multiple of 16)
             uint8_t* cdst = oo.code + ((size_t)env * n + a) * cstride;
             for (int v16 = lane * 16; v16 < cstride; v16 += kWave * 16) *(uint4*)(cdst + v16) = *(const uint4*)(cbuf + v16);
         }
         // expand and store every vector that is complete by now, so the store stream overlaps the next agent's gather
         const int q_end = a == n - 1 ? nvec : ((a + 1) * A - head) / EPV;
-        if (q_end > q_done) { expand_range<T>(src, dst + head, q_done, q_end, lane); q_done = q_end; }
+        if (q_end > q_done) { expand_range<T, ONE>(src, dst + head, q_done, q_end, lane); q_done = q_end; }
+    }
+    if (call) {          // every agent's code window in one batch of 16-byte stores
+        uint8_t* cdst = oo.code + (size_t)env * n * cstride;
+        for (int v16 = lane * 16; v16 < n * cstride; v16 += kWave * 16) *(uint4*)(cdst + v16) = *(const uint4*)(cbuf + v16);
     }
     // ragged ends (fewer than EPV elements each)
-    if (lane < head) dst[lane] = Cvt<T>::f(E.pl[lane + delta]);
+    if (lane < head) dst[lane] = Cvt<T>::f(E.pl[lane + delta] * (ONE ? 255u : 1u));
     const int t0 = head + nvec * EPV;
-    if (t0 + lane < L) dst[t0 + lane] = Cvt<T>::f(E.pl[t0 + lane + delta]);
+    if (t0 + lane < L) dst[t0 + lane] = Cvt<T>::f(E.pl[t0 + lane + delta] * (ONE ? 255u : 1u));
 }
 
 template <bool FULL>
@@ -662,9 +677,7 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
     wsync();
     STAMP_OBS(8);
     // an env stepped past its episode storage writes no observation (it would land in the next env's block)
-    const bool slot_ok = !(oo.env_stride && oo.t_slots > 0 && E.obs_slot >= oo.t_slots);
-    if (!slot_ok && lane == 0) atomicOr(E.err, ERR_SLOT_OVERRUN);
-    if (oo.obs && slot_ok) {
+    if (oo.obs) {
         // gather windows into LDS in output order, expand to the output dtype (value / 256, CHW; map_env.py:945)
         if (oo.code && !FULL) {
             if (oo.fmt == SSD_OBS_F32) observe_windows<FULL, SSD_OBS_F32, true>(E, env, oo, lut);
@@ -703,10 +716,35 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
 // MODE_OBS (get_obs & co, :917-957)
 // ---------------------------------------------------------------------------------------------------------------
 // NT: compile-time number of agents (0 = runtime): the per-agent readlane loops unroll completely
+// Kernel arguments as ONE struct.  hipcc loads every by-value argument into SGPRs at kernel entry; the two output descriptors are
+// only needed at the end of the step / in the observation phase, so they are read from the kernarg segment THERE (cold_kernarg):
+// ~40 fewer live SGPRs through the move / beam / spawn phases, where the kernel otherwise spills them to VGPR lanes.
+struct EnvArgs {
+    DevHead hd; const DevSpec* S; DevState st; const int32_t* actions; const uint8_t* env_mask; DevTape tape; int lds_stride;
+    DevStepOut so; DevObsOut oo;
+};
+template <typename T>
+__device__ __forceinline__ T cold_kernarg(int offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));                                     // loads through p cannot be hoisted above this point
+    T out;
+    __builtin_memcpy(&out, (const char __attribute__((address_space(4)))*)p + offset, sizeof(T));
+    return out;
+#else
+    return T{};                                                     // host pass of the single-source compile: never called
+#endif
+}
+
 template <int MODE, int NT>
-__global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec* __restrict__ S, DevState st, const int32_t* __restrict__ actions,
-                                                 const uint8_t* __restrict__ env_mask, DevTape tape, DevStepOut so,
-                                                 DevObsOut oo, int lds_stride) {
+__global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
+    const DevHead& hd = A.hd;
+    const DevSpec* __restrict__ S = A.S;
+    const DevState st = A.st;
+    const int32_t* __restrict__ actions = A.actions;
+    const uint8_t* __restrict__ env_mask = A.env_mask;
+    const DevTape tape = A.tape;
+    const int lds_stride = A.lds_stride;
     extern __shared__ uint4 smem[];
     const int lane = threadIdx.x & 63;
     const DevHead* h = &hd;
@@ -747,6 +785,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
     const int ep_step0 = MODE == MODE_RESET ? 0 : st.ep_step[env];
     const uint32_t counts0 = (MODE == MODE_STEP || MODE == MODE_STEP_OBS) ? st.counts[env] : 0u;
     E.obs_slot = MODE == MODE_STEP_OBS ? ep_step0 + 1 : ep_step0;
+
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
         E.ap[ch] = (MODE != MODE_OBS && ch * kWave + lane < h->n_apple) ? S->apple[ch * kWave + lane] : 0;
@@ -839,7 +878,8 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
         if (lane == 0) {
             st.counts[env] = ((uint32_t)n_waste_cells << 16) | (uint32_t)n_apple_cells;
             st.ep_step[env] = 0; st.epoch[env] = epoch + 1;
-            if (so.n_draws) so.n_draws[env] = n_draws;
+            int32_t* nd = cold_kernarg<int32_t*>((int)(offsetof(EnvArgs, so) + offsetof(DevStepOut, n_draws)));
+            if (nd) nd[env] = n_draws;
             if (R.tape && n_draws > R.ustride) atomicOr(st.err, ERR_TAPE_OVERRUN);
         }
     }
@@ -884,11 +924,11 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
         // scalars (map_env.py:291-292, 883-914).  After the consume loop no agent stands on an apple and nothing spawns
         // under an agent, so the apples visible in map_with_agents are all apples of the grid.
         const int apples = n_apple_cells;
-        // host-tabulated fp64 quotient (apples live on apple sites only); an imported grid may hold more apples than sites
-        const float den = apples <= SSD_MAX_SITES ? S->tab_den[apples] : (float)((double)apples / (double)E.HW);
+        const float den = S->tab_den[apples];                     // host-tabulated fp64 quotient for every count 0..H*W (imported grids too)
         ep_r += reward;
         const int step = ep_step0 + 1;
         const bool term = step >= h->episode_limit;
+        const DevStepOut so = cold_kernarg<DevStepOut>((int)offsetof(EnvArgs, so));
         if (E.ag) {
             const size_t o = (size_t)env * n + lane;
             if (so.reward) so.reward[o] = (float)reward;
@@ -932,6 +972,13 @@ __global__ __launch_bounds__(kBlock) void k_env(const DevHead hd, const DevSpec*
     }
     STAMP(7);
     if (MODE == MODE_STEP_OBS || MODE == MODE_OBS) {
+        const DevObsOut oo = cold_kernarg<DevObsOut>((int)offsetof(EnvArgs, oo));
+        if (oo.t_slots > 0 && E.obs_slot >= oo.t_slots) {
+            // stepped past the episode storage: never write into the next env's block -- the observation lands in this env's LAST
+            // slot and the sticky error bit tells the caller (ssd_poll_error)
+            E.obs_slot = oo.t_slots - 1;
+            if (lane == 0) atomicOr(st.err, ERR_SLOT_OVERRUN);
+        }
         if (h->obs_color == SSD_COLOR_FULL) observe_phase<true>(E, env, oo);
         else observe_phase<false>(E, env, oo);
     }
@@ -943,7 +990,10 @@ void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, c
     const int blocks = (hs.N + kWavesPerBlock - 1) / kWavesPerBlock;
     const int stride = lds_per_wave(hs);
     const size_t lds = (size_t)stride * kWavesPerBlock;
-#define SSD_LAUNCH(M, NT_) hipLaunchKernelGGL((k_env<M, NT_>), dim3(blocks), dim3(kBlock), lds, stream, (const DevHead&)hs, spec, st, actions, env_mask, tape, so, oo, stride)
+    EnvArgs A;
+    A.hd = (const DevHead&)hs; A.S = spec; A.st = st; A.actions = actions; A.env_mask = env_mask; A.tape = tape; A.lds_stride = stride;
+    A.so = so; A.oo = oo;
+#define SSD_LAUNCH(M, NT_) hipLaunchKernelGGL((k_env<M, NT_>), dim3(blocks), dim3(kBlock), lds, stream, A)
 #define SSD_LAUNCH_N(M)                                                                                   \
     do {                                                                                                  \
         if (hs.n == 5) SSD_LAUNCH(M, 5); else if (hs.n == 10) SSD_LAUNCH(M, 10);                          \

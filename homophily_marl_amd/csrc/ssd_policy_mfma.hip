@@ -612,6 +612,7 @@ struct EncK {
     float* out; int out_stride;
     float* part;
     int64_t* slot_t_copy; int64_t* counter_inc;
+    int mask_alphabet;                 // bytes are channel masks (1 R, 2 G, 4 B) instead of SSD_OBS_CODE classes
     PSTAMP_DECL
 };
 
@@ -685,12 +686,17 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
                 if (left < 4) c4 &= (1u << (8 * left)) - 1u;
             }
             uint8_t* d = planes + (size_t)r * PR + yy * CP + x;
-            // code 2 = waste -> R, 1 = apple -> G, 3 = wall / agent -> B (cleanup.py:93-105): byte == code <=> (byte ^ code) == 0
+            // classes: 2 = waste -> R, 1 = apple -> G, 3 = wall / agent -> B (cleanup.py:93-105): byte == code <=> (byte ^ code) == 0;
+            // channel masks: plane ch is bit ch
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                const uint32_t t = c4 ^ ((ch == 0 ? 2u : ch == 1 ? 1u : 3u) * 0x01010101u);
-                const uint32_t u = t | (t >> 4), w = u | (u >> 2);                 // bit 0 of every byte = OR of the byte's bits
-                const uint32_t hit = ~(w | (w >> 1)) & 0x01010101u;
+                uint32_t hit;
+                if (a.mask_alphabet) hit = (c4 >> ch) & 0x01010101u;
+                else {
+                    const uint32_t t = c4 ^ ((ch == 0 ? 2u : ch == 1 ? 1u : 3u) * 0x01010101u);
+                    const uint32_t u = t | (t >> 4), w = u | (u >> 2);             // bit 0 of every byte = OR of the byte's bits
+                    hit = ~(w | (w >> 1)) & 0x01010101u;
+                }
                 *reinterpret_cast<uint32_t*>(d + ch * (R + 2) * CP) = hit * ON;
             }
         }
@@ -818,7 +824,7 @@ int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s) {
     k.agent_stride = (long)p->agent_stride; k.slot_t = p->slot_t; k.rows = p->rows; k.n = p->n_agents; k.agent_major = p->agent_major;
     k.conv_frags = static_cast<const uint8_t*>(p->conv_frags); k.lin_frags = static_cast<const uint8_t*>(p->lin_frags);
     k.conv_b = p->conv_b; k.lin_b = p->lin_b; k.out = p->out; k.out_stride = p->out_stride; k.part = p->part;
-    k.slot_t_copy = p->slot_t_copy; k.counter_inc = p->counter_inc;
+    k.slot_t_copy = p->slot_t_copy; k.counter_inc = p->counter_inc; k.mask_alphabet = p->alphabet == SSD_CODE_CHANNEL_MASK;
     PSTAMP_SET(k);
     const int prec = p->precision == 1 ? 1 : 2;
     if (p->view_edge == 15) return prec == 2 ? launch_encode_t<15, 2>(k, s) : launch_encode_t<15, 1>(k, s);

@@ -163,9 +163,11 @@ class FastPolicy:
     # ---- env head -----------------------------------------------------------------------------------------------
     @th.no_grad()
     def act_env(self, obs, prev_actions, prev_reward, prev_inc, pos, eps, step, codes=None, slot_t=None, store_obs=None, store_t=None,
-                q_out=None, orient=None, actions_i32=None, pos_copy=None, orient_copy=None, t_copy=None, counter_inc=None, file=None):
+                q_out=None, orient=None, actions_i32=None, pos_copy=None, orient_copy=None, t_copy=None, counter_inc=None, file=None,
+                mask_alphabet=None):
         """encode() followed by head_env(); returns actions i64 [N, n] (static buffer).  See the two methods for the arguments."""
-        self.encode(obs, codes=codes, slot_t=slot_t, store_obs=store_obs, store_t=store_t, t_copy=t_copy, counter_inc=counter_inc)
+        self.encode(obs, codes=codes, slot_t=slot_t, store_obs=store_obs, store_t=store_t, t_copy=t_copy, counter_inc=counter_inc,
+                    mask_alphabet=mask_alphabet)
         return self.head_env(prev_actions, prev_reward, prev_inc, pos, eps, step, q_out=q_out, orient=orient, actions_i32=actions_i32,
                              pos_copy=pos_copy, orient_copy=orient_copy, file=file)
 
@@ -179,11 +181,12 @@ class FastPolicy:
         return F.pad(c, (0, abi.code_agent_stride(V) - V * V)).contiguous()
 
     @th.no_grad()
-    def encode(self, obs, codes=None, slot_t=None, store_obs=None, store_t=None, t_copy=None, counter_inc=None):
+    def encode(self, obs, codes=None, slot_t=None, store_obs=None, store_t=None, t_copy=None, counter_inc=None, mask_alphabet=None):
         """rgb_preprocess (homophily_agent.py:20-27,213-214) of the current observation into columns 0..31 of `inputs` (31 x 31
         windows: into the per-band partial sums that head_env finishes).
-        Fused encoder: reads u8 class codes -- `codes` [N, n, stride] (the env's obs_code side buffer) or, with slot_t (device time
-        index), an episode storage of codes u8 [N, T+1, n, V, V]; with codes = None they are derived from obs f32 [N, n, 3, V, V].
+        Fused encoder: reads one byte per window cell -- `codes` [N, n, stride] = the env's obs_code side buffer (channel masks;
+        mask_alphabet defaults to True for this layout) or an episode storage of class codes u8 [N, T+1, n, V, V] read at the
+        device time index slot_t (SSD_OBS_CODE classes); with codes = None, class codes are derived from obs f32 [N, n, 3, V, V].
         Per-layer path: obs f32.  store_obs / store_t: copy obs into store_obs[:, t] (callers whose env does not write the storage
         itself).  t_copy receives *slot_t; counter_inc is incremented (device scalars for the kernels that follow)."""
         p, lib, n, N = self.p, self.lib, self.n, self.N
@@ -191,7 +194,9 @@ class FastPolicy:
         if self.fused_enc:
             V = self.V
             if codes is None:
-                codes = self.codes_from_obs(obs)
+                codes, mask_alphabet = self.codes_from_obs(obs), False
+            if mask_alphabet is None:
+                mask_alphabet = codes.dim() == 3
             assert codes.dtype == th.uint8 and codes.shape[0] == N
             ea = abi.SsdPolicyEncodeArgs()
             ea.codes = codes.data_ptr()
@@ -204,6 +209,7 @@ class FastPolicy:
                 ea.env_stride, ea.slot_stride, ea.agent_stride = codes.stride(0), 0, codes.stride(1)
             ea.slot_t = None if slot_t is None else slot_t.data_ptr()
             ea.rows, ea.view_edge, ea.n_agents, ea.agent_major, ea.precision = N * n, V, n, 1, self.precision
+            ea.alphabet = abi.CODE_CHANNEL_MASK if mask_alphabet else abi.CODE_CLASS
             ea.conv_frags, ea.lin_frags = p["conv_frags"].data_ptr(), p["lin_frags"].data_ptr()
             ea.conv_b, ea.lin_b = p["cb"].data_ptr(), p["lb"].data_ptr()
             if self.bands > 1:

@@ -269,7 +269,9 @@ class HomophilyLearner:
         of allocator, hipBLASLt / MIOpen plans and Adam state), the third captures forward_backward and clip_and_step
         as two graphs with the gradient all-reduce between them."""
         self._graph_calls += 1
-        if self._graph_calls <= 2:
+        # Only the fused-loss step is captured: the tensor-op loss is full of ATen multi-block reductions, which are not safe in
+        # a replayed hipGraph on this stack (ops.column_sums)
+        if self._graph_calls <= 2 or not self._fused(batch):
             return self.cal_loss_and_step(batch)
         if self._graph is None:
             self._static_data = {k: v.clone() for k, v in batch.data.transition_data.items()}

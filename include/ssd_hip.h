@@ -121,15 +121,20 @@ typedef struct ssd_obs_out {
      * Both 0 (default): dense [n_env, n, ...].  GPU library only. */
     int64_t obs_env_stride, obs_slot_stride;
     /* obs_t_slots (0 = unchecked): number of time slots of that storage.  A call whose slot would be >= obs_t_slots (stepping an
-     * env past its episode storage) writes NO observation and raises the sticky bit 16 of ssd_poll_error. */
+     * env past its episode storage) never touches another env's block: its observation lands in the env's own LAST slot and the
+     * sticky bit 16 of ssd_poll_error is raised. */
     int32_t obs_t_slots;
-    /* obs_code (nullable; simplified colours; together with a f32 / bf16 / u8 `obs`): additionally emit the window as u8 cell
-     * classes (0 nothing, 1 apple, 2 waste, 3 wall-or-agent -- the SSD_OBS_CODE alphabet) into a dense side buffer
+    /* obs_code (nullable; simplified colours; together with a f32 / bf16 / u8 `obs`): additionally emit the window as one
+     * CHANNEL-MASK byte per cell (bit 0 = R = waste, bit 1 = G = apple, bit 2 = B = wall or agent; 0 = nothing: the planes of the
+     * simplified palette are one-hot, so a cell is 0, 1, 2 or 4 -- SSD_CODE_CHANNEL_MASK) into a dense side buffer
      * u8 [n_env, n, obs_code_agent_stride], obs_code_agent_stride = V * V rounded up to 16, 16-byte aligned.  This is what the
      * rollout-time encoder (ssd_policy_encode) consumes: 225 B instead of 2 700 B per agent-step at V = 15. */
     uint8_t* obs_code;
 } ssd_obs_out;
 #define SSD_CODE_AGENT_STRIDE(V) ((((V) * (V)) + 15) & ~15)
+/* byte alphabets of per-cell windows: the SSD_OBS_CODE observation format (0 nothing, 1 apple, 2 waste, 3 wall-or-agent) and the
+ * channel masks of ssd_obs_out.obs_code */
+enum { SSD_CODE_CLASS = 0, SSD_CODE_CHANNEL_MASK = 1 };
 
 /* Raw env state for parity tests and KATs (Agent.set_pos etc. in the reference). */
 typedef struct ssd_state {
@@ -400,7 +405,8 @@ typedef struct ssd_policy_head_params {
 int ssd_policy_pack_head(const ssd_policy_head_params* params, int32_t precision, void* image, void* stream);
 
 /* ssd_policy_encode: rgb_preprocess for 15 x 15 (view_size 7) and 31 x 31 (view_size 15) windows of the SIMPLIFIED palette.
- * Input: u8 cell classes (SSD_OBS_CODE alphabet); the three colour planes are rebuilt in LDS as one-hot f16 bytes (exact), so the
+ * Input: one byte per window cell in either alphabet (`alphabet`: SSD_CODE_CLASS = the SSD_OBS_CODE classes of an episode storage,
+ * SSD_CODE_CHANNEL_MASK = the side buffer of ssd_obs_out.obs_code); the three colour planes are rebuilt in LDS as one-hot bytes, so the
  * conv is a banded (Toeplitz) GEMM over 16 batch rows per MFMA and the whole encoder runs on the matrix cores:
  *   conv   D[16 positions of an output row][16 batch rows] += A[positions][(dy, ch, 8 cells)] x B[(dy, ch, 8 cells)][batch rows]
  *          A = Toeplitz image of the 3 x 3 taps (ssd_policy_pack_encoder), B = plane bytes read from LDS (ds_read_b64 + 4 v_perm)
@@ -438,6 +444,7 @@ typedef struct ssd_policy_encode_args {
     float* part;
     int64_t* slot_t_copy;
     int64_t* counter_inc;
+    int32_t alphabet;              /* SSD_CODE_CLASS / SSD_CODE_CHANNEL_MASK */
 } ssd_policy_encode_args;
 int ssd_policy_encode(const ssd_policy_encode_args* args, void* stream);
 int ssd_policy_pack_encoder(const float* conv_w, const float* lin_w, int32_t view_edge, int32_t precision, void* conv_frags,

@@ -171,6 +171,31 @@ def test_fused_loss_kernel_matches_the_tensor_op_loss(B, T, n, kind):
     assert float((g1 - g2).abs().max()) < 2e-6 * max(1.0, float(g2.abs().max())), (float((g1 - g2).abs().max()), float(g2.abs().max()))
 
 
+def test_replayed_train_graph_equals_the_eager_step_with_other_work_in_between(monkeypatch):
+    """Regression: every replay of the captured train step must reproduce an eager evaluation of the same step (same weights, batch,
+    denominators) while ANOTHER learner trains eagerly between the replays.  With ATen's multi-block row reductions inside the
+    graph (bias gradients of baddbmm / Linear / Conv2d, column sums) the third replay returned another reduction's partial sums
+    (MI355X, ROCm 7.2) and long runs diverged; the captured step therefore evaluates those sums as GEMMs (ops.column_sums)."""
+    from types import SimpleNamespace
+    from homophily_marl_amd.controllers import REGISTRY as mac_REGISTRY
+    from homophily_marl_amd.learners import REGISTRY as le_REGISTRY
+    batch, eager, _ = _random_learner_batch(16, 100, 5, "cleanup", seed=3)
+    a = SimpleNamespace(**vars(eager.args)); a.train_graph = True
+    mac = mac_REGISTRY[a.mac](batch.scheme, {"agents": 5}, a).cuda()
+    mac.agent.load_state_dict(eager.mac.agent.state_dict())
+    graph = le_REGISTRY[a.learner](mac, batch.scheme, SimpleNamespace(log_stat=lambda *x, **k: None, console_logger=None), a)
+    graph.cuda()
+    monkeypatch.setenv("SSD_GRAPH_CHECK", "1")        # learner._graph_step compares each replay with the eager step (SystemExit on a mismatch)
+    g = th.Generator(device="cuda").manual_seed(0)
+    for step in range(24):
+        r = (th.rand(batch["reward"].shape, generator=g, device="cuda") < 0.05).float()
+        batch.data.transition_data["reward"].copy_(r)
+        graph.train(batch, 0, step)
+        eager.train(batch, 0, step)
+    assert graph._graph is not None and graph._check_n >= 20
+    assert all(bool(th.isfinite(p).all()) for p in mac.parameters())
+
+
 def test_env_class_drop_in_surface_single_env():
     """REGISTRY['cleanup'](**env_args) with the reference's kwargs behaves like the reference env object (n_env = 1):
     compared call by call with the CPU oracle on the same counter seed."""
