@@ -335,6 +335,13 @@ int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int
     return launched();
 }
 
+int ssd_column_sums(const float* x, float* out, int32_t groups, int32_t rows, int32_t cols, float* workspace, void* stream) {
+    if (!x || !out || groups < 1 || rows < 1 || cols < 1 || groups > 65535 || (rows + SSD_COLSUM_CHUNK - 1) / SSD_COLSUM_CHUNK > 65535)
+        return fail(SSD_ERR_INVALID, "bad argument");
+    launch_column_sums(x, out, groups, rows, cols, workspace, (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_td_sim_loss(const ssd_td_loss_args* a, int32_t mode, void* stream) {
     if (!a || a->batch < 1 || a->t_slots < 2 || a->n_agents < 2 || a->n_agents > SSD_MAX_AGENTS || a->n_actions < 1 || a->sim_horizon < 1)
         return fail(SSD_ERR_INVALID, "bad argument");

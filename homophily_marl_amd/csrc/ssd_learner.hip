@@ -202,6 +202,28 @@ __global__ __launch_bounds__(128) void k_td_sim_loss(ssd_td_loss_args a) {
     out[9] = clean * rv; out[10] = clean; out[11] = r * rv; out[12] = r;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_column_sums: out[g, c] = sum_r x[g, r, c] (bias gradients: the row sums of dL/dY).  One workgroup per (g, 64 columns): 4 waves
+// each sum every 4th row of their column (coalesced across the 64 columns), then the four partial sums are added in a fixed
+// order through LDS -- deterministic, no cross-workgroup hand-off (ATen's multi-block reductions keep arrival semaphores that a
+// memset node clears; inside replayed hipGraphs they were observed to return other reductions' partial sums on this stack).
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_column_sums(const float* __restrict__ x, float* __restrict__ out, int R, int C, int chunk) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + lane, g = blockIdx.y;
+    const int r0 = blockIdx.z * chunk, r1 = r0 + chunk < R ? r0 + chunk : R;       // this workgroup's rows
+    float s0 = 0.f, s1 = 0.f;                                          // two chains: independent loads in flight
+    if (c < C) {
+        const float* p = x + (size_t)g * R * C + c;
+        int r = r0 + rg;
+        for (; r + 4 < r1; r += 8) { s0 += p[(size_t)r * C]; s1 += p[(size_t)(r + 4) * C]; }
+        if (r < r1) s0 += p[(size_t)r * C];
+    }
+    part[rg][lane] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && c < C) out[((size_t)g * gridDim.z + blockIdx.z) * C + c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+
 static int grid_for(size_t total) {
     size_t b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : b > 4096 ? 4096 : b);
@@ -222,6 +244,17 @@ void launch_incentive_transfer(int32_t B, int32_t T, int32_t n, const int64_t* a
     const size_t total = (size_t)B * T * n;
     hipLaunchKernelGGL(k_incentive_transfer, dim3(grid_for(total)), dim3(256), 0, stream, B, T, n, a_inc, rewards,
                        effect_ratio, cost_ratio, incentive, seq_len, give, recv_pos, recv_neg, recv_zero, r_env, r_inc);
+}
+
+// Two deterministic stages when there are many rows: chunks of COLSUM_CHUNK rows -> workspace [G, chunks, C] -> out [G, C].
+void launch_column_sums(const float* x, float* out, int G, int R, int C, float* workspace, hipStream_t stream) {
+    const int chunks = (R + SSD_COLSUM_CHUNK - 1) / SSD_COLSUM_CHUNK;
+    if (chunks <= 1 || !workspace) {
+        hipLaunchKernelGGL(k_column_sums, dim3((C + 63) / 64, G, 1), dim3(256), 0, stream, x, out, R, C, R);
+        return;
+    }
+    hipLaunchKernelGGL(k_column_sums, dim3((C + 63) / 64, G, chunks), dim3(256), 0, stream, x, workspace, R, C, SSD_COLSUM_CHUNK);
+    hipLaunchKernelGGL(k_column_sums, dim3((C + 63) / 64, G, 1), dim3(256), 0, stream, workspace, out, chunks, C, chunks);
 }
 
 void launch_td_sim_loss(const ssd_td_loss_args* a, int mode, hipStream_t stream) {

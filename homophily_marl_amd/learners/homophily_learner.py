@@ -147,7 +147,7 @@ class HomophilyLearner:
         """optimiser_{inc,env}.zero_grad() + loss.backward() (homophily_learner.py:220-222): the gradients come back as fresh tensors
         and ONE concatenation writes them into the flat buffer (accumulating into 44 pre-zeroed .grad views costs a launch each)."""
         self._bind_flat_grad()
-        if getattr(self.args, "grad_by_cat", False):
+        if getattr(self.args, "grad_by_cat", True):
             grads = th.autograd.grad(loss, self.params)
             th.cat([g.reshape(-1) for g in grads], out=self._flat_grad)
         else:

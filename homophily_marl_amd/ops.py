@@ -139,28 +139,27 @@ def td_sim_loss(q_env, q_inc, tq_env, tq_inc, dens, batch, a):
     return _TdSimLoss.apply(q_env, q_inc, tq_env, tq_inc, dens, batch, a)
 
 
-_ONES = {}
-
-
-def _ones_row(rows, like):
-    key = (rows, like.device, like.dtype)
-    if key not in _ONES:
-        _ONES[key] = th.ones(1, rows, dtype=like.dtype, device=like.device)
-    return _ONES[key]
-
-
 def column_sums(x):
-    """x [R, C] -> [C] as a GEMM with a row of ones.  Inside a captured hipGraph the multi-block reduction kernels of ATen (their
-    block-arrival semaphores are cleared by a memset node) were observed to return another reduction's partial sums on MI355X /
-    ROCm 7.2 once other work ran between two replays; a GEMM has no such cross-block hand-off."""
+    """x [R, C] -> [C] or x [G, R, C] -> [G, C]: row sums by the HIP kernel k_column_sums (one launch, deterministic, no
+    cross-workgroup hand-off).  ATen's multi-block reduction kernels keep block-arrival semaphores that a memset node clears; inside a
+    captured hipGraph they were observed to return ANOTHER reduction's partial sums on MI355X / ROCm 7.2 once other work ran
+    between two replays (diverging / NaN training runs) -- so nothing inside the captured train step reduces over rows with them."""
     if not x.is_cuda:
-        return x.sum(0)
-    return (_ones_row(x.shape[0], x) @ x).squeeze(0)
+        return x.sum(-2)
+    lib = abi.load_library()
+    x = x.contiguous()
+    G = 1 if x.dim() == 2 else x.shape[0]
+    R, Cc = x.shape[-2], x.shape[-1]
+    out = th.empty((Cc,) if x.dim() == 2 else (G, Cc), dtype=th.float32, device=x.device)
+    chunks = -(-R // abi.COLSUM_CHUNK)
+    ws = th.empty(G, chunks, Cc, dtype=th.float32, device=x.device) if chunks > 1 else None
+    abi.check(lib, lib.ssd_column_sums(x.data_ptr(), out.data_ptr(), G, R, Cc, None if ws is None else ws.data_ptr(), _stream(x)))
+    return out
 
 
 class _BiasBmm(th.autograd.Function):
-    """baddbmm(b [n, 1, O], x [n, R, I], w [n, I, O]) whose bias gradient is a GEMM (ones [n, 1, R] @ dY) instead of ATen's
-    multi-block row reduction (see column_sums)."""
+    """baddbmm(b [n, 1, O], x [n, R, I], w [n, I, O]) whose bias gradient comes from ops.column_sums instead of ATen's multi-block
+    row reduction."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -173,7 +172,7 @@ class _BiasBmm(th.autograd.Function):
         g = g.contiguous()
         dx = th.bmm(g, w.transpose(1, 2)) if ctx.needs_input_grad[0] else None
         dw = th.bmm(x.transpose(1, 2), g) if ctx.needs_input_grad[1] else None
-        db = th.bmm(_ones_row(g.shape[1], g).expand(g.shape[0], 1, g.shape[1]), g) if ctx.needs_input_grad[2] else None
+        db = column_sums(g).unsqueeze(1) if ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 
@@ -185,7 +184,7 @@ def bias_bmm(x, w, b):
 
 
 class _BiasLinear(th.autograd.Function):
-    """F.linear(x [R, I], w [O, I], b [O]) with the bias gradient as a GEMM (see column_sums)."""
+    """F.linear(x [R, I], w [O, I], b [O]) with the bias gradient from ops.column_sums."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -201,8 +200,8 @@ class _BiasLinear(th.autograd.Function):
 
 
 class _ChannelBias(th.autograd.Function):
-    """y [R, C, H, W] + b [C] (the bias of a convolution) with the bias gradient as a GEMM over the R rows followed by a short
-    per-channel sum (see column_sums)."""
+    """y [R, C, H, W] + b [C] (the bias of a convolution) with the bias gradient from ops.column_sums over the R rows followed by a
+    short per-channel sum."""
 
     @staticmethod
     def forward(ctx, y, b):

@@ -201,6 +201,12 @@ int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int
                            float seq_len, float* give, float* recv_pos, float* recv_neg, float* recv_zero,
                            float* rewards_for_env, float* rewards_for_inc, void* stream);
 
+/* ssd_column_sums: out f32 [groups, cols] = sum over rows of x f32 [groups, rows, cols] (contiguous): the bias gradients of the
+ * learner's affine layers (the row sums of dL/dY).  Deterministic; with workspace f32 [groups, ceil(rows / SSD_COLSUM_CHUNK), cols]
+ * (nullable) two launches: chunk sums, then their sum -- no cross-workgroup hand-off inside a launch. */
+#define SSD_COLSUM_CHUNK 64
+int ssd_column_sums(const float* x, float* out, int32_t groups, int32_t rows, int32_t cols, float* workspace, void* stream);
+
 /* ssd_td_sim_loss: the loss of HomophilyLearner.cal_loss_and_step (learners/homophily_learner.py:94-217) -- incentive reward
  * transfer, double-Q TD losses of the env head and the incentive head, the similarity loss with the exact-value clustering rule --
  * AND its gradient w.r.t. the live Q-values in one launch (the reference builds it from ~100 tensor ops that autograd differentiates).

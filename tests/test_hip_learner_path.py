@@ -447,3 +447,15 @@ def test_graph_runner_with_non_shipped_input_flags():
         assert int(batch["filled"].sum()) == N * (T + 1)
     train_iteration(ctx, 0)
     ctx.runner.close_env()
+
+
+@pytest.mark.parametrize("shape", [(1616, 64), (5, 1616, 192), (10, 333, 10), (8080, 1014), (1, 7, 3)])
+def test_column_sums_kernel(shape):
+    """ssd_column_sums (the learner's bias gradients) against a float64 row sum; bit-identical between two launches."""
+    from homophily_marl_amd import ops
+    g = th.Generator(device="cuda").manual_seed(sum(shape))
+    x = th.randn(*shape, generator=g, device="cuda")
+    a, b = ops.column_sums(x), ops.column_sums(x)
+    ref = x.double().sum(-2)
+    assert a.shape == ref.shape and th.equal(a, b)
+    assert float((a.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
