@@ -133,9 +133,10 @@ def main():
                     help="e2e: arithmetic of the ROLLOUT controller kernels: fp32 (split-bf16 MFMA products, f32-equivalent; the headline) "
                          "or bf16 (single bf16 products; a second, labelled line -- the learner stays fp32)")
     ap.add_argument("--train-steps-per-rollout", type=int, default=1, help="e2e: learner.train calls per rollout (reference cadence: 1)")
-    ap.add_argument("--obs-storage", default="f32", choices=["f32", "code"],
-                    help="e2e: observation format of the episode storage / replay buffer: f32 planes (format R, the reference's) or "
-                         "u8 class codes (format C: 12x fewer observation bytes; the roofline object then uses format C bytes)")
+    ap.add_argument("--obs-storage", default="code", choices=["f32", "code"],
+                    help="e2e: observation format of the episode storage / replay buffer: u8 class codes (format C, default: lossless, "
+                         "12x fewer observation bytes, decoded bit-exactly where the learner reads the sample) or f32 planes (format R, "
+                         "the reference's in-memory layout); the env kernel's roofline entry uses the bytes of the format it emits")
     ap.add_argument("--warm", type=float, default=0.0,
                     help="env workload: fraction of the waste cells turned into clean river after every reset (SURVEY.md 8d 'warm' variant: "
                          "exercises apple spawning; 0 = start from the map's reset state)")

@@ -174,8 +174,8 @@ def encode_bands(V):
 
 def encode_frag_bytes(V, precision):
     """(conv fragment image, Linear fragment image) sizes in bytes (include/ssd_hip.h SSD_ENCODE_*)."""
-    ksteps, units = (7, 29 * 2 * 3) if V == 31 else (5, 13 * 3)
-    return precision * 6 * ksteps * 1024, units * 2 * precision * 1024
+    units = 29 * 2 * 3 if V == 31 else 13 * 3
+    return precision * 9 * 1024, units * 2 * precision * 1024
 
 
 def code_agent_stride(V):

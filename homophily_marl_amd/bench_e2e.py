@@ -124,7 +124,10 @@ def run_e2e(args, c, rank, world, local_rank):
     from bench import MFMA_BF16_PEAK_TF, algorithmic_bytes_per_env_step
     code = getattr(args, "obs_storage", "f32") == "code"
     V = 2 * c["view_size"] + 1
-    env_bytes = (algorithmic_bytes_per_env_step(c["H"], c["W"], n, V, 1, 1) if code else algorithmic_bytes_per_env_step(c["H"], c["W"], n, V)) * N
+    env_bytes = algorithmic_bytes_per_env_step(c["H"], c["W"], n, V, 1, 1) if code else algorithmic_bytes_per_env_step(c["H"], c["W"], n, V)
+    if not code and "code" in getattr(runner, "cur", {}):
+        env_bytes += n * V * V                      # f32 storage: plus the u8 channel-mask window the fused encoder reads
+    env_bytes *= N
     kernels = []
     fl = controller_flops(c, ctx.mac.input_shape)
     nprod = getattr(runner.fast, "n_products", None) if getattr(runner, "fast", None) is not None else None
@@ -151,20 +154,22 @@ def run_e2e(args, c, rank, world, local_rank):
     env = runner.env
     avail = th.nonzero(env.avail_actions_batch[0, 0]).squeeze(-1).to(th.int32)
     acts = [avail[th.randint(0, avail.numel(), (N, n), device=env.device)].contiguous() for _ in range(8)]
-    kfmt = abi.OBS_CODE if code else abi.OBS_F32   # the format the loop's env launches emit
-    env.reset_batch()
-    for i in range(20):                           # un-timed: the eager launch path has been idle during the graph replays
-        env.step_batch(acts[i % 8], observe=True, fmt=kfmt)
+    # the env launch exactly as the rollout issues it (_fast_stages.env_step): observation into slot ep_step of the episode storage
+    # (fresh HBM lines every launch -- a dense buffer rewritten in place would be absorbed by the 256 MiB Infinity Cache), plus the
+    # channel-mask side output when the encoder reads one
+    out = runner.cur if getattr(runner, "direct_obs", False) else None
     per = []
-    for rep in range(3):                          # three whole episodes, like the env workload: reset, then T back-to-back launches
-        env.reset_batch()
+    for rep in range(4):                          # whole episodes: reset, then T back-to-back launches (the first one is un-timed warm-up)
+        runner.begin_episode(False)
         s, e = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
         s.record()
         for i in range(T):
-            env.step_batch(acts[i % 8], observe=True, fmt=kfmt)
+            env.step_batch(acts[i % 8], observe=True, fmt=runner.obs_fmt, out=out)
         e.record()
         th.cuda.synchronize()
-        per.append(1e3 * s.elapsed_time(e) / T)
+        if rep:
+            per.append(1e3 * s.elapsed_time(e) / T)
+    assert env.native.poll_error() == 0
     per.sort()
     kernels.append(dict(name="ssd::k_env<MODE_STEP_OBS>", avg_us=sum(per) / len(per), median_us=per[len(per) // 2], bound="hbm",
                         bytes_per_launch=env_bytes))

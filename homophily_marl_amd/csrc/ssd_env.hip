@@ -28,8 +28,21 @@ namespace ssd {
         unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
         if ((buf) && lane == 0) (buf)[(size_t)env * 16 + (i)] = t_;                                    \
     } while (0)
+// slot i <- the chip-wide 100 MHz clock (s_memrealtime: comparable across XCDs, s_memtime is not), slot j <- XCC_ID | HW_ID << 8
+#define STAMP_REAL(buf, i)                                                                             \
+    do {                                                                                               \
+        unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                      \
+        if ((buf) && lane == 0) (buf)[(size_t)env * 16 + (i)] = t_;                                    \
+    } while (0)
+#define STAMP_HWID(buf, j)                                                                             \
+    do {                                                                                               \
+        unsigned x_ = __builtin_amdgcn_s_getreg((3 << 11) | 20), h_ = __builtin_amdgcn_s_getreg((31 << 11) | 4); \
+        if ((buf) && lane == 0) (buf)[(size_t)env * 16 + (j)] = (unsigned long long)x_ | ((unsigned long long)h_ << 8); \
+    } while (0)
 #else
 #define STAMP_TO(buf, i) do {} while (0)
+#define STAMP_REAL(buf, i) do {} while (0)
+#define STAMP_HWID(buf, j) do {} while (0)
 #endif
 #define STAMP(i) STAMP_TO(st.stamps, i)
 #define STAMP_OBS(i) STAMP_TO(oo.stamps, i)
@@ -774,6 +787,8 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     E.err = st.err;
     const int n = E.n, GS = E.GS;
     STAMP(0);
+    STAMP_REAL(st.stamps, 12);
+    STAMP_HWID(st.stamps, 11);
 
     uint8_t* ggrid = st.grid + (size_t)env * GS;
     // ---- issue every global load up front: grid (or reset image), agents, actions, counters, site lists ----
@@ -983,6 +998,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
         else observe_phase<false>(E, env, oo);
     }
     STAMP(10);
+    STAMP_REAL(st.stamps, 13);
 }
 
 void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, const int32_t* actions,

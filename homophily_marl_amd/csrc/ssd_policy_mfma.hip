@@ -66,11 +66,14 @@ static unsigned long long* g_policy_stamps = nullptr;
 void set_policy_stamps(unsigned long long* buf) { g_policy_stamps = buf; }
 #define PSTAMP_DECL unsigned long long* stamps;
 #define PSTAMP_SET(k) (k).stamps = g_policy_stamps
-#define PSTAMP(i) do { if (a.stamps && lane == 0) a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PSTAMP_AT(i, v) do { if (a.stamps && lane == 0) a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave) * 16 + (i)] = (v); } while (0)
+#define PSTAMP(i) PSTAMP_AT(i, __builtin_amdgcn_s_memtime())
+#define PSTAMP_REAL(i) PSTAMP_AT(i, __builtin_amdgcn_s_memrealtime())      // chip-wide 100 MHz clock: comparable across XCDs
 #else
 #define PSTAMP_DECL
 #define PSTAMP_SET(k)
 #define PSTAMP(i)
+#define PSTAMP_REAL(i)
 #endif
 
 // exact power-of-two scales (PREC 2; PREC 1 needs none: bf16 has the f32 exponent range)
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold
     const int N = a.N, n = a.n;
     constexpr int A = AT;
     PSTAMP(0);
+    PSTAMP_REAL(14);
     const int tiles = (N + 15) >> 4, tstep = a.bpa * HEAD_WAVES;
     int tile = wave * a.bpa + bia;                                     // consecutive tiles go to different CUs
     TileIn<INC> in;
@@ -497,6 +501,7 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold
         if (tile < tiles) { load_tile<INC>(a, tile, agent, lane, in); prepare(tile); }
     }
     PSTAMP(7);
+    PSTAMP_REAL(15);
 }
 
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
@@ -596,13 +601,29 @@ void launch_pack_head(const ssd_policy_head_params* p, int prec, void* image, hi
 // ===========================================================================================================================
 // encoder
 // ===========================================================================================================================
-// Geometry of one window size.  O output positions per row; a plane row is padded to CP cells; a position tile is 16 positions
-// fed by NF fragments of 8 cells; XT tiles per output row; the output rows are cut into bands of R rows (one workgroup each).
+// Geometry of one window size.  O output positions per output row, cut into NXT tiles of 8 positions; a conv MFMA tile is
+// (2 output channels) x (8 positions) and reads a 10-cell window of the three planes of ONE input row: K = 3 * 8 cells + the 2
+// trailing cells of each plane (the "tail" quarter) = 30 of 32.  Two neighbouring position tiles (a pair, XTP pairs per output row)
+// are one K-step of the Linear.  The output rows are cut into NB bands of R rows (one workgroup each).
 template <int V> struct Geo;
-template <> struct Geo<15> { static constexpr int O = 13, CP = 16, NF = 2, XT = 1, R = 13, NB = 1; };
-template <> struct Geo<31> { static constexpr int O = 29, CP = 40, NF = 3, XT = 2, R = 5, NB = 6; };
+template <> struct Geo<15> { static constexpr int O = 13, CP = 16, NXT = 2, XTP = 1, R = 13, NB = 1; };
+template <> struct Geo<31> { static constexpr int O = 29, CP = 32, NXT = 4, XTP = 2, R = 5, NB = 6; };
 constexpr int ENC_BT = 5;                      // batch tiles (16 rows each) per workgroup: Linear weights are fetched once per 80 rows
 constexpr int ENC_WAVES = 8;                     // 2 per SIMD: one wave's LDS / VALU work overlaps its partner's MFMAs
+// LDS record of (batch row, input row): [plane R: CP one-hot bytes][plane G][plane B][tail: NXT x 8 bytes].  tail[k] = cells 8 (k + 1)
+// and 8 (k + 1) + 1 of the three planes (+ 2 zero bytes): the 4th K-quarter of position tile k, so that every lane's B operand is
+// ONE 8-byte LDS read.  The per-batch-row stride is padded to 8 * odd (mod 256): the 16 rows of a read hit 16 different bank pairs.
+template <int V> constexpr int enc_row_bytes() { return 3 * Geo<V>::CP + 8 * Geo<V>::NXT; }
+template <int V> constexpr int enc_batch_row_bytes() {
+    int b = (Geo<V>::R + 2) * enc_row_bytes<V>();
+    while ((b & 255) % 16 != 8) b += 8;
+    return b;
+}
+template <int V, int PREC> constexpr size_t enc_lds_bytes() {
+    const size_t work = (size_t)ENC_BT * 16 * enc_batch_row_bytes<V>() + (size_t)PREC * 9 * 1024;
+    const size_t red = (size_t)ENC_WAVES * ENC_BT * 2 * 1024;           // the reduction scratch aliases planes + fragments
+    return work > red ? work : red;
+}
 
 struct EncK {
     const uint8_t* codes; long code_bytes, env_stride, slot_stride, agent_stride; const int64_t* slot_t;
@@ -619,18 +640,14 @@ struct EncK {
 template <int V, int PREC>
 __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
     using G = Geo<V>;
-    constexpr int O = G::O, CP = G::CP, NF = G::NF, XT = G::XT, R = G::R, BT = ENC_BT;
-    constexpr int KS = SSD_ENCODE_KSTEPS(V), NFR = 9 * NF;             // K-steps; real fragments of a position tile
-    constexpr int PR = 3 * (R + 2) * CP;                               // plane bytes per batch row (this band)
-    constexpr int PLANES = BT * 16 * PR, CONV_BYTES = PREC * 6 * KS * 1024;
+    constexpr int O = G::O, CP = G::CP, NXT = G::NXT, XTP = G::XTP, R = G::R, BT = ENC_BT;
+    constexpr int RB = enc_row_bytes<V>(), PR = enc_batch_row_bytes<V>();   // bytes of an input-row record / of a batch row (this band)
+    constexpr int PLANES = BT * 16 * PR, CONV_BYTES = PREC * 9 * 1024;
     constexpr uint32_t ON = PREC == 2 ? 0x3Cu : 0x3Fu;                 // f16 0x3C00 = 1.0;  bf16 0x3F00 = 0.5 (the conv weights carry the 2)
     constexpr float CS = PREC == 2 ? ENC_CSCALE : 1.f, INV = PREC == 2 ? 1.f / (ENC_CSCALE * ENC_LSCALE) : 1.f;
-    constexpr int ZPAD = 64;                                           // zeros: the B operand of the padding fragments of the last K-step
-    static_assert(ENC_WAVES * BT * 2 * 1024 <= PLANES + ZPAD + CONV_BYTES, "the reduction scratch aliases planes + fragments");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    uint8_t* planes = lds_raw;                                         // [BT * 16 rows][3 ch][R + 2][CP] one-hot bytes
-    uint8_t* zeros = lds_raw + PLANES;
-    uint8_t* cfr = lds_raw + PLANES + ZPAD;                            // conv fragments [term][oc][ks][lane][16 B]
+    uint8_t* planes = lds_raw;                                         // [BT * 16 rows][R + 2 input rows][RB]
+    uint8_t* cfr = lds_raw + PLANES;                                   // conv fragments [term][s][dy][lane][16 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int row0 = blockIdx.x * (BT * 16);
@@ -638,6 +655,7 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
     const int Rb = O - y0 < R ? O - y0 : R;                            // output rows of this band
     const long t_off = a.slot_t ? (long)(*a.slot_t) * a.slot_stride : 0;
     PSTAMP(0);
+    PSTAMP_REAL(14);
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
         if (a.slot_t_copy) *a.slot_t_copy = *a.slot_t;
         if (a.counter_inc) *a.counter_inc += 1;
@@ -670,7 +688,6 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
                 if (al + 8 <= cend) w1[k] = *reinterpret_cast<const uint32_t*>(al + 4);
             }
         }
-        if (tid < ZPAD / 4) reinterpret_cast<uint32_t*>(zeros)[tid] = 0u;
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
             const int it = tid + k * NT;
@@ -685,9 +702,10 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
                 const int left = V - x;                               // cells of this group inside the window row
                 if (left < 4) c4 &= (1u << (8 * left)) - 1u;
             }
-            uint8_t* d = planes + (size_t)r * PR + yy * CP + x;
+            uint8_t* d = planes + (size_t)r * PR + yy * RB;
             // classes: 2 = waste -> R, 1 = apple -> G, 3 = wall / agent -> B (cleanup.py:93-105): byte == code <=> (byte ^ code) == 0;
             // channel masks: plane ch is bit ch
+            uint32_t pb[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 uint32_t hit;
@@ -697,60 +715,64 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
                     const uint32_t u = t | (t >> 4), w = u | (u >> 2);             // bit 0 of every byte = OR of the byte's bits
                     hit = ~(w | (w >> 1)) & 0x01010101u;
                 }
-                *reinterpret_cast<uint32_t*>(d + ch * (R + 2) * CP) = hit * ON;
+                pb[ch] = hit * ON;
+                *reinterpret_cast<uint32_t*>(d + ch * CP + x) = pb[ch];
             }
+            // the tail quarter: the item that holds cells 8 (k + 1), 8 (k + 1) + 1 writes tail[k]; the last tail (cells past the
+            // planes) is zero
+            if (g4 == 0) *reinterpret_cast<u32x2*>(d + 3 * CP + 8 * (NXT - 1)) = u32x2{0u, 0u};
+            else if ((g4 & 1) == 0)
+                *reinterpret_cast<u32x2*>(d + 3 * CP + 8 * (g4 / 2 - 1)) = u32x2{(pb[0] & 0xFFFFu) | (pb[1] << 16), pb[2] & 0xFFFFu};
         }
 #pragma unroll
         for (int j = 0; j < PER; ++j) { const int e = tid + j * ENC_WAVES * 64; if (e < NV) dst[e] = tmp[j]; }
     }
     __syncthreads();
     PSTAMP(1);
-    // ---- units (output row y, position tile xt, output-channel pair s) of this band, a contiguous range per wave ---------------
+    // ---- units (output row y, position-tile pair xtp, output-channel pair s) of this band, a contiguous range per wave ---------
     f32x4 accl[BT][2];
 #pragma unroll
     for (int bt = 0; bt < BT; ++bt) { accl[bt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[bt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const int U = Rb * XT * 3;
+    const int U = Rb * XTP * 3;
     const int u_begin = (wave * U) / ENC_WAVES, u_end = ((wave + 1) * U) / ENC_WAVES;
-    const uint8_t* my_planes = planes + (size_t)m * PR;
+    const uint8_t* my_b = planes + (size_t)m * PR + q * CP;            // quarter q < 3: plane q, 8 cells; quarter 3: the tail
 #pragma unroll 1
     for (int u = u_begin; u < u_end; ++u) {
-        const int s = u % 3, xt = (u / 3) % XT, yl = u / (3 * XT);    // yl: output row inside the band
+        const int s = u % 3, xtp = (u / 3) % XTP, yl = u / (3 * XTP);  // yl: output row inside the band
         // Linear A fragments of this unit (global, L2-resident): requested now, used after the conv
-        const size_t gu = (size_t)((y0 + yl) * XT + xt) * 3 + s;
+        const size_t gu = (size_t)((y0 + yl) * XTP + xtp) * 3 + s;
         u32x4 la[2][PREC];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int t = 0; t < PREC; ++t)
                 la[mt][t] = *reinterpret_cast<const u32x4*>(a.lin_frags + (((gu * 2 + mt) * PREC + t) * 64 + lane) * 16);
-        f32x4 accc[2][BT];
+        f32x4 accc[2][BT];                                             // [position tile of the pair][batch tile]: rows (o2 = q >> 1, 8 positions)
         {
-            const float b0 = a.conv_b[2 * s] * CS, b1 = a.conv_b[2 * s + 1] * CS;
+            const float bq = a.conv_b[2 * s + (q >> 1)] * CS;
 #pragma unroll
-            for (int bt = 0; bt < BT; ++bt) { accc[0][bt] = f32x4{b0, b0, b0, b0}; accc[1][bt] = f32x4{b1, b1, b1, b1}; }
+            for (int bt = 0; bt < BT; ++bt) { accc[0][bt] = f32x4{bq, bq, bq, bq}; accc[1][bt] = f32x4{bq, bq, bq, bq}; }
         }
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int F = 4 * ks + q;                                  // fragment of this lane's quarter: (dy, ch, f)
-            const bool real = (4 * ks + 3 < NFR) || F < NFR;           // only the last K-step holds padding fragments: they read zeros
-            const int Fc = real ? F : 0, dy = Fc / (3 * NF), ch = (Fc / NF) % 3, f = Fc % NF;
-            const uint8_t* bp = real ? my_planes + (ch * (R + 2) + yl + dy) * CP + 16 * xt + 8 * f : zeros;
-            const int bstride = real ? 16 * PR : 0;
-            u32x4 bfr[BT];
+        for (int dy = 0; dy < 3; ++dy) {
+            u32x4 af[PREC];
 #pragma unroll
-            for (int bt = 0; bt < BT; ++bt) {
-                const u32x2 w = *reinterpret_cast<const u32x2*>(bp + bt * bstride);
-                bfr[bt][0] = __builtin_amdgcn_perm(0u, w[0], 0x010C000Cu); bfr[bt][1] = __builtin_amdgcn_perm(0u, w[0], 0x030C020Cu);
-                bfr[bt][2] = __builtin_amdgcn_perm(0u, w[1], 0x010C000Cu); bfr[bt][3] = __builtin_amdgcn_perm(0u, w[1], 0x030C020Cu);
-            }
+            for (int t = 0; t < PREC; ++t) af[t] = *reinterpret_cast<const u32x4*>(cfr + ((size_t)((t * 3 + s) * 3 + dy) * 64 + lane) * 16);
 #pragma unroll
-            for (int o2 = 0; o2 < 2; ++o2)
+            for (int tx = 0; tx < 2; ++tx) {
+                const uint8_t* bp = my_b + (yl + dy) * RB + 8 * (2 * xtp + tx);
+                u32x4 bfr[BT];
 #pragma unroll
-                for (int t = PREC - 1; t >= 0; --t) {
-                    const u32x4 af = *reinterpret_cast<const u32x4*>(cfr + ((size_t)((t * 6 + 2 * s + o2) * KS + ks) * 64 + lane) * 16);
-#pragma unroll
-                    for (int bt = 0; bt < BT; ++bt) accc[o2][bt] = mma<PREC>(af, bfr[bt], accc[o2][bt]);
+                for (int bt = 0; bt < BT; ++bt) {
+                    const u32x2 w = *reinterpret_cast<const u32x2*>(bp + bt * 16 * PR);
+                    bfr[bt][0] = __builtin_amdgcn_perm(0u, w[0], 0x010C000Cu); bfr[bt][1] = __builtin_amdgcn_perm(0u, w[0], 0x030C020Cu);
+                    bfr[bt][2] = __builtin_amdgcn_perm(0u, w[1], 0x010C000Cu); bfr[bt][3] = __builtin_amdgcn_perm(0u, w[1], 0x030C020Cu);
                 }
+#pragma unroll
+                for (int t = PREC - 1; t >= 0; --t)
+#pragma unroll
+                    for (int bt = 0; bt < BT; ++bt) accc[tx][bt] = mma<PREC>(af[t], bfr[bt], accc[tx][bt]);
+            }
         }
         // LeakyReLU (positively homogeneous: the scale CS rides through), split, Linear K-step of this unit
 #pragma unroll
@@ -800,12 +822,13 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
         }
     }
     PSTAMP(3);
+    PSTAMP_REAL(15);
 }
 
 template <int V, int PREC>
 static int launch_encode_t(const EncK& k, hipStream_t s) {
     using G = Geo<V>;
-    constexpr size_t lds = (size_t)ENC_BT * 16 * 3 * (G::R + 2) * G::CP + 64 + (size_t)PREC * 6 * SSD_ENCODE_KSTEPS(V) * 1024;
+    constexpr size_t lds = enc_lds_bytes<V, PREC>();
     static bool done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
@@ -836,23 +859,24 @@ int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s) {
 template <int V, int PREC>
 __global__ __launch_bounds__(256) void k_pack_encoder(const float* __restrict__ cw, const float* __restrict__ lw, uint8_t* conv_frags, uint8_t* lin_frags) {
     using G = Geo<V>;
-    constexpr int O = G::O, NF = G::NF, XT = G::XT, KS = SSD_ENCODE_KSTEPS(V), P = O * O, UNITS = SSD_ENCODE_UNITS(V);
-    constexpr int NCONV = 6 * KS * 512, NLIN = UNITS * 2 * 512;
+    constexpr int O = G::O, XTP = G::XTP, P = O * O, UNITS = SSD_ENCODE_UNITS(V);
+    constexpr int NCONV = 9 * 512, NLIN = UNITS * 2 * 512;
     constexpr float CS = PREC == 2 ? ENC_CSCALE : 2.f, LS = PREC == 2 ? ENC_LSCALE : 1.f;   // PREC 1: the plane value is 0.5
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < NCONV) {
-        const int oc = e / (KS * 512), ks = (e >> 9) % KS, lane = (e >> 3) & 63, j = e & 7, q = lane >> 4, m = lane & 15;
-        const int F = 4 * ks + q;
+        // fragment (s, dy): row m = (o2 = m >> 3, position p = m & 7); quarter q < 3: plane q, cells 0..7; quarter 3: the tail
+        // [R 8, R 9, G 8, G 9, B 8, B 9, 0, 0]; the tap index is d = cell - p
+        const int sd = e >> 9, s = sd / 3, dy = sd % 3, lane = (e >> 3) & 63, j = e & 7, q = lane >> 4, m = lane & 15;
+        const int oc = 2 * s + (m >> 3), pp = m & 7;
+        const int ch = q < 3 ? q : j >> 1, cell = q < 3 ? j : 8 + (j & 1), d = cell - pp;
         float w = 0.f;
-        if (F < 9 * NF) {
-            const int dy = F / (3 * NF), ch = (F / NF) % 3, f = F % NF, d = 8 * f + j - m;
-            if (d >= 0 && d <= 2) w = (float)((double)cw[((oc * 3 + ch) * 3 + dy) * 3 + d] * (255.0 / 256.0) * (double)CS);
-        }
-        store_term<PREC>(conv_frags + ((size_t)(oc * KS + ks) * 64 + lane) * 16 + 2 * j, w, (size_t)6 * KS * 1024);
+        if ((q < 3 || j < 6) && d >= 0 && d <= 2) w = (float)((double)cw[((oc * 3 + ch) * 3 + dy) * 3 + d] * (255.0 / 256.0) * (double)CS);
+        store_term<PREC>(conv_frags + ((size_t)sd * 64 + lane) * 16 + 2 * j, w, (size_t)9 * 1024);
     } else if (e < NCONV + NLIN) {
         const int i = e - NCONV, mt = (i >> 9) & 1, u = i >> 10, lane = (i >> 3) & 63, j = i & 7, q = lane >> 4, m = lane & 15;
-        const int s = u % 3, xt = (u / 3) % XT, y = u / (3 * XT);
-        const int oc = 2 * s + (j >> 2), x = 16 * xt + 4 * q + (j & 3);
+        const int s = u % 3, xtp = (u / 3) % XTP, y = u / (3 * XTP);
+        const int r = 4 * q + (j & 3);                                 // row of conv result tile (j >> 2) of the pair
+        const int oc = 2 * s + (r >> 3), x = 8 * (2 * xtp + (j >> 2)) + (r & 7);
         const float w = x < O ? lw[(size_t)(16 * mt + m) * (6 * P) + oc * P + y * O + x] * LS : 0.f;
         store_term<PREC>(lin_frags + (((size_t)(u * 2 + mt) * PREC) * 64 + lane) * 16 + 2 * j, w, (size_t)64 * 16);
     }
@@ -862,7 +886,7 @@ int launch_pack_encoder(const float* cw, const float* lw, int V, int prec, void*
     uint8_t *c = static_cast<uint8_t*>(conv_frags), *l = static_cast<uint8_t*>(lin_frags);
 #define SSD_PACK(V_, P_)                                                                                                     \
     do {                                                                                                                     \
-        const int total = 6 * SSD_ENCODE_KSTEPS(V_) * 512 + SSD_ENCODE_UNITS(V_) * 2 * 512;                                  \
+        const int total = 9 * 512 + SSD_ENCODE_UNITS(V_) * 2 * 512;                                  \
         hipLaunchKernelGGL((k_pack_encoder<V_, P_>), dim3((total + 255) / 256), dim3(256), 0, s, cw, lw, c, l);              \
     } while (0)
     if (V == 15) { if (prec == 2) SSD_PACK(15, 2); else SSD_PACK(15, 1); return 0; }

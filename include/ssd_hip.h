@@ -414,9 +414,12 @@ int ssd_policy_pack_head(const ssd_policy_head_params* params, int32_t precision
  * Input: one byte per window cell in either alphabet (`alphabet`: SSD_CODE_CLASS = the SSD_OBS_CODE classes of an episode storage,
  * SSD_CODE_CHANNEL_MASK = the side buffer of ssd_obs_out.obs_code); the three colour planes are rebuilt in LDS as one-hot bytes, so the
  * conv is a banded (Toeplitz) GEMM over 16 batch rows per MFMA and the whole encoder runs on the matrix cores:
- *   conv   D[16 positions of an output row][16 batch rows] += A[positions][(dy, ch, 8 cells)] x B[(dy, ch, 8 cells)][batch rows]
- *          A = Toeplitz image of the 3 x 3 taps (ssd_policy_pack_encoder), B = plane bytes read from LDS (ds_read_b64 + 4 v_perm)
- *   Linear the conv result tiles of an output-channel pair ARE the B operand of the Linear product (no transposition, no LDS)
+ *   conv   D[(2 output channels) x (8 positions of an output row)][16 batch rows] += A[.][K] x B[K][batch rows] per input row dy:
+ *          K = 3 planes x the 10-cell window of the 8 positions, laid out as three quarters of 8 cells + a "tail" quarter that holds
+ *          cells 8, 9 of the three planes (30 of 32 K entries carry data; 9 of them are taps of a given output).
+ *          A = Toeplitz image of the 3 x 3 taps (ssd_policy_pack_encoder), B = plane bytes read from LDS (one ds_read_b64 + 4 v_perm)
+ *   Linear two neighbouring conv result tiles (16 positions x 2 channels) ARE the B operand of a Linear K-step (no transposition,
+ *          no LDS)
  * The class of row (env b, agent i) cell c is read at codes[b * env_stride + (*slot_t) * slot_stride + i * agent_stride + c]
  * (slot_t NULL: slot 0): the dense side buffer of ssd_obs_out.obs_code (env_stride = n * agent_stride, slot_stride = 0) or an
  * episode storage of class codes u8 [n_env, t_slots, n, V, V] (agent_stride = V * V).  code_bytes = readable bytes behind `codes`;
@@ -430,14 +433,14 @@ int ssd_policy_pack_head(const ssd_policy_head_params* params, int32_t precision
  * (ssd_policy_head.t_index / next_t_out, ssd_store_step_launch).  counter_inc (nullable): *counter_inc += 1 (the exploration-draw
  * counter read by the heads that follow; this kernel does not read it).
  * Fragment images (ssd_policy_pack_encoder from conv_w f32 [6, 3, 3, 3] and lin_w f32 [32, 6 (V-2)^2]):
- *   conv_frags [term][oc 6][K-step][lane][8]: element (q, m, j) of K-step ks = tap weight w[oc][ch][dy][d] * 255/256 for fragment
- *              F = 4 ks + q = (dy * 3 + ch) * NF + f, cell 8 f + j, d = cell - m in 0..2, else 0   (NF = 2 / 3 fragments per plane row)
- *   lin_frags  [unit = ((y * XT + xt) * 3 + s)][output tile 2][term][lane][8]: element (q, m, j) = lin_w[16 Mt + m][oc * P + y * O + x],
- *              oc = 2 s + (j >> 2), x = 16 xt + 4 q + (j & 3), 0 where x >= O   (XT = 1 / 2 position tiles per output row) */
+ *   conv_frags [term][s 3][dy 3][lane][8]: element (q, m, j) = tap weight w[oc][ch][dy][d] * 255/256, oc = 2 s + (m >> 3),
+ *              position p = m & 7; q < 3: ch = q, cell = j; q = 3: ch = j >> 1, cell = 8 + (j & 1) (j < 6); d = cell - p in 0..2, else 0
+ *   lin_frags  [unit = ((y * XTP + xtp) * 3 + s)][output tile 2][term][lane][8]: element (q, m, j) = lin_w[16 Mt + m][oc * P + y * O + x],
+ *              r = 4 q + (j & 3), oc = 2 s + (r >> 3), x = 8 (2 xtp + (j >> 2)) + (r & 7), 0 where x >= O   (XTP = 1 / 2 pairs of
+ *              8-position tiles per output row) */
 #define SSD_ENCODE_BANDS(V) ((V) == 31 ? 6 : 1)
-#define SSD_ENCODE_KSTEPS(V) ((V) == 31 ? 7 : 5)
 #define SSD_ENCODE_UNITS(V) ((V) == 31 ? 29 * 2 * 3 : 13 * 1 * 3)
-#define SSD_ENCODE_CONV_FRAG_BYTES(V, precision) ((precision) * 6 * SSD_ENCODE_KSTEPS(V) * 1024)
+#define SSD_ENCODE_CONV_FRAG_BYTES(V, precision) ((precision) * 9 * 1024)
 #define SSD_ENCODE_LIN_FRAG_BYTES(V, precision) (SSD_ENCODE_UNITS(V) * 2 * (precision) * 1024)
 typedef struct ssd_policy_encode_args {
     const uint8_t* codes;

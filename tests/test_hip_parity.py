@@ -111,33 +111,51 @@ def test_counter_mode_vs_oracle(name, opts):
     dev.close(); orc.close()
 
 
-def test_full_size_cleanup5_4096_envs_vs_oracle():
-    """BASELINE.json configs[1] size: 4096 envs x 5 agents, one full 100-step episode, every step compared."""
+FULL_SIZE = {   # BASELINE.json configs[1], [2] and [3] at their full env counts and window sizes
+    "cleanup5": dict(env="cleanup", map="default5", num_agents=5, view_size=7, n_env=4096),
+    "harvest5": dict(env="harvest", map="default10", num_agents=5, view_size=15, n_env=4096),
+    "cleanup10": dict(env="cleanup", map="default10", num_agents=10, view_size=7, n_env=8192),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL_SIZE))
+def test_full_size_episode_vs_oracle(name):
+    """BASELINE.json sizes (4096 x 5 Cleanup, 4096 x 5 Harvest with 31 x 31 windows, 8192 x 10 Cleanup): one full 100-step
+    episode, rewards / info scalars / draw counts compared at every step, observations and the whole state every 25 steps."""
     from oracle.oracle_py import OracleEnv
     HipEnv, _ = _hip()
-    N, n, T = 4096, 5, 100
-    kw = dict(map="default5", num_agents=n, n_env=N, view_size=7, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=1)
-    dev, orc = HipEnv("cleanup", **kw), OracleEnv("cleanup", **kw)
+    cfg = FULL_SIZE[name]
+    N, n, T = cfg["n_env"], cfg["num_agents"], 100
+    kw = dict(map=cfg["map"], num_agents=n, n_env=N, view_size=cfg["view_size"], episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=1)
+    dev, orc = HipEnv(cfg["env"], **kw), OracleEnv(cfg["env"], **kw)
     rng = np.random.default_rng(0x5D5D)
-    avail = np.array([0, 1, 2, 3, 4, 8])
+    avail = np.array([a for a in range(dev.n_actions) if a not in (5, 6, 7)])     # the shipped action set (no rotation, no FIRE)
     dev.reset(); orc.reset()
     for t in range(T):
-        acts = avail[rng.integers(0, 6, (N, n))].astype(np.int32)
-        a, b = dev.step_observe(acts), orc.step(acts)
+        acts = avail[rng.integers(0, len(avail), (N, n))].astype(np.int32)
+        a, b = dev.step_observe(acts, fmt=abi.OBS_U8), orc.step(acts)
         _compare_step(t, a, b)
         if t % 25 == 24:
-            assert (a["obs"] == orc.observe()["obs"]).all(), t
+            ob = orc.observe(abi.OBS_U8)
+            for k in ("obs", "pos", "orient"):
+                assert (a[k] == ob[k]).all(), (t, k)
             _compare_state(t, dev, orc)
     assert a["terminated"].all()
     assert (a["collective_return"] == b["collective_return"]).all() and (a["equality"] == b["equality"]).all()
     # domain invariants that hold for any size (checked on the full batch)
     st = dev.export_state()
-    grid = st["grid"].reshape(N, 25, 18)
-    base = np.frombuffer(dev.e.spec.ascii, np.uint8).reshape(25, 18)
-    assert np.isin(grid[:, base == ord("B")], (0, 2)).all()          # apple sites hold ' ' or 'A'
-    assert np.isin(grid[:, base == ord("H")], (3, 4)).all()          # waste sites hold 'H' or 'R'
-    assert (grid[:, base == ord("R")] == 4).all() and (grid[:, base == ord("S")] == 5).all() and (grid[:, base == ord("@")] == 1).all()
-    assert (grid[:, (base == ord(" ")) | (base == ord("P"))] == 0).all()
+    H, W = dev.H, dev.W
+    grid = st["grid"].reshape(N, H, W)
+    base = np.frombuffer(dev.e.spec.ascii, np.uint8)[:H * W].reshape(H, W)
+    assert (grid[:, base == ord("@")] == 1).all()                     # walls stay walls
+    if cfg["env"] == "cleanup":
+        assert np.isin(grid[:, base == ord("B")], (0, 2)).all()          # apple sites hold ' ' or 'A'
+        assert np.isin(grid[:, base == ord("H")], (3, 4)).all()          # waste sites hold 'H' or 'R'
+        assert (grid[:, base == ord("R")] == 4).all() and (grid[:, base == ord("S")] == 5).all()
+        assert (grid[:, (base == ord(" ")) | (base == ord("P"))] == 0).all()
+    else:
+        assert np.isin(grid[:, base == ord("A")], (0, 2)).all()          # apples regrow only on the map's apple sites
+        assert (grid[:, (base == ord(" ")) | (base == ord("P"))] == 0).all()
     r, c = st["pos"][..., 0].astype(int), st["pos"][..., 1].astype(int)
     assert (base[r, c] != ord("@")).all()                            # nobody stands in a wall
     assert (st["ep_step"] == T).all()

@@ -74,3 +74,10 @@ for name, key, fn in r.timestep_launches():
         if d.numel():
             qs = th.quantile(d, th.tensor([0.0, 0.5, 0.9, 1.0], dtype=th.double))
             print("   %-22s waves %5d  min %7d  median %7d  p90 %7d  max %7d" % (labels[i - 1] + " -> " + labels[i], d.numel(), *[int(x) for x in qs]))
+    # timeline of the launch on the chip-wide 100 MHz clock (10 ns ticks)
+    t0, t1 = s[:, 14].double(), s[:, 15].double()
+    base = t0.min()
+    q = th.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=th.double)
+    print("   us after the first wave's start (min / p10 / median / p90 / max): start %s | end %s | kernel span %.2f us" % (
+        " ".join("%.2f" % (x / 100) for x in th.quantile(t0 - base, q).tolist()),
+        " ".join("%.2f" % (x / 100) for x in th.quantile(t1 - base, q).tolist()), (t1.max() - base).item() / 100))

@@ -14,6 +14,7 @@ import __graft_entry__ as G  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--n-env", type=int, default=4096)
 ap.add_argument("--mode", default="step_observe")
+ap.add_argument("--dest", default="dense", choices=["dense", "storage"])
 a = ap.parse_args()
 out = os.path.join(ROOT, "gpurun_out", "libssd_hip_stamps.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
@@ -31,12 +32,15 @@ env.lib.ssd_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
 env.lib.ssd_debug_set_stamps(env.h, stamps.data_ptr())
 avail = torch.tensor([0, 1, 2, 3, 4, 8], dtype=torch.int32, device="cuda")
 env.reset()
+out = None
+if a.dest == "storage":      # the rollout's destination: slot ep_step of an episode storage (every launch lands in fresh HBM lines)
+    out = env.storage_obs_buffers(torch.empty(N, 101, n, 3, 15, 15, device="cuda"), abi.OBS_F32)
 names = ["load", "moves", "consume+paint", "beams", "spawn", "scalars", "writeback", "obs pass0", "obs pass1", "obs pass2"]
 acc = []
 for t in range(40):
     acts = avail[torch.randint(0, 6, (N, n), device="cuda")].contiguous()
     if a.mode == "step_observe":
-        env.step_observe(acts)
+        env.step_observe(acts, out=out)
     else:
         env.step(acts)
     torch.cuda.synchronize()
@@ -50,3 +54,27 @@ for i, nm in enumerate(names):
     x = d[..., i].flatten()
     print("  %-14s %8.0f %8.0f" % (nm, x.median().item(), x.quantile(0.9).item()))
 print("  %-14s %8.0f %8.0f" % ("total", tot.flatten().median().item(), tot.flatten().quantile(0.9).item()))
+
+# timeline of ONE launch on the chip-wide 100 MHz clock (10 ns ticks): when do waves start (dispatch ramp) and end (tail)?
+one = acc[-1].cpu()
+t0, t1 = one[:, 12].double(), one[:, 13].double()
+base = t0.min()
+q = torch.tensor([0.0, 0.1, 0.5, 0.9, 0.99, 1.0], dtype=torch.double)
+print("one launch, microseconds after the first wave's start (min / p10 / median / p90 / p99 / max):")
+print("  wave start   ", " ".join("%6.2f" % (x / 100) for x in torch.quantile(t0 - base, q).tolist()))
+print("  wave end     ", " ".join("%6.2f" % (x / 100) for x in torch.quantile(t1 - base, q).tolist()))
+print("  wave lifetime", " ".join("%6.2f" % (x / 100) for x in torch.quantile(t1 - t0, q).tolist()))
+xcc = (one[:, 11] & 15)
+for x in sorted(set(xcc.tolist())):
+    m = xcc == x
+    print("  XCC %d: %4d waves, start %6.2f..%6.2f, end %6.2f..%6.2f" % (x, int(m.sum()), (t0[m].min() - base) / 100, (t0[m].max() - base) / 100,
+                                                                     (t1[m].min() - base) / 100, (t1[m].max() - base) / 100))
+late = torch.argsort(t1)[-8:]
+print("  last 8 waves: env", late.tolist(), "start", [round((t0[i].item() - base.item()) / 100, 2) for i in late], "life", [round((t1[i] - t0[i]).item() / 100, 2) for i in late])
+# which phases are long in the slowest 1% of waves?
+life = (one[:, 10] - one[:, 0]).double()
+slow = life >= torch.quantile(life, torch.tensor(0.99, dtype=torch.double))
+dd = (one[:, 1:11] - one[:, 0:10]).double()
+print("  phase medians, all waves vs the slowest 1%:")
+for i, nm in enumerate(names):
+    print("    %-14s %8.0f %8.0f" % (nm, dd[:, i].median().item(), dd[slow, i].median().item()))
