@@ -668,61 +668,81 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
         u32x4 tmp[PER];
 #pragma unroll
         for (int j = 0; j < PER; ++j) { const int e = tid + j * ENC_WAVES * 64; if (e < NV) tmp[j] = src[e]; }
-        // plane bytes: items = (batch row, band input row, group of 4 cells).  The 4 codes of an item come from the two aligned
-        // dwords that hold them (window rows of 15 / 31 bytes are not dword aligned; only dwords that contain readable codes are
-        // touched).  Every load of the workgroup is in flight before the first plane byte is written.
-        constexpr int GPR = CP / 4, ITEMS = BT * 16 * (R + 2) * GPR, NT = ENC_WAVES * 64, IPT = (ITEMS + NT - 1) / NT;
-        uint32_t w0[IPT], w1[IPT];
-        const uintptr_t cbase = reinterpret_cast<uintptr_t>(a.codes), cend = (cbase + (uintptr_t)a.code_bytes + 3) & ~(uintptr_t)3;
+        // plane bytes: one item = one window row (V codes at any byte alignment) of a (batch row, band input row): NQ unaligned
+        // 16-byte loads (gfx950 global loads take any byte address); an item whose last load would cross the end of the readable
+        // bytes is assembled from aligned dwords instead.  Every load of the workgroup is in flight before the first plane byte
+        // is written.
+        constexpr int NQ = CP / 16, ITEMS = BT * 16 * (R + 2), NT = ENC_WAVES * 64, IPT = (ITEMS + NT - 1) / NT;
+        typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+        u32x4 cw[IPT][NQ];
+        const uintptr_t cbase = reinterpret_cast<uintptr_t>(a.codes), cend = cbase + (uintptr_t)a.code_bytes;
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
             const int it = tid + k * NT;
-            const int g4 = it % GPR, yy = (it / GPR) % (R + 2), r = it / (GPR * (R + 2));
-            const int row = row0 + r, y = y0 + yy, x = 4 * g4;
-            w0[k] = w1[k] = 0u;
-            if (it < ITEMS && row < a.rows && y < V && x < V) {
+            const int yy = it % (R + 2), r = it / (R + 2);
+            const int row = row0 + r, y = y0 + yy;
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) cw[k][h] = u32x4{0u, 0u, 0u, 0u};
+            if (it < ITEMS && row < a.rows && y < V) {
                 const int b = row / a.n, i = row - b * a.n;
-                const uintptr_t ptr = cbase + (uintptr_t)((long)b * a.env_stride + t_off + (long)i * a.agent_stride + y * V + x);
-                const uintptr_t al = ptr & ~(uintptr_t)3;
-                w0[k] = *reinterpret_cast<const uint32_t*>(al);
-                if (al + 8 <= cend) w1[k] = *reinterpret_cast<const uint32_t*>(al + 4);
+                const uintptr_t ptr = cbase + (uintptr_t)((long)b * a.env_stride + t_off + (long)i * a.agent_stride + y * V);
+                if (ptr + 16 * NQ <= cend) {
+#pragma unroll
+                    for (int h = 0; h < NQ; ++h) cw[k][h] = *reinterpret_cast<const u32x4_u*>(ptr + 16 * h);
+                } else {                                               // the last rows of the buffer: aligned dwords that hold readable bytes
+                    const uintptr_t al = ptr & ~(uintptr_t)3, lim = (cend + 3) & ~(uintptr_t)3;
+                    uint32_t prev = *reinterpret_cast<const uint32_t*>(al);
+#pragma unroll
+                    for (int h = 0; h < NQ; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uintptr_t nx = al + 4 * (4 * h + e + 1);
+                            const uint32_t next = nx + 4 <= lim ? *reinterpret_cast<const uint32_t*>(nx) : 0u;
+                            cw[k][h][e] = __builtin_amdgcn_alignbyte(next, prev, (uint32_t)(ptr & 3));
+                            prev = next;
+                        }
+                }
             }
         }
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
             const int it = tid + k * NT;
             if (it >= ITEMS) continue;
-            const int g4 = it % GPR, yy = (it / GPR) % (R + 2), r = it / (GPR * (R + 2));
-            const int row = row0 + r, y = y0 + yy, x = 4 * g4;
-            uint32_t c4 = 0;
-            if (row < a.rows && y < V && x < V) {
-                const int b = row / a.n, i = row - b * a.n;
-                const uintptr_t ptr = cbase + (uintptr_t)((long)b * a.env_stride + t_off + (long)i * a.agent_stride + y * V + x);
-                c4 = __builtin_amdgcn_alignbyte(w1[k], w0[k], (uint32_t)(ptr & 3));
-                const int left = V - x;                               // cells of this group inside the window row
-                if (left < 4) c4 &= (1u << (8 * left)) - 1u;
-            }
+            const int yy = it % (R + 2), r = it / (R + 2);
             uint8_t* d = planes + (size_t)r * PR + yy * RB;
-            // classes: 2 = waste -> R, 1 = apple -> G, 3 = wall / agent -> B (cleanup.py:93-105): byte == code <=> (byte ^ code) == 0;
-            // channel masks: plane ch is bit ch
-            uint32_t pb[3];
+            // classes (SSD_OBS_CODE, 0..3): 2 = waste -> R, 1 = apple -> G, 3 = wall / agent -> B (cleanup.py:93-105): with the class
+            // bits (b1 b0), B = b1 & b0, R = b1 ^ B, G = b0 ^ B.  Channel masks: plane ch is bit ch.  Cells >= V of the row are cleared.
+            u32x4 pl[3][NQ];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                uint32_t hit;
-                if (a.mask_alphabet) hit = (c4 >> ch) & 0x01010101u;
-                else {
-                    const uint32_t t = c4 ^ ((ch == 0 ? 2u : ch == 1 ? 1u : 3u) * 0x01010101u);
-                    const uint32_t u = t | (t >> 4), w = u | (u >> 2);             // bit 0 of every byte = OR of the byte's bits
-                    hit = ~(w | (w >> 1)) & 0x01010101u;
+            for (int h = 0; h < NQ; ++h) {
+                u32x4 c = cw[k][h];
+                if (h == NQ - 1) c[3] &= 0x00FFFFFFu;                  // byte 16 NQ - 1 is cell V (the next row's first cell)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t b0 = c[e] & 0x01010101u, b1 = (c[e] >> 1) & 0x01010101u;
+                    if (a.mask_alphabet) {
+                        pl[0][h][e] = b0 * ON; pl[1][h][e] = b1 * ON; pl[2][h][e] = ((c[e] >> 2) & 0x01010101u) * ON;
+                    } else {
+                        const uint32_t bb = b1 & b0;
+                        pl[0][h][e] = (b1 ^ bb) * ON; pl[1][h][e] = (b0 ^ bb) * ON; pl[2][h][e] = bb * ON;
+                    }
                 }
-                pb[ch] = hit * ON;
-                *reinterpret_cast<uint32_t*>(d + ch * CP + x) = pb[ch];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {                        // records are 8-byte aligned (see enc_batch_row_bytes)
+                    *reinterpret_cast<u32x2*>(d + ch * CP + 16 * h) = u32x2{pl[ch][h][0], pl[ch][h][1]};
+                    *reinterpret_cast<u32x2*>(d + ch * CP + 16 * h + 8) = u32x2{pl[ch][h][2], pl[ch][h][3]};
+                }
             }
-            // the tail quarter: the item that holds cells 8 (k + 1), 8 (k + 1) + 1 writes tail[k]; the last tail (cells past the
-            // planes) is zero
-            if (g4 == 0) *reinterpret_cast<u32x2*>(d + 3 * CP + 8 * (NXT - 1)) = u32x2{0u, 0u};
-            else if ((g4 & 1) == 0)
-                *reinterpret_cast<u32x2*>(d + 3 * CP + 8 * (g4 / 2 - 1)) = u32x2{(pb[0] & 0xFFFFu) | (pb[1] << 16), pb[2] & 0xFFFFu};
+            // the tail quarters: tail[k] = cells 8 (k + 1), 8 (k + 1) + 1 of the three planes; the last one (cells past the planes) is zero
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) {
+                u32x4 tl;
+                tl[0] = (pl[0][h][2] & 0xFFFFu) | (pl[1][h][2] << 16); tl[1] = pl[2][h][2] & 0xFFFFu;          // cells 16 h + 8, + 9
+                if (h + 1 < NQ) { tl[2] = (pl[0][h + 1][0] & 0xFFFFu) | (pl[1][h + 1][0] << 16); tl[3] = pl[2][h + 1][0] & 0xFFFFu; }   // 16 h + 16, + 17
+                else { tl[2] = 0u; tl[3] = 0u; }
+                *reinterpret_cast<u32x2*>(d + 3 * CP + 16 * h) = u32x2{tl[0], tl[1]};
+                *reinterpret_cast<u32x2*>(d + 3 * CP + 16 * h + 8) = u32x2{tl[2], tl[3]};
+            }
         }
 #pragma unroll
         for (int j = 0; j < PER; ++j) { const int e = tid + j * ENC_WAVES * 64; if (e < NV) dst[e] = tmp[j]; }
@@ -736,17 +756,26 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
     const int U = Rb * XTP * 3;
     const int u_begin = (wave * U) / ENC_WAVES, u_end = ((wave + 1) * U) / ENC_WAVES;
     const uint8_t* my_b = planes + (size_t)m * PR + q * CP;            // quarter q < 3: plane q, 8 cells; quarter 3: the tail
-#pragma unroll 1
-    for (int u = u_begin; u < u_end; ++u) {
-        const int s = u % 3, xtp = (u / 3) % XTP, yl = u / (3 * XTP);  // yl: output row inside the band
-        // Linear A fragments of this unit (global, L2-resident): requested now, used after the conv
+    // Linear A fragments of a unit (global, L2-resident) are requested one unit ahead of their use
+    auto load_la = [&](int u, u32x4 (&la)[2][PREC]) {
+        const int s = u % 3, xtp = (u / 3) % XTP, yl = u / (3 * XTP);
         const size_t gu = (size_t)((y0 + yl) * XTP + xtp) * 3 + s;
-        u32x4 la[2][PREC];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int t = 0; t < PREC; ++t)
                 la[mt][t] = *reinterpret_cast<const u32x4*>(a.lin_frags + (((gu * 2 + mt) * PREC + t) * 64 + lane) * 16);
+    };
+    u32x4 la[2][PREC], la_next[2][PREC];
+    if (u_begin < u_end) load_la(u_begin, la_next);
+#pragma unroll 1
+    for (int u = u_begin; u < u_end; ++u) {
+        const int s = u % 3, xtp = (u / 3) % XTP, yl = u / (3 * XTP);  // yl: output row inside the band
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < PREC; ++t) la[mt][t] = la_next[mt][t];
+        if (u + 1 < u_end) load_la(u + 1, la_next);
         f32x4 accc[2][BT];                                             // [position tile of the pair][batch tile]: rows (o2 = q >> 1, 8 positions)
         {
             const float bq = a.conv_b[2 * s + (q >> 1)] * CS;
@@ -774,7 +803,8 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
                     for (int bt = 0; bt < BT; ++bt) accc[tx][bt] = mma<PREC>(af[t], bfr[bt], accc[tx][bt]);
             }
         }
-        // LeakyReLU (positively homogeneous: the scale CS rides through), split, Linear K-step of this unit
+        // LeakyReLU (positively homogeneous: the scale CS rides through), split, Linear K-step of this unit (the two output tiles'
+        // accumulation chains are interleaved)
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt) {
             float v[8];
@@ -782,14 +812,14 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
             for (int j = 0; j < 8; ++j) v[j] = leaky(accc[j >> 2][bt][j & 3]);
             u32x4 xh, xl;
             split8<PREC>(v, xh, xl);
+            if (PREC == 2) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                if (PREC == 2) {
-                    accl[bt][mt] = mma<PREC>(la[mt][PREC - 1], xh, accl[bt][mt]);
-                    accl[bt][mt] = mma<PREC>(la[mt][0], xl, accl[bt][mt]);
-                }
-                accl[bt][mt] = mma<PREC>(la[mt][0], xh, accl[bt][mt]);
+                for (int mt = 0; mt < 2; ++mt) accl[bt][mt] = mma<PREC>(la[mt][PREC - 1], xh, accl[bt][mt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) accl[bt][mt] = mma<PREC>(la[mt][0], xl, accl[bt][mt]);
             }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) accl[bt][mt] = mma<PREC>(la[mt][0], xh, accl[bt][mt]);
         }
     }
     PSTAMP(2);
