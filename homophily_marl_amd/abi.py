@@ -144,7 +144,7 @@ class SsdPolicyEncodeArgs(C.Structure):
                 ("rows", C.c_int32), ("view_edge", C.c_int32), ("n_agents", C.c_int32), ("agent_major", C.c_int32), ("precision", C.c_int32),
                 ("conv_frags", C.c_void_p), ("lin_frags", C.c_void_p), ("conv_b", C.c_void_p), ("lin_b", C.c_void_p),
                 ("out", C.c_void_p), ("out_stride", C.c_int32), ("part", C.c_void_p), ("slot_t_copy", C.c_void_p), ("counter_inc", C.c_void_p),
-                ("alphabet", C.c_int32)]
+                ("alphabet", C.c_int32), ("act", C.c_void_p)]
 
 
 class SsdTdLossArgs(C.Structure):
@@ -185,7 +185,9 @@ def code_agent_stride(V):
 HIP_SIGNATURES["ssd_policy_head_env"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.c_void_p])
 HIP_SIGNATURES["ssd_policy_head_inc"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_fwd"] = (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_void_p])
-HIP_SIGNATURES["ssd_gru_seq_bwd"] = (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 3 + [C.c_void_p])
+HIP_SIGNATURES["ssd_gru_seq_bwd"] = (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 3 + [C.c_void_p])
+HIP_SIGNATURES["ssd_bias_bmm_fwd"] = (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p])
+HIP_SIGNATURES["ssd_bias_bmm_bwd"] = (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_policy_encode"] = (C.c_int, [C.POINTER(SsdPolicyEncodeArgs), C.c_void_p])
 HIP_SIGNATURES["ssd_policy_pack_encoder"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_column_sums"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p])

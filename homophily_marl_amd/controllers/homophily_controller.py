@@ -99,11 +99,8 @@ class HomophilyMAC(nn.Module):
     # ---- inputs ---------------------------------------------------------------------------------------------
     @staticmethod
     def expand_codes(codes):
-        """u8 class codes [..., V, V] of the simplified palette (0 nothing, 1 apple, 2 waste, 3 wall / agent; include/ssd_hip.h
-        SSD_OBS_CODE) -> f32 [..., 3, V, V]: waste = R, apple = G, wall / agent = B at 255/256 -- the observation the env emits in
-        f32 form (map_env.py:945, cleanup.py:96-105)."""
-        c = codes.unsqueeze(-3)
-        return th.cat([c == 2, c == 1, c == 3], dim=-3).float() * (255.0 / 256.0)
+        """u8 class codes [..., V, V] -> f32 planes [..., 3, V, V] (ops.expand_codes)."""
+        return ops.expand_codes(codes)
 
     def encode_obs(self, obs):
         """obs [B, n, 3, V, V] (any float dtype; or u8 class codes [B, n, V, V]) -> conv features [B * n, obs_dim_net]."""
@@ -165,19 +162,23 @@ class HomophilyMAC(nn.Module):
         a = self.args
         B, T, n = batch.batch_size, batch.max_seq_length, self.n_agents
         obs = batch["obs"]
+        codes = None
         if obs.dtype == th.uint8:                                                      # compact storage (class codes)
-            obs = self.expand_codes(obs)
+            if a.rgb_input and self.agent.encoder_kernel_shape and ops.encode_codes_supported(obs):
+                codes = obs                        # the encoder kernel reads the codes themselves (ops.encode_codes)
+            else:
+                obs = self.expand_codes(obs)
         acts = batch["actions"].squeeze(-1)                                            # [B, T, n]
         # history features of step t come from t - 1; at t = 0 they are zero: action -1 has an all-zero one-hot
         prev = lambda x, fill: th.cat([th.full_like(x[:, :1], fill), x[:, :-1]], dim=1)
         hist = (prev(acts, -1).reshape(B * T, n), prev(batch["reward"], 0).reshape(B * T, n),
                 prev(batch["actions_inc"].squeeze(-1), 0).reshape(B * T, n, n), batch["agent_pos"].reshape(B * T, n, 2))
         onehot = F.one_hot(acts, num_classes=a.n_actions)
-        sh = dict(obs=obs.float() if a.rgb_input else obs, hist=hist, onehot=onehot, tail=None,
+        sh = dict(obs=None if codes is not None else (obs.float() if a.rgb_input else obs), codes=codes, hist=hist, onehot=onehot, tail=None,
                   other=self.agent.unroll_other(onehot, batch["agent_pos"] / self.pos_scale, batch["agent_orientation"], batch["reward"],
                                                 batch["clean_num"], batch["apple_den"], th.float32))
         if self.shipped_flags and a.rgb_input:      # the non-visual input columns do not depend on the weights either
-            tail = th.empty(B * T * n, self.input_shape - a.obs_dim_net, dtype=th.float32, device=obs.device)
+            tail = th.empty(B * T * n, self.input_shape - a.obs_dim_net, dtype=th.float32, device=batch["obs"].device)
             ops.build_inputs_tail(tail, 0, hist[0], hist[1], hist[2], hist[3], self.pos_scale, a.n_actions, False)
             sh["tail"] = tail
         return sh
@@ -187,7 +188,9 @@ class HomophilyMAC(nn.Module):
         a = self.args
         B, T, n = batch.batch_size, batch.max_seq_length, self.n_agents
         obs = shared["obs"]
-        if a.rgb_input:
+        if shared.get("codes") is not None:
+            feat = self.agent.rgb_preprocess_codes(shared["codes"].reshape(B * T * n, a.obs_dims[0], a.obs_dims[1]))
+        elif a.rgb_input:
             feat = self.agent.rgb_preprocess(obs.reshape(B * T * n, 3, a.obs_dims[0], a.obs_dims[1]))
         else:
             feat = obs.reshape(B * T * n, -1)

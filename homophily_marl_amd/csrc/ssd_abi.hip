@@ -417,15 +417,29 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 int ssd_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int32_t T, int32_t G, int32_t B,
                     void* stream) {
     if (!gi || !wh || !bh || !hs || T < 1 || G < 1 || B < 1 || (!rzn) != (!ghn)) return fail(SSD_ERR_INVALID, "bad argument");
+    if (B % 16) return fail(SSD_ERR_INVALID, "B must be a multiple of 16 (pad the sequences)");
     if (!al16(gi) || !al16(wh) || !al16(bh) || !al16(hs) || !al16(rzn) || !al16(ghn)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
     launch_gru_seq_fwd(gi, wh, bh, hs, rzn, ghn, T, G, B, (hipStream_t)stream);
     return launched();
 }
-int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* d_wh_part,
-                    float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream) {
-    if (!dhs || !hs || !rzn || !ghn || !wh || !d_gi || !d_wh_part || !d_bh_part || T < 1 || G < 1 || B < 1) return fail(SSD_ERR_INVALID, "bad argument");
-    if (!al16(dhs) || !al16(hs) || !al16(rzn) || !al16(ghn) || !al16(wh) || !al16(d_gi)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
-    launch_gru_seq_bwd(dhs, hs, rzn, ghn, wh, d_gi, d_wh_part, d_bh_part, T, G, B, (hipStream_t)stream);
+int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* dgh,
+                    float* d_wh, float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream) {
+    if (!dhs || !hs || !rzn || !ghn || !wh || !d_gi || !dgh || !d_wh || !d_bh_part || T < 1 || G < 1 || B < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if (B % 16) return fail(SSD_ERR_INVALID, "B must be a multiple of 16 (pad the sequences)");
+    if (!al16(dhs) || !al16(hs) || !al16(rzn) || !al16(ghn) || !al16(wh) || !al16(d_gi) || !al16(dgh)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
+    launch_gru_seq_bwd(dhs, hs, rzn, ghn, wh, d_gi, dgh, d_wh, d_bh_part, T, G, B, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in, int32_t out, void* stream) {
+    if (!x || !w || !b || !y || n < 1 || rows < 1 || in < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if (launch_bias_bmm_fwd(x, w, b, y, n, rows, in, out, (hipStream_t)stream)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_fwd: at most 192 output features");
+    return launched();
+}
+int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, int32_t n, int32_t rows, int32_t in,
+                     int32_t out, void* stream) {
+    if (!g || !x || !w || n < 1 || rows < 1 || in < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if (launch_bias_bmm_bwd(g, x, w, dx, dw, db, n, rows, in, out, (hipStream_t)stream)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_bwd: at most 256 input features");
     return launched();
 }
 
@@ -436,6 +450,7 @@ int ssd_policy_encode(const ssd_policy_encode_args* a, void* stream) {
         return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode is instantiated for view_size 7 and 15 (15 x 15 / 31 x 31 windows); use ssd_conv_leaky + GEMM");
     if (a->precision != 0 && a->precision != 1 && a->precision != 2) return fail(SSD_ERR_INVALID, "precision must be 1 (bf16) or 2 (f32-equivalent)");
     if (a->alphabet != SSD_CODE_CLASS && a->alphabet != SSD_CODE_CHANNEL_MASK) return fail(SSD_ERR_INVALID, "alphabet");
+    if (a->act && a->precision == 1) return fail(SSD_ERR_INVALID, "the activation output needs precision 2");
     const int bands = SSD_ENCODE_BANDS(a->view_edge);
     if (bands == 1 ? (!a->out || a->part || a->out_stride < 32) : (!a->part || a->out)) return fail(SSD_ERR_INVALID, "one band writes `out`, several bands write `part`");
     if ((reinterpret_cast<uintptr_t>(a->conv_frags) | reinterpret_cast<uintptr_t>(a->lin_frags) | reinterpret_cast<uintptr_t>(a->part)) & 15)

@@ -134,9 +134,11 @@ int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s);
 int launch_pack_encoder(const float* cw, const float* lw, int V, int prec, void* conv_frags, void* lin_frags, hipStream_t s);
 void launch_pack_head(const ssd_policy_head_params* p, int prec, void* image, hipStream_t s);
 void launch_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T, int G, int B, hipStream_t s);
-void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* d_wh_part,
-                        float* d_bh_part, int T, int G, int B, hipStream_t s);
+void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* dgh,
+                        float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s);
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s);
+int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int n, int R, int I, int O, hipStream_t s);
+int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, int n, int R, int I, int O, hipStream_t s);
 #ifdef SSD_STAMPS
 void set_policy_stamps(unsigned long long* buf);
 #endif

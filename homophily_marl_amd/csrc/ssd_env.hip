@@ -554,7 +554,6 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
     constexpr bool CODE = FMT == SSD_OBS_CODE;
     constexpr bool ONE = false;                                   // (0 / 1 plane flags + integer-multiply expansion: measured no faster)
     constexpr int EPV = 16 / (int)sizeof(T);
-    const DevSpec* S = E.S;
     const DevHead* h = E.h;
     const int lane = E.lane, n = E.n, W = E.W, V = h->V, VV = h->VV, Wp = h->Wp;
     const int A = CODE ? VV : 3 * VV;                             // elements per agent

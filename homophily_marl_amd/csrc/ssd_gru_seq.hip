@@ -7,171 +7,264 @@
 // (one batched GEMM); what is left per step is a [B, 64] x [64, 192] product and the gate arithmetic -- at the learner's batch
 // (B = 16 episodes) a latency chain of ~10 tiny launches per step and direction.  Here one workgroup owns one (weight set g,
 // 16-row tile) and walks the whole sequence:
-//   * 4 waves, wave w owns hidden features 16 w .. 16 w + 15 (all three gates); its slice of W_h lives in registers for all T
-//     (48 VGPRs as MFMA A operand), products are v_mfma_f32_16x16x4_f32 in the transposed form of ssd_policy_fused.hip
-//     (activation row on the lane, 4 consecutive features in the lane's registers), so the gate arithmetic is lane-local;
-//   * the new state is exchanged through a double-buffered LDS tile: one barrier per step;
-//   * backward walks t = T-1 .. 0 with the carried dL/dh in registers, dL/dW_h accumulates in MFMA accumulators over all T
-//     (A = h_{t-1}^T, B = dL/dgh_t read k-major from LDS) and is written once.
+//   * 4 waves, wave w owns hidden features 16 w .. 16 w + 15 (all three gates); its slice of W_h lives in registers for all T as
+//     MFMA A operands, products are computed in the transposed form of ssd_policy_mfma.hip (activation row on the lane, 4
+//     consecutive features in the lane's registers), so the gate arithmetic is lane-local;
+//   * forward: v_mfma_f32_16x16x32_f16 on two-term f16 splits (f32-equivalent; |h| < 1), the new state crosses the waves through a
+//     double-buffered LDS image of the split terms: one barrier per step;
+//   * backward walks t = T-1 .. 0 with the carried dL/dh in registers (exact f32 MFMAs); dL/dW_h is one product over all
+//     (t, row) pairs computed after the walk by k_gru_dwh.
 // H = 64 is fixed.  Rows are independent sequences: any B (tiles of 16, the last one masked).
 #include "ssd_policy_common.h"
 
 namespace ssd {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using h4 = __attribute__((ext_vector_type(4))) _Float16;
 
-constexpr int GH = 64, G3 = 192, HS = 68, DS = 196;     // hidden, 3 * hidden, LDS row strides (floats)
+constexpr int GH = 64, G3 = 192;                        // hidden, 3 * hidden
+constexpr int HSH = 72;                                  // LDS row stride of the f16 state image (halves): 144 B = 16 * odd -> conflict-free b128 reads
+// forward: f32-equivalent products on the f16 matrix cores from two-term splits (ssd_policy_mfma.hip); exact power-of-two scales
+// keep the low terms in f16's normal range (|h| < 1, |W_h| ~ 0.1)
+constexpr float GRU_WS = 64.f, GRU_XS = 16.f, GRU_INV = 1.f / (GRU_WS * GRU_XS);
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }   // as k_gru_fwd_train
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }   // backward-side helpers keep libm accuracy
+// sigmoid / tanh on v_exp_f32 + v_rcp_f32 (1 ulp each), as the rollout heads
+__device__ __forceinline__ float sigm_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast_(float x) {
+    const float ax = fminf(fabsf(x), 15.f);
+    const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * ax) + 1.f);
+    return copysignf(t, x);
+}
+__device__ __forceinline__ f32x4 mma16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
 
 // gi [T, G, B, 192], wh [G, 64, 192], bh [G, 192] -> hs [G, T, B, 64]; optional (training) rzn [T, G, B, 192], ghn [T, G, B, 64]
+// One workgroup per (weight set g, 16-row tile), 4 waves; wave ft owns hidden features 16 ft .. 16 ft + 15 of the three gates.
+// Per step: gh^T = W_h^T h^T as 18 v_mfma_f32_16x16x32_f16 (3 gates x 2 K-steps x 3 split products; the W_h slice stays in
+// registers as hi / lo fragments for all T), lane-local gate arithmetic, and the new state goes to the other waves through a
+// double-buffered LDS image that already holds the hi / lo f16 terms (one barrier per step; each lane splits only its own 4 values).
+// B is a multiple of 16 (the host pads): no row predicate and no branch inside the steps, so that the compiler's vmcnt accounting
+// stays exact and the prefetched loads are never waited for together with younger stores.
+template <bool TRAIN>
 __global__ __launch_bounds__(256) void k_gru_seq_fwd(const float* __restrict__ gi, const float* __restrict__ wh, const float* __restrict__ bh,
                                                      float* __restrict__ hs, float* __restrict__ rzn, float* __restrict__ ghn, int T, int G,
                                                      int B, int tiles) {
-    __shared__ float hbuf[2][16][HS];
+    __shared__ __attribute__((aligned(16))) _Float16 hx[2][2][16][HSH];   // [buffer][term][row][feature]
     const int tid = threadIdx.x, lane = tid & 63, ft = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int g = blockIdx.x / tiles, tile = blockIdx.x - g * tiles;
-    const int row = tile * 16 + m;
-    const bool valid = row < B;
-    const int rc = valid ? row : B - 1;
-    // resident slice of W_h^T: wa[gate][ct][r] = W_h[k = 16 ct + 4 q + r][gate * 64 + 16 ft + m]
-    float wa[3][4][4];
+    const int row = tile * 16 + m, rc = row;
+    // resident A fragments: lane (q, m) = output feature gate * 64 + 16 ft + m, reduction indices k = 32 s + 8 q + j
+    u32x4 ah[3][2], al[3][2];
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int s = 0; s < 2; ++s) {
+            h8 h, l;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) wa[gate][ct][r] = wh[((size_t)g * GH + 16 * ct + 4 * q + r) * G3 + gate * GH + 16 * ft + m];
+            for (int j = 0; j < 8; ++j) {
+                const float w = wh[((size_t)g * GH + 32 * s + 8 * q + j) * G3 + gate * GH + 16 * ft + m] * GRU_WS;
+                h[j] = (_Float16)w; l[j] = (_Float16)(w - (float)h[j]);
+            }
+            ah[gate][s] = __builtin_bit_cast(u32x4, h); al[gate][s] = __builtin_bit_cast(u32x4, l);
+        }
     f32x4 bias[3];
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) bias[gate] = *reinterpret_cast<const f32x4*>(bh + (size_t)g * G3 + gate * GH + 16 * ft + 4 * q);
-    f32x4 hp[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) hp[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fo = 16 * ft + 4 * q;                                   // this lane's 4 features
-    for (int t = 0; t < T; ++t) {
+    f32x4 hown = {0.f, 0.f, 0.f, 0.f};                                // h_{t-1}[row m][fo .. fo + 3]
+    u32x4 xh[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, xl[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};   // B operand: h_0 = 0
+    // The step's input-side projections are requested PF steps ahead.  gfx950 retires loads and stores through one in-order
+    // counter (vmcnt): a load issued after a step's result stores cannot be waited for before those stores have completed, so with
+    // a distance of one step the recurrence would wait for every step's stores; at PF steps the stores have long landed.
+    constexpr int PF = 4;
+    f32x4 gbuf[PF][3];
+    auto load_gi = [&](int t, f32x4 (&d)[3]) {
+        const float* gir = gi + (((size_t)t * G + g) * B + rc) * G3 + fo;
+        d[0] = *reinterpret_cast<const f32x4*>(gir); d[1] = *reinterpret_cast<const f32x4*>(gir + GH); d[2] = *reinterpret_cast<const f32x4*>(gir + 2 * GH);
+    };
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+        if (d < T) load_gi(d, gbuf[d]);
+    auto step = [&](int t, f32x4 (&gb)[3]) {
         const size_t tr = ((size_t)t * G + g) * B + rc;                // row of the [T, G, B, .] tensors
-        const float* gir = gi + tr * G3 + fo;
-        const f32x4 gr = *reinterpret_cast<const f32x4*>(gir), gz = *reinterpret_cast<const f32x4*>(gir + GH),
-                    gn = *reinterpret_cast<const f32x4*>(gir + 2 * GH);
-        f32x4 acc[3] = {bias[0], bias[1], bias[2]};
+        const f32x4 gr = gb[0], gz = gb[1], gn = gb[2];
+        if (t + PF < T) load_gi(t + PF, gb);
+        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (t > 0) {                                                   // small terms first; the three gates' chains interleave
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+            for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int gate = 0; gate < 3; ++gate) acc[gate] = mma16(al[gate][s], xh[s], acc[gate]);
 #pragma unroll
-                for (int gate = 0; gate < 3; ++gate)
-                    acc[gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[gate][ct][r], hp[ct][r], acc[gate], 0, 0, 0);
-        // own previous state: hp[ft] holds features 16 ft + 4 q + r -- ft is wave-uniform, select without dynamic indexing
-        const f32x4 hown = ft == 0 ? hp[0] : ft == 1 ? hp[1] : ft == 2 ? hp[2] : hp[3];
-        f32x4 hn, rg, zg, ng;
+                for (int gate = 0; gate < 3; ++gate) acc[gate] = mma16(ah[gate][s], xl[s], acc[gate]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            rg[r] = sigm(gr[r] + acc[0][r]);
-            zg[r] = sigm(gz[r] + acc[1][r]);
-            ng[r] = tanhf(gn[r] + rg[r] * acc[2][r]);
-            hn[r] = (1.f - zg[r]) * ng[r] + zg[r] * hown[r];
-        }
-        if (valid) {
-            *reinterpret_cast<f32x4*>(hs + (((size_t)g * T + t) * B + row) * GH + fo) = hn;
-            if (rzn) {
-                float* s = rzn + tr * G3 + fo;
-                *reinterpret_cast<f32x4*>(s) = rg; *reinterpret_cast<f32x4*>(s + GH) = zg; *reinterpret_cast<f32x4*>(s + 2 * GH) = ng;
-                *reinterpret_cast<f32x4*>(ghn + tr * GH + fo) = acc[2];
+                for (int gate = 0; gate < 3; ++gate) acc[gate] = mma16(ah[gate][s], xh[s], acc[gate]);
             }
         }
-        *reinterpret_cast<f32x4*>(&hbuf[t & 1][m][fo]) = hn;
+        f32x4 hn, rg, zg, ng, an;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rg[r] = sigm_fast(gr[r] + fmaf(acc[0][r], GRU_INV, bias[0][r]));
+            zg[r] = sigm_fast(gz[r] + fmaf(acc[1][r], GRU_INV, bias[1][r]));
+            an[r] = fmaf(acc[2][r], GRU_INV, bias[2][r]);              // gh_n
+            ng[r] = tanh_fast_(gn[r] + rg[r] * an[r]);
+            hn[r] = (1.f - zg[r]) * ng[r] + zg[r] * hown[r];
+        }
+        hown = hn;
+        {   // this lane's 4 new values as scaled hi / lo f16 terms -> the LDS image the other waves read their B operand from
+            h4 h, l;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float x = hn[r] * GRU_XS; h[r] = (_Float16)x; l[r] = (_Float16)(x - (float)h[r]); }
+            *reinterpret_cast<u32x2*>(&hx[t & 1][0][m][fo]) = __builtin_bit_cast(u32x2, h);
+            *reinterpret_cast<u32x2*>(&hx[t & 1][1][m][fo]) = __builtin_bit_cast(u32x2, l);
+        }
+        *reinterpret_cast<f32x4*>(hs + (((size_t)g * T + t) * B + row) * GH + fo) = hn;
+        if constexpr (TRAIN) {
+            float* s = rzn + tr * G3 + fo;
+            *reinterpret_cast<f32x4*>(s) = rg; *reinterpret_cast<f32x4*>(s + GH) = zg; *reinterpret_cast<f32x4*>(s + 2 * GH) = ng;
+            *reinterpret_cast<f32x4*>(ghn + tr * GH + fo) = an;
+        }
         __syncthreads();
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) hp[ct] = *reinterpret_cast<const f32x4*>(&hbuf[t & 1][m][16 * ct + 4 * q]);
+        for (int s = 0; s < 2; ++s) {
+            xh[s] = *reinterpret_cast<const u32x4*>(&hx[t & 1][0][m][32 * s + 8 * q]);
+            xl[s] = *reinterpret_cast<const u32x4*>(&hx[t & 1][1][m][32 * s + 8 * q]);
+        }
+    };
+    int t0 = 0;
+    for (; t0 + PF <= T; t0 += PF) {                                   // whole groups: the PF register sets rotate by unrolling
+#pragma unroll
+        for (int d = 0; d < PF; ++d) step(t0 + d, gbuf[d]);
     }
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+        if (t0 + d < T) step(t0 + d, gbuf[d]);
 }
 
-// dhs [G, T, B, 64] (dL/d hs), hs, rzn, ghn, wh as above -> d_gi [T, G, B, 192], d_wh_part [G, tiles, 64, 192], d_bh_part [G, tiles, 192]
+// dhs [G, T, B, 64] (dL/d hs), hs, rzn, ghn, wh as above -> d_gi [T, G, B, 192], dgh [G, T, B, 192] (dL/dgh_t, the B operand of the
+// weight gradient), d_bh_part [G, tiles, 192].  The recurrence carries dL/dh only: dL/dh_{t-1} = direct + dL/dgh_t W_h^T.  Gradients
+// span too many decades for fixed-scale f16 splits, and gfx950's f32 MFMA runs at the VALU rate (48 of them per step were the
+// kernel's critical path), so the product is evaluated on v_mfma_f32_16x16x32_bf16 from THREE-term bf16 splits x = b1 + b2 + b3
+// (bf16 has f32's exponent range; 3 x 8 significand bits) keeping the six partial products of order <= 2^-16: f32-equivalent,
+// 36 MFMAs of 16 cycles per step.  dL/dW_h = sum_t h_{t-1}^T dL/dgh_t does not feed the recurrence: it is one product per weight
+// set over all (t, row) pairs, computed afterwards by k_gru_dwh instead of inside this kernel's 100-step latency chain.
+constexpr int DSB = 200;               // LDS row stride of the bf16 dL/dgh image (halves): 400 B = 16 * odd (mod 256)
+using b8 = __attribute__((ext_vector_type(8))) __bf16;
+using b4 = __attribute__((ext_vector_type(4))) __bf16;
+__device__ __forceinline__ f32x4 mmab(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void split3(float x, __bf16& t1, __bf16& t2, __bf16& t3) {
+    t1 = (__bf16)x; const float r1 = x - (float)t1;                   // both subtractions are exact
+    t2 = (__bf16)r1; const float r2 = r1 - (float)t2;
+    t3 = (__bf16)r2;
+}
+
 __global__ __launch_bounds__(256) void k_gru_seq_bwd(const float* __restrict__ dhs, const float* __restrict__ hs, const float* __restrict__ rzn,
                                                      const float* __restrict__ ghn, const float* __restrict__ wh, float* __restrict__ d_gi,
-                                                     float* __restrict__ d_wh_part, float* __restrict__ d_bh_part, int T, int G, int B, int tiles) {
-    __shared__ float dg[2][16][DS];     // dL/dgh of the step, [row][192]
-    __shared__ float hb[2][16][HS];     // h_{t-1}, [row][64]
+                                                     float* __restrict__ dgh, float* __restrict__ d_bh_part, int T, int G, int B, int tiles) {
+    __shared__ __attribute__((aligned(16))) __bf16 dgb[2][3][16][DSB];   // dL/dgh of the step: [buffer][term][row][192]
     const int tid = threadIdx.x, lane = tid & 63, ft = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int g = blockIdx.x / tiles, tile = blockIdx.x - g * tiles;
-    const int row = tile * 16 + m;
-    const bool valid = row < B;
-    const int rc = valid ? row : B - 1;
+    const int row = tile * 16 + m, rc = row;                          // B is a multiple of 16 (the host pads): see k_gru_seq_fwd
     const int fo = 16 * ft + 4 * q;
-    // resident slice of W_h for dL/dh_{t-1} = dL/dgh W_h^T: A[m = hidden feature 16 ft + m][k = gate output 16 c + 4 q + r]
-    f32x4 wd[12];
+    // resident A fragments of W_h: lane (q, m) = hidden feature 16 ft + m, reduction indices (gate outputs) k = 32 s + 8 q + j
+    u32x4 wa[6][3];
 #pragma unroll
-    for (int c = 0; c < 12; ++c) wd[c] = *reinterpret_cast<const f32x4*>(wh + ((size_t)g * GH + 16 * ft + m) * G3 + 16 * c + 4 * q);
-    f32x4 aw[3][4];                                                    // dL/dW_h[16 ht + 4 q + reg][16 (3 ft + o) + m]
+    for (int s = 0; s < 6; ++s) {
+        b8 t1, t2, t3;
 #pragma unroll
-    for (int o = 0; o < 3; ++o)
-#pragma unroll
-        for (int ht = 0; ht < 4; ++ht) aw[o][ht] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 8; ++j) {
+            __bf16 x1, x2, x3;
+            split3(wh[((size_t)g * GH + 16 * ft + m) * G3 + 32 * s + 8 * q + j], x1, x2, x3);
+            t1[j] = x1; t2[j] = x2; t3[j] = x3;
+        }
+        wa[s][0] = __builtin_bit_cast(u32x4, t1); wa[s][1] = __builtin_bit_cast(u32x4, t2); wa[s][2] = __builtin_bit_cast(u32x4, t3);
+    }
     f32x4 dbh[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 carry = {0.f, 0.f, 0.f, 0.f};                                // dL/dh_t arriving from step t + 1
-    for (int t = T - 1; t >= 0; --t) {
+    // everything a step reads from global memory is requested PF steps ahead (see k_gru_seq_fwd: one in-order counter for loads and
+    // stores)
+    constexpr int PF = 4;
+    struct StepIn { f32x4 dout, rg, zg, ng, gn, hprev; };
+    auto load_step = [&](int t, StepIn& in) {
+        const size_t tr = ((size_t)t * G + g) * B + rc;
+        in.dout = *reinterpret_cast<const f32x4*>(dhs + (((size_t)g * T + t) * B + rc) * GH + fo);
+        const float* s = rzn + tr * G3 + fo;
+        in.rg = *reinterpret_cast<const f32x4*>(s); in.zg = *reinterpret_cast<const f32x4*>(s + GH); in.ng = *reinterpret_cast<const f32x4*>(s + 2 * GH);
+        in.gn = *reinterpret_cast<const f32x4*>(ghn + tr * GH + fo);
+        in.hprev = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t > 0) in.hprev = *reinterpret_cast<const f32x4*>(hs + (((size_t)g * T + (t - 1)) * B + rc) * GH + fo);
+    };
+    StepIn buf[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+        if (T - 1 - d >= 0) load_step(T - 1 - d, buf[d]);
+    auto step = [&](int t, StepIn& in) {
         const int pb = t & 1;
         const size_t tr = ((size_t)t * G + g) * B + rc;
-        const f32x4 dout = *reinterpret_cast<const f32x4*>(dhs + (((size_t)g * T + t) * B + rc) * GH + fo);
-        const float* s = rzn + tr * G3 + fo;
-        const f32x4 rg = *reinterpret_cast<const f32x4*>(s), zg = *reinterpret_cast<const f32x4*>(s + GH), ng = *reinterpret_cast<const f32x4*>(s + 2 * GH);
-        const f32x4 gn = *reinterpret_cast<const f32x4*>(ghn + tr * GH + fo);
-        f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
-        if (t > 0) hprev = *reinterpret_cast<const f32x4*>(hs + (((size_t)g * T + (t - 1)) * B + rc) * GH + fo);
+        const f32x4 dout = in.dout, rg = in.rg, zg = in.zg, ng = in.ng, gn = in.gn, hprev = in.hprev;
+        if (t - PF >= 0) load_step(t - PF, in);
         f32x4 d_r, d_z, d_n, d_hn, direct;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float dh = valid ? dout[r] + carry[r] : 0.f;
+            const float dh = dout[r] + carry[r];
             d_n[r] = dh * (1.f - zg[r]) * (1.f - ng[r] * ng[r]);       // through tanh
             d_z[r] = dh * (hprev[r] - ng[r]) * zg[r] * (1.f - zg[r]);  // through sigmoid
             d_r[r] = d_n[r] * gn[r] * rg[r] * (1.f - rg[r]);
             d_hn[r] = d_n[r] * rg[r];                                  // dL/dgh_n
             direct[r] = dh * zg[r];
         }
-        if (valid) {
+        {   // this lane's 12 values as three bf16 terms -> the LDS image the other waves read their B operand from
+            const f32x4 v[3] = {d_r, d_z, d_hn};
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate) {
+                b4 t1, t2, t3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { __bf16 x1, x2, x3; split3(v[gate][r], x1, x2, x3); t1[r] = x1; t2[r] = x2; t3[r] = x3; }
+                *reinterpret_cast<u32x2*>(&dgb[pb][0][m][gate * GH + fo]) = __builtin_bit_cast(u32x2, t1);
+                *reinterpret_cast<u32x2*>(&dgb[pb][1][m][gate * GH + fo]) = __builtin_bit_cast(u32x2, t2);
+                *reinterpret_cast<u32x2*>(&dgb[pb][2][m][gate * GH + fo]) = __builtin_bit_cast(u32x2, t3);
+            }
+        }
+        {
             float* o = d_gi + tr * G3 + fo;
             *reinterpret_cast<f32x4*>(o) = d_r; *reinterpret_cast<f32x4*>(o + GH) = d_z; *reinterpret_cast<f32x4*>(o + 2 * GH) = d_n;
+            float* o2 = dgh + (((size_t)g * T + t) * B + row) * G3 + fo;
+            *reinterpret_cast<f32x4*>(o2) = d_r; *reinterpret_cast<f32x4*>(o2 + GH) = d_z; *reinterpret_cast<f32x4*>(o2 + 2 * GH) = d_hn;
         }
         dbh[0] += d_r; dbh[1] += d_z; dbh[2] += d_hn;
-        *reinterpret_cast<f32x4*>(&dg[pb][m][fo]) = d_r;
-        *reinterpret_cast<f32x4*>(&dg[pb][m][GH + fo]) = d_z;
-        *reinterpret_cast<f32x4*>(&dg[pb][m][2 * GH + fo]) = d_hn;
-        *reinterpret_cast<f32x4*>(&hb[pb][m][fo]) = hprev;
         __syncthreads();
-        // dL/dh_{t-1}, matrix part: D[feature 16 ft + 4 q + reg][row m] = sum_k W_h[feature][k] dL/dgh[row][k]  (4 chains of 12)
-        f32x4 ah[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // dL/dh_{t-1}, matrix part: D[feature 16 ft + 4 q + reg][row m] = sum_k W_h[feature][k] dL/dgh[row][k]; partial products by
+        // order of magnitude into three accumulators (smallest first when they are added)
+        f32x4 a3 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 12; ++c) {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(&dg[pb][m][16 * c + 4 * q]);
+        for (int s = 0; s < 6; ++s) {
+            u32x4 bt[3];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ah[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[c][r], bq[r], ah[r], 0, 0, 0);
+            for (int term = 0; term < 3; ++term) bt[term] = *reinterpret_cast<const u32x4*>(&dgb[pb][term][m][32 * s + 8 * q]);
+            a3 = mmab(wa[s][0], bt[2], a3); a2 = mmab(wa[s][0], bt[1], a2); a1 = mmab(wa[s][0], bt[0], a1);
+            a3 = mmab(wa[s][2], bt[0], a3); a2 = mmab(wa[s][1], bt[0], a2);
+            a3 = mmab(wa[s][1], bt[1], a3);
         }
-        carry = direct + (ah[0] + ah[1]) + (ah[2] + ah[3]);
-        // dL/dW_h += h_{t-1}^T dL/dgh: A[m = hidden feature][k = row], B[k = row][n = gate output]; this wave: outputs 48 ft .. 48 ft + 47
+        carry = direct + ((a3 + a2) + a1);
+        // the next step writes the other LDS buffer; the one after next is ordered behind the next barrier
+    };
+    int t0 = T - 1;
+    for (; t0 - (PF - 1) >= 0; t0 -= PF) {                             // whole groups: the PF register sets rotate by unrolling
 #pragma unroll
-        for (int sk = 0; sk < 4; ++sk) {
-            float a_h[4], b_d[3];
-#pragma unroll
-            for (int ht = 0; ht < 4; ++ht) a_h[ht] = hb[pb][4 * sk + q][16 * ht + m];
-#pragma unroll
-            for (int o = 0; o < 3; ++o) b_d[o] = dg[pb][4 * sk + q][16 * (3 * ft + o) + m];
-#pragma unroll
-            for (int o = 0; o < 3; ++o)
-#pragma unroll
-                for (int ht = 0; ht < 4; ++ht) aw[o][ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_h[ht], b_d[o], aw[o][ht], 0, 0, 0);
-        }
-        // the next step writes the other LDS buffers; the one after next is ordered behind the next barrier
+        for (int d = 0; d < PF; ++d) step(t0 - d, buf[d]);
     }
-    float* wp = d_wh_part + ((size_t)g * tiles + tile) * GH * G3;
 #pragma unroll
-    for (int o = 0; o < 3; ++o)
-#pragma unroll
-        for (int ht = 0; ht < 4; ++ht)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) wp[(size_t)(16 * ht + 4 * q + r) * G3 + 16 * (3 * ft + o) + m] = aw[o][ht][r];
+    for (int d = 0; d < PF; ++d)
+        if (t0 - d >= 0) step(t0 - d, buf[d]);
     // dL/db_h: column sums over the tile's rows (the 16 lanes that share q)
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate)
@@ -184,14 +277,46 @@ __global__ __launch_bounds__(256) void k_gru_seq_bwd(const float* __restrict__ d
         }
 }
 
+// dL/dW_h[g] = sum_{t >= 1, b} h_{t-1}[b]^T dL/dgh_t[b]: hs, dgh [G, T, B, .] -> d_wh [G, 64, 192].  Workgroup (g, c): gate-output
+// tile c (16 columns), wave ht: hidden-feature tile ht; K = (T - 1) B rows in steps of 4 (v_mfma_f32_16x16x4_f32, exact f32), one
+// accumulation chain in a fixed order (deterministic).  A[m = feature][k] = hs row k, B[k][n = gate output] = dgh row B + k.
+__global__ __launch_bounds__(256) void k_gru_dwh(const float* __restrict__ hs, const float* __restrict__ dgh, float* __restrict__ d_wh, int T, int B) {
+    const int lane = threadIdx.x & 63, ht = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int g = blockIdx.x, c = blockIdx.y;
+    const long K = (long)(T - 1) * B;
+    const float* a = hs + (size_t)g * T * B * GH + 16 * ht + m;        // row k at + k * 64
+    const float* b = dgh + ((size_t)g * T + 1) * B * G3 + 16 * c + m;  // row k at + k * 192 (step t = 1 is row 0)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int UN = 8;
+    long k0 = 0;
+    for (; k0 + 4 * UN <= K; k0 += 4 * UN) {
+        float av[UN], bv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { const long k = k0 + 4 * u + q; av[u] = a[k * GH]; bv[u] = b[k * G3]; }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    for (; k0 < K; k0 += 4) {
+        const long k = k0 + q;
+        const float av = k < K ? a[k * GH] : 0.f, bv = k < K ? b[k * G3] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    float* o = d_wh + ((size_t)g * GH + 16 * ht + 4 * q) * G3 + 16 * c + m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[(size_t)r * G3] = acc[r];
+}
+
 void launch_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T, int G, int B, hipStream_t s) {
     const int tiles = (B + 15) / 16;
-    hipLaunchKernelGGL(k_gru_seq_fwd, dim3(G * tiles), dim3(256), 0, s, gi, wh, bh, hs, rzn, ghn, T, G, B, tiles);
+    if (rzn) hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(G * tiles), dim3(256), 0, s, gi, wh, bh, hs, rzn, ghn, T, G, B, tiles);
+    else hipLaunchKernelGGL(k_gru_seq_fwd<false>, dim3(G * tiles), dim3(256), 0, s, gi, wh, bh, hs, rzn, ghn, T, G, B, tiles);
 }
-void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* d_wh_part,
-                        float* d_bh_part, int T, int G, int B, hipStream_t s) {
+void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* dgh,
+                        float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s) {
     const int tiles = (B + 15) / 16;
-    hipLaunchKernelGGL(k_gru_seq_bwd, dim3(G * tiles), dim3(256), 0, s, dhs, hs, rzn, ghn, wh, d_gi, d_wh_part, d_bh_part, T, G, B, tiles);
+    hipLaunchKernelGGL(k_gru_seq_bwd, dim3(G * tiles), dim3(256), 0, s, dhs, hs, rzn, ghn, wh, d_gi, dgh, d_bh_part, T, G, B, tiles);
+    hipLaunchKernelGGL(k_gru_dwh, dim3(G, 12), dim3(256), 0, s, hs, dgh, d_wh, T, B);
 }
 
 }  // namespace ssd

@@ -632,15 +632,16 @@ struct EncK {
     const float *conv_b, *lin_b;
     float* out; int out_stride;
     float* part;
+    float* act;                        // ACT kernels: LeakyReLU(conv) f32 [rows, 6, O, O] (what the learner's backward needs)
     int64_t* slot_t_copy; int64_t* counter_inc;
     int mask_alphabet;                 // bytes are channel masks (1 R, 2 G, 4 B) instead of SSD_OBS_CODE classes
     PSTAMP_DECL
 };
 
-template <int V, int PREC>
+template <int V, int PREC, bool ACT>
 __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
     using G = Geo<V>;
-    constexpr int O = G::O, CP = G::CP, NXT = G::NXT, XTP = G::XTP, R = G::R, BT = ENC_BT;
+    constexpr int O = G::O, CP = G::CP, XTP = G::XTP, R = G::R, BT = ENC_BT;
     constexpr int RB = enc_row_bytes<V>(), PR = enc_batch_row_bytes<V>();   // bytes of an input-row record / of a batch row (this band)
     constexpr int PLANES = BT * 16 * PR, CONV_BYTES = PREC * 9 * 1024;
     constexpr uint32_t ON = PREC == 2 ? 0x3Cu : 0x3Fu;                 // f16 0x3C00 = 1.0;  bf16 0x3F00 = 0.5 (the conv weights carry the 2)
@@ -810,6 +811,17 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = leaky(accc[j >> 2][bt][j & 3]);
+            if constexpr (ACT) {                                       // the training forward keeps the conv activations
+                const int row = row0 + bt * 16 + m;
+                if (row < a.rows) {
+                    float* ar = a.act + ((size_t)row * 6 + 2 * s + (q >> 1)) * (O * O) + (y0 + yl) * O;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int x = 8 * (2 * xtp + (j >> 2)) + 4 * (q & 1) + (j & 3);
+                        if (x < O) ar[x] = v[j] * (1.f / CS);
+                    }
+                }
+            }
             u32x4 xh, xl;
             split8<PREC>(v, xh, xl);
             if (PREC == 2) {
@@ -855,7 +867,7 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
     PSTAMP_REAL(15);
 }
 
-template <int V, int PREC>
+template <int V, int PREC, bool ACT>
 static int launch_encode_t(const EncK& k, hipStream_t s) {
     using G = Geo<V>;
     constexpr size_t lds = enc_lds_bytes<V, PREC>();
@@ -863,11 +875,11 @@ static int launch_encode_t(const EncK& k, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
     if (!done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode<V, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode<V, PREC, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         done[dev] = true;
     }
     const int groups = (k.rows + ENC_BT * 16 - 1) / (ENC_BT * 16);
-    hipLaunchKernelGGL((k_encode<V, PREC>), dim3(groups, G::NB), dim3(ENC_WAVES * 64), lds, s, k);
+    hipLaunchKernelGGL((k_encode<V, PREC, ACT>), dim3(groups, G::NB), dim3(ENC_WAVES * 64), lds, s, k);
     return 0;
 }
 
@@ -876,12 +888,18 @@ int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s) {
     k.codes = p->codes; k.code_bytes = (long)p->code_bytes; k.env_stride = (long)p->env_stride; k.slot_stride = (long)p->slot_stride;
     k.agent_stride = (long)p->agent_stride; k.slot_t = p->slot_t; k.rows = p->rows; k.n = p->n_agents; k.agent_major = p->agent_major;
     k.conv_frags = static_cast<const uint8_t*>(p->conv_frags); k.lin_frags = static_cast<const uint8_t*>(p->lin_frags);
-    k.conv_b = p->conv_b; k.lin_b = p->lin_b; k.out = p->out; k.out_stride = p->out_stride; k.part = p->part;
+    k.conv_b = p->conv_b; k.lin_b = p->lin_b; k.out = p->out; k.out_stride = p->out_stride; k.part = p->part; k.act = p->act;
     k.slot_t_copy = p->slot_t_copy; k.counter_inc = p->counter_inc; k.mask_alphabet = p->alphabet == SSD_CODE_CHANNEL_MASK;
     PSTAMP_SET(k);
     const int prec = p->precision == 1 ? 1 : 2;
-    if (p->view_edge == 15) return prec == 2 ? launch_encode_t<15, 2>(k, s) : launch_encode_t<15, 1>(k, s);
-    if (p->view_edge == 31) return prec == 2 ? launch_encode_t<31, 2>(k, s) : launch_encode_t<31, 1>(k, s);
+    if (p->act) {       // the learner's forward: f32-equivalent products only
+        if (prec != 2) return -2;
+        if (p->view_edge == 15) return launch_encode_t<15, 2, true>(k, s);
+        if (p->view_edge == 31) return launch_encode_t<31, 2, true>(k, s);
+        return -2;
+    }
+    if (p->view_edge == 15) return prec == 2 ? launch_encode_t<15, 2, false>(k, s) : launch_encode_t<15, 1, false>(k, s);
+    if (p->view_edge == 31) return prec == 2 ? launch_encode_t<31, 2, false>(k, s) : launch_encode_t<31, 1, false>(k, s);
     return -2;
 }
 

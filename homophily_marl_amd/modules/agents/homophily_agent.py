@@ -28,6 +28,8 @@ class HomophilyAgent(nn.Module):
             flat = args.conv_out * (args.obs_dims[0] - k + 1) * (args.obs_dims[1] - k + 1)
             self.conv_to_fc = nn.Sequential(nn.Conv2d(3, args.conv_out, k, args.conv_stride), nn.LeakyReLU(), nn.Flatten(),
                                             nn.Linear(flat, args.obs_dim_net), nn.LeakyReLU())
+        # the encoder kernel (ops.encode_codes) is instantiated for the shipped encoder: Conv2d(3, 6, 3, 1) + Linear(., 32)
+        self.encoder_kernel_shape = bool(args.rgb_input) and (args.conv_out, args.conv_kernel, args.conv_stride, args.obs_dim_net) == (6, 3, 1, 32)
 
         def weight(fan_in, fan_out, kaiming=False):
             t = th.empty(1, n, fan_in, fan_out)
@@ -77,6 +79,12 @@ class HomophilyAgent(nn.Module):
             y = ops.channel_bias(F.conv2d(x, c[0].weight, None, c[0].stride), c[0].bias)
             return c[4](ops.bias_linear(c[2](c[1](y)), c[3].weight, c[3].bias))
         return self.conv_to_fc(x)
+
+    def rgb_preprocess_codes(self, codes):
+        """rgb_preprocess of windows stored as u8 class codes [R, V, V] on the device (obs_storage: code), through the encoder
+        kernel (ops.encode_codes) instead of expanding them to f32 planes first."""
+        c = self.conv_to_fc
+        return ops.encode_codes(codes, c[0].weight, c[0].bias, c[3].weight, c[3].bias)
 
     # ---- building blocks ----------------------------------------------------------------------------------------
     # squeeze, not [0]: the backward of a select materialises a zero tensor + copy per parameter (36 of them per step)

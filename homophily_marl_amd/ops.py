@@ -157,29 +157,54 @@ def column_sums(x):
     return out
 
 
+def _bmm_kernel_ok(x, w, b):
+    return (x.is_cuda and x.dtype == th.float32 and w.dtype == th.float32 and x.dim() == 3 and w.dim() == 3 and w.shape[2] <= 192
+            and w.shape[1] <= 256)
+
+
+def _bias_bmm_fwd(x, w, b):
+    lib = abi.load_library()
+    x, w, b = x.contiguous(), w.contiguous(), b.contiguous()
+    n, R, I = x.shape
+    O = w.shape[2]
+    y = th.empty(n, R, O, dtype=th.float32, device=x.device)
+    abi.check(lib, lib.ssd_bias_bmm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, R, I, O, _stream(x)))
+    return y
+
+
 class _BiasBmm(th.autograd.Function):
-    """baddbmm(b [n, 1, O], x [n, R, I], w [n, I, O]) whose bias gradient comes from ops.column_sums instead of ATen's multi-block
-    row reduction."""
+    """baddbmm(b [n, 1, O], x [n, R, I], w [n, I, O]) on the device: one launch forward (ssd_bias_bmm_fwd) and ONE launch for the three
+    gradients (ssd_bias_bmm_bwd: dx, dw and the bias gradient as column sums -- deterministic, no ATen multi-block reduction);
+    csrc/ssd_bmm.hip."""
 
     @staticmethod
     def forward(ctx, x, w, b):
+        x, w = x.contiguous(), w.contiguous()
         ctx.save_for_backward(x, w)
-        return th.baddbmm(b, x, w)
+        return _bias_bmm_fwd(x, w, b)
 
     @staticmethod
     def backward(ctx, g):
+        lib = abi.load_library()
         x, w = ctx.saved_tensors
         g = g.contiguous()
-        dx = th.bmm(g, w.transpose(1, 2)) if ctx.needs_input_grad[0] else None
-        dw = th.bmm(x.transpose(1, 2), g) if ctx.needs_input_grad[1] else None
-        db = column_sums(g).unsqueeze(1) if ctx.needs_input_grad[2] else None
+        n, R, I = x.shape
+        O = w.shape[2]
+        need = ctx.needs_input_grad
+        dx = th.empty_like(x) if need[0] else None
+        dw = th.empty_like(w) if need[1] else None
+        db = th.empty(n, 1, O, dtype=th.float32, device=x.device) if need[2] else None
+        ptr = lambda t: None if t is None else t.data_ptr()
+        abi.check(lib, lib.ssd_bias_bmm_bwd(g.data_ptr(), x.data_ptr(), w.data_ptr(), ptr(dx), ptr(dw), ptr(db), n, R, I, O, _stream(x)))
         return dx, dw, db
 
 
 def bias_bmm(x, w, b):
     """x @ w + b for per-agent weights: x [n, R, I], w [n, I, O], b [n, 1, O]."""
-    if x.is_cuda and (w.requires_grad or b.requires_grad or x.requires_grad):
-        return _BiasBmm.apply(x, w, b)
+    if _bmm_kernel_ok(x, w, b):
+        if th.is_grad_enabled() and (w.requires_grad or b.requires_grad or x.requires_grad):
+            return _BiasBmm.apply(x, w, b)
+        return _bias_bmm_fwd(x, w, b)
     return th.baddbmm(b, x, w)
 
 
@@ -224,6 +249,81 @@ def bias_linear(x, w, b):
     return th.nn.functional.linear(x, w, b)
 
 
+def expand_codes(codes):
+    """u8 class codes [..., V, V] of the simplified palette (0 nothing, 1 apple, 2 waste, 3 wall / agent; include/ssd_hip.h
+    SSD_OBS_CODE) -> f32 [..., 3, V, V]: waste = R, apple = G, wall / agent = B at 255/256 -- the observation the env emits in
+    f32 form (map_env.py:945, cleanup.py:96-105)."""
+    c = codes.unsqueeze(-3)
+    return th.cat([c == 2, c == 1, c == 3], dim=-3).float() * (255.0 / 256.0)
+
+
+def encode_codes_supported(codes):
+    return codes.is_cuda and codes.dtype == th.uint8 and codes.shape[-1] == codes.shape[-2] and codes.shape[-1] in (15, 31)
+
+
+class _EncodeCodes(th.autograd.Function):
+    """rgb_preprocess (Conv2d 3->6 3x3 + LeakyReLU + Flatten + Linear -> 32 + LeakyReLU; homophily_agent.py:20-27,213-214) of windows
+    given as u8 class codes [R, V, V], forward on the matrix cores (ssd_policy_encode: the rollout's encoder kernel, f32-equivalent
+    products): 2 launches (weight fragments, encoder) instead of the expansion to f32 planes + MIOpen convolution + GEMM + 4
+    elementwise kernels.  With gradients the kernel also emits LeakyReLU(conv) [R, 6, O, O]; the backward is the reference's
+    arithmetic on it: two GEMMs for the Linear, the convolution's weight gradient (MIOpen) on the re-expanded planes, the bias
+    gradients by ops.column_sums."""
+
+    @staticmethod
+    def forward(ctx, codes, conv_w, conv_b, lin_w, lin_b):
+        lib = abi.load_library()
+        codes = codes.contiguous()
+        R, V = codes.shape[0], codes.shape[-1]
+        O = V - 2
+        dev = codes.device
+        st = _stream(codes)
+        cw, lw = conv_w.detach().contiguous(), lin_w.detach().contiguous()
+        cb, lb = conv_b.detach().contiguous(), lin_b.detach().contiguous()
+        cbytes, lbytes = abi.encode_frag_bytes(V, 2)
+        cf, lf = th.empty(cbytes, dtype=th.uint8, device=dev), th.empty(lbytes, dtype=th.uint8, device=dev)
+        abi.check(lib, lib.ssd_policy_pack_encoder(cw.data_ptr(), lw.data_ptr(), V, 2, cf.data_ptr(), lf.data_ptr(), st))
+        need = any(ctx.needs_input_grad[1:])
+        act = th.empty(R, 6, O, O, dtype=th.float32, device=dev) if need else None
+        bands = abi.encode_bands(V)
+        ea = abi.SsdPolicyEncodeArgs()
+        ea.codes, ea.code_bytes = codes.data_ptr(), codes.numel()
+        ea.env_stride, ea.slot_stride, ea.agent_stride, ea.slot_t = V * V, 0, V * V, None
+        ea.rows, ea.view_edge, ea.n_agents, ea.agent_major, ea.precision = R, V, 1, 0, 2
+        ea.alphabet = abi.CODE_CLASS
+        ea.conv_frags, ea.lin_frags, ea.conv_b, ea.lin_b = cf.data_ptr(), lf.data_ptr(), cb.data_ptr(), lb.data_ptr()
+        ea.act = None if act is None else act.data_ptr()
+        if bands == 1:
+            feat = th.empty(R, 32, dtype=th.float32, device=dev)
+            ea.out, ea.out_stride = feat.data_ptr(), 32
+            abi.check(lib, lib.ssd_policy_encode(C.byref(ea), st))
+        else:       # 31 x 31 windows: per-band partial sums of the Linear, finished here (each output adds `bands` values)
+            part = th.empty(bands, R, 32, dtype=th.float32, device=dev)
+            ea.part = part.data_ptr()
+            abi.check(lib, lib.ssd_policy_encode(C.byref(ea), st))
+            feat = th.nn.functional.leaky_relu(column_sums(part.view(bands, R * 32)).view(R, 32) + lb)
+        if need:
+            ctx.save_for_backward(codes, act, feat, cw, lw)
+        return feat
+
+    @staticmethod
+    def backward(ctx, d_feat):
+        codes, act, feat, cw, lw = ctx.saved_tensors
+        R = codes.shape[0]
+        slope = lambda y: th.where(y > 0, 1.0, 0.01)                # LeakyReLU'(x) from the sign of LeakyReLU(x)
+        g2 = d_feat * slope(feat)                                   # dL/d(Linear output)
+        d_lin_b = column_sums(g2)
+        d_lin_w = g2.t() @ act.reshape(R, -1)
+        d_act = (g2 @ lw).reshape(act.shape) * slope(act)           # dL/d(conv output)
+        d_conv_b = column_sums(d_act.reshape(R, -1)).view(act.shape[1], -1).sum(1)
+        d_conv_w = th.nn.grad.conv2d_weight(expand_codes(codes), cw.shape, d_act)
+        return None, d_conv_w, d_conv_b, d_lin_w, d_lin_b
+
+
+def encode_codes(codes, conv_w, conv_b, lin_w, lin_b):
+    """features [R, 32] of windows given as u8 class codes [R, V, V] (V = 15 or 31, on the device): see _EncodeCodes."""
+    return _EncodeCodes.apply(codes, conv_w, conv_b, lin_w, lin_b)
+
+
 class _GruGates(th.autograd.Function):
     """h' = GRU gate arithmetic (homophily_agent.py:162-165,188-191) on gi = x W_i + b_i, gh = h W_h + b_h ([R, 3H], (r, z, n)
     order) as ONE forward and ONE backward HIP kernel instead of ~9 + ~20 pointwise launches per recurrence step."""
@@ -260,29 +360,37 @@ class _GruSeq(th.autograd.Function):
         gi, wh, bh = gi.contiguous(), wh.contiguous(), bh.contiguous()
         T, G, B, H3 = gi.shape
         H = H3 // 3
-        hs = th.empty(G, T, B, H, dtype=gi.dtype, device=gi.device)
+        Bp = (B + 15) // 16 * 16                    # the kernels walk whole 16-row tiles: ragged batches are padded with zero rows
+        if Bp != B:
+            gi = th.nn.functional.pad(gi, (0, 0, 0, Bp - B))
+        hs = th.empty(G, T, Bp, H, dtype=gi.dtype, device=gi.device)
         need = any(ctx.needs_input_grad)
         rzn = th.empty_like(gi) if need else None
-        ghn = th.empty(T, G, B, H, dtype=gi.dtype, device=gi.device) if need else None
+        ghn = th.empty(T, G, Bp, H, dtype=gi.dtype, device=gi.device) if need else None
         abi.check(lib, lib.ssd_gru_seq_fwd(gi.data_ptr(), wh.data_ptr(), bh.data_ptr(), hs.data_ptr(), None if rzn is None else rzn.data_ptr(),
-                                           None if ghn is None else ghn.data_ptr(), T, G, B, _stream(gi)))
+                                           None if ghn is None else ghn.data_ptr(), T, G, Bp, _stream(gi)))
         if need:
             ctx.save_for_backward(hs, rzn, ghn, wh)
-        return hs
+            ctx.B = B
+        return hs if Bp == B else hs[:, :, :B].contiguous()
 
     @staticmethod
     def backward(ctx, dhs):
         lib = abi.load_library()
         hs, rzn, ghn, wh = ctx.saved_tensors
-        dhs = dhs.contiguous()
-        T, G, B, H3 = rzn.shape
-        tiles = (B + 15) // 16
-        d_gi = th.empty_like(rzn) if B % 16 == 0 else th.zeros_like(rzn)
-        d_wh = th.empty(G, tiles, H3 // 3, H3, dtype=rzn.dtype, device=rzn.device)
+        T, G, Bp, H3 = rzn.shape
+        B = ctx.B
+        dhs = dhs.contiguous() if Bp == B else th.nn.functional.pad(dhs, (0, 0, 0, Bp - B))      # padded rows: zero gradient
+        tiles = Bp // 16
+        d_gi = th.empty_like(rzn)
+        dgh = th.empty(G, T, Bp, H3, dtype=rzn.dtype, device=rzn.device)      # workspace: dL/dgh_t, the operand of the W_h gradient
+        d_wh = th.empty(G, H3 // 3, H3, dtype=rzn.dtype, device=rzn.device)
         d_bh = th.empty(G, tiles, H3, dtype=rzn.dtype, device=rzn.device)
         abi.check(lib, lib.ssd_gru_seq_bwd(dhs.data_ptr(), hs.data_ptr(), rzn.data_ptr(), ghn.data_ptr(), wh.data_ptr(), d_gi.data_ptr(),
-                                           d_wh.data_ptr(), d_bh.data_ptr(), T, G, B, _stream(rzn)))
-        return d_gi, d_wh.sum(1) if tiles > 1 else d_wh[:, 0], (d_bh.sum(1) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)
+                                           dgh.data_ptr(), d_wh.data_ptr(), d_bh.data_ptr(), T, G, Bp, _stream(rzn)))
+        if Bp != B:
+            d_gi = d_gi[:, :, :B].contiguous()
+        return d_gi, d_wh, (d_bh.sum(1) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)
 
 
 def gru_sequence(gi, wh, bh):

@@ -300,14 +300,23 @@ int ssd_dueling_pick(const float* av, int32_t rows, int32_t n_actions, const uin
 /* ---- the learner's recurrence over all T timesteps in one launch per direction (csrc/ssd_gru_seq.hip) -----------------------
  * The GRU cell of HomophilyAgent (homophily_agent.py:162-165,188-191) unrolled from a zero state as the learner does
  * (homophily_learner.py:68-91), hidden = 64.  gi f32 [T, G, B, 192] = x_t W_i + b_i in (r, z, n) order for G independent weight
- * sets (agents x heads) and B sequences; wh [G, 64, 192], bh [G, 192]; hs f32 [G, T, B, 64] receives h_1..h_T.
+ * sets (agents x heads) and B sequences (B a multiple of 16: pad); wh [G, 64, 192], bh [G, 192]; hs f32 [G, T, B, 64] receives h_1..h_T.
  * Training: rzn [T, G, B, 192] and ghn [T, G, B, 64] (both or neither) receive the gates and the hidden-side n pre-activation.
- * Backward: dhs = dL/dhs -> d_gi [T, G, B, 192], d_wh_part [G, ceil(B/16), 64, 192], d_bh_part [G, ceil(B/16), 192] (partial sums
- * per 16-row tile; the caller adds them over the tile axis). */
+ * Backward: dhs = dL/dhs -> d_gi [T, G, B, 192], d_wh [G, 64, 192], d_bh_part [G, ceil(B/16), 192] (partial sums per 16-row tile;
+ * the caller adds them over the tile axis); dgh [G, T, B, 192] is workspace (dL/d(h W_h + b_h) per step, the operand of d_wh). */
 int ssd_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int32_t T, int32_t G, int32_t B,
                     void* stream);
-int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* d_wh_part,
-                    float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream);
+int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* dgh,
+                    float* d_wh, float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream);
+
+/* ---- the learner's per-agent affine layers (csrc/ssd_bmm.hip) ---------------------------------------------------------------
+ * th.baddbmm(b, x, w) over the agent axis (homophily_agent.py:154-208: fc1, GRU input projections, dueling heads) and its backward,
+ * f32 (exact-f32 MFMAs), contiguous tensors: x [n, rows, in], w [n, in, out], b [n, out], y / g [n, rows, out].
+ *   fwd: y = b + x w                                             (out <= 192)
+ *   bwd: dx = g w^T, dw = x^T g, db = column sums of g; each output nullable; one launch, deterministic   (in <= 256) */
+int ssd_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in, int32_t out, void* stream);
+int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, int32_t n, int32_t rows, int32_t in,
+                     int32_t out, void* stream);
 
 /* ---- fused rollout-time controller step (csrc/ssd_policy_mfma.hip) -------------------------------------------------------
  * What HomophilyMAC.select_actions_env / select_actions_inc evaluate (homophily_controller.py:30-65, 127-184 on top of
@@ -454,6 +463,8 @@ typedef struct ssd_policy_encode_args {
     int64_t* slot_t_copy;
     int64_t* counter_inc;
     int32_t alphabet;              /* SSD_CODE_CLASS / SSD_CODE_CHANNEL_MASK */
+    float* act;                    /* nullable (precision 2 only): LeakyReLU(conv) f32 [rows, 6, V-2, V-2], row = b * n + i: the
+                                      activations the learner's backward needs (the training forward of the encoder) */
 } ssd_policy_encode_args;
 int ssd_policy_encode(const ssd_policy_encode_args* args, void* stream);
 int ssd_policy_pack_encoder(const float* conv_w, const float* lin_w, int32_t view_edge, int32_t precision, void* conv_frags,

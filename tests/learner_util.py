@@ -22,9 +22,10 @@ def load_fixture(name):
     return z, meta
 
 
-def build(z, meta, device="cpu", sl=slice(None), overrides=None):
+def build(z, meta, device="cpu", sl=slice(None), overrides=None, code_obs=False):
     """Returns (args, batch, mac, learner) with the fixture's initial weights (random-init when the fixture holds none); `sl`
-    selects episodes (DP shards); `overrides`: extra config keys."""
+    selects episodes (DP shards); `overrides`: extra config keys; code_obs: the batch holds the observations as u8 class codes
+    [B, T, n, V, V] (obs_storage: code; simplified palette only) instead of f32 planes."""
     cfg = load_config(meta["env"], overrides=dict(dict(env_args=meta["env_args"], use_cuda=device != "cpu", batch_size=4),
                                                   **dict(meta.get("overrides", {}), **(overrides or {}))))
     args = SimpleNamespace(**cfg)
@@ -38,7 +39,7 @@ def build(z, meta, device="cpu", sl=slice(None), overrides=None):
         if meta["env"] == "cleanup" else (9, 38)
     args.state_dims = (H, W)
     scheme = {
-        "obs": {"vshape": tuple(obs.shape[3:]), "group": "agents"},
+        "obs": {"vshape": tuple(obs.shape[4:]), "group": "agents", "dtype": th.uint8} if code_obs else {"vshape": tuple(obs.shape[3:]), "group": "agents"},
         "actions": {"vshape": (1,), "group": "agents", "dtype": th.long},
         "avail_actions": {"vshape": (args.n_actions,), "group": "agents", "dtype": th.int},
         "reward": {"vshape": (n,)}, "terminated": {"vshape": (1,), "dtype": th.uint8},
@@ -51,7 +52,12 @@ def build(z, meta, device="cpu", sl=slice(None), overrides=None):
     batch = EpisodeBatch(scheme, groups, B, T, preprocess=preprocess, device=device)
     data = {k: th.as_tensor(z["batch_" + k][sl]) for k in ("actions", "actions_inc", "reward", "terminated", "clean_num", "apple_den",
                                                             "agent_pos", "agent_orientation", "avail_actions")}
-    data["obs"] = th.as_tensor(z["batch_obs"][sl]).float() / 256
+    if code_obs:
+        r, g, b = (obs[:, :, :, c] == 255 for c in range(3))
+        assert (np.isin(obs, (0, 255))).all() and (r.astype(int) + g + b <= 1).all()          # one colour per cell, full intensity
+        data["obs"] = th.as_tensor((2 * r + 1 * g + 3 * b).astype(np.uint8))              # include/ssd_hip.h SSD_OBS_CODE classes
+    else:
+        data["obs"] = th.as_tensor(z["batch_obs"][sl]).float() / 256
     batch.update(data)
     assert (batch["filled"].cpu().numpy() == z["batch_filled"][sl]).all()
     mac = mac_REGISTRY[args.mac](batch.scheme, groups, args)

@@ -55,18 +55,21 @@ LOG_KEYS = ("loss_value_env", "loss_value_inc", "loss_sim", "value_give_mean", "
             "incentives_to_cleanup_per", "incentives_to_harvest_per")
 
 
-@pytest.mark.parametrize("train_graph", [False, True])
+@pytest.mark.parametrize("train_graph,storage", [(False, "f32"), (True, "f32"), (False, "code"), (True, "code")])
 @pytest.mark.parametrize("name", ["learner_cleanup5.npz", "learner_harvest5.npz"])
-def test_learner_on_device_matches_reference_fixture(name, train_graph):
+def test_learner_on_device_matches_reference_fixture(name, train_graph, storage):
     """Same fixtures as the CPU suite, network + HIP kernels on the GPU (fused loss kernel, sequence GRU kernels): inputs, Q-values,
     every logged value of two optimisation steps within 1e-5 (fp32) and every parameter after each step (pins the two-Adam /
     double-clip order on the device) -- eagerly and with the train step captured as hipGraphs (the captured step is compared with
-    the REFERENCE's numbers, not only with the eager step)."""
+    the REFERENCE's numbers, not only with the eager step).  storage "code": the sampled batch holds the observations as u8 class
+    codes (obs_storage: code) and both networks' encoders run through the matrix-core encoder kernel (ops.encode_codes: forward
+    in the kernel, backward from the activations it emits) -- against the same reference numbers."""
     from tests.learner_util import build, load_fixture, param_checksums
     th.backends.cuda.matmul.allow_tf32 = False
     z, meta = load_fixture(name)
-    args, batch, mac, learner = build(z, meta, device="cuda:0", overrides=dict(train_graph=train_graph))
+    args, batch, mac, learner = build(z, meta, device="cuda:0", overrides=dict(train_graph=train_graph), code_obs=storage == "code")
     assert learner._fused(batch) and learner.use_graph == train_graph
+    assert (batch["obs"].dtype == th.uint8) == (storage == "code")
     with th.no_grad():
         got = mac._build_inputs(batch, 3).cpu().numpy()
         nf = args.obs_dim_net
@@ -425,6 +428,30 @@ def test_gru_sequence_kernels_match_the_stepwise_recurrence(T, G, B):
         assert (a - b).abs().max() < 2e-5 * max(1.0, b.abs().max().item()), name
     with th.no_grad():       # inference form (no saved gates)
         assert (ops.gru_sequence(gi, wh, bh) - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("n,R,I,O", [(5, 1616, 64, 192), (5, 1616, 73, 64), (5, 333, 64, 9), (3, 8080, 80, 3), (5, 50, 64, 1), (2, 17, 5, 20)])
+def test_bias_bmm_kernels_match_baddbmm_autograd(n, R, I, O):
+    """ssd_bias_bmm_fwd / _bwd (csrc/ssd_bmm.hip: the learner's per-agent affine layers, exact-f32 MFMAs) against th.baddbmm and
+    its autograd at the learner's shapes and at ragged ones (rows, inputs, outputs not multiples of 16)."""
+    from homophily_marl_amd import ops
+    g = th.Generator(device="cuda").manual_seed(R + I + O)
+    x = th.randn(n, R, I, generator=g, device="cuda").requires_grad_()
+    w = (th.randn(n, I, O, generator=g, device="cuda") * 0.2).requires_grad_()
+    b = (th.randn(n, 1, O, generator=g, device="cuda") * 0.1).requires_grad_()
+    wout = th.randn(n, R, O, generator=g, device="cuda")
+    y = ops.bias_bmm(x, w, b)
+    (y * wout).sum().backward()
+    got = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    ref = th.baddbmm(b, x, w)
+    (ref * wout).sum().backward()
+    assert (y - ref).abs().max() < 1e-5 * max(1.0, ref.abs().max().item())
+    for a, t, name in zip(got, (x, w, b), ("dx", "dw", "db")):
+        assert (a - t.grad).abs().max() < 2e-5 * max(1.0, t.grad.abs().max().item()), (name, (a - t.grad).abs().max().item())
+    with th.no_grad():
+        assert (ops.bias_bmm(x, w, b) - ref).abs().max() < 1e-5 * max(1.0, ref.abs().max().item())
 
 
 def test_graph_runner_with_non_shipped_input_flags():

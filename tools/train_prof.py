@@ -5,7 +5,7 @@ import torch as th
 from homophily_marl_amd.run import load_config, setup
 N = int(os.environ.get("N_ENV", 512))
 cfg = load_config("cleanup", overrides=dict(runner="hip_graph", train_graph=int(os.environ.get("TRAIN_GRAPH", 1)), batch_size_run=N, batch_size=16, buffer_size=N,
-                                             buffer_cpu_only=False, store_state=False,
+                                             buffer_cpu_only=False, store_state=False, obs_storage=os.environ.get("OBS_STORAGE", "code"),
                                              env_args=dict(num_agents=5, map="default5", episode_limit=100, seed=1),
                                              use_cuda=True, save_model=False, runner_stats=False, learner_log_interval=10 ** 12))
 th.manual_seed(0)
