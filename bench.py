@@ -244,9 +244,10 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):      # PMC traffic of the committed rocprofv3 --pmc passes, per launch (same kernel, same sizes only)
             tr = json.load(open(tj))
+            suffix = "@env_workload" if args.workload == "env" else ("@f32storage" if args.obs_storage == "f32" else "")
             for k in kernels:
-                rec = tr.get("kernels", {}).get("%s@%s" % (k["name"], args.config))
-                if rec and rec.get("n_env") == N and rec.get("obs_format", "f32") == getattr(args, "obs_storage", "f32"):
+                rec = tr.get("kernels", {}).get("%s@%s%s" % (k["name"], args.config, suffix))
+                if rec and rec.get("n_env") == N:
                     k["traffic"] = rec.get("hbm_bytes_per_launch")
         entries = [roofline_entry(k) for k in kernels]
         dominant = max(entries, key=lambda e: e["kernel_avg_us"])

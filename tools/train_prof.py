@@ -26,7 +26,9 @@ if os.environ.get("TORCH_PROFILE"):
     ctx.learner.use_graph = False
     ctx.learner.cal_loss_and_step(sample)
     th.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
         ctx.learner.cal_loss_and_step(sample)
         th.cuda.synchronize()
     print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=60, max_name_column_width=60))
+    if os.environ.get("TORCH_PROFILE") == "shapes":
+        print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=120, max_name_column_width=40, max_shapes_column_width=90))
