@@ -433,13 +433,21 @@ int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const f
 
 int ssd_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in, int32_t out, void* stream) {
     if (!x || !w || !b || !y || n < 1 || rows < 1 || in < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
-    if (launch_bias_bmm_fwd(x, w, b, y, n, rows, in, out, (hipStream_t)stream)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_fwd: at most 192 output features");
+    launch_bias_bmm_fwd(x, w, b, y, n, rows, in, out, (hipStream_t)stream);
     return launched();
 }
-int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, int32_t n, int32_t rows, int32_t in,
-                     int32_t out, void* stream) {
-    if (!g || !x || !w || n < 1 || rows < 1 || in < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
-    if (launch_bias_bmm_bwd(g, x, w, dx, dw, db, n, rows, in, out, (hipStream_t)stream)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_bwd: at most 256 input features");
+int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int32_t n,
+                     int32_t rows, int32_t in, int32_t out, void* stream) {
+    if (!g || n < 1 || rows < 1 || in < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if ((dx && !w) || ((dw || db) && !x) || (slope_of && !dx)) return fail(SSD_ERR_INVALID, "dx needs w, dw / db need x, slope_of needs dx");
+    launch_bias_bmm_bwd(g, x, w, dx, dw, db, slope_of, n, rows, in, out, (hipStream_t)stream);
+    return launched();
+}
+
+int ssd_conv_wgrad_partial_rows(int32_t rows) { return rows < 1 ? 0 : conv_wgrad_partial_rows(rows); }
+int ssd_conv_wgrad_codes(const uint8_t* codes, const float* d_conv, float* partial, int32_t rows, int32_t view_edge, void* stream) {
+    if (!codes || !d_conv || !partial || rows < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if (launch_conv_wgrad(codes, d_conv, partial, rows, view_edge, (hipStream_t)stream)) return fail(SSD_ERR_UNSUPPORTED, "ssd_conv_wgrad_codes is instantiated for 15 x 15 and 31 x 31 windows");
     return launched();
 }
 

@@ -23,7 +23,9 @@ typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));     // 16
 struct BmmK {
     const float *x, *w, *b, *g;
     float *y, *dx, *dw, *db;
+    const float* slope_of;     // backward, nullable: dx is multiplied by LeakyReLU'(.) taken from the sign of slope_of[g][row][i]
     int n, R, I, O;
+    long x_set, g_set;         // elements between two weight sets of x / g (default R * I, R * O; larger when the rows are a slice)
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -38,48 +40,50 @@ __device__ __forceinline__ f32x4 load4(const float* p, int k0, int len) {
     return v;
 }
 
-// y[g][row][o] = b[g][o] + sum_i x[g][row][i] w[g][i][o].  grid (ceil(R / 16), n), 256 threads: wave v takes the output tiles
-// v, v + 4, ...  D[row 4 q + r][col m]; K-step (chunk c, r) uses k = 16 c + 4 q + r for lane quarter q.
-constexpr int BMM_MAX_TPW = 3;                  // output tiles per wave: O <= 192
+// y[g][row][o] = b[g][o] + sum_i x[g][row][i] w[g][i][o].  A wave owns one unit = (16-row tile, group of up to BMM_TPW output tiles);
+// units are dealt to the waves of the grid in order (grid (ceil(units / 4), n), 256 threads).  D[row 4 q + r][col m]; K-step
+// (chunk c, r) uses k = 16 c + 4 q + r for lane quarter q.
+constexpr int BMM_TPW = 3;                      // output tiles per wave
 __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, q = lane >> 4;
-    const int g = blockIdx.y, row0 = blockIdx.x * 16;
-    const int otiles = (a.O + 15) >> 4;
-    if (wave >= otiles) return;
     const int R = a.R, I = a.I, O = a.O;
+    const int otiles = (O + 15) >> 4, groups = (otiles + BMM_TPW - 1) / BMM_TPW, rtiles = (R + 15) >> 4;
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= rtiles * groups) return;
+    const int g = blockIdx.y, row0 = (unit / groups) * 16, t0 = (unit % groups) * BMM_TPW;
     const int rowc = row0 + m < R ? row0 + m : R - 1;
     const float* xr = a.x + ((size_t)g * R + rowc) * I;
     const float* wg = a.w + (size_t)g * I * O;
-    f32x4 acc[BMM_MAX_TPW];
+    f32x4 acc[BMM_TPW];
 #pragma unroll
-    for (int t = 0; t < BMM_MAX_TPW; ++t) {
-        const int o = 16 * (wave + 4 * t) + m;
-        const float bv = (wave + 4 * t < otiles && o < O) ? a.b[(size_t)g * O + o] : 0.f;
+    for (int t = 0; t < BMM_TPW; ++t) {
+        const int o = 16 * (t0 + t) + m;
+        const float bv = (t0 + t < otiles && o < O) ? a.b[(size_t)g * O + o] : 0.f;
         acc[t] = f32x4{bv, bv, bv, bv};
     }
     const int chunks = (I + 15) >> 4;
     for (int c = 0; c < chunks; ++c) {
         const int k0 = 16 * c + 4 * q;
         const f32x4 xa = load4(xr, k0, I);
-        float bs[BMM_MAX_TPW][4];
+        float bs[BMM_TPW][4];
 #pragma unroll
-        for (int t = 0; t < BMM_MAX_TPW; ++t) {
-            const int o = 16 * (wave + 4 * t) + m;
-            const bool on = wave + 4 * t < otiles && o < O;
+        for (int t = 0; t < BMM_TPW; ++t) {
+            const int o = 16 * (t0 + t) + m;
+            const bool on = t0 + t < otiles && o < O;
 #pragma unroll
             for (int r = 0; r < 4; ++r) bs[t][r] = (on && k0 + r < I) ? wg[(size_t)(k0 + r) * O + o] : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int t = 0; t < BMM_MAX_TPW; ++t)
-                if (wave + 4 * t < otiles) acc[t] = mfma4(xa[r], bs[t][r], acc[t]);
+            for (int t = 0; t < BMM_TPW; ++t)
+                if (t0 + t < otiles) acc[t] = mfma4(xa[r], bs[t][r], acc[t]);
     }
 #pragma unroll
-    for (int t = 0; t < BMM_MAX_TPW; ++t) {
-        const int o = 16 * (wave + 4 * t) + m;
-        if (wave + 4 * t >= otiles || o >= O) continue;
+    for (int t = 0; t < BMM_TPW; ++t) {
+        const int o = 16 * (t0 + t) + m;
+        if (t0 + t >= otiles || o >= O) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = row0 + 4 * q + r;
@@ -88,11 +92,10 @@ __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
     }
 }
 
-// One launch, grid (DX + DW, n): blocks [0, DX) compute dx = g w^T for a 16-row tile (wave v: input tiles v, v + 4, ...); blocks
-// [DX, DX + DW) compute one 16 x 16 tile of dw = x^T g (rows of the batch = K, a sixteenth per wave, partials added in LDS in wave
-// order) and, for input tile 0, the matching 16 entries of db = column sums of g.
+// One launch, grid (DX + DW, n): blocks [0, DX) compute dx = g w^T, one unit = (16-row tile, 16-input tile) per wave, units dealt to
+// the waves in order; blocks [DX, DX + DW) compute one 16 x 16 tile of dw = x^T g (rows of the batch = K, a sixteenth per wave,
+// partials added in LDS in wave order) and, for input tile 0, the matching 16 entries of db = column sums of g.
 constexpr int BMM_BWD_WAVES = 16;               // the row axis (K of dw: up to T B n = 8080 rows) is split 16 ways
-constexpr int BMM_MAX_ITPW = 1;                 // input tiles per wave in the dx role: I <= 256
 __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int dx_blocks) {
     __shared__ f32x4 red[BMM_BWD_WAVES][64];
     __shared__ float redb[BMM_BWD_WAVES][16];
@@ -101,40 +104,31 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
     const int g = blockIdx.y;
     const int R = a.R, I = a.I, O = a.O;
     const int itiles = (I + 15) >> 4, otiles = (O + 15) >> 4;
-    const float* gg = a.g + (size_t)g * R * O;
+    const float* gg = a.g + (size_t)g * a.g_set;
     if ((int)blockIdx.x < dx_blocks) {
-        if (!a.dx || wave >= itiles) return;
-        const int row0 = blockIdx.x * 16;
+        const int unit = blockIdx.x * BMM_BWD_WAVES + wave, rtiles = (R + 15) >> 4;
+        if (unit >= rtiles * itiles) return;
+        const int row0 = (unit / itiles) * 16, i = 16 * (unit % itiles) + m;
         const int rowc = row0 + m < R ? row0 + m : R - 1;
         const float* gr = gg + (size_t)rowc * O;
-        const float* wg = a.w + (size_t)g * I * O;
-        f32x4 acc[BMM_MAX_ITPW];
-#pragma unroll
-        for (int t = 0; t < BMM_MAX_ITPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* wr = a.w + ((size_t)g * I + (i < I ? i : I - 1)) * O;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int chunks = (O + 15) >> 4;
         for (int c = 0; c < chunks; ++c) {
             const int k0 = 16 * c + 4 * q;                             // reduction index = output feature
-            const f32x4 ga = load4(gr, k0, O);
-            f32x4 wb[BMM_MAX_ITPW];
+            const f32x4 ga = load4(gr, k0, O), wb = load4(wr, k0, O);
 #pragma unroll
-            for (int t = 0; t < BMM_MAX_ITPW; ++t) {
-                const int i = 16 * (wave + BMM_BWD_WAVES * t) + m;
-                wb[t] = (wave + BMM_BWD_WAVES * t < itiles && i < I) ? load4(wg + (size_t)i * O, k0, O) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int t = 0; t < BMM_MAX_ITPW; ++t)
-                    if (wave + BMM_BWD_WAVES * t < itiles) acc[t] = mfma4(ga[r], wb[t][r], acc[t]);
+            for (int r = 0; r < 4; ++r) acc = mfma4(ga[r], wb[r], acc);
         }
-#pragma unroll
-        for (int t = 0; t < BMM_MAX_ITPW; ++t) {
-            const int i = 16 * (wave + BMM_BWD_WAVES * t) + m;
-            if (wave + BMM_BWD_WAVES * t >= itiles || i >= I) continue;
+        if (i < I) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + 4 * q + r;
-                if (row < R) a.dx[((size_t)g * R + row) * I + i] = acc[t][r];
+                if (row >= R) continue;
+                const size_t e = ((size_t)g * R + row) * I + i;
+                float v = acc[r];
+                if (a.slope_of) v *= a.slope_of[e] > 0.f ? 1.f : 0.01f;   // nn.LeakyReLU default slope
+                a.dx[e] = v;
             }
         }
         return;
@@ -143,7 +137,7 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
     const int tile = blockIdx.x - dx_blocks, it = tile / otiles, ot = tile - it * otiles;
     const int i = 16 * it + m, o = 16 * ot + m;
     const bool ion = i < I, oon = o < O;
-    const float* xg = a.x + (size_t)g * R * I;
+    const float* xg = a.x + (size_t)g * a.x_set;
     const int steps = (R + 3) >> 2, per = (steps + BMM_BWD_WAVES - 1) / BMM_BWD_WAVES;
     const int s0 = wave * per, s1 = s0 + per < steps ? s0 + per : steps;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -193,21 +187,128 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
 }
 
 int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int n, int R, int I, int O, hipStream_t s) {
-    if (O > 16 * 4 * BMM_MAX_TPW) return -3;
     BmmK k = {};
     k.x = x; k.w = w; k.b = b; k.y = y; k.n = n; k.R = R; k.I = I; k.O = O;
-    hipLaunchKernelGGL(k_bias_bmm_fwd, dim3((R + 15) / 16, n), dim3(256), 0, s, k);
+    const int otiles = (O + 15) / 16, units = ((R + 15) / 16) * ((otiles + BMM_TPW - 1) / BMM_TPW);
+    hipLaunchKernelGGL(k_bias_bmm_fwd, dim3((units + 3) / 4, n), dim3(256), 0, s, k);
     return 0;
 }
 
-int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, int n, int R, int I, int O, hipStream_t s) {
-    if (I > 16 * BMM_BWD_WAVES * BMM_MAX_ITPW) return -3;
+int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int n, int R,
+                        int I, int O, hipStream_t s, long x_set, long g_set) {
     BmmK k = {};
-    k.g = g; k.x = x; k.w = w; k.dx = dx; k.dw = dw; k.db = db; k.n = n; k.R = R; k.I = I; k.O = O;
-    const int dxb = dx ? (R + 15) / 16 : 0;
+    k.g = g; k.x = x; k.w = w; k.dx = dx; k.dw = dw; k.db = db; k.slope_of = slope_of; k.n = n; k.R = R; k.I = I; k.O = O;
+    k.x_set = x_set ? x_set : (long)R * I; k.g_set = g_set ? g_set : (long)R * O;
+    const int dxb = dx ? (((R + 15) / 16) * ((I + 15) / 16) + BMM_BWD_WAVES - 1) / BMM_BWD_WAVES : 0;
     const int dwb = (dw || db) ? ((I + 15) / 16) * ((O + 15) / 16) : 0;
     if (dxb + dwb == 0) return 0;
     hipLaunchKernelGGL(k_bias_bmm_bwd, dim3(dxb + dwb, n), dim3(BMM_BWD_WAVES * 64), 0, s, k, dxb);
+    return 0;
+}
+
+
+// ---- weight gradient of the encoder's convolution on class-code windows ----------------------------------------------------------
+// Reference: the Conv2d(3, 6, 3) of HomophilyAgent.conv_to_fc (homophily_agent.py:20-27) applied to the simplified-palette
+// observation: every window cell is one of four classes and lights at most one colour plane at 255/256 (cleanup.py:93-105).  So
+//   d_w[oc][ch][dy][dx] = 255/256 * sum over (row, y, x) of d_conv[row][oc][y][x] * [class(row, y + dy, x + dx) lights plane ch]
+// needs no im2col and no f32 planes: a lane owns an output position, reads the 9 class bytes of its 3 x 3 patch from the wave's LDS
+// copy of the window and adds the six channel gradients of its position into 6 x 27 (+ 6 bias) per-lane accumulators selected by
+// 0/1 masks.  A wave walks CW_ROWS windows, then the accumulators are summed over its lanes and written as one row of
+// `partial` [waves, 168]; the caller adds the rows (ops.column_sums: deterministic).  HBM: d_conv is read once (the term that
+// matters: 4 * 6 * O * O bytes per window), codes V * V bytes per window.
+constexpr int CW_ROWS = 8, CW_OUT = 6 * 27 + 6;
+// sum over the 64 lanes with DPP (no LDS crossbar): quad swaps, row rotations, row broadcasts; lane 63 ends with the total
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+    v = dpp_add<0x124, 0xF>(v);    // row_ror:4
+    v = dpp_add<0x128, 0xF>(v);    // row_ror:8
+    v = dpp_add<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3
+    return v;
+}
+template <int V>
+__global__ __launch_bounds__(256) void k_conv_wgrad(const uint8_t* __restrict__ codes, const float* __restrict__ d_conv, float* __restrict__ partial, int R) {
+    constexpr int O = V - 2, P = O * O, VV = V * V, VVP = (VV + 15) & ~15;
+    __shared__ uint8_t win[4][VVP];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg = blockIdx.x * 4 + wave;                              // global wave = row of `partial`
+    float acc[6][27], accb[6];
+#pragma unroll
+    for (int oc = 0; oc < 6; ++oc) {
+        accb[oc] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[oc][k] = 0.f;
+    }
+    // items = (window, pass of 64 positions); the six gradient values of the NEXT item are requested before the current one is
+    // accumulated (a wave has nothing else to hide the load latency behind)
+    constexpr int PASSES = (P + 63) / 64;
+    const int row_begin = wg * CW_ROWS, rows_here = row_begin >= R ? 0 : (R - row_begin < CW_ROWS ? R - row_begin : CW_ROWS);
+    const int items = rows_here * PASSES;
+    auto fetch = [&](int it, float (&v)[6]) {
+        const int row = row_begin + it / PASSES, p = (it % PASSES) * 64 + lane;
+        const float* dr = d_conv + (size_t)row * 6 * P;
+#pragma unroll
+        for (int oc = 0; oc < 6; ++oc) v[oc] = p < P ? dr[oc * P + p] : 0.f;
+    };
+    float cur[6], nxt[6];
+    if (items > 0) fetch(0, nxt);
+    for (int it = 0; it < items; ++it) {
+#pragma unroll
+        for (int oc = 0; oc < 6; ++oc) cur[oc] = nxt[oc];
+        if (it + 1 < items) fetch(it + 1, nxt);
+        const int pass = it % PASSES;
+        if (pass == 0) {                                               // a new window: its class codes into the wave's LDS buffer
+            const int row = row_begin + it / PASSES;
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < VV; e += 64) win[wave][e] = codes[(size_t)row * VV + e];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int p = pass * 64 + lane;
+        const int pc = p < P ? p : 0, y = pc / O, x = pc - y * O;
+        float mk[27];                                                  // [tap = dy * 3 + dx][plane]: 1 where the patch cell lights the plane
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int c = win[wave][(y + t / 3) * V + x + t % 3];
+            mk[3 * t + 0] = c == 2 ? 1.f : 0.f;                        // waste -> R
+            mk[3 * t + 1] = c == 1 ? 1.f : 0.f;                        // apple -> G
+            mk[3 * t + 2] = c == 3 ? 1.f : 0.f;                        // wall / agent -> B
+        }
+#pragma unroll
+        for (int oc = 0; oc < 6; ++oc) {
+            const float v = cur[oc];                                   // 0 for the lanes past the last position
+            accb[oc] += v;
+#pragma unroll
+            for (int k = 0; k < 27; ++k) acc[oc][k] = fmaf(v, mk[k], acc[oc][k]);
+        }
+    }
+    // sum over the 64 lanes (fixed order), lane 63 writes; layout: [oc][ch][dy][dx] then the 6 bias sums
+    float* out = partial + (size_t)wg * CW_OUT;
+#pragma unroll
+    for (int oc = 0; oc < 6; ++oc) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const float v = wave_sum_to_lane63(acc[oc][k]);
+            const int t = k / 3, ch = k - 3 * t;
+            if (lane == 63) out[(oc * 3 + ch) * 9 + t] = v * (255.f / 256.f);
+        }
+        const float b = wave_sum_to_lane63(accb[oc]);
+        if (lane == 63) out[6 * 27 + oc] = b;
+    }
+}
+
+int conv_wgrad_partial_rows(int R) { return ((R + CW_ROWS - 1) / CW_ROWS + 3) / 4 * 4; }
+
+int launch_conv_wgrad(const uint8_t* codes, const float* d_conv, float* partial, int R, int V, hipStream_t s) {
+    const int waves = conv_wgrad_partial_rows(R);
+    if (V == 15) hipLaunchKernelGGL(k_conv_wgrad<15>, dim3(waves / 4), dim3(256), 0, s, codes, d_conv, partial, R);
+    else if (V == 31) hipLaunchKernelGGL(k_conv_wgrad<31>, dim3(waves / 4), dim3(256), 0, s, codes, d_conv, partial, R);
+    else return -2;
     return 0;
 }
 

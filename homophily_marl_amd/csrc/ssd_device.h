@@ -137,8 +137,11 @@ void launch_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float
 void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* dgh,
                         float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s);
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s);
+int conv_wgrad_partial_rows(int R);
+int launch_conv_wgrad(const uint8_t* codes, const float* d_conv, float* partial, int R, int V, hipStream_t s);
 int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int n, int R, int I, int O, hipStream_t s);
-int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, int n, int R, int I, int O, hipStream_t s);
+int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int n, int R,
+                        int I, int O, hipStream_t s, long x_set = 0, long g_set = 0);
 #ifdef SSD_STAMPS
 void set_policy_stamps(unsigned long long* buf);
 #endif

@@ -13,7 +13,7 @@
 //   * forward: v_mfma_f32_16x16x32_f16 on two-term f16 splits (f32-equivalent; |h| < 1), the new state crosses the waves through a
 //     double-buffered LDS image of the split terms: one barrier per step;
 //   * backward walks t = T-1 .. 0 with the carried dL/dh in registers (exact f32 MFMAs); dL/dW_h is one product over all
-//     (t, row) pairs computed after the walk by k_gru_dwh.
+//     (t, row) pairs computed after the walk (the x^T g role of csrc/ssd_bmm.hip).
 // H = 64 is fixed.  Rows are independent sequences: any B (tiles of 16, the last one masked).
 #include "ssd_policy_common.h"
 
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_gru_seq_fwd(const float* __restrict__ g
 // kernel's critical path), so the product is evaluated on v_mfma_f32_16x16x32_bf16 from THREE-term bf16 splits x = b1 + b2 + b3
 // (bf16 has f32's exponent range; 3 x 8 significand bits) keeping the six partial products of order <= 2^-16: f32-equivalent,
 // 36 MFMAs of 16 cycles per step.  dL/dW_h = sum_t h_{t-1}^T dL/dgh_t does not feed the recurrence: it is one product per weight
-// set over all (t, row) pairs, computed afterwards by k_gru_dwh instead of inside this kernel's 100-step latency chain.
+// set over all (t, row) pairs, computed afterwards (launch_gru_seq_bwd) instead of inside this kernel's 100-step latency chain.
 constexpr int DSB = 200;               // LDS row stride of the bf16 dL/dgh image (halves): 400 B = 16 * odd (mod 256)
 using b8 = __attribute__((ext_vector_type(8))) __bf16;
 using b4 = __attribute__((ext_vector_type(4))) __bf16;
@@ -277,36 +277,6 @@ __global__ __launch_bounds__(256) void k_gru_seq_bwd(const float* __restrict__ d
         }
 }
 
-// dL/dW_h[g] = sum_{t >= 1, b} h_{t-1}[b]^T dL/dgh_t[b]: hs, dgh [G, T, B, .] -> d_wh [G, 64, 192].  Workgroup (g, c): gate-output
-// tile c (16 columns), wave ht: hidden-feature tile ht; K = (T - 1) B rows in steps of 4 (v_mfma_f32_16x16x4_f32, exact f32), one
-// accumulation chain in a fixed order (deterministic).  A[m = feature][k] = hs row k, B[k][n = gate output] = dgh row B + k.
-__global__ __launch_bounds__(256) void k_gru_dwh(const float* __restrict__ hs, const float* __restrict__ dgh, float* __restrict__ d_wh, int T, int B) {
-    const int lane = threadIdx.x & 63, ht = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m = lane & 15, q = lane >> 4;
-    const int g = blockIdx.x, c = blockIdx.y;
-    const long K = (long)(T - 1) * B;
-    const float* a = hs + (size_t)g * T * B * GH + 16 * ht + m;        // row k at + k * 64
-    const float* b = dgh + ((size_t)g * T + 1) * B * G3 + 16 * c + m;  // row k at + k * 192 (step t = 1 is row 0)
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    constexpr int UN = 8;
-    long k0 = 0;
-    for (; k0 + 4 * UN <= K; k0 += 4 * UN) {
-        float av[UN], bv[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) { const long k = k0 + 4 * u + q; av[u] = a[k * GH]; bv[u] = b[k * G3]; }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
-    }
-    for (; k0 < K; k0 += 4) {
-        const long k = k0 + q;
-        const float av = k < K ? a[k * GH] : 0.f, bv = k < K ? b[k * G3] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-    }
-    float* o = d_wh + ((size_t)g * GH + 16 * ht + 4 * q) * G3 + 16 * c + m;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[(size_t)r * G3] = acc[r];
-}
-
 void launch_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T, int G, int B, hipStream_t s) {
     const int tiles = (B + 15) / 16;
     if (rzn) hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(G * tiles), dim3(256), 0, s, gi, wh, bh, hs, rzn, ghn, T, G, B, tiles);
@@ -316,7 +286,10 @@ void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, con
                         float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s) {
     const int tiles = (B + 15) / 16;
     hipLaunchKernelGGL(k_gru_seq_bwd, dim3(G * tiles), dim3(256), 0, s, dhs, hs, rzn, ghn, wh, d_gi, dgh, d_bh_part, T, G, B, tiles);
-    hipLaunchKernelGGL(k_gru_dwh, dim3(G, 12), dim3(256), 0, s, hs, dgh, d_wh, T, B);
+    // dL/dW_h[g] = sum_{t >= 1, b} h_{t-1}[b]^T dL/dgh_t[b]: rows (t, b) of hs [G, T, B, 64] against rows (t + 1, b) of dgh [G, T, B, 192] --
+    // the x^T g role of the per-agent-layer kernel (csrc/ssd_bmm.hip: K = (T - 1) B rows split over 16 waves per tile, exact f32)
+    if (T > 1) launch_bias_bmm_bwd(dgh + (size_t)B * G3, hs, nullptr, nullptr, d_wh, nullptr, nullptr, G, (T - 1) * B, GH, G3, s, (long)T * B * GH, (long)T * B * G3);
+    else (void)hipMemsetAsync(d_wh, 0, (size_t)G * GH * G3 * sizeof(float), s);
 }
 
 }  // namespace ssd

@@ -158,8 +158,7 @@ def column_sums(x):
 
 
 def _bmm_kernel_ok(x, w, b):
-    return (x.is_cuda and x.dtype == th.float32 and w.dtype == th.float32 and x.dim() == 3 and w.dim() == 3 and w.shape[2] <= 192
-            and w.shape[1] <= 256)
+    return (x.is_cuda and x.dtype == th.float32 and w.dtype == th.float32 and x.dim() == 3 and w.dim() == 3)
 
 
 def _bias_bmm_fwd(x, w, b):
@@ -195,7 +194,7 @@ class _BiasBmm(th.autograd.Function):
         dw = th.empty_like(w) if need[1] else None
         db = th.empty(n, 1, O, dtype=th.float32, device=x.device) if need[2] else None
         ptr = lambda t: None if t is None else t.data_ptr()
-        abi.check(lib, lib.ssd_bias_bmm_bwd(g.data_ptr(), x.data_ptr(), w.data_ptr(), ptr(dx), ptr(dw), ptr(db), n, R, I, O, _stream(x)))
+        abi.check(lib, lib.ssd_bias_bmm_bwd(g.data_ptr(), x.data_ptr(), w.data_ptr(), ptr(dx), ptr(dw), ptr(db), None, n, R, I, O, _stream(x)))
         return dx, dw, db
 
 
@@ -307,16 +306,27 @@ class _EncodeCodes(th.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_feat):
+        lib = abi.load_library()
         codes, act, feat, cw, lw = ctx.saved_tensors
         R = codes.shape[0]
-        slope = lambda y: th.where(y > 0, 1.0, 0.01)                # LeakyReLU'(x) from the sign of LeakyReLU(x)
-        g2 = d_feat * slope(feat)                                   # dL/d(Linear output)
+        K = act[0].numel()
+        st = _stream(codes)
+        g2 = d_feat * th.where(feat > 0, 1.0, 0.01)                 # dL/d(Linear output): LeakyReLU'(x) from the sign of LeakyReLU(x)
         d_lin_b = column_sums(g2)
-        d_lin_w = g2.t() @ act.reshape(R, -1)
-        d_act = (g2 @ lw).reshape(act.shape) * slope(act)           # dL/d(conv output)
-        d_conv_b = column_sums(d_act.reshape(R, -1)).view(act.shape[1], -1).sum(1)
-        d_conv_w = th.nn.grad.conv2d_weight(expand_codes(codes), cw.shape, d_act)
-        return None, d_conv_w, d_conv_b, d_lin_w, d_lin_b
+        # the two products of the Linear's backward on the per-agent-layer kernels (csrc/ssd_bmm.hip, one weight set):
+        #   d_lin_w [32, K] = g2^T act   (its "dw" role: rows = K of the product, split over 16 waves per tile)
+        #   d_act   [R, K]  = (g2 lin_w) * LeakyReLU'(conv)   (its "dx" role with w = lin_w^T [K, 32]; the slope from the sign of act)
+        d_lin_w = th.empty(32, K, dtype=th.float32, device=codes.device)
+        abi.check(lib, lib.ssd_bias_bmm_bwd(act.data_ptr(), g2.data_ptr(), None, None, d_lin_w.data_ptr(), None, None, 1, R, 32, K, st))
+        d_act = th.empty_like(act)
+        lwt = lw.t().contiguous()
+        abi.check(lib, lib.ssd_bias_bmm_bwd(g2.data_ptr(), None, lwt.data_ptr(), d_act.data_ptr(), None, None, act.data_ptr(), 1, R, K, 32, st))
+        # conv weight / bias gradient straight from the class codes (no f32 planes, no im2col): per-wave partial sums + one column sum
+        P = lib.ssd_conv_wgrad_partial_rows(R)
+        part = th.empty(P, 168, dtype=th.float32, device=codes.device)
+        abi.check(lib, lib.ssd_conv_wgrad_codes(codes.data_ptr(), d_act.data_ptr(), part.data_ptr(), R, codes.shape[-1], st))
+        tot = column_sums(part)
+        return None, tot[:162].view(cw.shape), tot[162:], d_lin_w, d_lin_b
 
 
 def encode_codes(codes, conv_w, conv_b, lin_w, lin_b):

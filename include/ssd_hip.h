@@ -312,11 +312,21 @@ int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const f
 /* ---- the learner's per-agent affine layers (csrc/ssd_bmm.hip) ---------------------------------------------------------------
  * th.baddbmm(b, x, w) over the agent axis (homophily_agent.py:154-208: fc1, GRU input projections, dueling heads) and its backward,
  * f32 (exact-f32 MFMAs), contiguous tensors: x [n, rows, in], w [n, in, out], b [n, out], y / g [n, rows, out].
- *   fwd: y = b + x w                                             (out <= 192)
- *   bwd: dx = g w^T, dw = x^T g, db = column sums of g; each output nullable; one launch, deterministic   (in <= 256) */
+ *   fwd: y = b + x w
+ *   bwd: dx = g w^T, dw = x^T g, db = column sums of g; each output nullable (dx needs w, dw / db need x); one launch,
+ *        deterministic.  slope_of (nullable, [n, rows, in]): dx is multiplied elementwise by LeakyReLU'(.) taken from
+ *        the sign of slope_of (the backward through a LeakyReLU whose OUTPUT is slope_of). */
 int ssd_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in, int32_t out, void* stream);
-int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, int32_t n, int32_t rows, int32_t in,
-                     int32_t out, void* stream);
+int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int32_t n,
+                     int32_t rows, int32_t in, int32_t out, void* stream);
+
+/* Weight (and bias) gradient of the encoder's Conv2d(3, 6, 3) on windows given as SSD_OBS_CODE class codes u8 [rows, V, V]
+ * (V = 15 / 31): d_conv = dL/d(conv output) f32 [rows, 6, V-2, V-2] -> partial f32 [ssd_conv_wgrad_partial_rows(rows), 168]: per
+ * wave, 162 weight-gradient sums in conv_w order [oc][ch][dy][dx] (the planes' 255/256 included) followed by the 6 bias sums; the
+ * caller adds the rows (ssd_column_sums).  Rows past the last wave's windows are written as zeros. */
+#define SSD_CONV_WGRAD_COLS 168
+int ssd_conv_wgrad_partial_rows(int32_t rows);
+int ssd_conv_wgrad_codes(const uint8_t* codes, const float* d_conv, float* partial, int32_t rows, int32_t view_edge, void* stream);
 
 /* ---- fused rollout-time controller step (csrc/ssd_policy_mfma.hip) -------------------------------------------------------
  * What HomophilyMAC.select_actions_env / select_actions_inc evaluate (homophily_controller.py:30-65, 127-184 on top of
