@@ -112,6 +112,11 @@ def roofline_entry(k):
         for key in ("mfma_dtype", "note"):
             if key in k:
                 e[key] = k[key]
+        if "algorithmic_f32" in k:      # informational: reference-f32 FLOPs / duration against the f32-MFMA (= f32 vector) peak
+            a32 = k["algorithmic_f32"]
+            ach = a32["flops_per_launch"] / (k["avg_us"] * 1e-6) / 1e12
+            e["algorithmic_f32"] = {"achieved": ach, "peak": a32["peak_tf"], "unit": "TFLOP/s", "frac": ach / a32["peak_tf"],
+                                    "algorithmic_flops_per_launch": a32["flops_per_launch"]}
     e.update(kernel=k["name"], kernel_avg_us=k["avg_us"], kernel_median_us=k.get("median_us", k["avg_us"]))
     if "share_of_timestep" in k:
         e["share_of_timestep"] = k["share_of_timestep"]

@@ -121,7 +121,7 @@ def run_e2e(args, c, rank, world, local_rank):
     # the SAME live objects (runner.timestep_launches(): the closures the graph was captured from) are timed right after the timed
     # region with HIP events around runs of back-to-back launches of one kernel (every launch is idempotent in its cost: the data it
     # reads is whatever the rollout left).  The env kernel is timed over three whole episodes (reset, then T launches).
-    from bench import MFMA_BF16_PEAK_TF, algorithmic_bytes_per_env_step
+    from bench import MFMA_BF16_PEAK_TF, MFMA_F32_PEAK_TF, algorithmic_bytes_per_env_step
     code = getattr(args, "obs_storage", "f32") == "code"
     V = 2 * c["view_size"] + 1
     env_bytes = algorithmic_bytes_per_env_step(c["H"], c["W"], n, V, 1, 1) if code else algorithmic_bytes_per_env_step(c["H"], c["W"], n, V)
@@ -150,6 +150,9 @@ def run_e2e(args, c, rank, world, local_rank):
                 k.update(flops_per_launch=issued, peak_tf=MFMA_BF16_PEAK_TF,
                          mfma_dtype=("f16 two-term splits, f32 accumulate (f32-equivalent)" if max(nprod.values()) > 1 else "bf16, f32 accumulate"),
                          note="algorithmic f32 FLOPs %d; 16-bit MFMA products per f32 product: %s" % (alg, {p: nprod[p] for p in parts}))
+                if max(nprod.values()) > 1:
+                    # the same launch priced the way round 1's f32 kernels were: the reference's f32 FLOPs against the f32-MFMA peak
+                    k["algorithmic_f32"] = dict(flops_per_launch=alg, peak_tf=MFMA_F32_PEAK_TF)
             kernels.append(k)
     env = runner.env
     avail = th.nonzero(env.avail_actions_batch[0, 0]).squeeze(-1).to(th.int32)

@@ -19,6 +19,9 @@ def _check_roofline(r):
     else:
         assert r["peak"] == 2500.0                 # the ISSUED 16-bit MFMA products (2-3 per f32-equivalent product) against the dense f16/bf16 peak
         assert r["algorithmic_flops_per_launch"] > 0
+        a32 = r.get("algorithmic_f32")      # informational second pricing: the reference's f32 FLOPs against the f32-MFMA peak
+        assert a32 is None or (a32["peak"] == 157.3 and abs(a32["frac"] - a32["achieved"] / a32["peak"]) < 1e-9
+                               and a32["algorithmic_flops_per_launch"] <= r["algorithmic_flops_per_launch"])
 
 
 @pytest.mark.parametrize("name", ["r02_bench_e2e_cleanup5.json", "r02_bench_e2e_harvest5.json", "r02_bench_e2e_cleanup10.json",
