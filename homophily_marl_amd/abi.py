@@ -169,7 +169,7 @@ def policy_image_bytes(precision):
 
 
 def encode_bands(V):
-    return 6 if V == 31 else 1
+    return 3 if V == 31 else 1
 
 
 def encode_frag_bytes(V, precision):

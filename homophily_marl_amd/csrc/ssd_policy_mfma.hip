@@ -607,7 +607,7 @@ void launch_pack_head(const ssd_policy_head_params* p, int prec, void* image, hi
 // are one K-step of the Linear.  The output rows are cut into NB bands of R rows (one workgroup each).
 template <int V> struct Geo;
 template <> struct Geo<15> { static constexpr int O = 13, CP = 16, NXT = 2, XTP = 1, R = 13, NB = 1; };
-template <> struct Geo<31> { static constexpr int O = 29, CP = 32, NXT = 4, XTP = 2, R = 5, NB = 6; };
+template <> struct Geo<31> { static constexpr int O = 29, CP = 32, NXT = 4, XTP = 2, R = 10, NB = 3; };
 constexpr int ENC_BT = 5;                      // batch tiles (16 rows each) per workgroup: Linear weights are fetched once per 80 rows
 constexpr int ENC_WAVES = 8;                     // 2 per SIMD: one wave's LDS / VALU work overlaps its partner's MFMAs
 // LDS record of (batch row, input row): [plane R: CP one-hot bytes][plane G][plane B][tail: NXT x 8 bytes].  tail[k] = cells 8 (k + 1)

@@ -445,7 +445,7 @@ int ssd_policy_pack_head(const ssd_policy_head_params* params, int32_t precision
  * the kernel reads whole aligned 4-byte words, never one that holds no byte of [codes, codes + code_bytes).
  * Output rows are agent-major (i * n_env + b) when agent_major, else (b * n + i).
  *   V = 15: one launch computes the whole Linear sum; out[row * out_stride + 0..31] = LeakyReLU(. + lin_b)   (part = NULL)
- *   V = 31: the 29 output rows are cut into SSD_ENCODE_BANDS(31) = 6 bands evaluated by different workgroups; band k writes its
+ *   V = 31: the 29 output rows are cut into SSD_ENCODE_BANDS(31) = 3 bands evaluated by different workgroups; band k writes its
  *           partial Linear sum to part[k][row][32] and the consumer (ssd_policy_head_env: feat_part / feat_bands / lin_b) adds
  *           them in band order, adds the bias and applies the LeakyReLU (out = NULL).
  * slot_t_copy (nullable) receives *slot_t: a second copy of the time index for the kernels that file results and advance slot_t
@@ -457,7 +457,7 @@ int ssd_policy_pack_head(const ssd_policy_head_params* params, int32_t precision
  *   lin_frags  [unit = ((y * XTP + xtp) * 3 + s)][output tile 2][term][lane][8]: element (q, m, j) = lin_w[16 Mt + m][oc * P + y * O + x],
  *              r = 4 q + (j & 3), oc = 2 s + (r >> 3), x = 8 (2 xtp + (j >> 2)) + (r & 7), 0 where x >= O   (XTP = 1 / 2 pairs of
  *              8-position tiles per output row) */
-#define SSD_ENCODE_BANDS(V) ((V) == 31 ? 6 : 1)
+#define SSD_ENCODE_BANDS(V) ((V) == 31 ? 3 : 1)
 #define SSD_ENCODE_UNITS(V) ((V) == 31 ? 29 * 2 * 3 : 13 * 1 * 3)
 #define SSD_ENCODE_CONV_FRAG_BYTES(V, precision) ((precision) * 9 * 1024)
 #define SSD_ENCODE_LIN_FRAG_BYTES(V, precision) (SSD_ENCODE_UNITS(V) * 2 * (precision) * 1024)
