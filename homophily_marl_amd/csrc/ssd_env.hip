@@ -573,6 +573,43 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
         for (int i = lane * 16; i < lds_planes_bytes(*h); i += kWave * 16) *(uint4*)(E.pl + i) = make_uint4(0, 0, 0, 0);
         wsync();
     }
+    if (CODE && !WC) {
+        // Class-code windows (the episode storage's format): ONE flat loop over all (agent, cell) pairs -- the agent's window origin
+        // and its rot90 coefficients become lane arithmetic (3 x n words in LDS) instead of wave-uniform control per agent, whose
+        // scalar instructions (orientation selects, loop bounds, exec masks: ~120 per agent) were the kernel's tightest issue slot.
+        int32_t* prm = (int32_t*)E.cbuf;                              // the side-output window buffer is free without WC (16-byte aligned)
+        if (lane < n) {
+            const int pr = (int)udiv((uint32_t)E.P, h->magic_W), pc = E.P - pr * W;
+            int ci, cj, c0;
+            if (E.O == O_UP) { ci = Wp; cj = 1; c0 = 0; }
+            else if (E.O == O_LEFT) { ci = -1; cj = Wp; c0 = V - 1; }
+            else if (E.O == O_DOWN) { ci = -Wp; cj = -1; c0 = (V - 1) * Wp + (V - 1); }
+            else { ci = 1; cj = -Wp; c0 = (V - 1) * Wp; }
+            prm[4 * lane] = pr * Wp + pc + c0; prm[4 * lane + 1] = ci; prm[4 * lane + 2] = cj;
+        }
+        wsync();
+        for (int e0 = 0; e0 < L; e0 += 4 * kWave) {                   // 4 cells per lane in flight
+            int cls[4], e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                e[u] = e0 + u * kWave + lane;
+                const int ec = e[u] < L ? e[u] : 0;
+                const int a = (int)udiv((uint32_t)ec, h->magic_VV), r = ec - a * VV;
+                const int i = (int)udiv((uint32_t)r, h->magic_V), jj = r - i * V;
+                const int4 p4 = *(const int4*)(prm + 4 * a);
+                cls[u] = E.pm[p4.x + i * p4.y + jj * p4.z];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e[u] < L) E.pl[delta + e[u]] = (uint8_t)((0x30120u >> (4 * cls[u])) & 0xFu);   // class bit 1 / 2 / 4 -> code 2 / 1 / 3
+        }
+        wsync();
+        expand_range<T, ONE>(src, dst + head, 0, nvec, lane);
+        if (lane < head) dst[lane] = Cvt<T>::f(E.pl[lane + delta]);
+        const int t0 = head + nvec * EPV;
+        if (t0 + lane < L) dst[t0 + lane] = Cvt<T>::f(E.pl[t0 + lane + delta]);
+        return;
+    }
     int q_done = 0;
     const int dump = (int)(lut - E.pl);
     // code windows: every agent's in LDS when they fit (stored in ONE batch behind the last agent, off the per-agent critical
