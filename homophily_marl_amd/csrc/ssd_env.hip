@@ -574,34 +574,32 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
         wsync();
     }
     if (CODE && !WC) {
-        // Class-code windows (the episode storage's format): ONE flat loop over all (agent, cell) pairs -- the agent's window origin
-        // and its rot90 coefficients become lane arithmetic (3 x n words in LDS) instead of wave-uniform control per agent, whose
-        // scalar instructions (orientation selects, loop bounds, exec masks: ~120 per agent) were the kernel's tightest issue slot.
-        int32_t* prm = (int32_t*)E.cbuf;                              // the side-output window buffer is free without WC (16-byte aligned)
-        if (lane < n) {
-            const int pr = (int)udiv((uint32_t)E.P, h->magic_W), pc = E.P - pr * W;
-            int ci, cj, c0;
-            if (E.O == O_UP) { ci = Wp; cj = 1; c0 = 0; }
-            else if (E.O == O_LEFT) { ci = -1; cj = Wp; c0 = V - 1; }
-            else if (E.O == O_DOWN) { ci = -Wp; cj = -1; c0 = (V - 1) * Wp + (V - 1); }
-            else { ci = 1; cj = -Wp; c0 = (V - 1) * Wp; }
-            prm[4 * lane] = pr * Wp + pc + c0; prm[4 * lane + 1] = ci; prm[4 * lane + 2] = cj;
-        }
-        wsync();
-        for (int e0 = 0; e0 < L; e0 += 4 * kWave) {                   // 4 cells per lane in flight
-            int cls[4], e[4];
+        // Class-code windows (the episode storage's format).  The wave-uniform control per agent of the general path (orientation
+        // selects, loop bounds, one exec mask per predicated store, an expand call per agent: ~120 scalar instructions per agent)
+        // was the kernel's tightest issue slot.  Here lane a < n computes agent a's window origin and rot90 coefficients as vector
+        // code, the per-agent loop fetches them with three v_readlane, every pass is address arithmetic + one class read + one code
+        // write (idle lanes and cells outside the window write to a dump byte: no exec masks), and the codes leave in ONE batch.
+        const int pr0 = (int)udiv((uint32_t)E.P, h->magic_W), pc0 = E.P - pr0 * W;
+        int ci0, cj0, c00;
+        if (E.O == O_UP) { ci0 = Wp; cj0 = 1; c00 = 0; }
+        else if (E.O == O_LEFT) { ci0 = -1; cj0 = Wp; c00 = V - 1; }
+        else if (E.O == O_DOWN) { ci0 = -Wp; cj0 = -1; c00 = (V - 1) * Wp + (V - 1); }
+        else { ci0 = 1; cj0 = -Wp; c00 = (V - 1) * Wp; }
+        const int base0 = pr0 * Wp + pc0 + c00;
+        const int dumpc = delta + L;                                  // one byte behind the last window (inside the planes' slack)
+        for (int a = 0; a < n; ++a) {
+            const int sb = rl(base0, a), sci = rl(ci0, a), scj = rl(cj0, a);
+            const int sstep = rpi * sci, dstep = rpi * V;
+            int sidx = sb + il * sci + j * scj;
+            int d = delta + a * VV + il * V + j;
+            for (int i = il; i < V; i += 4 * rpi, sidx += 4 * sstep, d += 4 * dstep) {
+                int cls[4];
+                bool ok[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                e[u] = e0 + u * kWave + lane;
-                const int ec = e[u] < L ? e[u] : 0;
-                const int a = (int)udiv((uint32_t)ec, h->magic_VV), r = ec - a * VV;
-                const int i = (int)udiv((uint32_t)r, h->magic_V), jj = r - i * V;
-                const int4 p4 = *(const int4*)(prm + 4 * a);
-                cls[u] = E.pm[p4.x + i * p4.y + jj * p4.z];
+                for (int u = 0; u < 4; ++u) { ok[u] = jv && i + u * rpi < V; cls[u] = E.pm[ok[u] ? sidx + u * sstep : 0]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) E.pl[ok[u] ? d + u * dstep : dumpc] = (uint8_t)((0x30120u >> (4 * cls[u])) & 0xFu);   // class bit 1 / 2 / 4 -> code 2 / 1 / 3
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (e[u] < L) E.pl[delta + e[u]] = (uint8_t)((0x30120u >> (4 * cls[u])) & 0xFu);   // class bit 1 / 2 / 4 -> code 2 / 1 / 3
         }
         wsync();
         expand_range<T, ONE>(src, dst + head, 0, nvec, lane);
