@@ -4,7 +4,18 @@
 
 namespace ssd {
 
-__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.01f * x; }   // nn.LeakyReLU default slope
+// nn.LeakyReLU, default slope: x > 0 ? x : 0.01 x == max(x, 0.01 x) for every finite x and both zeros (one v_max instead of a
+// compare + select per value; the compiler may not make this substitution itself under IEEE NaN rules; values here are never NaN)
+__device__ __forceinline__ float leaky(float x) {
+    const float y = 0.01f * x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));          // fmaxf() adds a canonicalising v_max per operand
+    return r;
+#else
+    return x > y ? x : y;
+#endif
+}
 
 __device__ __forceinline__ uint32_t mix32p(uint32_t x) {
     x ^= x >> 17; x *= 0xed5ad4bbu; x ^= x >> 11; x *= 0xac4c1b51u; x ^= x >> 15; x *= 0x31848babu; x ^= x >> 14;
