@@ -479,11 +479,15 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold
                 }
             }
         } else {
+            if (first) PSTAMP(8);
             const float* w2o = tail + HT_W2O;                          // [E][4]: 3 advantages + value per extra feature
             int64_t *out_actions = COLD(int64_t, out_actions), *p_inc = COLD(int64_t, p_inc), *d_actions_inc = COLD(int64_t, d_actions_inc);
             float *q_out = COLD(float, q_out), *d_reward = COLD(float, d_reward), *p_rew = COLD(float, p_rew), *ep_ret = COLD(float, ep_ret);
+            if (first) PSTAMP(9);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
+                if (first && k == 1) PSTAMP(10);
+                if (first && k == 2) PSTAMP(11);
                 const int it = lane + 64 * k;
                 const int row = it / n, j = it - row * n, bb = tile * 16 + row;
                 if (it >= 16 * n || bb >= N) continue;
