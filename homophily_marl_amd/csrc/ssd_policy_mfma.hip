@@ -185,6 +185,33 @@ __device__ __forceinline__ void gemm_t(const uint8_t* img, int F0, const u32x4 (
     }
 }
 
+// One K-step (s) of a 4-output-tile product as two halves, so that a SEQUENCE of products can request the next step's A fragments
+// from LDS before the current step's MFMAs issue (a wave that is alone on its SIMD has nothing else to hide the ds_read latency):
+// frag4_load fetches the 4 (PREC 2: 8) fragments of tiles F0 + 2 ot + s, frag4_mma adds their products.
+template <int PREC>
+struct Frag4 { u32x4 h[4], l[4]; };
+template <int PREC>
+__device__ __forceinline__ void frag4_load(const uint8_t* img, int F0, int s, int lane, Frag4<PREC>& f) {
+    constexpr size_t TERM = (size_t)HF_TOT * 1024;
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+        const uint8_t* p = img + ((size_t)(F0 + 2 * ot + s) * 64 + lane) * 16;
+        f.h[ot] = *reinterpret_cast<const u32x4*>(p);
+        if (PREC == 2) f.l[ot] = *reinterpret_cast<const u32x4*>(p + TERM);
+    }
+}
+template <int PREC>
+__device__ __forceinline__ void frag4_mma(const Frag4<PREC>& f, u32x4 bh, u32x4 bl, f32x4* acc) {
+    if (PREC == 2) {
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) acc[ot] = mma<PREC>(f.l[ot], bh, acc[ot]);
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) acc[ot] = mma<PREC>(f.h[ot], bl, acc[ot]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) acc[ot] = mma<PREC>(f.h[ot], bh, acc[ot]);
+}
+
 // the B operand of a product from 4 x 4 features per lane (x[ct][r] = feature 16 ct + 4 q + r), scaled
 template <int PREC>
 __device__ __forceinline__ void operand(const f32x4 (&x)[4], float scale, u32x4 (&bh)[2], u32x4 (&bl)[2]) {
@@ -415,14 +442,25 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold
         f32x4 g[16];                                                   // 0-3 r, 4-7 z, 8-11 i_n, 12-15 h_n
 #pragma unroll
         for (int ot = 0; ot < 16; ++ot) g[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
-        operand<PREC>(x1, XS, bh, bl);
-        gemm_t<PREC, 4>(img, HF_WI, bh, bl, g, lane);
-        gemm_t<PREC, 4>(img, HF_WI + 8, bh, bl, g + 4, lane);
-        gemm_t<PREC, 4>(img, HF_WI + 16, bh, bl, g + 8, lane);
-        operand<PREC>(hp, XS, bh, bl);
-        gemm_t<PREC, 4>(img, HF_WH, bh, bl, g, lane);
-        gemm_t<PREC, 4>(img, HF_WH + 8, bh, bl, g + 4, lane);
-        gemm_t<PREC, 4>(img, HF_WH + 16, bh, bl, g + 12, lane);
+        {   // the six GRU products as 12 K-steps, each step's fragments requested one step ahead
+            u32x4 xh[2], xl[2], hh[2], hl[2];
+            operand<PREC>(x1, XS, xh, xl);
+            operand<PREC>(hp, XS, hh, hl);
+            Frag4<PREC> fa, fb;
+            frag4_load<PREC>(img, HF_WI, 0, lane, fa);
+            frag4_load<PREC>(img, HF_WI, 1, lane, fb);       frag4_mma<PREC>(fa, xh[0], xl[0], g);
+            frag4_load<PREC>(img, HF_WI + 8, 0, lane, fa);   frag4_mma<PREC>(fb, xh[1], xl[1], g);
+            frag4_load<PREC>(img, HF_WI + 8, 1, lane, fb);   frag4_mma<PREC>(fa, xh[0], xl[0], g + 4);
+            frag4_load<PREC>(img, HF_WI + 16, 0, lane, fa);  frag4_mma<PREC>(fb, xh[1], xl[1], g + 4);
+            frag4_load<PREC>(img, HF_WI + 16, 1, lane, fb);  frag4_mma<PREC>(fa, xh[0], xl[0], g + 8);
+            frag4_load<PREC>(img, HF_WH, 0, lane, fa);       frag4_mma<PREC>(fb, xh[1], xl[1], g + 8);
+            frag4_load<PREC>(img, HF_WH, 1, lane, fb);       frag4_mma<PREC>(fa, hh[0], hl[0], g);
+            frag4_load<PREC>(img, HF_WH + 8, 0, lane, fa);   frag4_mma<PREC>(fb, hh[1], hl[1], g);
+            frag4_load<PREC>(img, HF_WH + 8, 1, lane, fb);   frag4_mma<PREC>(fa, hh[0], hl[0], g + 4);
+            frag4_load<PREC>(img, HF_WH + 16, 0, lane, fa);  frag4_mma<PREC>(fb, hh[1], hl[1], g + 4);
+            frag4_load<PREC>(img, HF_WH + 16, 1, lane, fb);  frag4_mma<PREC>(fa, hh[0], hl[0], g + 12);
+            frag4_mma<PREC>(fb, hh[1], hl[1], g + 12);
+        }
         if (first) PSTAMP(4);
         f32x4 hn[4];
 #pragma unroll
