@@ -426,7 +426,12 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold
         f32x4 x1[4];
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) x1[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_t<PREC, 4>(img, HF_FC1, bh, bl, x1, lane);
+        Frag4<PREC> fa, fb;                                            // fragment double buffer of the whole tile chain
+        frag4_load<PREC>(img, HF_FC1, 0, lane, fa);
+        frag4_load<PREC>(img, HF_FC1, 1, lane, fb);
+        frag4_mma<PREC>(fa, bh[0], bl[0], x1);
+        frag4_load<PREC>(img, HF_WI, 0, lane, fa);                     // the GRU's first step: in flight under fc1's second half
+        frag4_mma<PREC>(fb, bh[1], bl[1], x1);
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
             const f32x4 bias = *reinterpret_cast<const f32x4*>(tail + HT_B1 + 16 * ot + 4 * q);
@@ -446,8 +451,6 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold
             u32x4 xh[2], xl[2], hh[2], hl[2];
             operand<PREC>(x1, XS, xh, xl);
             operand<PREC>(hp, XS, hh, hl);
-            Frag4<PREC> fa, fb;
-            frag4_load<PREC>(img, HF_WI, 0, lane, fa);
             frag4_load<PREC>(img, HF_WI, 1, lane, fb);       frag4_mma<PREC>(fa, xh[0], xl[0], g);
             frag4_load<PREC>(img, HF_WI + 8, 0, lane, fa);   frag4_mma<PREC>(fb, xh[1], xl[1], g);
             frag4_load<PREC>(img, HF_WI + 8, 1, lane, fb);   frag4_mma<PREC>(fa, xh[0], xl[0], g + 4);
@@ -462,6 +465,13 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold
             frag4_mma<PREC>(fb, hh[1], hl[1], g + 12);
         }
         if (first) PSTAMP(4);
+        u32x4 f2h[2], f2l[2];                                          // fc2's fragments: in flight under the gate arithmetic
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const uint8_t* p2 = img + ((size_t)(HF_FC2 + s2) * 64 + lane) * 16;
+            f2h[s2] = *reinterpret_cast<const u32x4*>(p2);
+            if (PREC == 2) f2l[s2] = *reinterpret_cast<const u32x4*>(p2 + (size_t)HF_TOT * 1024);
+        }
         f32x4 hn[4];
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) {
@@ -481,7 +491,11 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold
         // ---- fc2 (advantages + value, padded to 16 outputs) ---------------------------------------------------------------
         f32x4 o2 = f32x4{0.f, 0.f, 0.f, 0.f};
         operand<PREC>(hn, XS, bh, bl);
-        gemm_t<PREC, 1>(img, HF_FC2, bh, bl, &o2, lane);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (PREC == 2) { o2 = mma<PREC>(f2l[s2], bh[s2], o2); o2 = mma<PREC>(f2h[s2], bl[s2], o2); }
+            o2 = mma<PREC>(f2h[s2], bh[s2], o2);
+        }
         {
             const f32x4 b2 = *reinterpret_cast<const f32x4*>(tail + HT_B2 + 4 * q);
 #pragma unroll
