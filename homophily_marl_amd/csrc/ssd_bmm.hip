@@ -216,7 +216,7 @@ int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* d
 // 0/1 masks.  A wave walks CW_ROWS windows, then the accumulators are summed over its lanes and written as one row of
 // `partial` [waves, 168]; the caller adds the rows (ops.column_sums: deterministic).  HBM: d_conv is read once (the term that
 // matters: 4 * 6 * O * O bytes per window), codes V * V bytes per window.
-constexpr int CW_ROWS = 8, CW_OUT = 6 * 27 + 6;
+constexpr int CW_ROWS = 4, CW_OUT = 6 * 27 + 6;     // windows per wave (measured at 8080 windows: 8 -> 46 us, 4 -> 31.5 us, 2 -> 42 us)
 // sum over the 64 lanes with DPP (no LDS crossbar): quad swaps, row rotations, row broadcasts; lane 63 ends with the total
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {

@@ -901,10 +901,18 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
                 const int row = row0 + bt * 16 + m;
                 if (row < a.rows) {
                     float* ar = a.act + ((size_t)row * 6 + 2 * s + (q >> 1)) * (O * O) + (y0 + yl) * O;
+                    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte store at any dword address
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int x = 8 * (2 * xtp + (j >> 2)) + 4 * (q & 1) + (j & 3);
-                        if (x < O) ar[x] = v[j] * (1.f / CS);
+                    for (int tx = 0; tx < 2; ++tx) {                   // this lane's 4 consecutive positions of each tile
+                        const int x0 = 8 * (2 * xtp + tx) + 4 * (q & 1);
+                        if (x0 + 3 < O) {
+                            *reinterpret_cast<f32x4_u*>(ar + x0) = f32x4_u{v[4 * tx] * (1.f / CS), v[4 * tx + 1] * (1.f / CS), v[4 * tx + 2] * (1.f / CS),
+                                                                           v[4 * tx + 3] * (1.f / CS)};
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (x0 + r < O) ar[x0 + r] = v[4 * tx + r] * (1.f / CS);
+                        }
                     }
                 }
             }
