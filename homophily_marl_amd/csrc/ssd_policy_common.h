@@ -1,4 +1,4 @@
-// ssd_policy_common.h -- device helpers shared by the rollout-time controller kernels (ssd_policy.hip, ssd_policy_fused.hip).
+// ssd_policy_common.h -- device helpers shared by the rollout-time controller kernels (ssd_policy.hip, ssd_policy_mfma.hip, ssd_gru_seq.hip).
 #pragma once
 #include "ssd_device.h"
 
