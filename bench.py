@@ -148,6 +148,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=None)
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: libraries that print banners to fd 1 (RCCL's version header at communicator
+    # creation) are sent to stderr for the lifetime of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     c = dict(CONFIGS[args.config])
     if args.n_env:
         c["n_env"] = args.n_env
@@ -165,7 +170,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = "none"
-    if args.gpus > 1 or world > 1:
+    force_dist = os.environ.get("SSD_FORCE_DIST") == "1"      # rehearsal: a 1-rank process group still runs every collective
+    if args.gpus > 1 or world > 1 or force_dist:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
         backend = os.environ.get("SSD_DIST_BACKEND", "nccl")     # "nccl" = RCCL; "gloo" only for rehearsing >1 rank on one GPU
         if backend == "nccl":
@@ -174,6 +180,7 @@ def main():
         else:
             local_rank = 0
             dist.init_process_group(backend)
+    in_group = dist.is_initialized()
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -210,7 +217,7 @@ def main():
         # back-to-back k_env<STEP_OBS> launches between two resets; average = bracket time / launches in it
         ev, run_len = [], []
         torch.cuda.synchronize()
-        if world > 1:
+        if in_group:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -226,7 +233,7 @@ def main():
             run_len[-1] += 1
         e = torch.cuda.Event(enable_timing=True); e.record(); ev.append((open_ev, e))
         torch.cuda.synchronize()
-        if world > 1:
+        if in_group:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -240,7 +247,7 @@ def main():
         units = N * n * args.steps * world
 
     elapsed = result["elapsed"]
-    if world > 1:
+    if in_group:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -273,8 +280,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             per_step = {"cleanup5": 2000, "harvest5": 600, "cleanup10": 500}[args.config]
             line["cpu_baseline"] = cpu_baseline(c, N, args.cpu_sample_steps or per_step)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if in_group:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -88,7 +88,7 @@ def run_e2e(args, c, rank, world, local_rank):
     for _ in range(args.warmup):
         iteration()
     th.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     th.cuda.synchronize()
     state["trains"] = state["timesteps"] = 0
@@ -96,7 +96,7 @@ def run_e2e(args, c, rank, world, local_rank):
     for _ in range(args.steps):
         iteration()
     th.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     th.cuda.synchronize()
     elapsed = time.perf_counter() - t0

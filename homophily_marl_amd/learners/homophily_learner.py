@@ -58,7 +58,9 @@ class HomophilyLearner:
         for p in self.target_mac.parameters():
             p.requires_grad_(False)
         self.log_stats_t = -self.args.learner_log_interval - 1
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # SSD_FORCE_DIST=1: a process group of ONE rank still issues every collective (RCCL rehearsal on a one-GPU box)
+        self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or
+                                                                               os.environ.get("SSD_FORCE_DIST") == "1")
 
     # ---- network unroll ---------------------------------------------------------------------------------------
     @staticmethod

@@ -23,6 +23,7 @@ class HomophilyAgent(nn.Module):
         self.input_shape = input_shape
         self.hidden = H = args.rnn_hidden_dim
         self.extra_input_shape = args.n_actions + 2 + 2 + 3   # action one-hot, pos, orientation, reward/clean_num/apple_den
+        self._gru_cache = None
         if args.rgb_input:
             k = args.conv_kernel
             flat = args.conv_out * (args.obs_dims[0] - k + 1) * (args.obs_dims[1] - k + 1)
@@ -111,12 +112,37 @@ class HomophilyAgent(nn.Module):
 
     # ---- whole-sequence evaluation (learner) -------------------------------------------------------------------
     def _gru_weights(self, head):
+        """(W_i, W_h, b_i, b_h) of a head with the r, z, n blocks side by side.  A frozen copy of the net (the learner's target
+        network: no parameter requires grad) keeps them in buffers that are refreshed in place whenever its weights are loaded
+        (load_state_dict) -- 8 concatenations per evaluation otherwise, and captured graphs keep reading the same addresses."""
+        frozen = not self.rnn_env_ir_w.requires_grad
+        if frozen and self._gru_cache is not None:
+            return self._gru_cache[head]
+        got = self._gru_weights_cat(head)
+        if frozen and not th.is_grad_enabled():
+            self._gru_cache = {h: (got if h == head else self._gru_weights_cat(h)) for h in ("env", "inc")}
+        return got
+
+    def _gru_weights_cat(self, head):
         p = "rnn_%s_" % head
         wi = th.cat([self._w(p + "ir_w"), self._w(p + "iz_w"), self._w(p + "in_w")], dim=2)
         wh = th.cat([self._w(p + "hr_w"), self._w(p + "hz_w"), self._w(p + "hn_w")], dim=2)
         bi = th.cat([self._b(p + "ir_b"), self._b(p + "iz_b"), self._b(p + "in_b")], dim=2)
         bh = th.cat([self._b(p + "hr_b"), self._b(p + "hz_b"), self._b(p + "hn_b")], dim=2)
         return wi, wh, bi, bh
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        if self._gru_cache is not None:          # refresh in place: a captured train step reads these buffers
+            with th.no_grad():
+                for h, bufs in self._gru_cache.items():
+                    for dst, src in zip(bufs, self._gru_weights_cat(h)):
+                        dst.copy_(src)
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        self._gru_cache = None                   # .cuda() / .to(): the cache is rebuilt on the new device at the next use
+        return super()._apply(fn, *args, **kwargs)
 
     def unroll(self, inputs, act_onehot, agent_pos, agent_orientation, reward, clean_num, apple_den):
         """Evaluate both heads on whole episodes: inputs [B, T, n, in], act_onehot [B, T, n, A] (the env action taken at
