@@ -16,6 +16,9 @@ RNG_TAPE, RNG_COUNTER = 0, 1
 OBS_F32, OBS_BF16, OBS_U8, OBS_CODE = 0, 1, 2, 3
 COLOR_SIMPLIFIED, COLOR_FULL = 0, 1
 CODE_CLASS, CODE_CHANNEL_MASK = 0, 1
+# ssd_policy_head.input_flags (include/ssd_hip.h, SSD_INPUT_*): the _build_inputs blocks in the reference's order
+INPUT_LAST_ACTION, INPUT_AGENT_ID, INPUT_REWARD, INPUT_INC_REWARD, INPUT_DISTANCE, INPUT_AGENT_POS = 1, 2, 4, 8, 16, 32
+INPUT_EXPLICIT = 0x80000000   # marks a given flag word: the empty set is INPUT_EXPLICIT alone, 0 means the shipped set
 STREAM_UNIFORM, STREAM_MOVE, STREAM_WASTE, STREAM_SPAWN_ROT = 0, 1, 2, 3
 
 SSD_OK, SSD_ERR_INVALID, SSD_ERR_DEVICE, SSD_ERR_NOMEM, SSD_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
@@ -127,7 +130,7 @@ class SsdPolicyHead(C.Structure):
                 ("dst_actions", C.c_void_p), ("dst_actions_inc", C.c_void_p), ("prev_actions_out", C.c_void_p),
                 ("prev_actions_inc_out", C.c_void_p), ("prev_reward_out", C.c_void_p), ("ep_return", C.c_void_p), ("next_t_out", C.c_void_p),
                 ("precision", C.c_int32), ("env_id_base", C.c_uint32), ("feat_part", C.c_void_p), ("feat_bands", C.c_int32),
-                ("lin_b", C.c_void_p)]
+                ("lin_b", C.c_void_p), ("input_flags", C.c_uint32)]
 
 
 class SsdPolicyHeadParams(C.Structure):

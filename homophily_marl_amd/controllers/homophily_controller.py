@@ -25,6 +25,11 @@ class HomophilyMAC(nn.Module):
         self.shipped_flags = bool(args.obs_last_action and args.obs_agent_id and args.obs_reward and args.obs_inc_reward
                                   and args.obs_agent_pos and not getattr(args, "obs_others_last_action", False)
                                   and not getattr(args, "obs_distance", False))
+        # the same flags as the ssd_policy_head.input_flags word of the fused rollout heads (None: obs_others_last_action, whose
+        # n * n_actions columns do not fit the heads' 64-column weight image -> the generic captured timestep)
+        self.input_flags = None if getattr(args, "obs_others_last_action", False) else (
+            1 * bool(args.obs_last_action) | 2 * bool(args.obs_agent_id) | 4 * bool(args.obs_reward) | 8 * bool(args.obs_inc_reward)
+            | 16 * bool(getattr(args, "obs_distance", False)) | 32 * bool(args.obs_agent_pos))
         self.input_shape = self._get_input_shape(scheme)
         self.agent = agent_REGISTRY[args.agent](self.input_shape, args)
         self.agent_output_type = args.agent_output_type

@@ -512,8 +512,15 @@ static int policy_head(const ssd_policy_head* a, int inc, void* stream) {
     if (inc ? (!a->actions || !a->pos_pre || !a->orient_pre || !a->reward || !a->clean_num || !a->apple_den)
             : (!a->prev_actions || !a->prev_reward || !a->prev_actions_inc || !a->pos)) return fail(SSD_ERR_INVALID, "missing head input");
     // layout limits of the fused kernel: 32 encoder features + tail (+ one-hot action for inc) within 64 columns, 16 fc2 rows
-    if (a->input_shape != 32 + a->n_actions + a->n_agents + 4 || a->input_shape + a->n_actions > 64 || a->n_actions + 7 > 16)
-        return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_head: input_shape must be 32 + n_actions + n + 4 and fit 64 columns");
+    {
+        const uint32_t fl = a->input_flags ? (a->input_flags & ~SSD_INPUT_EXPLICIT) : (uint32_t)SSD_INPUT_FLAGS_SHIPPED;
+        if (fl & ~63u) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_head: input_flags holds a block the fused head does not build");
+        const int tail = ((fl & SSD_INPUT_LAST_ACTION) ? a->n_actions : 0) + ((fl & SSD_INPUT_AGENT_ID) ? a->n_agents : 0) +
+                         ((fl & SSD_INPUT_REWARD) ? 1 : 0) + ((fl & SSD_INPUT_INC_REWARD) ? 1 : 0) +
+                         ((fl & SSD_INPUT_DISTANCE) ? a->n_agents : 0) + ((fl & SSD_INPUT_AGENT_POS) ? 2 : 0);
+        if (a->input_shape != 32 + tail || a->input_shape + a->n_actions > 64 || a->n_actions + 7 > 16)
+            return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_head: input_shape must be 32 + the width of the input_flags blocks and fit 64 columns");
+    }
     if ((reinterpret_cast<uintptr_t>(a->inputs) | reinterpret_cast<uintptr_t>(a->h) | reinterpret_cast<uintptr_t>(a->weights)) & 15)
         return fail(SSD_ERR_INVALID, "inputs / h / weights must be 16-byte aligned");
     const int rc = launch_policy_head(a, inc, (hipStream_t)stream);

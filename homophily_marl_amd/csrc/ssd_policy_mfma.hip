@@ -150,7 +150,10 @@ struct HeadCold {
     int64_t *d_actions, *d_actions_inc, *p_act, *p_inc;
     float *p_rew, *ep_ret;
     int64_t* next_t;
+    uint64_t tail_layout;          // env head: first tail column of each _build_inputs block as 6 signed bytes (TAIL_ABSENT = not present):
+                                   // last action | agent id | sign(r) | sign(received incentives) | 1 - distances | pos
 };
+constexpr int TAIL_ABSENT = -64;
 constexpr int HEAD_COLD_OFFSET = (int)((sizeof(HeadK) + alignof(HeadCold) - 1) / alignof(HeadCold) * alignof(HeadCold));   // second kernel argument
 template <typename T>
 __device__ __forceinline__ T* cold_ptr(int field_offset) {
@@ -160,6 +163,7 @@ __device__ __forceinline__ T* cold_ptr(int field_offset) {
     return reinterpret_cast<T*>(v);
 }
 #define COLD(T, field) cold_ptr<T>((int)offsetof(HeadCold, field))
+#define COLD_U64(field) reinterpret_cast<uint64_t>(cold_ptr<void>((int)offsetof(HeadCold, field)))
 
 // acc[ot] += (W^T tile ot of the block starting at fragment F0) x B for OT output tiles, both K-steps; small terms first
 template <int PREC, int OT>
@@ -308,8 +312,10 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
     }
 }
 
-// AT: the env's action count (9 Cleanup, 8 Harvest) at compile time: the one-hot / dueling loops unroll
-template <int INC, int PREC, int AT>
+// AT: the env's action count (9 Cleanup, 8 Harvest) at compile time: the one-hot / dueling loops unroll.  GEN (env head): the
+// tail blocks sit where HeadCold::tail_layout says (any _build_inputs flag set that fits); GEN = 0 is the shipped layout with
+// compile-time columns -- the register allocation of the tuned kernel is left as it was.
+template <int INC, int PREC, int AT, int GEN = 0>
 __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold_unused) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     constexpr int FRAG_BYTES = PREC * HF_TOT * 1024, IMAGE_BYTES = FRAG_BYTES + HT_TOT * 4;
@@ -362,22 +368,43 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold
                     d_pos[sr] = in.p0; d_pos[sr + 1] = in.p1; d_orient[sr] = in.o0; d_orient[sr + 1] = in.o1;
                 }
             }
-            // tail columns: one-hot(last action) | one-hot(agent id) | sign(r) | sign(received incentives) | pos / scale
+            // tail columns (controller :137-184, each block present iff its flag is set): one-hot(last action) | one-hot(agent id)
+            // | sign(r) | sign(received incentives) | 1 - distance to every agent / scale | pos / scale; absent blocks sit at a
+            // negative column and never match
+            int o_act = 0, o_id = A, o_r = A + n, o_i = A + n + 1, o_dist = TAIL_ABSENT, o_pos = A + n + 2;
+            if (GEN) {
+                const uint64_t lay = COLD_U64(tail_layout);
+                o_act = (int8_t)lay; o_id = (int8_t)(lay >> 8); o_r = (int8_t)(lay >> 16); o_i = (int8_t)(lay >> 24);
+                o_dist = (int8_t)(lay >> 32); o_pos = (int8_t)(lay >> 40);
+            }
             const float px = in.p0 / a.pos_scale, py = in.p1 / a.pos_scale;
             const float sg_r = (float)((in.pr > 0.f) - (in.pr < 0.f)), sg_i = (float)((in.recv > 0) - (in.recv < 0));
-            const int c_id = A + agent, c0 = A + n;
+            const int c_pa = o_act + in.pa, c_id = o_id + agent;       // pa in [-1, A): -1 (no previous step) lands left of the block
 #pragma unroll
             for (int ct = 2; ct < 4; ++ct) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = 16 * ct + 4 * q + r - 32;
-                    float v = (j == in.pa || j == c_id) ? 1.f : 0.f;   // pa in [-1, A): a hit is a one-hot column
-                    v = j == c0 ? sg_r : v;
-                    v = j == c0 + 1 ? sg_i : v;
-                    v = j == c0 + 2 ? px : v;
-                    v = j == c0 + 3 ? py : v;
+                    float v = (j == c_pa || j == c_id) ? 1.f : 0.f;    // a hit is a one-hot column
+                    v = j == o_r ? sg_r : v;
+                    v = j == o_i ? sg_i : v;
+                    v = j == o_pos ? px : v;
+                    v = j == o_pos + 1 ? py : v;
                     x[ct][r] = v;
                 }
+            }
+            if (GEN && o_dist >= 0) {      // obs_distance (wave-uniform; not in the shipped flag set): 1 - |pos_i - pos_g| / scale, g = 0..n-1
+                for (int g = 0; g < n; ++g) {
+                    const float dx = in.p0 - a.pos[((size_t)bc * n + g) * 2], dy = in.p1 - a.pos[((size_t)bc * n + g) * 2 + 1];
+                    const float d = 1.f - sqrtf(dx * dx + dy * dy) / a.pos_scale;
+#pragma unroll
+                    for (int ct = 2; ct < 4; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[ct][r] = (16 * ct + 4 * q + r - 32 == o_dist + g) ? d : x[ct][r];
+                }
+            }
+#pragma unroll
+            for (int ct = 2; ct < 4; ++ct) {
                 if (valid) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = x[ct];   // the inc head reads the full row
             }
         } else {
@@ -604,6 +631,20 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     c.d_clean = p->dst_clean_num; c.d_den = p->dst_apple_den; c.d_term = p->dst_terminated; c.term = p->terminated;
     c.d_actions = p->dst_actions; c.d_actions_inc = p->dst_actions_inc; c.p_act = p->prev_actions_out; c.p_inc = p->prev_actions_inc_out;
     c.p_rew = p->prev_reward_out; c.ep_ret = p->ep_return; c.next_t = p->next_t_out;
+    {   // first tail column of each block, reference order (homophily_controller.py:137-184); input_flags 0 = the shipped set
+        const uint32_t fl = p->input_flags ? (p->input_flags & ~SSD_INPUT_EXPLICIT) : (uint32_t)SSD_INPUT_FLAGS_SHIPPED;
+        const int width[6] = {k.A, k.n, 1, 1, k.n, 2};
+        const uint32_t bit[6] = {SSD_INPUT_LAST_ACTION, SSD_INPUT_AGENT_ID, SSD_INPUT_REWARD, SSD_INPUT_INC_REWARD, SSD_INPUT_DISTANCE,
+                                 SSD_INPUT_AGENT_POS};
+        uint64_t lay = 0;
+        int col = 0;
+        for (int f = 0; f < 6; ++f) {
+            const int o = (fl & bit[f]) ? col : TAIL_ABSENT;
+            if (fl & bit[f]) col += width[f];
+            lay |= (uint64_t)(uint8_t)(int8_t)o << (8 * f);
+        }
+        c.tail_layout = lay;
+    }
     PSTAMP_SET(k);
     const int prec = p->precision == 1 ? 1 : 2;
     const int tiles = (k.N + 15) / 16;
@@ -626,8 +667,18 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess) return -1;
         attr_done_dev[dev] = true;
     }
+    const void* gen_fns[4] = {reinterpret_cast<const void*>(&k_head<0, 2, 9, 1>), reinterpret_cast<const void*>(&k_head<0, 1, 9, 1>),
+                              reinterpret_cast<const void*>(&k_head<0, 2, 8, 1>), reinterpret_cast<const void*>(&k_head<0, 1, 8, 1>)};
+    static bool gen_attr_done_dev[64] = {};
+    const bool gen = !inc && p->input_flags && (p->input_flags & ~SSD_INPUT_EXPLICIT) != (uint32_t)SSD_INPUT_FLAGS_SHIPPED;
+    if (gen && !gen_attr_done_dev[dev]) {
+        const size_t l2 = (size_t)SSD_POLICY_IMAGE_BYTES(2) + HEAD_WAVES * SCRATCH * sizeof(float);
+        for (const void* f : gen_fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess) return -1;
+        gen_attr_done_dev[dev] = true;
+    }
     void* args[2] = {&k, &c};
-    const void* fn = fns[(k.A == 8 ? 4 : 0) + (prec == 1 ? 2 : 0) + (inc ? 1 : 0)];
+    const void* fn = gen ? gen_fns[(k.A == 8 ? 2 : 0) + (prec == 1 ? 1 : 0)] : fns[(k.A == 8 ? 4 : 0) + (prec == 1 ? 2 : 0) + (inc ? 1 : 0)];
     if (hipLaunchKernel(fn, dim3(k.n * bpa), dim3(HEAD_WAVES * 64), args, lds, s) != hipSuccess) return -1;
     return 0;
 }

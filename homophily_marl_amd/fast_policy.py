@@ -39,7 +39,9 @@ class FastPolicy:
         f32 = dict(dtype=th.float32, device=self.dev)
         # fused: one launch per head (csrc/ssd_policy_mfma.hip), inputs padded to 64 columns; otherwise the per-layer
         # composition below (batched hipBLASLt GEMMs + the small kernels of csrc/ssd_policy.hip)
-        self.fused = bool(fused) and H == 64 and self.inp + self.A <= 64 and self.A + 7 <= 16
+        self.fused = bool(fused) and H == 64 and self.inp + self.A <= 64 and self.A + 7 <= 16 and mac.input_flags is not None
+        # the per-layer composition assembles the shipped input layout only (ssd_build_inputs)
+        assert self.fused or mac.shipped_flags, "FastPolicy: this _build_inputs flag set needs the fused heads (FastPolicy.supports)"
         # the fused encoder exists for 15 x 15 and 31 x 31 windows (view_size 7 / 15: the shipped configurations)
         self.fused_enc = self.fused and self.V in (15, 31) and tuple(a.obs_dims) == (self.V, self.V)
         self.bands = abi.encode_bands(self.V) if self.fused_enc else 1
@@ -127,6 +129,17 @@ class FastPolicy:
             abi.check(self.lib, self.lib.ssd_policy_pack_encoder(ag.conv_to_fc[0].weight.data_ptr(), lin.data_ptr(), self.V, self.precision,
                                                                  self.p["conv_frags"].data_ptr(), self.p["lin_frags"].data_ptr(), st))
 
+    @staticmethod
+    def supports(mac, fused=True):
+        """Whether the rollout kernels build this controller's input layout: the shipped flag set on either path, any other
+        combination of the _build_inputs flags (homophily_controller.py:137-184) on the fused heads as long as the inputs (+ the inc
+        head's one-hot action) fit the 64-column weight image -- obs_others_last_action never does."""
+        a = mac.args
+        if mac.shipped_flags:
+            return True
+        return bool(fused) and mac.input_flags is not None and a.rnn_hidden_dim == 64 and mac.input_shape + a.n_actions <= 64 \
+            and a.n_actions + 7 <= 16
+
     def _head_params(self, head):
         """ssd_policy_head_params of one head: pointers to the reference-shaped parameters (homophily_agent.py:37-125)."""
         ag = self.agent
@@ -155,6 +168,7 @@ class FastPolicy:
         a.epsilon, a.step = eps.data_ptr(), step.data_ptr()
         a.q_out = None if q_out is None else q_out.data_ptr()
         a.precision, a.env_id_base = self.precision, self.env_id_base
+        a.input_flags = abi.INPUT_EXPLICIT | int(self.mac.input_flags)
         return a
 
     def reset(self):

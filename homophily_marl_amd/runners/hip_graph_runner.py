@@ -73,8 +73,9 @@ class HipGraphRunner(HipVecRunner):
         self.inc_mask = (1 - th.eye(n, device=dev, dtype=th.long)).reshape(1, n, n)
         self.fast = None
         self.direct_obs = self.fold_store = False
-        if getattr(a, "fast_policy", True) and getattr(self.mac, "shipped_flags", True):   # FastPolicy implements the shipped input layout
-            from ..fast_policy import FastPolicy
+        from ..fast_policy import FastPolicy
+        use_fused = bool(getattr(a, "fused_policy", True)) and simplified
+        if getattr(a, "fast_policy", True) and FastPolicy.supports(self.mac, use_fused):   # else: the generic captured timestep
             # Optionally the policy work of a timestep is evaluated per env GROUP on separate streams (fork/join inside the
             # captured graph) around the single full-batch env launch.  Measured on MI355X / ROCm 7.2: no gain (the graph
             # runs the branches back to back), so the default is one group.
@@ -94,7 +95,7 @@ class HipGraphRunner(HipVecRunner):
                 self.fasts.append(FastPolicy(self.mac, hsz, avail, seed=seed, actions_out=self.actions_full[sl],
                                              actions_inc_out=self.actions_inc_full[sl],
                                              share_packs_from=self.fasts[0] if g else None,
-                                             fused=bool(getattr(a, "fused_policy", True)) and simplified, precision=prec,
+                                             fused=use_fused, precision=prec,
                                              env_id_base=base + g * hsz))
             self.fast = self.fasts[0]
             self.gslices = [slice(g * hsz, (g + 1) * hsz) for g in range(G)]

@@ -413,7 +413,22 @@ typedef struct ssd_policy_head {
     const float* feat_part;
     int32_t feat_bands;
     const float* lin_b;            /* [32] */
+    /* ---- ABI 3 ---- */
+    /* env head: which blocks _build_inputs appends after the 32 encoder features (homophily_controller.py:137-184, in that order;
+     * SSD_INPUT_* bits, or-ed with SSD_INPUT_EXPLICIT so that the empty set can be told from 0).  0 = SSD_INPUT_FLAGS_SHIPPED
+     * (config/default.yaml).  input_shape must equal 32 + the blocks' widths and
+     * input_shape + n_actions <= 64; obs_others_last_action (n * n_actions more columns) does not fit the 64-column image and is
+     * rejected with SSD_ERR_UNSUPPORTED. */
+    uint32_t input_flags;
 } ssd_policy_head;
+#define SSD_INPUT_LAST_ACTION 1u   /* obs_last_action: one-hot of the previous env action, n_actions columns */
+#define SSD_INPUT_AGENT_ID    2u   /* obs_agent_id: one-hot of the agent, n columns */
+#define SSD_INPUT_REWARD      4u   /* obs_reward: sign of the previous reward */
+#define SSD_INPUT_INC_REWARD  8u   /* obs_inc_reward: sign(#rewards - #punishments received at the previous step) */
+#define SSD_INPUT_DISTANCE    16u  /* obs_distance: 1 - |pos - pos_g| / pos_scale for every agent g, n columns */
+#define SSD_INPUT_AGENT_POS   32u  /* obs_agent_pos: pos / pos_scale, 2 columns */
+#define SSD_INPUT_EXPLICIT    0x80000000u   /* marks a given flag word (the empty set is SSD_INPUT_EXPLICIT alone) */
+#define SSD_INPUT_FLAGS_SHIPPED (SSD_INPUT_LAST_ACTION | SSD_INPUT_AGENT_ID | SSD_INPUT_REWARD | SSD_INPUT_INC_REWARD | SSD_INPUT_AGENT_POS)
 int ssd_policy_head_env(const ssd_policy_head* args, void* stream);
 int ssd_policy_head_inc(const ssd_policy_head* args, void* stream);
 

@@ -486,3 +486,32 @@ def test_column_sums_kernel(shape):
     ref = x.double().sum(-2)
     assert a.shape == ref.shape and th.equal(a, b)
     assert float((a.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_graph_runner_takes_the_fused_heads_for_flag_sets_that_fit():
+    """A non-shipped _build_inputs flag set without obs_others_last_action (here + obs_distance, - obs_reward) stays on the
+    FastPolicy kernels (ssd_policy_head.input_flags).  Greedy episodes: every stored env action must be the argmax of the
+    Q-values the torch controller computes from the stored batch (mac.unroll = the learner's view of the same inputs) wherever
+    the top two are not a numerical tie, and a train step runs on the batch."""
+    from homophily_marl_amd.run import load_config, setup, train_iteration
+    N, T, n = 48, 12, 5
+    th.manual_seed(0)
+    cfg = load_config("cleanup", overrides=dict(
+        runner="hip_graph", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False, store_state=False,
+        obs_distance=True, obs_reward=False,
+        env_args=dict(num_agents=n, map="default5", episode_limit=T, seed=5), use_cuda=True, save_model=False, runner_stats=False))
+    ctx = setup(cfg)
+    assert not ctx.mac.shipped_flags and ctx.mac.input_shape == 32 + 9 + n + 1 + n + 2
+    avail = ctx.runner.env.avail_actions_batch[0, 0]
+    for ep in range(3):                                  # eager, captured, replayed
+        batch = ctx.runner.run(test_mode=True)
+        assert ctx.runner.fast is not None and ctx.runner.fast.fused and (ep == 0 or ctx.runner._graph is not None)
+        with th.no_grad():
+            q_env, _ = ctx.mac.unroll(batch)
+        q = q_env[:, :T].masked_fill(avail.view(1, 1, 1, -1) == 0, -float("inf"))
+        top2 = q.topk(2, dim=-1).values
+        clear = (top2[..., 0] - top2[..., 1]) > 1e-4
+        acts = batch["actions"][:, :T].squeeze(-1)
+        assert clear.float().mean() > 0.9 and (acts == q.argmax(-1))[clear].all(), ep
+    train_iteration(ctx, 0)
+    ctx.runner.close_env()
