@@ -114,6 +114,15 @@ class SsdStoreStep(C.Structure):
                 ("next_t_out", C.c_void_p), ("counter_inc", C.c_void_p)]
 
 
+COPY_BLOCKS_MAX = 32
+
+
+class SsdBlockCopy(C.Structure):
+    """ssd_block_copy (include/ssd_hip.h): one strided 2-D f32 block copy of ssd_copy_blocks."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("src_stride", C.c_int32),
+                ("dst_stride", C.c_int32)]
+
+
 class SsdPolicyHead(C.Structure):
     """include/ssd_hip.h: ssd_policy_head (fused controller step, one launch per head)."""
     _fields_ = [("n_env", C.c_int32), ("n_agents", C.c_int32), ("n_actions", C.c_int32), ("input_shape", C.c_int32),
@@ -189,6 +198,7 @@ HIP_SIGNATURES["ssd_policy_head_env"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.c
 HIP_SIGNATURES["ssd_policy_head_inc"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_fwd"] = (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_bwd"] = (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 3 + [C.c_void_p])
+HIP_SIGNATURES["ssd_copy_blocks"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_fwd"] = (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_bwd"] = (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_conv_wgrad_partial_rows"] = (C.c_int, [C.c_int32])

@@ -342,6 +342,18 @@ int ssd_column_sums(const float* x, float* out, int32_t groups, int32_t rows, in
     return launched();
 }
 
+int ssd_copy_blocks(const ssd_block_copy* blocks, int32_t count, void* stream) {
+    if (!blocks || count < 1 || count > SSD_COPY_BLOCKS_MAX) return fail(SSD_ERR_INVALID, "ssd_copy_blocks: 1..SSD_COPY_BLOCKS_MAX blocks");
+    for (int i = 0; i < count; ++i) {
+        const ssd_block_copy& b = blocks[i];
+        if (!b.src || !b.dst || b.rows < 1 || b.cols < 1 || b.src_stride < b.cols || b.dst_stride < b.cols ||
+            (int64_t)b.rows * b.cols > INT32_MAX)
+            return fail(SSD_ERR_INVALID, "ssd_copy_blocks: bad block");
+    }
+    launch_copy_blocks(blocks, count, (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_td_sim_loss(const ssd_td_loss_args* a, int32_t mode, void* stream) {
     if (!a || a->batch < 1 || a->t_slots < 2 || a->n_agents < 2 || a->n_agents > SSD_MAX_AGENTS || a->n_actions < 1 || a->sim_horizon < 1)
         return fail(SSD_ERR_INVALID, "bad argument");

@@ -224,6 +224,32 @@ __global__ __launch_bounds__(256) void k_column_sums(const float* __restrict__ x
     if (rg == 0 && c < C) out[((size_t)g * gridDim.z + blockIdx.z) * C + c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_copy_blocks: up to SSD_COPY_BLOCKS_MAX strided 2-D block copies in one launch (blockIdx.y = block, table by value in the
+// kernel arguments): the side-by-side r | z | n images of the GRU parameters and the split of their gradients.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct CopyTable { ssd_block_copy e[SSD_COPY_BLOCKS_MAX]; };
+__global__ __launch_bounds__(256) void k_copy_blocks(CopyTable t) {
+    const ssd_block_copy b = t.e[blockIdx.y];
+    const int total = b.rows * b.cols;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / b.cols, c = i - r * b.cols;
+        b.dst[(size_t)r * b.dst_stride + c] = b.src[(size_t)r * b.src_stride + c];
+    }
+}
+
+void launch_copy_blocks(const ssd_block_copy* blocks, int count, hipStream_t stream) {
+    CopyTable t;
+    int most = 1;
+    for (int i = 0; i < SSD_COPY_BLOCKS_MAX; ++i) {
+        t.e[i] = blocks[i < count ? i : 0];
+        if (i < count && blocks[i].rows * blocks[i].cols > most) most = blocks[i].rows * blocks[i].cols;
+    }
+    int gx = (most + 1023) / 1024;                                     // 4 elements per thread for the largest block
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_copy_blocks, dim3(gx, count), dim3(256), 0, stream, t);
+}
+
 static int grid_for(size_t total) {
     size_t b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : b > 4096 ? 4096 : b);

@@ -10,6 +10,7 @@ Differences in HOW, not WHAT:
   * data parallel: loss denominators and gradients are all-reduced over the process group (RCCL) before clipping.
 """
 import os
+from collections.abc import Mapping
 from types import SimpleNamespace
 
 import torch as th
@@ -21,6 +22,31 @@ from ..components.episode_buffer import EpisodeBatch
 from ..controllers import REGISTRY as mac_REGISTRY
 
 NEG = -9999999
+
+
+class _FusedLogs(Mapping):
+    """The nine logged scalars of a train step (homophily_learner.py:228-246) as a read-only mapping over the loss kernel's sums:
+    a quotient is formed when it is read (the logger reads every learner_log_interval steps), not as ~14 scalar launches per step.
+    Inside a captured train step the mapping keeps reading the replayed buffers."""
+    KEYS = ("incentives_to_cleanup_per", "incentives_to_harvest_per", "value_give_mean", "value_receive_mean", "q_env_taken_mean",
+            "q_inc_taken_mean", "loss_value_env", "loss_value_inc", "loss_sim")
+
+    def __init__(self, sums, dens, rows, n):
+        self.sums, self.dens, self.rows, self.n = sums, dens, rows, n
+
+    def __getitem__(self, k):
+        s, d, rows = self.sums, self.dens, self.rows
+        with th.no_grad():
+            return {"incentives_to_cleanup_per": lambda: s[9] / (s[10] + 1e-6), "incentives_to_harvest_per": lambda: s[11] / (s[12] + 1e-6),
+                    "value_give_mean": lambda: s[7] / rows, "value_receive_mean": lambda: s[8] / rows,
+                    "q_env_taken_mean": lambda: s[5] / rows, "q_inc_taken_mean": lambda: s[6] / (rows * self.n),
+                    "loss_value_env": lambda: s[2] / d[0], "loss_value_inc": lambda: s[3] / d[0], "loss_sim": lambda: s[4] / (1 + d[1])}[k]()
+
+    def __iter__(self):
+        return iter(self.KEYS)
+
+    def __len__(self):
+        return len(self.KEYS)
 
 
 class HomophilyLearner:
@@ -166,14 +192,7 @@ class HomophilyLearner:
         q_env, q_inc, tq_env, tq_inc = self.unroll_pair(batch)
         loss, sums = ops.td_sim_loss(q_env, q_inc, tq_env, tq_inc, dens, batch, a)
         self._backward(loss)
-        with th.no_grad():
-            rows = float(batch.batch_size * (batch.max_seq_length - 1) * n)
-            return {
-                "incentives_to_cleanup_per": sums[9] / (sums[10] + 1e-6), "incentives_to_harvest_per": sums[11] / (sums[12] + 1e-6),
-                "value_give_mean": sums[7] / rows, "value_receive_mean": sums[8] / rows,
-                "q_env_taken_mean": sums[5] / rows, "q_inc_taken_mean": sums[6] / (rows * n),
-                "loss_value_env": sums[2] / dens[0], "loss_value_inc": sums[3] / dens[0], "loss_sim": sums[4] / (1 + dens[1]),
-            }
+        return _FusedLogs(sums, dens, float(batch.batch_size * (batch.max_seq_length - 1) * n), n)
 
     def _forward_backward_ops(self, batch, dens):
         a = self.args

@@ -115,13 +115,26 @@ class HomophilyAgent(nn.Module):
         """(W_i, W_h, b_i, b_h) of a head with the r, z, n blocks side by side.  A frozen copy of the net (the learner's target
         network: no parameter requires grad) keeps them in buffers that are refreshed in place whenever its weights are loaded
         (load_state_dict) -- 8 concatenations per evaluation otherwise, and captured graphs keep reading the same addresses."""
+        return self._gru_weights_both()[0 if head == "env" else 1]
+
+    def _gru_weights_both(self):
+        """_gru_weights of the env and the inc head; a live net packs all eight images with ONE launch (ops.cat_groups: 8
+        concatenations forward, 24 strided gradient copies backward otherwise)."""
         frozen = not self.rnn_env_ir_w.requires_grad
-        if frozen and self._gru_cache is not None:
-            return self._gru_cache[head]
-        got = self._gru_weights_cat(head)
-        if frozen and not th.is_grad_enabled():
-            self._gru_cache = {h: (got if h == head else self._gru_weights_cat(h)) for h in ("env", "inc")}
-        return got
+        if frozen:
+            if self._gru_cache is None:
+                got = {h: self._gru_weights_cat(h) for h in ("env", "inc")}
+                if th.is_grad_enabled():
+                    return got["env"], got["inc"]
+                self._gru_cache = got
+            return self._gru_cache["env"], self._gru_cache["inc"]
+        groups = []
+        for head in ("env", "inc"):
+            p = "rnn_%s_" % head
+            groups += [[self._w(p + g + "_w") for g in ("ir", "iz", "in")], [self._w(p + g + "_w") for g in ("hr", "hz", "hn")],
+                       [self._b(p + g + "_b") for g in ("ir", "iz", "in")], [self._b(p + g + "_b") for g in ("hr", "hz", "hn")]]
+        out = ops.cat_groups(groups)
+        return tuple(out[:4]), tuple(out[4:])
 
     def _gru_weights_cat(self, head):
         p = "rnn_%s_" % head
@@ -165,8 +178,7 @@ class HomophilyAgent(nn.Module):
         x, act = tm(inputs), tm(act_onehot.to(inputs.dtype))
         xe = F.leaky_relu(ops.bias_bmm(x, self._w("fc1_env_w"), self._b("fc1_env_b")))
         xi = F.leaky_relu(ops.bias_bmm(th.cat([x, act], dim=-1), self._w("fc1_inc_w"), self._b("fc1_inc_b")))
-        wie, whe, bie, bhe = self._gru_weights("env")
-        wii, whi, bii, bhi = self._gru_weights("inc")
+        (wie, whe, bie, bhe), (wii, whi, bii, bhi) = self._gru_weights_both()
         gi = th.cat([ops.bias_bmm(xe, wie, bie), ops.bias_bmm(xi, wii, bii)], dim=0).reshape(2 * n, T, B, 3 * H)
         gi = gi.transpose(0, 1).contiguous()                                           # [T, 2n, B, 3H]: gi[t] is one contiguous block
         return gi, th.cat([whe, whi], dim=0), th.cat([bhe, bhi], dim=0)

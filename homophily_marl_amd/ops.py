@@ -157,6 +157,76 @@ def column_sums(x):
     return out
 
 
+def _copy_blocks(entries, like):
+    """entries: (src_ptr, dst_ptr, rows, cols, src_stride, dst_stride) -> ONE ssd_copy_blocks launch."""
+    lib = abi.load_library()
+    tab = (abi.SsdBlockCopy * len(entries))()
+    for e, (src, dst, rows, cols, ss, ds) in zip(tab, entries):
+        e.src, e.dst, e.rows, e.cols, e.src_stride, e.dst_stride = src, dst, rows, cols, ss, ds
+    abi.check(lib, lib.ssd_copy_blocks(tab, len(entries), _stream(like)))
+
+
+class _CatGroups(th.autograd.Function):
+    """Several last-axis concatenations as ONE launch (ssd_copy_blocks), their gradients split again by ONE launch into contiguous
+    per-input tensors -- what th.cat + CatBackward + the flattening of its strided gradient views do with one launch per tensor."""
+
+    @staticmethod
+    def forward(ctx, sizes, *tensors):
+        ctx.sizes, ctx.shapes = sizes, [t.shape for t in tensors]
+        tensors = [t.contiguous() for t in tensors]
+        outs, entries, k = [], [], 0
+        for cnt in sizes:
+            grp = tensors[k:k + cnt]
+            k += cnt
+            total = sum(t.shape[-1] for t in grp)
+            out = th.empty(grp[0].shape[:-1] + (total,), dtype=th.float32, device=grp[0].device)
+            col = 0
+            for t in grp:
+                c = t.shape[-1]
+                entries.append((t.data_ptr(), out.data_ptr() + 4 * col, t.numel() // c, c, c, total))
+                col += c
+            outs.append(out)
+        _copy_blocks(entries, tensors[0])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        dev = next(g for g in grads if g is not None).device
+        k = 0
+        full = []
+        for cnt, g in zip(ctx.sizes, grads):      # an unused output has no gradient: zeros
+            if g is None:
+                sh = ctx.shapes[k]
+                g = th.zeros(tuple(sh[:-1]) + (sum(s_[-1] for s_ in ctx.shapes[k:k + cnt]),), dtype=th.float32, device=dev)
+            full.append(g.contiguous())
+            k += cnt
+        grads = full
+        flat = th.empty(sum(int(th.Size(sh).numel()) for sh in ctx.shapes), dtype=th.float32, device=dev)
+        res, entries, k, off = [], [], 0, 0
+        for cnt, g in zip(ctx.sizes, grads):
+            total, col = g.shape[-1], 0
+            for sh in ctx.shapes[k:k + cnt]:
+                c, numel = sh[-1], int(th.Size(sh).numel())
+                d = flat[off:off + numel]
+                entries.append((g.data_ptr() + 4 * col, d.data_ptr(), numel // c, c, total, c))
+                res.append(d.view(sh))
+                col += c
+                off += numel
+            k += cnt
+        _copy_blocks(entries, flat)
+        return (None,) + tuple(res)
+
+
+def cat_groups(groups):
+    """[th.cat(g, dim=-1) for g in groups] for f32 tensors whose leading axes agree within a group.  On the device (at most
+    abi.COPY_BLOCKS_MAX tensors): one launch forward, one backward, contiguous gradients."""
+    flat = [t for g in groups for t in g]
+    if (flat[0].is_cuda and len(flat) <= abi.COPY_BLOCKS_MAX and all(t.dtype == th.float32 and t.is_cuda for t in flat)
+            and all(t.shape[:-1] == g[0].shape[:-1] for g in groups for t in g)):
+        return list(_CatGroups.apply(tuple(len(g) for g in groups), *flat))
+    return [th.cat(list(g), dim=-1) for g in groups]
+
+
 def _bmm_kernel_ok(x, w, b):
     return (x.is_cuda and x.dtype == th.float32 and w.dtype == th.float32 and x.dim() == 3 and w.dim() == 3)
 

@@ -207,6 +207,19 @@ int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int
 #define SSD_COLSUM_CHUNK 64
 int ssd_column_sums(const float* x, float* out, int32_t groups, int32_t rows, int32_t cols, float* workspace, void* stream);
 
+/* ssd_copy_blocks: `count` (1..SSD_COPY_BLOCKS_MAX) strided 2-D f32 block copies as ONE launch,
+ * dst[r * dst_stride + c] = src[r * src_stride + c] for r < rows, c < cols (strides in floats; blocks must not overlap).  `blocks` is a
+ * HOST array read during the call.  The learner packs the r / z / n blocks of the GRU parameters of both heads side by side with it
+ * (homophily_agent.py:83-112 keeps them as 24 separate tensors) and splits the gradients again: 2 launches instead of 8 concatenations
+ * and 24 strided copies per train step. */
+#define SSD_COPY_BLOCKS_MAX 32
+typedef struct ssd_block_copy {
+    const float* src;
+    float* dst;
+    int32_t rows, cols, src_stride, dst_stride;
+} ssd_block_copy;
+int ssd_copy_blocks(const ssd_block_copy* blocks, int32_t count, void* stream);
+
 /* ssd_td_sim_loss: the loss of HomophilyLearner.cal_loss_and_step (learners/homophily_learner.py:94-217) -- incentive reward
  * transfer, double-Q TD losses of the env head and the incentive head, the similarity loss with the exact-value clustering rule --
  * AND its gradient w.r.t. the live Q-values in one launch (the reference builds it from ~100 tensor ops that autograd differentiates).

@@ -515,3 +515,26 @@ def test_graph_runner_takes_the_fused_heads_for_flag_sets_that_fit():
         assert clear.float().mean() > 0.9 and (acts == q.argmax(-1))[clear].all(), ep
     train_iteration(ctx, 0)
     ctx.runner.close_env()
+
+
+def test_cat_groups_op_forward_and_backward_match_th_cat():
+    """ops.cat_groups (ssd_copy_blocks: the GRU parameter images of both heads in one launch, their gradients split in one) against
+    th.cat and its autograd; one output left unused (no gradient arrives for it)."""
+    from homophily_marl_amd import ops
+    g = th.Generator(device="cuda").manual_seed(4)
+    mk = lambda *sh: th.randn(*sh, generator=g, device="cuda").requires_grad_()
+    groups = [[mk(5, 64, 64) for _ in range(3)], [mk(5, 64, 64) for _ in range(3)], [mk(5, 1, 64) for _ in range(3)],
+              [mk(5, 1, 64) for _ in range(3)], [mk(5, 73, 64), mk(5, 73, 7), mk(5, 73, 1)], [mk(3, 2, 5), mk(3, 2, 9)]]
+    outs = ops.cat_groups(groups)
+    refs = [th.cat(gr, dim=-1) for gr in groups]
+    assert all(th.equal(a, b) for a, b in zip(outs, refs))
+    ws = [th.randn(r.shape, generator=g, device="cuda") for r in refs]
+    flat = [t for gr in groups for t in gr]
+    use = [0, 1, 2, 3, 4]                                                        # the last group's output stays unused
+    got = th.autograd.grad(sum((outs[i] * ws[i]).sum() for i in use), flat[:15])
+    ref = th.autograd.grad(sum((refs[i] * ws[i]).sum() for i in use), flat[:15])
+    assert all(a.is_contiguous() and th.equal(a, b) for a, b in zip(got, ref))
+    got = th.autograd.grad((ops.cat_groups(groups)[5] * ws[5]).sum(), flat[15:])
+    assert all(th.equal(a, b) for a, b in zip(got, th.autograd.grad((th.cat(groups[5], dim=-1) * ws[5]).sum(), flat[15:])))
+    lib = abi.load_library()
+    assert lib.ssd_copy_blocks(None, 1, None) == abi.SSD_ERR_INVALID and lib.ssd_copy_blocks((abi.SsdBlockCopy * 1)(), 33, None) == abi.SSD_ERR_INVALID
