@@ -139,7 +139,8 @@ class SsdPolicyHead(C.Structure):
                 ("dst_actions", C.c_void_p), ("dst_actions_inc", C.c_void_p), ("prev_actions_out", C.c_void_p),
                 ("prev_actions_inc_out", C.c_void_p), ("prev_reward_out", C.c_void_p), ("ep_return", C.c_void_p), ("next_t_out", C.c_void_p),
                 ("precision", C.c_int32), ("env_id_base", C.c_uint32), ("feat_part", C.c_void_p), ("feat_bands", C.c_int32),
-                ("lin_b", C.c_void_p), ("input_flags", C.c_uint32)]
+                ("lin_b", C.c_void_p), ("input_flags", C.c_uint32),
+                ("next_step_out", C.c_void_p), ("t_copy_out", C.c_void_p), ("step_copy_out", C.c_void_p)]
 
 
 class SsdPolicyHeadParams(C.Structure):
@@ -156,7 +157,7 @@ class SsdPolicyEncodeArgs(C.Structure):
                 ("rows", C.c_int32), ("view_edge", C.c_int32), ("n_agents", C.c_int32), ("agent_major", C.c_int32), ("precision", C.c_int32),
                 ("conv_frags", C.c_void_p), ("lin_frags", C.c_void_p), ("conv_b", C.c_void_p), ("lin_b", C.c_void_p),
                 ("out", C.c_void_p), ("out_stride", C.c_int32), ("part", C.c_void_p), ("slot_t_copy", C.c_void_p), ("counter_inc", C.c_void_p),
-                ("alphabet", C.c_int32), ("act", C.c_void_p)]
+                ("alphabet", C.c_int32), ("act", C.c_void_p), ("slot_add", C.c_int32)]
 
 
 class SsdTdLossArgs(C.Structure):
@@ -204,6 +205,7 @@ HIP_SIGNATURES["ssd_bias_bmm_bwd"] = (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 
 HIP_SIGNATURES["ssd_conv_wgrad_partial_rows"] = (C.c_int, [C.c_int32])
 HIP_SIGNATURES["ssd_conv_wgrad_codes"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_policy_encode"] = (C.c_int, [C.POINTER(SsdPolicyEncodeArgs), C.c_void_p])
+HIP_SIGNATURES["ssd_policy_head_inc_encode"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.POINTER(SsdPolicyEncodeArgs), C.c_void_p])
 HIP_SIGNATURES["ssd_policy_pack_encoder"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_column_sums"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p])
 COLSUM_CHUNK = 64

@@ -140,7 +140,8 @@ def run_e2e(args, c, rank, world, local_rank):
             if key == "env":
                 continue
             avg, med = _event_time(fn, 50)
-            parts = ["encode_conv", "encode_lin"] if key == "encode" else [key]
+            # pipelined rollout: the inc head of t and the encoder of t + 1 are one launch (ssd::k_inc_encode)
+            parts = {"encode": ["encode_conv", "encode_lin"], "inc_encode": ["head_inc", "encode_conv", "encode_lin"]}.get(key, [key])
             alg = sum(fl[p] for p in parts) * N * n
             k = dict(name=name, avg_us=avg, median_us=med, bound="mfma", flops_per_launch=alg)
             if nprod:

@@ -463,7 +463,7 @@ int ssd_conv_wgrad_codes(const uint8_t* codes, const float* d_conv, float* parti
     return launched();
 }
 
-int ssd_policy_encode(const ssd_policy_encode_args* a, void* stream) {
+static int check_encode(const ssd_policy_encode_args* a) {
     if (!a || !a->codes || !a->conv_frags || !a->lin_frags || !a->conv_b || !a->lin_b || a->rows < 1 || a->n_agents < 1 || a->rows % a->n_agents)
         return fail(SSD_ERR_INVALID, "bad argument");
     if (a->view_edge != 15 && a->view_edge != 31)
@@ -481,6 +481,12 @@ int ssd_policy_encode(const ssd_policy_encode_args* a, void* stream) {
     if (a->code_bytes < (long)(a->rows / a->n_agents - 1) * a->env_stride + (long)(a->n_agents - 1) * a->agent_stride + VV)
         return fail(SSD_ERR_INVALID, "code_bytes does not cover the rows");
     if (a->slot_t_copy && (!a->slot_t || a->slot_t_copy == a->slot_t)) return fail(SSD_ERR_INVALID, "slot_t_copy needs a distinct slot_t");
+    if (a->slot_add < 0 || (a->slot_add && !a->slot_t)) return fail(SSD_ERR_INVALID, "slot_add needs slot_t");
+    return SSD_OK;
+}
+
+int ssd_policy_encode(const ssd_policy_encode_args* a, void* stream) {
+    if (const int bad = check_encode(a)) return bad;
     const int rc = launch_policy_encode(a, (hipStream_t)stream);
     if (rc) return fail(SSD_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS) failed");
     return launched();
@@ -507,7 +513,7 @@ int ssd_policy_pack_head(const ssd_policy_head_params* p, int32_t precision, voi
     return launched();
 }
 
-static int policy_head(const ssd_policy_head* a, int inc, void* stream) {
+static int check_head(const ssd_policy_head* a, int inc) {
     if (!a || !a->inputs || !a->h || !a->weights || !a->epsilon || !a->step || !a->out_actions) return fail(SSD_ERR_INVALID, "bad argument");
     if (a->n_env < 1 || a->n_agents < 1 || a->n_actions < 1) return fail(SSD_ERR_INVALID, "bad argument");
     if (a->precision != 0 && a->precision != 1 && a->precision != 2) return fail(SSD_ERR_INVALID, "precision must be 1 (bf16) or 2 (f32-equivalent)");
@@ -535,9 +541,32 @@ static int policy_head(const ssd_policy_head* a, int inc, void* stream) {
     }
     if ((reinterpret_cast<uintptr_t>(a->inputs) | reinterpret_cast<uintptr_t>(a->h) | reinterpret_cast<uintptr_t>(a->weights)) & 15)
         return fail(SSD_ERR_INVALID, "inputs / h / weights must be 16-byte aligned");
+    if (inc ? (a->t_copy_out || a->step_copy_out) : (a->next_step_out != nullptr))
+        return fail(SSD_ERR_INVALID, "counter hand-over: the env head writes the copies, the inc head the next values");
+    if ((a->next_step_out && a->next_step_out == a->step) || (a->t_copy_out && (!a->t_index || a->t_copy_out == a->t_index)) ||
+        (a->step_copy_out && a->step_copy_out == a->step))
+        return fail(SSD_ERR_INVALID, "counter hand-over: a launch must not write a scalar it reads");
+    return SSD_OK;
+}
+
+static int policy_head(const ssd_policy_head* a, int inc, void* stream) {
+    if (const int bad = check_head(a, inc)) return bad;
     const int rc = launch_policy_head(a, inc, (hipStream_t)stream);
     if (rc == -3) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_head is instantiated for n_actions 9 (Cleanup) and 8 (Harvest)");
     if (rc) return fail(SSD_ERR_DEVICE, "ssd_policy_head: launch / hipFuncSetAttribute(max dynamic LDS) failed");
+    return launched();
+}
+int ssd_policy_head_inc_encode(const ssd_policy_head* h, const ssd_policy_encode_args* e, void* stream) {
+    if (const int bad = check_head(h, 1)) return bad;
+    if (const int bad = check_encode(e)) return bad;
+    if (e->act || e->slot_t_copy || e->counter_inc) return fail(SSD_ERR_INVALID, "ssd_policy_head_inc_encode: no act / slot_t_copy / counter_inc");
+    if ((h->precision == 1) != (e->precision == 1)) return fail(SSD_ERR_INVALID, "ssd_policy_head_inc_encode: one precision for both halves");
+    if (e->out == h->inputs) return fail(SSD_ERR_INVALID, "ssd_policy_head_inc_encode: the encoder must write the other inputs buffer");
+    if (e->slot_t && (e->slot_t == h->next_t_out)) return fail(SSD_ERR_INVALID, "ssd_policy_head_inc_encode: the encoder must not read the scalar the inc head writes");
+    const int rc = launch_policy_inc_encode(h, e, (hipStream_t)stream);
+    if (rc == -3) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_head is instantiated for n_actions 9 (Cleanup) and 8 (Harvest)");
+    if (rc == -2) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode is instantiated for 15 x 15 / 31 x 31 windows");
+    if (rc) return fail(SSD_ERR_DEVICE, "ssd_policy_head_inc_encode: launch / hipFuncSetAttribute(max dynamic LDS) failed");
     return launched();
 }
 int ssd_policy_head_env(const ssd_policy_head* a, void* stream) { return policy_head(a, 0, stream); }

@@ -138,6 +138,7 @@ void launch_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float
 void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* dgh,
                         float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s);
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s);
+int launch_policy_inc_encode(const ssd_policy_head* ph, const ssd_policy_encode_args* pe, hipStream_t s);
 int conv_wgrad_partial_rows(int R);
 int launch_conv_wgrad(const uint8_t* codes, const float* d_conv, float* partial, int R, int V, hipStream_t s);
 int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int n, int R, int I, int O, hipStream_t s);

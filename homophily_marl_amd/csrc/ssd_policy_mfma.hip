@@ -150,6 +150,7 @@ struct HeadCold {
     int64_t *d_actions, *d_actions_inc, *p_act, *p_inc;
     float *p_rew, *ep_ret;
     int64_t* next_t;
+    int64_t *next_step, *t_copy, *step_copy;   // inc head: *next_step = *step + 1; env head: *t_copy = *t_index, *step_copy = *step
     uint64_t tail_layout;          // env head: first tail column of each _build_inputs block as 6 signed bytes (TAIL_ABSENT = not present):
                                    // last action | agent id | sign(r) | sign(received incentives) | 1 - distances | pos
 };
@@ -315,13 +316,12 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
 // AT: the env's action count (9 Cleanup, 8 Harvest) at compile time: the one-hot / dueling loops unroll.  GEN (env head): the
 // tail blocks sit where HeadCold::tail_layout says (any _build_inputs flag set that fits); GEN = 0 is the shipped layout with
 // compile-time columns -- the register allocation of the tuned kernel is left as it was.
-template <int INC, int PREC, int AT, int GEN = 0>
-__global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold_unused) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+template <int INC, int PREC, int AT, int GEN>
+__device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, const int block) {
     constexpr int FRAG_BYTES = PREC * HF_TOT * 1024, IMAGE_BYTES = FRAG_BYTES + HT_TOT * 4;
     constexpr float XS = PREC == 2 ? HEAD_XSCALE : 1.f, INV = PREC == 2 ? 1.f / (HEAD_WSCALE * HEAD_XSCALE) : 1.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int agent = blockIdx.x / a.bpa, bia = blockIdx.x - agent * a.bpa;
+    const int agent = block / a.bpa, bia = block - agent * a.bpa;
     const int m = lane & 15, q = lane >> 4;
     const int N = a.N, n = a.n;
     constexpr int A = AT;
@@ -439,9 +439,19 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold
     const uint8_t* img = lds_raw;
     const float* tail = reinterpret_cast<const float*>(lds_raw + FRAG_BYTES);
     float* scratch = reinterpret_cast<float*>(lds_raw + IMAGE_BYTES) + wave * SCRATCH;
-    if (INC && blockIdx.x == 0 && tid == 0) {                          // not read by this kernel (t_index is a copy)
-        int64_t* next_t = COLD(int64_t, next_t);
-        if (next_t) *next_t = slot_t + 1;
+    // Device-side counters advance by ping-pong copies, never by a kernel incrementing a scalar it (or a workgroup of the same
+    // launch) also reads: the inc head reads the copies and writes the masters' next values, the env head (pipelined rollout) reads
+    // the masters and writes the copies.
+    if (block == 0 && tid == 0) {
+        if (INC) {
+            int64_t *next_t = COLD(int64_t, next_t), *next_step = COLD(int64_t, next_step);
+            if (next_t) *next_t = slot_t + 1;
+            if (next_step) *next_step = *a.step + 1;
+        } else {
+            int64_t *t_copy = COLD(int64_t, t_copy), *step_copy = COLD(int64_t, step_copy);
+            if (t_copy) *t_copy = slot_t;
+            if (step_copy) *step_copy = *a.step;
+        }
     }
     while (tile < tiles) {
         const int b = tile * 16 + m;
@@ -615,9 +625,13 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold
     PSTAMP_REAL(15);
 }
 
-int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
-    HeadK k;
-    HeadCold c;
+template <int INC, int PREC, int AT, int GEN = 0>
+__global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold_unused) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    head_body<INC, PREC, AT, GEN>(a, lds_raw, (int)blockIdx.x);
+}
+
+static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c) {
     k.N = p->n_env; k.n = p->n_agents; k.A = p->n_actions; k.inp = p->input_shape;
     k.pos_scale = p->pos_scale; k.seed = p->seed; k.env_id_base = p->env_id_base;
     k.inputs = p->inputs; k.h = p->h; k.weights = static_cast<const uint8_t*>(p->weights); k.avail = p->avail; k.eps = p->epsilon; k.step = p->step;
@@ -645,13 +659,21 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
         }
         c.tail_layout = lay;
     }
+    c.next_step = p->next_step_out; c.t_copy = p->t_copy_out; c.step_copy = p->step_copy_out;
     PSTAMP_SET(k);
-    const int prec = p->precision == 1 ? 1 : 2;
     const int tiles = (k.N + 15) / 16;
     int bpa = 256 / k.n;                                               // one workgroup per CU (the image fills most of the LDS)
     if (bpa > tiles) bpa = tiles;
     if (bpa < 1) bpa = 1;
     k.bpa = bpa;
+}
+
+int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
+    HeadK k;
+    HeadCold c;
+    head_args(p, k, c);
+    const int prec = p->precision == 1 ? 1 : 2;
+    const int bpa = k.bpa;
     const size_t lds = (size_t)SSD_POLICY_IMAGE_BYTES(prec) + HEAD_WAVES * SCRATCH * sizeof(float);
     if (k.A != 9 && k.A != 8) return -3;                               // instantiated for Cleanup (9 actions) and Harvest (8)
     static bool attr_done_dev[64] = {};                               // the attribute is per device
@@ -762,6 +784,7 @@ template <int V, int PREC> constexpr size_t enc_lds_bytes() {
 
 struct EncK {
     const uint8_t* codes; long code_bytes, env_stride, slot_stride, agent_stride; const int64_t* slot_t;
+    int slot_add;                      // the time slot read is *slot_t + slot_add
     int rows, n, agent_major;
     const uint8_t *conv_frags, *lin_frags;
     const float *conv_b, *lin_b;
@@ -774,25 +797,24 @@ struct EncK {
 };
 
 template <int V, int PREC, bool ACT>
-__global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
+__device__ __forceinline__ void encode_body(const EncK& a, uint8_t* lds_raw, const int block_x, const int block_y) {
     using G = Geo<V>;
     constexpr int O = G::O, CP = G::CP, XTP = G::XTP, R = G::R, BT = ENC_BT;
     constexpr int RB = enc_row_bytes<V>(), PR = enc_batch_row_bytes<V>();   // bytes of an input-row record / of a batch row (this band)
     constexpr int PLANES = BT * 16 * PR, CONV_BYTES = PREC * 9 * 1024;
     constexpr uint32_t ON = PREC == 2 ? 0x3Cu : 0x3Fu;                 // f16 0x3C00 = 1.0;  bf16 0x3F00 = 0.5 (the conv weights carry the 2)
     constexpr float CS = PREC == 2 ? ENC_CSCALE : 1.f, INV = PREC == 2 ? 1.f / (ENC_CSCALE * ENC_LSCALE) : 1.f;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint8_t* planes = lds_raw;                                         // [BT * 16 rows][R + 2 input rows][RB]
     uint8_t* cfr = lds_raw + PLANES;                                   // conv fragments [term][s][dy][lane][16 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * (BT * 16);
-    const int band = blockIdx.y, y0 = band * R;
+    const int row0 = block_x * (BT * 16);
+    const int band = block_y, y0 = band * R;
     const int Rb = O - y0 < R ? O - y0 : R;                            // output rows of this band
-    const long t_off = a.slot_t ? (long)(*a.slot_t) * a.slot_stride : 0;
+    const long t_off = a.slot_t ? ((long)(*a.slot_t) + a.slot_add) * a.slot_stride : 0;
     PSTAMP(0);
     PSTAMP_REAL(14);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    if (block_x == 0 && block_y == 0 && tid == 0) {
         if (a.slot_t_copy) *a.slot_t_copy = *a.slot_t;
         if (a.counter_inc) *a.counter_inc += 1;
     }
@@ -1014,6 +1036,33 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
 }
 
 template <int V, int PREC, bool ACT>
+__global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    encode_body<V, PREC, ACT>(a, lds_raw, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_inc_encode: the inc head of timestep t and the encoder of timestep t + 1 as ONE launch (pipelined rollout).  Both follow the env
+// step of t and share no data: the inc head reads the input rows of t (one buffer of a pair), the encoder reads the observation the
+// env step just stored in slot t + 1 and writes the other buffer.  Either kernel fills the register file of a CU with one workgroup,
+// so nothing co-resides -- what is saved is one launch-to-launch floor per timestep (3.1 us of 64), and the second half of the grid
+// starts on each CU the moment its head workgroup retires.  Workgroups [0, heads) run head_body, the rest encode_body with the
+// (x, band) index unfolded; EncK sits behind the two head arguments (the heads' cold-argument offsets are unchanged).
+// ---------------------------------------------------------------------------------------------------------------------------
+static_assert(HEAD_WAVES == ENC_WAVES, "k_inc_encode: one block size for both bodies");
+template <int PREC, int AT, int V>
+__global__ __launch_bounds__(HEAD_WAVES * 64) void k_inc_encode(HeadK a, HeadCold cold_unused, EncK e, int heads, int enc_groups) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const int b = (int)blockIdx.x;
+    if (b < heads) {
+        head_body<1, PREC, AT, 0>(a, lds_raw, b);
+    } else {
+        const int i = b - heads, by = i / enc_groups;
+        encode_body<V, PREC, false>(e, lds_raw, i - by * enc_groups, by);
+    }
+}
+
+template <int V, int PREC, bool ACT>
 static int launch_encode_t(const EncK& k, hipStream_t s) {
     using G = Geo<V>;
     constexpr size_t lds = enc_lds_bytes<V, PREC>();
@@ -1029,14 +1078,54 @@ static int launch_encode_t(const EncK& k, hipStream_t s) {
     return 0;
 }
 
-int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s) {
-    EncK k;
+static void encode_args(const ssd_policy_encode_args* p, EncK& k) {
     k.codes = p->codes; k.code_bytes = (long)p->code_bytes; k.env_stride = (long)p->env_stride; k.slot_stride = (long)p->slot_stride;
     k.agent_stride = (long)p->agent_stride; k.slot_t = p->slot_t; k.rows = p->rows; k.n = p->n_agents; k.agent_major = p->agent_major;
     k.conv_frags = static_cast<const uint8_t*>(p->conv_frags); k.lin_frags = static_cast<const uint8_t*>(p->lin_frags);
     k.conv_b = p->conv_b; k.lin_b = p->lin_b; k.out = p->out; k.out_stride = p->out_stride; k.part = p->part; k.act = p->act;
     k.slot_t_copy = p->slot_t_copy; k.counter_inc = p->counter_inc; k.mask_alphabet = p->alphabet == SSD_CODE_CHANNEL_MASK;
+    k.slot_add = p->slot_add;
     PSTAMP_SET(k);
+}
+
+template <int PREC, int AT, int V>
+static int launch_inc_encode_t(HeadK& k, HeadCold& c, EncK& e, hipStream_t s) {
+    const size_t lh = (size_t)SSD_POLICY_IMAGE_BYTES(PREC) + HEAD_WAVES * SCRATCH * sizeof(float), le = enc_lds_bytes<V, PREC>();
+    const size_t lds = lh > le ? lh : le;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    const void* fn = reinterpret_cast<const void*>(&k_inc_encode<PREC, AT, V>);
+    if (!done[dev]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        done[dev] = true;
+    }
+    int heads = k.n * k.bpa, groups = (e.rows + ENC_BT * 16 - 1) / (ENC_BT * 16);
+    void* args[5] = {&k, &c, &e, &heads, &groups};
+    if (hipLaunchKernel(fn, dim3(heads + groups * Geo<V>::NB), dim3(HEAD_WAVES * 64), args, lds, s) != hipSuccess) return -1;
+    return 0;
+}
+
+// inc head (timestep t) + encoder (timestep t + 1) as one launch; -2: no instance for this window size, -3: for this action count
+int launch_policy_inc_encode(const ssd_policy_head* ph, const ssd_policy_encode_args* pe, hipStream_t s) {
+    HeadK k;
+    HeadCold c;
+    EncK e;
+    head_args(ph, k, c);
+    encode_args(pe, e);
+    const int prec = ph->precision == 1 ? 1 : 2, V = pe->view_edge;
+    if (k.A != 9 && k.A != 8) return -3;
+    if (V != 15 && V != 31) return -2;
+#define SSD_IE(P_, A_, V_) if (prec == P_ && k.A == A_ && V == V_) return launch_inc_encode_t<P_, A_, V_>(k, c, e, s)
+    SSD_IE(2, 9, 15); SSD_IE(2, 9, 31); SSD_IE(2, 8, 15); SSD_IE(2, 8, 31);
+    SSD_IE(1, 9, 15); SSD_IE(1, 9, 31); SSD_IE(1, 8, 15); SSD_IE(1, 8, 31);
+#undef SSD_IE
+    return -2;
+}
+
+int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s) {
+    EncK k;
+    encode_args(p, k);
     const int prec = p->precision == 1 ? 1 : 2;
     if (p->act) {       // the learner's forward: f32-equivalent products only
         if (prec != 2) return -2;

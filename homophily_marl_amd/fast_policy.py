@@ -48,7 +48,10 @@ class FastPolicy:
         # bf16 MFMA products an f32-equivalent product costs (bench.py's roofline accounting); conv: the planes are exact, 2
         self.n_products = dict(encode_conv=2, encode_lin=3, head_env=3, head_inc=3) if precision == 2 else \
             dict(encode_conv=1, encode_lin=1, head_env=1, head_inc=1)
-        self.inputs = th.zeros(n, N, 64 if self.fused else self.inp, **f32)          # [feat | tail (| 0)], agent-major
+        # [feat | tail (| 0)], agent-major; a PAIR of buffers: the pipelined rollout (act_inc_encode) encodes timestep t + 1 into
+        # the other buffer while the inc head still reads the rows of t.  Everything else uses buffer 0 (`inputs`).
+        self.inputs_pair = th.zeros(2, n, N, 64 if self.fused else self.inp, **f32)
+        self.inputs = self.inputs_pair[0]
         self.feat_part = th.zeros(self.bands, n * N, 32, **f32) if self.bands > 1 else None
         self.h_env = th.zeros(n, N, H, **f32)
         self.h_inc = th.zeros(n, N, H, **f32)
@@ -157,12 +160,12 @@ class FastPolicy:
         hp.fc2_in, hp.fc2_out = g("fc2_%s_w" % head).shape[2], g("fc2_%s_w" % head).shape[3]
         return hp
 
-    def _head_args(self, inc, eps, step, q_out=None):
+    def _head_args(self, inc, eps, step, q_out=None, buf=0):
         a = abi.SsdPolicyHead()
         a.n_env, a.n_agents, a.n_actions, a.input_shape = self.N, self.n, self.A, self.inp
         a.pos_scale = float(self.mac.pos_scale)
         a.seed = (self.seed ^ 0x5bd1e995) if inc else self.seed
-        a.inputs = self.inputs.data_ptr()
+        a.inputs = self.inputs_pair[buf].data_ptr()
         a.h = (self.h_inc if inc else self.h_env).data_ptr()
         a.weights = self.p["img_inc" if inc else "img_env"].data_ptr()
         a.epsilon, a.step = eps.data_ptr(), step.data_ptr()
@@ -194,8 +197,39 @@ class FastPolicy:
         c = ((obs[:, :, 0] > 0) * 2 + (obs[:, :, 1] > 0) * 1 + (obs[:, :, 2] > 0) * 3).to(th.uint8).reshape(N, n, V * V)
         return F.pad(c, (0, abi.code_agent_stride(V) - V * V)).contiguous()
 
+    def _encode_args(self, obs, codes, slot_t, mask_alphabet, buf=0, slot_add=0, t_copy=None, counter_inc=None):
+        """ssd_policy_encode_args of the fused encoder (see encode) writing inputs_pair[buf] / the band sums; returns (args, codes)."""
+        p, n, N, V = self.p, self.n, self.N, self.V
+        if codes is None:
+            codes, mask_alphabet = self.codes_from_obs(obs), False
+        if mask_alphabet is None:
+            mask_alphabet = codes.dim() == 3
+        assert codes.dtype == th.uint8 and codes.shape[0] == N
+        ea = abi.SsdPolicyEncodeArgs()
+        ea.codes = codes.data_ptr()
+        ea.code_bytes = codes.untyped_storage().nbytes() - codes.storage_offset()
+        if codes.dim() == 5:        # an episode storage [N, T+1, n, V, V], time slot *slot_t (+ slot_add)
+            assert slot_t is not None and codes[0, 0].is_contiguous()
+            ea.env_stride, ea.slot_stride, ea.agent_stride = codes.stride(0), codes.stride(1), V * V
+        else:                       # the dense side buffer [N, n, stride]
+            assert codes.dim() == 3 and codes[0].is_contiguous()
+            ea.env_stride, ea.slot_stride, ea.agent_stride = codes.stride(0), 0, codes.stride(1)
+        ea.slot_t = None if slot_t is None else slot_t.data_ptr()
+        ea.slot_add = int(slot_add) if slot_t is not None else 0
+        ea.rows, ea.view_edge, ea.n_agents, ea.agent_major, ea.precision = N * n, V, n, 1, self.precision
+        ea.alphabet = abi.CODE_CHANNEL_MASK if mask_alphabet else abi.CODE_CLASS
+        ea.conv_frags, ea.lin_frags = p["conv_frags"].data_ptr(), p["lin_frags"].data_ptr()
+        ea.conv_b, ea.lin_b = p["cb"].data_ptr(), p["lb"].data_ptr()
+        if self.bands > 1:
+            ea.part = self.feat_part.data_ptr()
+        else:
+            ea.out, ea.out_stride = self.inputs_pair[buf].data_ptr(), self.inputs_pair.shape[-1]
+        ea.slot_t_copy = None if t_copy is None else t_copy.data_ptr()
+        ea.counter_inc = None if counter_inc is None else counter_inc.data_ptr()
+        return ea, codes
+
     @th.no_grad()
-    def encode(self, obs, codes=None, slot_t=None, store_obs=None, store_t=None, t_copy=None, counter_inc=None, mask_alphabet=None):
+    def encode(self, obs, codes=None, slot_t=None, store_obs=None, store_t=None, t_copy=None, counter_inc=None, mask_alphabet=None, buf=0):
         """rgb_preprocess (homophily_agent.py:20-27,213-214) of the current observation into columns 0..31 of `inputs` (31 x 31
         windows: into the per-band partial sums that head_env finishes).
         Fused encoder: reads one byte per window cell -- `codes` [N, n, stride] = the env's obs_code side buffer (channel masks;
@@ -206,37 +240,13 @@ class FastPolicy:
         p, lib, n, N = self.p, self.lib, self.n, self.N
         st = self._stream()
         if self.fused_enc:
-            V = self.V
-            if codes is None:
-                codes, mask_alphabet = self.codes_from_obs(obs), False
-            if mask_alphabet is None:
-                mask_alphabet = codes.dim() == 3
-            assert codes.dtype == th.uint8 and codes.shape[0] == N
-            ea = abi.SsdPolicyEncodeArgs()
-            ea.codes = codes.data_ptr()
-            ea.code_bytes = codes.untyped_storage().nbytes() - codes.storage_offset()
-            if codes.dim() == 5:        # an episode storage [N, T+1, n, V, V], time slot *slot_t
-                assert slot_t is not None and codes[0, 0].is_contiguous()
-                ea.env_stride, ea.slot_stride, ea.agent_stride = codes.stride(0), codes.stride(1), V * V
-            else:                       # the dense side buffer [N, n, stride]
-                assert codes.dim() == 3 and codes[0].is_contiguous()
-                ea.env_stride, ea.slot_stride, ea.agent_stride = codes.stride(0), 0, codes.stride(1)
-            ea.slot_t = None if slot_t is None else slot_t.data_ptr()
-            ea.rows, ea.view_edge, ea.n_agents, ea.agent_major, ea.precision = N * n, V, n, 1, self.precision
-            ea.alphabet = abi.CODE_CHANNEL_MASK if mask_alphabet else abi.CODE_CLASS
-            ea.conv_frags, ea.lin_frags = p["conv_frags"].data_ptr(), p["lin_frags"].data_ptr()
-            ea.conv_b, ea.lin_b = p["cb"].data_ptr(), p["lb"].data_ptr()
-            if self.bands > 1:
-                ea.part = self.feat_part.data_ptr()
-            else:
-                ea.out, ea.out_stride = self.inputs.data_ptr(), self.inputs.shape[-1]
-            ea.slot_t_copy = None if t_copy is None else t_copy.data_ptr()
-            ea.counter_inc = None if counter_inc is None else counter_inc.data_ptr()
+            ea, codes = self._encode_args(obs, codes, slot_t, mask_alphabet, buf=buf, t_copy=t_copy, counter_inc=counter_inc)
             abi.check(lib, lib.ssd_policy_encode(C.byref(ea), st))
             self._keep_codes = codes
             if store_obs is not None and obs is not None:
                 store_obs.index_copy_(1, store_t, obs.unsqueeze(1))
             return
+        assert buf == 0
         V = obs.shape[-1]
         so = (None if store_obs is None else store_obs.data_ptr(), 0 if store_obs is None else store_obs.stride(0),
               None if store_t is None else store_t.data_ptr())
@@ -251,12 +261,12 @@ class FastPolicy:
 
     @th.no_grad()
     def head_env(self, prev_actions, prev_reward, prev_inc, pos, eps, step, q_out=None, orient=None, actions_i32=None, pos_copy=None,
-                 orient_copy=None, file=None):
+                 orient_copy=None, file=None, buf=0):
         """input tail + fc1 + GRU + dueling + epsilon-greedy of the env head on the features encode() left in `inputs`."""
         p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
         st = self._stream()
         if self.fused:
-            ha = self._head_args(False, eps, step, q_out)
+            ha = self._head_args(False, eps, step, q_out, buf)
             ha.avail = self.avail.data_ptr()
             ha.prev_actions, ha.prev_reward, ha.prev_actions_inc, ha.pos = (prev_actions.data_ptr(), prev_reward.data_ptr(),
                                                                           prev_inc.data_ptr(), pos.data_ptr())
@@ -286,20 +296,39 @@ class FastPolicy:
 
     # ---- incentive head ---------------------------------------------------------------------------------------------
     @th.no_grad()
-    def act_inc(self, actions, pos, orient, reward, clean_num, apple_den, eps, step, q_out=None, file=None):
+    def _inc_args(self, actions, pos, orient, reward, clean_num, apple_den, eps, step, q_out=None, file=None, buf=0):
+        ha = self._head_args(True, eps, step, q_out, buf)
+        ha.actions, ha.pos_pre, ha.orient_pre = actions.data_ptr(), pos.data_ptr(), orient.data_ptr()
+        ha.reward, ha.clean_num, ha.apple_den = reward.data_ptr(), clean_num.data_ptr(), apple_den.data_ptr()
+        ha.out_actions = self.actions_inc.data_ptr()
+        for k, v in (file or {}).items():
+            setattr(ha, k, v)
+        return ha
+
+    @th.no_grad()
+    def act_inc_encode(self, actions, pos, orient, reward, clean_num, apple_den, eps, step, codes, slot_t=None, slot_add=0, buf=0,
+                       q_out=None, file=None, mask_alphabet=None):
+        """act_inc of timestep t on inputs_pair[buf] AND encode of timestep t + 1 into inputs_pair[buf ^ 1] (31 x 31 windows: into
+        the band sums) as ONE launch (ssd_policy_head_inc_encode): the pipelined rollout's third launch of a timestep.  `codes` /
+        slot_t / slot_add as in encode(): the observation the env step of t just produced (storage slot *slot_t + slot_add)."""
+        assert self.fused and self.fused_enc
+        ha = self._inc_args(actions, pos, orient, reward, clean_num, apple_den, eps, step, q_out=q_out, file=file, buf=buf)
+        ea, codes = self._encode_args(None, codes, slot_t, mask_alphabet, buf=buf ^ 1, slot_add=slot_add)
+        abi.check(self.lib, self.lib.ssd_policy_head_inc_encode(C.byref(ha), C.byref(ea), self._stream()))
+        self._keep_codes = codes
+        return self.actions_inc
+
+    @th.no_grad()
+    def act_inc(self, actions, pos, orient, reward, clean_num, apple_den, eps, step, q_out=None, file=None, buf=0):
         """actions i64 [N, n] (the env actions just taken); pos / orient: the PRE-step pose [N, n, 2]; reward, clean_num,
         apple_den [N, n] of this step.  Returns actions_inc i64 [N, n, n] with a zero diagonal (static buffer)."""
         p, lib, n, N, H = self.p, self.lib, self.n, self.N, self.H
         st = self._stream()
         if self.fused:
-            ha = self._head_args(True, eps, step, q_out)
-            ha.actions, ha.pos_pre, ha.orient_pre = actions.data_ptr(), pos.data_ptr(), orient.data_ptr()
-            ha.reward, ha.clean_num, ha.apple_den = reward.data_ptr(), clean_num.data_ptr(), apple_den.data_ptr()
-            ha.out_actions = self.actions_inc.data_ptr()
-            for k, v in (file or {}).items():
-                setattr(ha, k, v)
+            ha = self._inc_args(actions, pos, orient, reward, clean_num, apple_den, eps, step, q_out=q_out, file=file, buf=buf)
             abi.check(lib, lib.ssd_policy_head_inc(C.byref(ha), st))
             return self.actions_inc
+        assert buf == 0
         x = th.baddbmm(p["b1i"], self.inputs, p["w1i_x"]) + p["w1i_a"][self.arange_n, actions.t()]    # one-hot(a) @ W_a = row gather
         x = F.leaky_relu(x)
         gi = th.baddbmm(p["bii"], x, p["wii"])

@@ -111,6 +111,19 @@ class HipGraphRunner(HipVecRunner):
                 # class-code storage is consumed by the fused encoder only; other window sizes take the generic timestep
                 # (the torch controller expands the codes itself)
                 self.fast, self.fasts, self.fold_store = None, [], False
+        # Pipelined timestep (3 launches): env head -> env step -> [inc head of t + encoder of t + 1] as one launch
+        # (FastPolicy.act_inc_encode).  The encoder writes the OTHER buffer of FastPolicy.inputs_pair, so the buffer of a timestep is
+        # its parity -- baked into the captured graph, hence an even number of timesteps per graph.
+        K = max(1, int(getattr(a, "steps_per_graph", 10)))
+        while self.episode_limit % K:
+            K -= 1
+        self._graph_steps_planned = K
+        use_graph = bool(getattr(a, "rollout_graph", True))
+        self.pipe = bool(self.fast is not None and self.fold_store and self.fast.fused and self.fast.fused_enc and self.groups == 1
+                         and getattr(a, "pipeline_encode", True) and (K % 2 == 0 or not use_graph)
+                         and (self.obs_fmt == abi.OBS_CODE or self._want_code))
+        self.rng_copy = th.zeros(1, dtype=th.long, device=dev)          # pipelined: the env head's copy of rng_ctr for the inc head
+        self._par = 0
         self._ready = True
 
     def _bind_store(self, store):
@@ -141,6 +154,13 @@ class HipGraphRunner(HipVecRunner):
                                       dst_terminated=st["terminated"].data_ptr(), terminated=out["terminated"].data_ptr(),
                                       prev_reward_out=self.prev_reward.data_ptr(), ep_return=self.ep_return.data_ptr(),
                                       next_t_out=self.t_dev.data_ptr())
+                    if self.pipe:
+                        # counter hand-over without a launch writing a scalar it reads: the env head reads the masters (t_dev, rng_ctr)
+                        # and writes the copies (t_store, rng_copy); the inc head reads the copies and writes the masters' next values
+                        b.file_env = dict(b.file_env, t_index=self.t_dev.data_ptr(), t_copy_out=self.t_store.data_ptr(),
+                                          step_copy_out=self.rng_copy.data_ptr())
+                        b.file_inc = dict(b.file_inc, next_step_out=self.rng_ctr.data_ptr())
+                        b.file_inc_last = dict(b.file_inc_last, next_step_out=self.rng_ctr.data_ptr())
             self._bundles[key] = b
         self._bundle, self.cur, self._ss, self._ss_last, self._graph = b, b.cur, b.ss, b.ss_last, b.graph
 
@@ -179,6 +199,31 @@ class HipGraphRunner(HipVecRunner):
         actions = self.actions_full
         pos_t, orient_t = self.pos_t, self.orient_t                     # forward_inc sees the PRE-step pose (controller :78-82)
         bundle = self._bundle
+
+        if self.pipe:
+            par = self._par                                             # buffer of this timestep = its parity
+            codes = st["obs"] if self.obs_fmt == abi.OBS_CODE else self.cur["code"]
+
+            def env_head_p():
+                self.fast.head_env(self.prev_actions, self.prev_reward, self.prev_inc, pos, self.eps, self.rng_ctr, file=bundle.file_env,
+                                   orient=orient, actions_i32=self.actions_i32, pos_copy=pos_t, orient_copy=orient_t, buf=par)
+
+            def env_step_p():
+                self.env.step_batch(self.actions_i32, observe=True, fmt=self.obs_fmt, out=self.cur)
+
+            def inc_encode_p():
+                out = self.env.native.out
+                self.fast.act_inc_encode(actions, pos_t, orient_t, out["reward"], out["clean_num"], out["apple_den"], self.eps, self.rng_copy,
+                                         codes, slot_t=self.t_store, slot_add=1, buf=par, file=bundle.file_inc)
+
+            def inc_last_p():      # slot T: zeros for reward / clean_num / apple_den, nothing left to encode
+                z = self._zeros_nn
+                self.fast.act_inc(actions, pos_t, orient_t, z, z, z, self.eps, self.rng_copy, file=bundle.file_inc_last, buf=par)
+
+            if store_env_step:
+                return [("ssd::k_head<env>", "head_env", env_head_p), ("ssd::k_env<MODE_STEP_OBS>", "env", env_step_p),
+                        ("ssd::k_inc_encode", "inc_encode", inc_encode_p)]
+            return [("ssd::k_head<env>", "head_env", env_head_p), ("ssd::k_head<inc>", "head_inc", inc_last_p)]
 
         def encode(g):
             sl = self.gslices[g]
@@ -222,6 +267,7 @@ class HipGraphRunner(HipVecRunner):
         captured from; bench.py times them one by one with HIP events (a graph replay has no host call to bracket)."""
         if self.fast is None or not self.fast.fused or not self.fold_store:
             return []
+        self._par = self.t & 1
         return self._fast_stages(True)
 
     def _select_fast(self, store_env_step):
@@ -338,16 +384,19 @@ class HipGraphRunner(HipVecRunner):
             g = th.cuda.CUDAGraph()
             # K consecutive timesteps per graph (the device-side time index makes every step of the replay land in its own
             # slot); K divides the episode length, so an episode is episode_limit / K replays
-            K = max(1, int(getattr(self.args, "steps_per_graph", 10)))
-            while self.episode_limit % K:
-                K -= 1
+            K = self._graph_steps_planned
             self._graph_steps = K
             with th.no_grad(), th.cuda.graph(g, capture_error_mode="thread_local"):
-                for _ in range(K):
+                for k in range(K):
+                    self._par = k & 1        # a replay starts at a multiple of K (even when pipelined)
                     self._select(True)
             self._graph = self._bundle.graph = g
             # capture records but does not run: re-establish the episode start state
             self.t_dev.zero_()
+        if self.pipe:       # the encoder runs one timestep ahead of the heads: the observation of slot 0 is encoded here
+            with th.no_grad():
+                codes = self.store.data.transition_data["obs"] if self.obs_fmt == abi.OBS_CODE else self.cur["code"]
+                self.fast.encode(None, codes=codes, slot_t=self.t_dev, buf=0)
 
     @th.no_grad()
     def step_once(self):
@@ -357,12 +406,14 @@ class HipGraphRunner(HipVecRunner):
             if self.t % self._graph_steps == 0:       # one replay advances _graph_steps timesteps
                 self._graph.replay()
         else:
+            self._par = self.t & 1
             self._select(True)
         self.t += 1
         return self.t >= self.episode_limit
 
     @th.no_grad()
     def finish_episode(self):
+        self._par = self.t & 1
         self._select(False)
         self._out = dict(collective_return=self.env.native.out["collective_return"], equality=self.env.native.out["equality"])
         self._ep_return = self.ep_return

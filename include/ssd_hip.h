@@ -433,6 +433,10 @@ typedef struct ssd_policy_head {
      * input_shape + n_actions <= 64; obs_others_last_action (n * n_actions more columns) does not fit the 64-column image and is
      * rejected with SSD_ERR_UNSUPPORTED. */
     uint32_t input_flags;
+    /* Counter hand-over of the pipelined rollout (all nullable).  inc head: *next_step_out = *step + 1 (like next_t_out for the time
+     * index).  env head: *t_copy_out = *t_index, *step_copy_out = *step.  A launch never writes a scalar that it reads: the env head
+     * reads the masters and writes the copies, the inc head reads the copies and writes the masters. */
+    int64_t *next_step_out, *t_copy_out, *step_copy_out;
 } ssd_policy_head;
 #define SSD_INPUT_LAST_ACTION 1u   /* obs_last_action: one-hot of the previous env action, n_actions columns */
 #define SSD_INPUT_AGENT_ID    2u   /* obs_agent_id: one-hot of the agent, n columns */
@@ -444,6 +448,8 @@ typedef struct ssd_policy_head {
 #define SSD_INPUT_FLAGS_SHIPPED (SSD_INPUT_LAST_ACTION | SSD_INPUT_AGENT_ID | SSD_INPUT_REWARD | SSD_INPUT_INC_REWARD | SSD_INPUT_AGENT_POS)
 int ssd_policy_head_env(const ssd_policy_head* args, void* stream);
 int ssd_policy_head_inc(const ssd_policy_head* args, void* stream);
+/* The inc head of timestep t and ssd_policy_encode of timestep t + 1 as ONE launch (declared below the encoder's arguments):
+ * ssd_policy_head_inc_encode. */
 
 /* The reference-shaped parameters of one head (homophily_agent.py:37-125; every tensor [1, n, in, out] / [1, n, 1, out] f32,
  * contiguous, device memory).  w_i / w_h / b_i / b_h in (r, z, n) order.  env: fc1_in = input_shape, fc2_in = 64, fc2_out = n_actions;
@@ -503,8 +509,15 @@ typedef struct ssd_policy_encode_args {
     int32_t alphabet;              /* SSD_CODE_CLASS / SSD_CODE_CHANNEL_MASK */
     float* act;                    /* nullable (precision 2 only): LeakyReLU(conv) f32 [rows, 6, V-2, V-2], row = b * n + i: the
                                       activations the learner's backward needs (the training forward of the encoder) */
+    int32_t slot_add;              /* the time slot read is *slot_t + slot_add (the pipelined rollout encodes slot t + 1 while the
+                                      device time index still says t); the caller keeps it inside the storage */
 } ssd_policy_encode_args;
 int ssd_policy_encode(const ssd_policy_encode_args* args, void* stream);
+/* ssd_policy_head_inc(inc_args) and ssd_policy_encode(enc_args) as ONE launch -- the pipelined rollout's third launch of a timestep:
+ * both follow the env step of t and share no data (the inc head reads the input rows of t, the encoder reads the observation of slot
+ * t + 1 and must write a DIFFERENT `inputs` buffer / `part`), so one launch-to-launch gap of the timestep disappears.  enc_args: no
+ * act, no slot_t_copy / counter_inc (the heads hand the counters over, see ssd_policy_head); same precision as inc_args. */
+int ssd_policy_head_inc_encode(const ssd_policy_head* inc_args, const ssd_policy_encode_args* enc_args, void* stream);
 int ssd_policy_pack_encoder(const float* conv_w, const float* lin_w, int32_t view_edge, int32_t precision, void* conv_frags,
                             void* lin_frags, void* stream);
 

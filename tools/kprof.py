@@ -16,7 +16,8 @@ from homophily_marl_amd.run import load_config, setup  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="cleanup5", choices=sorted(CONFIGS))
 ap.add_argument("--reps", type=int, default=40)
-ap.add_argument("--only", default="encode,head_env,head_inc,env")
+ap.add_argument("--only", default="encode,head_env,head_inc,inc_encode,env")
+ap.add_argument("--pipeline", type=int, default=1, help="0: the four standalone launches (encode, env head, env, inc head)")
 ap.add_argument("--qnet-dtype", default="fp32")
 ap.add_argument("--n-env", type=int, default=None)
 ap.add_argument("--obs-storage", default="code", choices=["f32", "code"])
@@ -25,7 +26,7 @@ c = CONFIGS[args.config]
 N, n, T = args.n_env or c["n_env"], c["n_agents"], 100
 cfg = load_config(c["env"], overrides=dict(
     runner="hip_graph", rollout_graph=False, batch_size_run=N, batch_size=16, buffer_size=N, buffer_cpu_only=False, store_state=False,
-    qnet_dtype=args.qnet_dtype, obs_storage=args.obs_storage, env_args=dict(num_agents=n, map=c["map"], episode_limit=T, view_size=c["view_size"], seed=1),
+    qnet_dtype=args.qnet_dtype, obs_storage=args.obs_storage, pipeline_encode=bool(args.pipeline), env_args=dict(num_agents=n, map=c["map"], episode_limit=T, view_size=c["view_size"], seed=1),
     use_cuda=True, save_model=False, runner_stats=False, learner_log_interval=10 ** 12))
 th.manual_seed(0)
 ctx = setup(cfg)

@@ -20,7 +20,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/kp_w -- py
 python3 - "$OUT" <<'PY'
 import collections, csv, glob, json, sys
 out = sys.argv[1]
-keys = {"k_encode": "k_encode", "k_head<0": "k_head<env>", "k_head<1": "k_head<inc>", "k_env<2": "k_env<STEP_OBS>", "k_env<(ssd::MODE)2": "k_env<STEP_OBS>"}
+keys = {"k_inc_encode": "k_inc_encode", "k_encode": "k_encode", "k_head<0": "k_head<env>", "k_head<1": "k_head<inc>", "k_env<2": "k_env<STEP_OBS>", "k_env<(ssd::MODE)2": "k_env<STEP_OBS>"}
 res = collections.defaultdict(dict)
 for d in ("kp_p1", "kp_p2", "kp_p3", "kp_f", "kp_w"):
     fs = glob.glob("/tmp/%s/*/*counter_collection.csv" % d)

@@ -20,7 +20,7 @@ for f in sorted(os.listdir(src)):
         open(os.path.join(dst, "%s_%s" % (rnd, f)), "w").write(lines[-1] + "\n")
     elif f.endswith("_kernel_stats.csv"):
         shutil.copy(p, os.path.join(dst, "%s_%s" % (rnd, f)))
-names = {"k_encode": "ssd::k_encode", "k_head<env>": "ssd::k_head<env>", "k_head<inc>": "ssd::k_head<inc>", "k_env<STEP_OBS>": "ssd::k_env<MODE_STEP_OBS>"}
+names = {"k_inc_encode": "ssd::k_inc_encode", "k_encode": "ssd::k_encode", "k_head<env>": "ssd::k_head<env>", "k_head<inc>": "ssd::k_head<inc>", "k_env<STEP_OBS>": "ssd::k_env<MODE_STEP_OBS>"}
 traffic = dict(note="HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/kprof.py (the rollout's "
                     "launches on live data); FETCH_SIZE x2 (gfx950 reports half of a 16 B/lane coalesced stream, MI355X_MICROARCH.md "
                     "HBM), WRITE_SIZE as counted.  Infinity-Cache hits are counted: kernels that re-read their weights show L2-miss "
