@@ -330,10 +330,12 @@ def test_stepwise_forward_equals_time_batched_unroll():
             assert (a - q_env[:, t]).abs().max() < 1e-5 and (b - q_inc[:, t]).abs().max() < 1e-5, t
 
 
-@pytest.mark.parametrize("groups,kind,n,view,storage", [(1, "cleanup", 5, 7, "f32"), (2, "cleanup", 5, 7, "f32"), (1, "harvest", 5, 7, "f32"),
-                                                          (1, "cleanup", 10, 7, "f32"), (1, "harvest", 5, 15, "f32"),
-                                                          (1, "cleanup", 5, 7, "code"), (2, "harvest", 5, 15, "code")])
-def test_fast_graph_runner_stores_a_consistent_batch(groups, kind, n, view, storage):
+@pytest.mark.parametrize("groups,kind,n,view,storage,spg", [(1, "cleanup", 5, 7, "f32", 2), (2, "cleanup", 5, 7, "f32", 2), (1, "harvest", 5, 7, "f32", 2),
+                                                              (1, "cleanup", 10, 7, "f32", 2), (1, "harvest", 5, 15, "f32", 2),
+                                                              (1, "cleanup", 5, 7, "code", 2), (2, "harvest", 5, 15, "code", 2),
+                                                              (1, "harvest", 5, 15, "code", 14), (1, "cleanup", 5, 7, "code", 7),
+                                                              (1, "cleanup", 5, 7, "f32", 10)])
+def test_fast_graph_runner_stores_a_consistent_batch(groups, kind, n, view, storage, spg):
     """hip_graph + FastPolicy (encoder-fused obs store, store-step kernel): the stored batch must be self-consistent
     with the env dynamics (replayed on the CPU oracle with the stored actions), exactly like the generic runner's."""
     from homophily_marl_amd.run import load_config, setup
@@ -344,8 +346,11 @@ def test_fast_graph_runner_stores_a_consistent_batch(groups, kind, n, view, stor
     cfg = load_config(kind, overrides=dict(
         runner="hip_graph", batch_size_run=N, batch_size=8, buffer_size=N, buffer_cpu_only=False, store_state=False,
         env_args=dict(num_agents=n, map=mp, episode_limit=T, seed=21, view_size=view), use_cuda=True, save_model=False, runner_stats=False,
-        policy_groups=groups, obs_storage=storage))
+        policy_groups=groups, obs_storage=storage, steps_per_graph=spg))
     ctx = setup(cfg)
+    # an even number of timesteps per graph (2, 14; 10 -> 7 divides T = 14: odd) with one env group takes the pipelined timestep
+    # (env head, env step, [inc head of t + encoder of t + 1]); otherwise the four standalone launches
+    pipe = groups == 1 and spg in (2, 14)
     ofmt = abi.OBS_CODE if storage == "code" else abi.OBS_F32            # compact storage: u8 class codes instead of f32 planes
     assert ctx.runner.env.native.V == 2 * view + 1
     orc = OracleEnv(kind, map=mp, num_agents=n, n_env=N, view_size=view, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=21)
@@ -354,7 +359,7 @@ def test_fast_graph_runner_stores_a_consistent_batch(groups, kind, n, view, stor
         batch = ctx.runner.run(test_mode=False)
         # 15 x 15 and 31 x 31 windows both take the fused matrix-core encoder (it reads class codes: the env's side buffer under
         # f32 storage, the storage itself under code storage) and the heads file the small fields: 4 launches per timestep
-        assert ctx.runner.fast is not None and ctx.runner.fast.fused_enc and ctx.runner.fold_store == (groups == 1)
+        assert ctx.runner.fast is not None and ctx.runner.fast.fused_enc and ctx.runner.fold_store == (groups == 1) and ctx.runner.pipe == pipe
         assert ep == 0 or ctx.runner._graph is not None
         orc.reset()
         acts = batch["actions"].squeeze(-1).cpu().numpy()

@@ -32,11 +32,14 @@ for f in sorted(os.listdir(src)):
     tag = f[len("kprof_"):]
     cfg = tag.split("_")[0]
     storage = "f32" if tag.endswith("f32storage") else "code"
+    standalone = tag.endswith("standalone")
     for g in ("pmc.json", "kernel_stats.csv", "events.txt"):
         if os.path.exists(os.path.join(d, g)):
             shutil.copy(os.path.join(d, g), os.path.join(dst, "%s_kprof_%s_%s" % (rnd, tag, g)))
     pmc = json.load(open(os.path.join(d, "pmc.json")))
     for k, v in pmc.items():
+        if standalone and k not in ("k_encode", "k_head<inc>"):
+            continue                    # the standalone pass adds only the two kernels the pipelined timestep fuses
         if k in names and "hbm_bytes_per_launch" in v:
             key = "%s@%s" % (names[k], cfg) + ("" if storage == "code" else "@f32storage")
             traffic["kernels"][key] = dict(n_env=CONFIGS[cfg]["n_env"], obs_format=storage, hbm_bytes_per_launch=v["hbm_bytes_per_launch"],
