@@ -17,6 +17,6 @@ run pktcap0 DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 run pktcap1 DEBUG_CLR_GRAPH_PACKET_CAPTURE=1
 run batch1 DEBUG_HIP_GRAPH_BATCH_SIZE=1
 run batch1000 DEBUG_HIP_GRAPH_BATCH_SIZE=1000
-run sysscope0 ROC_SYSTEM_SCOPE_SIGNAL=0
+# ROC_SYSTEM_SCOPE_SIGNAL=0 was tried once: the process hangs (killed by the timeout) -- do not set it
 run graphq1 DEBUG_HIP_FORCE_GRAPH_QUEUES=1
 run base2 SSD_KNOB=none
