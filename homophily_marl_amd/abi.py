@@ -18,6 +18,7 @@ COLOR_SIMPLIFIED, COLOR_FULL = 0, 1
 CODE_CLASS, CODE_CHANNEL_MASK = 0, 1
 # ssd_policy_head.input_flags (include/ssd_hip.h, SSD_INPUT_*): the _build_inputs blocks in the reference's order
 INPUT_LAST_ACTION, INPUT_AGENT_ID, INPUT_REWARD, INPUT_INC_REWARD, INPUT_DISTANCE, INPUT_AGENT_POS = 1, 2, 4, 8, 16, 32
+INPUT_OTHERS_LAST_ACTION = 64     # ssd_build_inputs_flags only (the fused rollout heads do not build it)
 INPUT_EXPLICIT = 0x80000000   # marks a given flag word: the empty set is INPUT_EXPLICIT alone, 0 means the shipped set
 STREAM_UNIFORM, STREAM_MOVE, STREAM_WASTE, STREAM_SPAWN_ROT = 0, 1, 2, 3
 
@@ -199,6 +200,9 @@ HIP_SIGNATURES["ssd_policy_head_env"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.c
 HIP_SIGNATURES["ssd_policy_head_inc"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_fwd"] = (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_bwd"] = (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 3 + [C.c_void_p])
+HIP_SIGNATURES["ssd_build_inputs_width"] = (C.c_int, [C.c_int32, C.c_int32, C.c_uint32])
+HIP_SIGNATURES["ssd_build_inputs_flags"] = (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_copy_blocks"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_fwd"] = (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_bwd"] = (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p])

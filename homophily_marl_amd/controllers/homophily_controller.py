@@ -30,6 +30,11 @@ class HomophilyMAC(nn.Module):
         self.input_flags = None if getattr(args, "obs_others_last_action", False) else (
             1 * bool(args.obs_last_action) | 2 * bool(args.obs_agent_id) | 4 * bool(args.obs_reward) | 8 * bool(args.obs_inc_reward)
             | 16 * bool(getattr(args, "obs_distance", False)) | 32 * bool(args.obs_agent_pos))
+        # all seven blocks as ssd_build_inputs_flags bits (the learner-side input assembly on the device takes any set)
+        self.input_flags_all = ((self.input_flags if self.input_flags is not None else
+                                 (1 * bool(args.obs_last_action) | 2 * bool(args.obs_agent_id) | 4 * bool(args.obs_reward)
+                                  | 8 * bool(args.obs_inc_reward) | 16 * bool(getattr(args, "obs_distance", False)) | 32 * bool(args.obs_agent_pos)))
+                                | 64 * bool(getattr(args, "obs_others_last_action", False)))
         self.input_shape = self._get_input_shape(scheme)
         self.agent = agent_REGISTRY[args.agent](self.input_shape, args)
         self.agent_output_type = args.agent_output_type
@@ -122,9 +127,12 @@ class HomophilyMAC(nn.Module):
         n, A = self.n_agents, a.n_actions
         B = pos.shape[0]
         F0 = feat.shape[1]
-        if self.shipped_flags:
+        if self.shipped_flags or feat.is_cuda:      # the device kernel builds any flag set; on the CPU the shipped one has a fast path
+            if self.input_shape == F0:
+                return feat
             tail = th.empty(B * n, self.input_shape - F0, dtype=th.float32, device=feat.device)
-            ops.build_inputs_tail(tail, 0, last_actions, last_reward, last_actions_inc, pos, self.pos_scale, A, t0)
+            ops.build_inputs_tail(tail, 0, last_actions, last_reward, last_actions_inc, pos, self.pos_scale, A, t0,
+                                  flags=None if self.shipped_flags else self.input_flags_all)
             return th.cat([feat, tail], dim=1)
         dev = feat.device
         if t0:
@@ -182,9 +190,12 @@ class HomophilyMAC(nn.Module):
         sh = dict(obs=None if codes is not None else (obs.float() if a.rgb_input else obs), codes=codes, hist=hist, onehot=onehot, tail=None,
                   other=self.agent.unroll_other(onehot, batch["agent_pos"] / self.pos_scale, batch["agent_orientation"], batch["reward"],
                                                 batch["clean_num"], batch["apple_den"], th.float32))
-        if self.shipped_flags and a.rgb_input:      # the non-visual input columns do not depend on the weights either
+        on_dev = batch["reward"].is_cuda
+        if (self.shipped_flags or on_dev) and a.rgb_input and self.input_shape > a.obs_dim_net:
+            # the non-visual input columns do not depend on the weights either
             tail = th.empty(B * T * n, self.input_shape - a.obs_dim_net, dtype=th.float32, device=batch["obs"].device)
-            ops.build_inputs_tail(tail, 0, hist[0], hist[1], hist[2], hist[3], self.pos_scale, a.n_actions, False)
+            ops.build_inputs_tail(tail, 0, hist[0], hist[1], hist[2], hist[3], self.pos_scale, a.n_actions, False,
+                                  flags=None if self.shipped_flags else self.input_flags_all)
             sh["tail"] = tail
         return sh
 

@@ -342,6 +342,23 @@ int ssd_column_sums(const float* x, float* out, int32_t groups, int32_t rows, in
     return launched();
 }
 
+int ssd_build_inputs_width(int32_t n_agents, int32_t n_actions, uint32_t input_flags) {
+    if (n_agents < 1 || n_actions < 1 || ((input_flags & ~SSD_INPUT_EXPLICIT) & ~127u)) return -1;
+    return build_inputs_layout(n_agents, n_actions, input_flags).width;
+}
+
+int ssd_build_inputs_flags(int32_t batch, int32_t n_agents, int32_t n_actions, int32_t t0, uint32_t input_flags, const int64_t* last_actions,
+                           const float* last_reward, const int64_t* last_actions_inc, const float* pos, float pos_scale, float* out,
+                           int32_t out_stride, int32_t out_offset, void* stream) {
+    if (batch < 1 || n_agents < 1 || n_actions < 1 || !out || !pos) return fail(SSD_ERR_INVALID, "bad argument");
+    if ((input_flags & ~SSD_INPUT_EXPLICIT) & ~127u) return fail(SSD_ERR_UNSUPPORTED, "ssd_build_inputs_flags: unknown input_flags bit");
+    if (!(t0 & 1) && (!last_actions || !last_reward || !last_actions_inc)) return fail(SSD_ERR_INVALID, "t > 0 needs the t-1 tensors");
+    if (out_stride < out_offset + build_inputs_layout(n_agents, n_actions, input_flags).width) return fail(SSD_ERR_INVALID, "out_stride too small");
+    launch_build_inputs_flags(batch, n_agents, n_actions, t0, input_flags, last_actions, last_reward, last_actions_inc, pos, pos_scale, out,
+                              out_stride, out_offset, (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_copy_blocks(const ssd_block_copy* blocks, int32_t count, void* stream) {
     if (!blocks || count < 1 || count > SSD_COPY_BLOCKS_MAX) return fail(SSD_ERR_INVALID, "ssd_copy_blocks: 1..SSD_COPY_BLOCKS_MAX blocks");
     for (int i = 0; i < count; ++i) {

@@ -113,6 +113,11 @@ void launch_import(const DevSpec* spec, const DevSpec& hs, DevState st, ssd_stat
 void launch_build_inputs(int32_t batch, int32_t n, int32_t A, int32_t t0, const int64_t* last_actions,
                          const float* last_reward, const int64_t* last_actions_inc, const float* pos, float pos_scale,
                          float* out, int32_t out_stride, int32_t out_offset, hipStream_t stream);
+struct BuildInputsLayout { int o_act, o_id, o_r, o_i, o_oth, o_dist, o_pos, width; };   // first column of each block, < 0: absent
+BuildInputsLayout build_inputs_layout(int n, int A, uint32_t input_flags);
+void launch_build_inputs_flags(int32_t batch, int32_t n, int32_t A, int32_t t0, uint32_t input_flags, const int64_t* last_actions,
+                               const float* last_reward, const int64_t* last_actions_inc, const float* pos, float pos_scale,
+                               float* out, int32_t out_stride, int32_t out_offset, hipStream_t stream);
 void launch_incentive_transfer(int32_t B, int32_t T, int32_t n, const int64_t* a_inc, const float* rewards,
                                float effect_ratio, float cost_ratio, float incentive, float seq_len, float* give,
                                float* recv_pos, float* recv_neg, float* recv_zero, float* r_env, float* r_inc,

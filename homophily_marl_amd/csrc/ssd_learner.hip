@@ -40,6 +40,61 @@ __global__ void k_build_inputs(int32_t rows, int32_t n, int32_t A, int32_t t0, c
     }
 }
 
+// The same rows for any _build_inputs flag set: every block at the column the layout gives it (negative = absent).
+__global__ void k_build_inputs_flags(int32_t rows, int32_t n, int32_t A, int32_t t0, BuildInputsLayout L,
+                                     const int64_t* __restrict__ last_actions, const float* __restrict__ last_reward,
+                                     const int64_t* __restrict__ last_actions_inc, const float* __restrict__ pos, float pos_scale,
+                                     float* __restrict__ out, int32_t out_stride, int32_t out_offset) {
+    const int width = L.width;
+    const size_t total = (size_t)rows * width;
+    const int agent_major = t0 & 2, t_zero = t0 & 1;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / width), k = (int)(idx - (size_t)row * width);
+        const int b = row / n, i = row - b * n;
+        float v = 0.f;
+        if (L.o_act >= 0 && k >= L.o_act && k < L.o_act + A) v = (!t_zero && last_actions[row] == k - L.o_act) ? 1.f : 0.f;   // (:137-141)
+        else if (L.o_id >= 0 && k >= L.o_id && k < L.o_id + n) v = (k - L.o_id == i) ? 1.f : 0.f;                              // (:142-143)
+        else if (k == L.o_r) {                                                                                                   // (:145-150)
+            const float r = t_zero ? 0.f : last_reward[row];
+            v = (float)((r > 0.f) - (r < 0.f));
+        } else if (k == L.o_i) {                                                                                                 // (:152-164)
+            int recv = 0;
+            if (!t_zero)
+                for (int g = 0; g < n; ++g) {
+                    if (g == i) continue;
+                    const int64_t x = last_actions_inc[((size_t)b * n + g) * n + i];
+                    recv += (x == 1) - (x == 2);
+                }
+            v = (float)((recv > 0) - (recv < 0));
+        } else if (L.o_oth >= 0 && k >= L.o_oth && k < L.o_oth + n * A) {          // everybody's last action, agent order (:166-173)
+            const int g = (k - L.o_oth) / A, a = (k - L.o_oth) - g * A;
+            v = (!t_zero && last_actions[(size_t)b * n + g] == a) ? 1.f : 0.f;
+        } else if (L.o_dist >= 0 && k >= L.o_dist && k < L.o_dist + n) {           // 1 - |pos_i - pos_g| / ||(H, W)|| (:174-178)
+            const int g = k - L.o_dist;
+            const float dx = pos[(size_t)row * 2] - pos[((size_t)b * n + g) * 2], dy = pos[(size_t)row * 2 + 1] - pos[((size_t)b * n + g) * 2 + 1];
+            v = 1.f - sqrtf(dx * dx + dy * dy) / pos_scale;
+        } else if (L.o_pos >= 0 && k >= L.o_pos && k < L.o_pos + 2) v = pos[(size_t)row * 2 + (k - L.o_pos)] / pos_scale;       // (:179-181)
+        const size_t orow = agent_major ? (size_t)i * (rows / n) + b : (size_t)row;
+        out[orow * out_stride + out_offset + k] = v;
+    }
+}
+
+BuildInputsLayout build_inputs_layout(int n, int A, uint32_t input_flags) {
+    const uint32_t fl = input_flags ? (input_flags & ~SSD_INPUT_EXPLICIT) : (uint32_t)SSD_INPUT_FLAGS_SHIPPED;
+    BuildInputsLayout L;
+    int col = 0;
+    auto take = [&](uint32_t bit, int w) { const int o = (fl & bit) ? col : -1; if (fl & bit) col += w; return o; };
+    L.o_act = take(SSD_INPUT_LAST_ACTION, A);                            // the reference's order (homophily_controller.py:137-184)
+    L.o_id = take(SSD_INPUT_AGENT_ID, n);
+    L.o_r = take(SSD_INPUT_REWARD, 1);
+    L.o_i = take(SSD_INPUT_INC_REWARD, 1);
+    L.o_oth = take(SSD_INPUT_OTHERS_LAST_ACTION, n * A);
+    L.o_dist = take(SSD_INPUT_DISTANCE, n);
+    L.o_pos = take(SSD_INPUT_AGENT_POS, 2);
+    L.width = col;
+    return L;
+}
+
 __global__ void k_incentive_transfer(int32_t B, int32_t T, int32_t n, const int64_t* __restrict__ a_inc,
                                      const float* __restrict__ rewards, float effect_ratio, float cost_ratio,
                                      float incentive, float seq_len, float* __restrict__ give, float* __restrict__ recv_pos,
@@ -260,6 +315,16 @@ void launch_build_inputs(int32_t batch, int32_t n, int32_t A, int32_t t0, const 
                          float* out, int32_t out_stride, int32_t out_offset, hipStream_t stream) {
     const size_t total = (size_t)batch * n * (A + n + 4);
     hipLaunchKernelGGL(k_build_inputs, dim3(grid_for(total)), dim3(256), 0, stream, batch * n, n, A, t0, last_actions,
+                       last_reward, last_actions_inc, pos, pos_scale, out, out_stride, out_offset);
+}
+
+void launch_build_inputs_flags(int32_t batch, int32_t n, int32_t A, int32_t t0, uint32_t input_flags, const int64_t* last_actions,
+                               const float* last_reward, const int64_t* last_actions_inc, const float* pos, float pos_scale,
+                               float* out, int32_t out_stride, int32_t out_offset, hipStream_t stream) {
+    const BuildInputsLayout L = build_inputs_layout(n, A, input_flags);
+    if (L.width < 1) return;                                            // no tail blocks at all
+    const size_t total = (size_t)batch * n * L.width;
+    hipLaunchKernelGGL(k_build_inputs_flags, dim3(grid_for(total)), dim3(256), 0, stream, batch * n, n, A, t0, L, last_actions,
                        last_reward, last_actions_inc, pos, pos_scale, out, out_stride, out_offset);
 }
 

@@ -444,8 +444,17 @@ typedef struct ssd_policy_head {
 #define SSD_INPUT_INC_REWARD  8u   /* obs_inc_reward: sign(#rewards - #punishments received at the previous step) */
 #define SSD_INPUT_DISTANCE    16u  /* obs_distance: 1 - |pos - pos_g| / pos_scale for every agent g, n columns */
 #define SSD_INPUT_AGENT_POS   32u  /* obs_agent_pos: pos / pos_scale, 2 columns */
+#define SSD_INPUT_OTHERS_LAST_ACTION 64u   /* obs_others_last_action: every agent's last-action one-hot, n * n_actions columns, between
+                                             the received-incentive sign and the distances -- ssd_build_inputs_flags only */
 #define SSD_INPUT_EXPLICIT    0x80000000u   /* marks a given flag word (the empty set is SSD_INPUT_EXPLICIT alone) */
 #define SSD_INPUT_FLAGS_SHIPPED (SSD_INPUT_LAST_ACTION | SSD_INPUT_AGENT_ID | SSD_INPUT_REWARD | SSD_INPUT_INC_REWARD | SSD_INPUT_AGENT_POS)
+/* ssd_build_inputs for ANY _build_inputs flag set (homophily_controller.py:137-184; the learner's time-batched input assembly):
+ * input_flags as in ssd_policy_head (0 = the shipped set) plus SSD_INPUT_OTHERS_LAST_ACTION.  Writes the blocks, in the reference's
+ * order, into out[:, out_offset : out_offset + width]; width = ssd_build_inputs_width(...). */
+int ssd_build_inputs_width(int32_t n_agents, int32_t n_actions, uint32_t input_flags);
+int ssd_build_inputs_flags(int32_t batch, int32_t n_agents, int32_t n_actions, int32_t t0, uint32_t input_flags,
+                           const int64_t* last_actions, const float* last_reward, const int64_t* last_actions_inc, const float* pos,
+                           float pos_scale, float* out, int32_t out_stride, int32_t out_offset, void* stream);
 int ssd_policy_head_env(const ssd_policy_head* args, void* stream);
 int ssd_policy_head_inc(const ssd_policy_head* args, void* stream);
 /* The inc head of timestep t and ssd_policy_encode of timestep t + 1 as ONE launch (declared below the encoder's arguments):

@@ -543,3 +543,38 @@ def test_cat_groups_op_forward_and_backward_match_th_cat():
     assert all(th.equal(a, b) for a, b in zip(got, th.autograd.grad((th.cat(groups[5], dim=-1) * ws[5]).sum(), flat[15:])))
     lib = abi.load_library()
     assert lib.ssd_copy_blocks(None, 1, None) == abi.SSD_ERR_INVALID and lib.ssd_copy_blocks((abi.SsdBlockCopy * 1)(), 33, None) == abi.SSD_ERR_INVALID
+
+
+def test_build_inputs_flags_kernel_matches_the_reference_controller():
+    """ssd_build_inputs_flags (the device-side _build_inputs tail for ANY flag set, incl. obs_others_last_action / obs_distance and
+    blocks switched off) against the REFERENCE controller's output on the cleanup fixture batch (tests/golden/inputs_flags.npz,
+    oracle/gen_inputs_golden.py): stepwise (_build_inputs at the fixture's timesteps) and time-batched (the learner's unroll agrees
+    with stepping forward())."""
+    import json
+    import os
+    from types import SimpleNamespace
+    from homophily_marl_amd.controllers import REGISTRY as mac_REGISTRY
+    from tests.learner_util import build, load_fixture
+    z, meta = load_fixture("learner_cleanup5.npz")
+    zi = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs_flags.npz"))
+    flag_sets = json.loads(bytes(zi["flag_sets"]).decode())
+    args, batch, _, _ = build(z, meta, device="cuda:0")
+    lib = abi.load_library()
+    for i, flags in enumerate(flag_sets):
+        a = SimpleNamespace(**dict(vars(args), **flags))
+        mac = mac_REGISTRY[a.mac](batch.scheme, {"agents": a.n_agents}, a)
+        mac.cuda()
+        assert not mac.shipped_flags
+        assert lib.ssd_build_inputs_width(a.n_agents, a.n_actions, abi.INPUT_EXPLICIT | mac.input_flags_all) == mac.input_shape - a.obs_dim_net
+        for t in zi["ts"]:
+            ref = zi["tail_%d_t%d" % (i, t)]
+            with th.no_grad():
+                got = mac._build_inputs(batch, int(t))[:, a.obs_dim_net:].cpu().numpy()
+            assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-6, (i, int(t), flags)
+        with th.no_grad():
+            q_env, q_inc = mac.unroll(batch)
+            mac.init_hidden(batch.batch_size)
+            for t in range(3):
+                qe, qi, _ = mac.forward(batch, t)
+                assert (qe - q_env[:, t]).abs().max() < 1e-5 and (qi - q_inc[:, t]).abs().max() < 1e-5
+    assert lib.ssd_build_inputs_width(5, 9, abi.INPUT_EXPLICIT | 128) == -1
