@@ -74,7 +74,7 @@ def run_e2e(args, c, rank, world, local_rank):
         buf.insert_episode_batch(batch)
         if buf.can_sample(a.batch_size):
             for _ in range(tspr):
-                sample = buf.sample(a.batch_size)[:, :T + 1]
+                sample = buf.sample(a.batch_size, out=learner.sample_out())[:, :T + 1]
                 learner.train(sample, runner.t_env, ctx.train_steps if a.schedule_unit == "rollouts" else state["episode"])
                 ctx.train_steps += 1
                 state["trains"] += 1

@@ -192,11 +192,19 @@ class ReplayBuffer(EpisodeBatch):
     def can_sample(self, batch_size):
         return self.episodes_in_buffer >= batch_size
 
-    def sample(self, batch_size):
+    def sample(self, batch_size, out=None):
+        """batch_size episodes drawn without replacement (episode_buffer.py:240-244).  out: an EpisodeBatch of batch_size whole
+        episodes (a learner's static copy of the sampled batch) that receives the episodes directly -- one gather per field
+        instead of a gather into fresh tensors and a second copy into the consumer's buffers."""
         assert self.can_sample(batch_size)
         if self.episodes_in_buffer == batch_size:
             return self[:batch_size]
         ep_ids = np.random.choice(self.episodes_in_buffer, batch_size, replace=False)   # episode_buffer.py:243
+        if out is not None and out.batch_size == batch_size and out.max_seq_length == self.max_seq_length and not self.data.episode_data:
+            ids = th.as_tensor(ep_ids, dtype=th.long, device=self.device)
+            for k, v in self.data.transition_data.items():
+                th.index_select(v, 0, ids, out=out.data.transition_data[k])
+            return out
         return self[ep_ids]
 
     def sample_latest(self, batch_size):

@@ -77,6 +77,7 @@ class HomophilyLearner:
         self.optimiser_inc = Adam(params=self.params_inc, lr=args.lr_inc, capturable=self.use_graph, fused=self.fused_adam or None)
         self._flat_grad = None
         self._graph = None
+        self._static_batch = None
         self._graph_calls = 0
         # target network: a second controller with the same weights (the reference deep-copies the controller, :47)
         self.target_mac = mac_REGISTRY[args.mac](scheme, None, args)
@@ -309,7 +310,9 @@ class HomophilyLearner:
                 self.clip_and_step()
             self._graph = (g1, g2)
         for k, v in batch.data.transition_data.items():
-            self._static_data[k].copy_(v)
+            dst = self._static_data[k]
+            if v.data_ptr() != dst.data_ptr() or v.shape != dst.shape:      # not sampled straight into the static batch (sample_out)
+                dst.copy_(v)
         self._static_dens.copy_(self.denominators(self._static_batch))
         self._graph[0].replay()
         if os.environ.get("SSD_GRAPH_CHECK"):      # diagnostic: the replayed gradient against an eager evaluation of the same step
@@ -332,6 +335,11 @@ class HomophilyLearner:
             dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
         self._graph[1].replay()
         return self._static_logs
+
+    def sample_out(self):
+        """The static batch of the captured train step once it exists (else None): ReplayBuffer.sample(batch_size, out=...) gathers
+        the sampled episodes straight into it and train() then copies nothing."""
+        return self._static_batch if self._graph is not None else None
 
     def train(self, batch, t_env, episode_num):
         logs = self._graph_step(batch) if self.use_graph else self.cal_loss_and_step(batch)

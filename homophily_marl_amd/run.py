@@ -101,7 +101,7 @@ def train_iteration(ctx, episode):
     ctx.buffer.insert_episode_batch(batch)
     if ctx.buffer.can_sample(a.batch_size):
         for _ in range(a.train_steps_per_rollout):
-            sample = ctx.buffer.sample(a.batch_size)
+            sample = ctx.buffer.sample(a.batch_size, out=ctx.learner.sample_out() if hasattr(ctx.learner, "sample_out") else None)
             sample = sample[:, :sample.max_t_filled()]
             if str(sample.device) != str(a.device):
                 sample.to(a.device)

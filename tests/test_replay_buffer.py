@@ -50,3 +50,21 @@ def test_reserve_is_insert_without_the_copy():
     assert odd.buffer_index == 2 and odd.episodes_in_buffer == 6
     np.random.seed(0)
     assert odd.sample(3).batch_size == 3
+
+
+def test_sample_into_a_given_batch_draws_the_same_episodes():
+    """sample(batch_size, out=...) gathers straight into a consumer's batch (the learner's static copy of the captured train step):
+    same np.random draw, same episodes as the plain sample (episode_buffer.py:240-244), no new tensors."""
+    buf = ReplayBuffer(_scheme(), {"agents": 2}, 12, 4)
+    for seed in (1, 2, 3):
+        buf.insert_episode_batch(_episodes(4, 4, seed))
+    np.random.seed(7)
+    ref = buf.sample(5)
+    out = EpisodeBatch(_scheme(), {"agents": 2}, 5, 4)
+    ptrs = {k: v.data_ptr() for k, v in out.data.transition_data.items()}
+    np.random.seed(7)
+    got = buf.sample(5, out=out)
+    assert got is out and all(v.data_ptr() == ptrs[k] for k, v in out.data.transition_data.items())
+    for k in ref.data.transition_data:
+        assert th.equal(ref[k], got[k]), k
+    assert buf.sample(5, out=EpisodeBatch(_scheme(), {"agents": 2}, 4, 4)).batch_size == 5      # a batch of another size is not used
