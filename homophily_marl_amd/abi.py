@@ -116,6 +116,20 @@ class SsdStoreStep(C.Structure):
 
 
 COPY_BLOCKS_MAX = 32
+ADAM_MAX_JOBS = 64
+
+
+class SsdAdamJob(C.Structure):
+    """ssd_adam_job (include/ssd_hip.h): one parameter tensor of ssd_clip_adam_step."""
+    _fields_ = [("param", C.c_void_p), ("offset", C.c_int64), ("numel", C.c_int32), ("segment", C.c_int32),
+                ("exp_avg", C.c_void_p * 2), ("exp_avg_sq", C.c_void_p * 2), ("step", C.c_void_p * 2)]
+
+
+class SsdClipAdamArgs(C.Structure):
+    """ssd_clip_adam_args (include/ssd_hip.h)."""
+    _fields_ = [("flat_grad", C.c_void_p), ("total", C.c_int64), ("jobs", C.c_void_p),
+                ("n_jobs", C.c_int32), ("partials", C.c_void_p), ("lr_inc", C.c_float), ("lr_env", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("clip", C.c_float)]
 
 
 class SsdBlockCopy(C.Structure):
@@ -203,6 +217,7 @@ HIP_SIGNATURES["ssd_gru_seq_bwd"] = (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 3
 HIP_SIGNATURES["ssd_build_inputs_width"] = (C.c_int, [C.c_int32, C.c_int32, C.c_uint32])
 HIP_SIGNATURES["ssd_build_inputs_flags"] = (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
+HIP_SIGNATURES["ssd_clip_adam_step"] = (C.c_int, [C.POINTER(SsdClipAdamArgs), C.c_void_p])
 HIP_SIGNATURES["ssd_copy_blocks"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_fwd"] = (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_bwd"] = (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p])

@@ -359,6 +359,16 @@ int ssd_build_inputs_flags(int32_t batch, int32_t n_agents, int32_t n_actions, i
     return launched();
 }
 
+int ssd_clip_adam_step(const ssd_clip_adam_args* a, void* stream) {
+    if (!a || !a->flat_grad || !a->jobs || !a->partials || a->total < 1 || a->n_jobs < 1 || a->n_jobs > SSD_ADAM_MAX_JOBS)
+        return fail(SSD_ERR_INVALID, "ssd_clip_adam_step: bad argument");
+    if (a->total > (int64_t)INT32_MAX) return fail(SSD_ERR_INVALID, "ssd_clip_adam_step: total");
+    if (!(a->beta1 >= 0.f && a->beta1 < 1.f) || !(a->beta2 >= 0.f && a->beta2 < 1.f) || !(a->eps > 0.f) || !(a->clip > 0.f))
+        return fail(SSD_ERR_INVALID, "ssd_clip_adam_step: betas / eps / clip");
+    launch_clip_adam(a, (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_copy_blocks(const ssd_block_copy* blocks, int32_t count, void* stream) {
     if (!blocks || count < 1 || count > SSD_COPY_BLOCKS_MAX) return fail(SSD_ERR_INVALID, "ssd_copy_blocks: 1..SSD_COPY_BLOCKS_MAX blocks");
     for (int i = 0; i < count; ++i) {

@@ -305,6 +305,130 @@ void launch_copy_blocks(const ssd_block_copy* blocks, int count, hipStream_t str
     hipLaunchKernelGGL(k_copy_blocks, dim3(gx, count), dim3(256), 0, stream, t);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_gradsq_partials / k_clip_adam: both gradient clips and both Adam steps of the learner over the flat gradient buffer
+// (include/ssd_hip.h: ssd_clip_adam_step; homophily_learner.py:223-226).  1024 elements per workgroup, 4 per thread.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int ADAM_CHUNK = 1024;
+__device__ __forceinline__ float block_sum_256(float v, float* red) {      // fixed-order tree over 256 threads
+    const int t = threadIdx.x;
+    red[t] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// job (parameter tensor) of flat element `base`, given the ascending first elements j_off[0 .. n_jobs]
+__device__ __forceinline__ int adam_job_of(const long* j_off, int n_jobs, long base) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (j_off[mid] <= base) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_gradsq_partials(ssd_clip_adam_args a) {
+    __shared__ float red[256];
+    __shared__ long j_off[SSD_ADAM_MAX_JOBS + 1];
+    __shared__ int j_seg[SSD_ADAM_MAX_JOBS];
+    if ((int)threadIdx.x < a.n_jobs) {
+        const ssd_adam_job j = a.jobs[threadIdx.x];
+        j_off[threadIdx.x] = j.offset; j_seg[threadIdx.x] = j.segment;
+        if ((int)threadIdx.x == a.n_jobs - 1) j_off[a.n_jobs] = j.offset + j.numel;
+    }
+    __syncthreads();
+    const long base = (long)blockIdx.x * ADAM_CHUNK + threadIdx.x * 4;
+    float s[3] = {0.f, 0.f, 0.f};
+    if (base < a.total) {
+        int job = adam_job_of(j_off, a.n_jobs, base);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long i = base + r;
+            if (i < a.total) {
+                while (i >= j_off[job + 1]) ++job;
+                const float g = a.flat_grad[i];
+                const float gg = g * g;
+                const int seg = j_seg[job];
+                s[0] += seg == 0 ? gg : 0.f; s[1] += seg == 1 ? gg : 0.f; s[2] += seg == 2 ? gg : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = block_sum_256(s[k], red);
+        if (threadIdx.x == 0) a.partials[(size_t)blockIdx.x * 3 + k] = v;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < a.n_jobs) {                   // step counters (read by the second launch only)
+        const ssd_adam_job j = a.jobs[threadIdx.x];
+        if (j.step[0]) *j.step[0] += 1.f;
+        if (j.step[1]) *j.step[1] += 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_clip_adam(ssd_clip_adam_args a, int chunks) {
+    __shared__ float red[256];
+    __shared__ long j_off[SSD_ADAM_MAX_JOBS + 1];
+    __shared__ float j_size[SSD_ADAM_MAX_JOBS][2], j_rsq[SSD_ADAM_MAX_JOBS][2];   // lr / (1 - b1^t), 1 / sqrt(1 - b2^t) per optimiser
+    const int t = threadIdx.x;
+    float S[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                                          // the chunk sums in a fixed order
+        float v = 0.f;
+        for (int c = t; c < chunks; c += 256) v += a.partials[(size_t)c * 3 + k];
+        S[k] = block_sum_256(v, red);
+    }
+    const float c_inc = fminf(1.f, a.clip / (sqrtf(S[0] + S[2]) + 1e-6f));
+    const float c_env = fminf(1.f, a.clip / (sqrtf(c_inc * c_inc * S[0] + S[1]) + 1e-6f));
+    if (t < a.n_jobs) {
+        const ssd_adam_job j = a.jobs[t];
+        j_off[t] = j.offset;
+        if (t == a.n_jobs - 1) j_off[a.n_jobs] = j.offset + j.numel;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const float st = j.step[o] ? *j.step[o] : 1.f;
+            const float bc1 = (float)(1.0 - pow((double)a.beta1, (double)st)), bc2 = (float)(1.0 - pow((double)a.beta2, (double)st));
+            j_size[t][o] = (o == 0 ? a.lr_inc : a.lr_env) / bc1;
+            j_rsq[t][o] = sqrtf(bc2);
+        }
+    }
+    __syncthreads();
+    const long base = (long)blockIdx.x * ADAM_CHUNK + t * 4;
+    if (base >= a.total) return;
+    int job = adam_job_of(j_off, a.n_jobs, base);
+    const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2;
+    for (int r = 0; r < 4; ++r) {
+        const long i = base + r;
+        if (i >= a.total) break;
+        while (i >= j_off[job + 1]) ++job;
+        const ssd_adam_job j = a.jobs[job];
+        const long e = i - j.offset;
+        float g = a.flat_grad[i];
+        g = j.segment == 0 ? (g * c_inc) * c_env : (j.segment == 1 ? g * c_env : g * c_inc);   // clip inc first, then env
+        a.flat_grad[i] = g;
+        float p = j.param[e];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {                                      // optimiser_inc.step(), then optimiser_env.step()
+            if (!j.exp_avg[o]) continue;
+            float m = j.exp_avg[o][e], v = j.exp_avg_sq[o][e];
+            m = m + w1 * (g - m);                                          // lerp(m, g, 1 - beta1)
+            v = a.beta2 * v + (w2 * g) * g;
+            j.exp_avg[o][e] = m; j.exp_avg_sq[o][e] = v;
+            const float denom = sqrtf(v) / j_rsq[job][o] + a.eps;
+            p -= (j_size[job][o] * m) / denom;
+        }
+        j.param[e] = p;
+    }
+}
+
+void launch_clip_adam(const ssd_clip_adam_args* a, hipStream_t stream) {
+    const int chunks = (int)((a->total + ADAM_CHUNK - 1) / ADAM_CHUNK);
+    hipLaunchKernelGGL(k_gradsq_partials, dim3(chunks), dim3(256), 0, stream, *a);
+    hipLaunchKernelGGL(k_clip_adam, dim3(chunks), dim3(256), 0, stream, *a, chunks);
+}
+
 static int grid_for(size_t total) {
     size_t b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : b > 4096 ? 4096 : b);

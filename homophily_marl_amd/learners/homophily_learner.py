@@ -77,6 +77,7 @@ class HomophilyLearner:
         self.optimiser_inc = Adam(params=self.params_inc, lr=args.lr_inc, capturable=self.use_graph, fused=self.fused_adam or None)
         self._flat_grad = None
         self._graph = None
+        self._opt_plan = None          # see _optimiser_plan (None: look again, False: tensor-op tail)
         self._static_batch = None
         self._graph_calls = 0
         # target network: a second controller with the same weights (the reference deep-copies the controller, :47)
@@ -270,7 +271,65 @@ class HomophilyLearner:
             logs["loss_sim"] = sim_loss.detach()
         return logs
 
+    def _optimiser_plan(self):
+        """Arguments of ssd_clip_adam_step (both clips + both Adam steps as two launches over the flat gradient buffer), or None when
+        the tensor-op tail below has to run: CPU, optimiser state not created yet (the first step creates it), options the kernel does
+        not implement.  The plan holds pointers into the optimisers' own state tensors (checkpoints see the same state)."""
+        if self._opt_plan is not None:
+            return self._opt_plan or None
+        self._opt_plan = False
+        a = self.args
+        if not (getattr(a, "fused_optimiser", True) and self._flat_grad is not None and self._flat_grad.is_cuda):
+            return None
+        import ctypes as C
+        from .. import abi
+        opts = (self.optimiser_inc, self.optimiser_env)
+        for opt in opts:
+            g = opt.param_groups
+            if len(g) != 1 or g[0].get("weight_decay", 0) != 0 or g[0].get("amsgrad") or g[0].get("maximize") or \
+                    tuple(g[0]["betas"]) != tuple(opts[0].param_groups[0]["betas"]) or g[0]["eps"] != opts[0].param_groups[0]["eps"]:
+                return None
+        inc_ids, env_ids = {id(p) for p in self.params_inc}, {id(p) for p in self.params_env}
+        if len(self.params) > abi.ADAM_MAX_JOBS:
+            return None
+        jobs = (abi.SsdAdamJob * len(self.params))()
+        off = 0
+        for j, p in zip(jobs, self.params):
+            seg = 0 if (id(p) in inc_ids and id(p) in env_ids) else (1 if id(p) in env_ids else 2)
+            if not (p.is_cuda and p.dtype == th.float32 and p.is_contiguous()) or \
+                    p.grad is None or p.grad.data_ptr() != self._flat_grad.data_ptr() + 4 * off:
+                self._opt_plan = None if p.grad is None else False
+                return None
+            for o, (opt, member) in enumerate(zip(opts, (id(p) in inc_ids, id(p) in env_ids))):
+                if not member:
+                    continue
+                st = opt.state.get(p)
+                if not st or not all(th.is_tensor(st.get(k)) and st[k].is_cuda and st[k].dtype == th.float32 and st[k].is_contiguous()
+                                     for k in ("step", "exp_avg", "exp_avg_sq")):
+                    self._opt_plan = None      # state is created by the first torch step: look again next time
+                    return None
+                j.exp_avg[o], j.exp_avg_sq[o], j.step[o] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()
+            j.param, j.offset, j.numel, j.segment = p.data_ptr(), off, p.numel(), seg
+            off += p.numel()
+        dev = self._flat_grad.device
+        table = th.frombuffer(bytearray(bytes(jobs)), dtype=th.uint8).to(dev)
+        args = abi.SsdClipAdamArgs()
+        args.flat_grad, args.total = self._flat_grad.data_ptr(), off
+        args.jobs, args.n_jobs = table.data_ptr(), len(self.params)
+        partials = th.zeros((off + 1023) // 1024, 3, dtype=th.float32, device=dev)
+        args.partials = partials.data_ptr()
+        gi, ge = opts[0].param_groups[0], opts[1].param_groups[0]
+        args.lr_inc, args.lr_env, args.beta1, args.beta2, args.eps = float(gi["lr"]), float(ge["lr"]), float(gi["betas"][0]), float(gi["betas"][1]), float(gi["eps"])
+        args.clip = float(a.grad_norm_clip)
+        self._opt_plan = SimpleNamespace(args=args, keep=(table, partials), lib=abi.load_library(), byref=C.byref)
+        return self._opt_plan
+
     def clip_and_step(self):
+        plan = self._optimiser_plan()
+        if plan is not None:
+            from .. import abi
+            abi.check(plan.lib, plan.lib.ssd_clip_adam_step(plan.byref(plan.args), th.cuda.current_stream(self._flat_grad.device).cuda_stream))
+            return
         a = self.args
         th.nn.utils.clip_grad_norm_(self.params_inc, a.grad_norm_clip)
         th.nn.utils.clip_grad_norm_(self.params_env, a.grad_norm_clip)
@@ -386,4 +445,4 @@ class HomophilyLearner:
                     if st and "step" in st:
                         step = st["step"] if th.is_tensor(st["step"]) else th.tensor(float(st["step"]))
                         st["step"] = step.to(device=p.device if (self.use_graph or self.fused_adam) else "cpu", dtype=th.float32)
-        self._graph, self._graph_calls = None, 0
+        self._graph, self._graph_calls, self._opt_plan = None, 0, None

@@ -220,6 +220,37 @@ typedef struct ssd_block_copy {
 } ssd_block_copy;
 int ssd_copy_blocks(const ssd_block_copy* blocks, int32_t count, void* stream);
 
+/* ssd_clip_adam_step: the optimiser tail of HomophilyLearner.cal_loss_and_step (homophily_learner.py:223-226) --
+ *   clip_grad_norm_(params_inc, clip); clip_grad_norm_(params_env, clip); optimiser_inc.step(); optimiser_env.step()
+ * with the conv encoder a member of BOTH parameter groups (homophily_agent.py:127-146: its gradient is scaled by both clips, the second
+ * norm sees the first scaling, and both Adams move it, each with its own moments) -- as TWO launches over the flat gradient buffer
+ * instead of ~20 (2 x multi-tensor norm + scalar arithmetic + multi-tensor scale, 2 x fused Adam + step counters):
+ *   1. per 1024-element chunk, the sums of squares of the three segments (encoder / env head / inc head, per job); every step counter += 1
+ *   2. every workgroup adds the chunk sums in a fixed order (deterministic; no atomics, no cross-workgroup hand-off), forms
+ *      c_inc = min(1, clip / (sqrt(S_enc + S_inc) + 1e-6)), c_env = min(1, clip / (sqrt(c_inc^2 S_enc + S_env) + 1e-6)), writes the
+ *      scaled gradients back and applies torch.optim.Adam's update (no weight decay / amsgrad; lerp form of the first moment,
+ *      bias corrections from the per-parameter step counters) -- inc optimiser first, then env, as the reference steps them.
+ * jobs: DEVICE array, one per parameter tensor in flat-buffer order; state index 0 = the inc optimiser's (exp_avg, exp_avg_sq, step),
+ * 1 = the env optimiser's; a parameter outside an optimiser has NULLs there.  partials: f32 [ceil(total / 1024)][3] workspace. */
+#define SSD_ADAM_MAX_JOBS 64
+typedef struct ssd_adam_job {
+    float* param;
+    int64_t offset;                /* first element in the flat gradient buffer */
+    int32_t numel, segment;        /* segment: 0 encoder (both optimisers), 1 env head, 2 inc head */
+    float* exp_avg[2];
+    float* exp_avg_sq[2];
+    float* step[2];                /* f32 device scalars (torch's capturable / fused Adam keeps them so) */
+} ssd_adam_job;
+typedef struct ssd_clip_adam_args {
+    float* flat_grad;
+    int64_t total;                 /* elements of flat_grad = sum of the jobs' numel (the jobs tile it in order) */
+    const ssd_adam_job* jobs;
+    int32_t n_jobs;
+    float* partials;
+    float lr_inc, lr_env, beta1, beta2, eps, clip;
+} ssd_clip_adam_args;
+int ssd_clip_adam_step(const ssd_clip_adam_args* args, void* stream);
+
 /* ssd_td_sim_loss: the loss of HomophilyLearner.cal_loss_and_step (learners/homophily_learner.py:94-217) -- incentive reward
  * transfer, double-Q TD losses of the env head and the incentive head, the similarity loss with the exact-value clustering rule --
  * AND its gradient w.r.t. the live Q-values in one launch (the reference builds it from ~100 tensor ops that autograd differentiates).

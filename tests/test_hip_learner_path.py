@@ -578,3 +578,30 @@ def test_build_inputs_flags_kernel_matches_the_reference_controller():
                 qe, qi, _ = mac.forward(batch, t)
                 assert (qe - q_env[:, t]).abs().max() < 1e-5 and (qi - q_inc[:, t]).abs().max() < 1e-5
     assert lib.ssd_build_inputs_width(5, 9, abi.INPUT_EXPLICIT | 128) == -1
+
+
+@pytest.mark.parametrize("name", ["learner_cleanup5.npz", "learner_harvest5.npz"])
+def test_clip_adam_kernel_equals_the_tensor_op_optimiser_tail(name):
+    """ssd_clip_adam_step (both gradient clips + both Adam steps, the encoder in both groups, as two launches) against the tensor-op
+    tail it replaces (clip_grad_norm_ x 2, torch.optim.Adam x 2) over four optimisation steps from the same start: parameters, both
+    optimisers' moments and step counters.  grad_norm_clip is lowered so that both clips actually scale."""
+    from tests.learner_util import build, load_fixture
+    th.backends.cuda.matmul.allow_tf32 = False
+    z, meta = load_fixture(name)
+    runs = []
+    for fused_opt in (False, True):
+        args, batch, mac, learner = build(z, meta, device="cuda:0", overrides=dict(train_graph=False, fused_optimiser=fused_opt, grad_norm_clip=0.05))
+        for _ in range(4):
+            learner.cal_loss_and_step(batch)
+        assert (learner._opt_plan not in (None, False)) == fused_opt
+        runs.append((learner, [p.detach().clone() for p in learner.params]))
+    (la, pa), (lb, pb) = runs
+    for x, y in zip(pa, pb):
+        assert (x - y).abs().max() < 2e-6, float((x - y).abs().max())
+    for oa, ob in ((la.optimiser_inc, lb.optimiser_inc), (la.optimiser_env, lb.optimiser_env)):
+        for qa, qb in zip(oa.param_groups[0]["params"], ob.param_groups[0]["params"]):
+            sa, sb = oa.state[qa], ob.state[qb]
+            assert float(sa["step"]) == float(sb["step"]) == 4.0
+            for k in ("exp_avg", "exp_avg_sq"):
+                # after the first step the two runs' parameters differ in the last bits, hence their gradients: 1e-4 of the largest moment
+                assert (sa[k] - sb[k]).abs().max() <= 1e-4 * max(1e-12, float(sa[k].abs().max())), k
