@@ -367,7 +367,9 @@ class HipGraphRunner(HipVecRunner):
         self.t = 0
         self.t_dev.zero_()
         self.prev_actions.fill_(-1); self.prev_reward.zero_(); self.prev_inc.zero_()
-        self.h_env.zero_(); self.h_inc.zero_(); self.ep_return.zero_()
+        self.ep_return.zero_()
+        if self.fast is None:
+            self.h_env.zero_(); self.h_inc.zero_()       # the generic timestep's hidden states (FastPolicy keeps its own)
         if self.fast is not None:
             for fp in self.fasts:
                 fp.reset()
