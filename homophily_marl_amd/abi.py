@@ -219,6 +219,8 @@ HIP_SIGNATURES["ssd_build_inputs_flags"] = (C.c_int, [C.c_int32, C.c_int32, C.c_
                                                      C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_clip_adam_step"] = (C.c_int, [C.POINTER(SsdClipAdamArgs), C.c_void_p])
 HIP_SIGNATURES["ssd_copy_blocks"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p])
+HIP_SIGNATURES["ssd_gru_seq_fwd_parts"] = (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p])
+HIP_SIGNATURES["ssd_gru_seq_bwd_parts"] = (C.c_int, [C.c_void_p] * 6 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_fwd"] = (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_bwd"] = (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_conv_wgrad_partial_rows"] = (C.c_int, [C.c_int32])

@@ -165,8 +165,8 @@ class HomophilyMAC(nn.Module):
         t = 0..T-1 from fresh hidden states returns (the learner's loops, homophily_learner.py:68-91) -- with the encoder,
         the input assembly and all non-recurrent layers evaluated once over all T."""
         shared = self.unroll_shared(batch)
-        gi, wh, bh = self.unroll_pre(batch, shared)
-        return self.agent.unroll_post(ops.gru_sequence(gi, wh, bh), shared["other"])
+        parts, wh, bh = self.unroll_pre(batch, shared)
+        return self.agent.unroll_post(ops.gru_sequence_parts(parts, batch.max_seq_length, batch.batch_size, wh, bh), shared["other"])
 
     def unroll_shared(self, batch):
         """Everything of an unroll that does not depend on the weights (the learner evaluates the live and the target net on the
@@ -200,7 +200,7 @@ class HomophilyMAC(nn.Module):
         return sh
 
     def unroll_pre(self, batch, shared):
-        """Encoder, input assembly, fc1 and the input-side GRU projections of this net: gi [T, 2n, B, 3H], wh, bh."""
+        """Encoder, input assembly, fc1 and the input-side GRU projections of this net: [gi_env, gi_inc] (each [n, T * B, 3H]), wh, bh."""
         a = self.args
         B, T, n = batch.batch_size, batch.max_seq_length, self.n_agents
         obs = shared["obs"]

@@ -140,9 +140,10 @@ void launch_gru_bwd(const float* dh, const float* rzn, const float* gh, const fl
 int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s);
 int launch_pack_encoder(const float* cw, const float* lw, int V, int prec, void* conv_frags, void* lin_frags, hipStream_t s);
 void launch_pack_head(const ssd_policy_head_params* p, int prec, void* image, hipStream_t s);
-void launch_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T, int G, int B, hipStream_t s);
-void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* dgh,
-                        float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s);
+void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T,
+                        int G, int B, hipStream_t s);
+void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* const* d_gi_parts,
+                        int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s);
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s);
 int launch_policy_inc_encode(const ssd_policy_head* ph, const ssd_policy_encode_args* pe, hipStream_t s);
 int conv_wgrad_partial_rows(int R);

@@ -50,8 +50,23 @@ __device__ __forceinline__ f32x4 mma16(u32x4 a, u32x4 b, f32x4 c) {
 // double-buffered LDS image that already holds the hi / lo f16 terms (one barrier per step; each lane splits only its own 4 values).
 // B is a multiple of 16 (the host pads): no row predicate and no branch inside the steps, so that the compiler's vmcnt accounting
 // stays exact and the prefetched loads are never waited for together with younger stores.
+// Where the input-side projections (forward) / their gradients (backward) live: up to 4 separately allocated parts of G / n_parts
+// weight sets each.  Time-major [T, G, B, 192] (one part) is t_stride = G B 192, set_stride = B 192; the per-agent affine layers'
+// own output [sets, T, B, 192] (set-major) is set_stride = T B 192, t_stride = B 192 -- the learner hands its four projection outputs
+// (live / target net x env / inc head) over as they are, without concatenating or transposing 12-25 MB copies.
+struct GruParts {
+    float* p[4];
+    int spp;                       // weight sets per part
+    long set_stride, t_stride;     // elements
+};
+__device__ __forceinline__ float* gru_part_base(const GruParts& P, int g) {
+    const int part = g / P.spp;
+    float* b = part == 0 ? P.p[0] : (part == 1 ? P.p[1] : (part == 2 ? P.p[2] : P.p[3]));
+    return b + (size_t)(g - part * P.spp) * P.set_stride;
+}
+
 template <bool TRAIN>
-__global__ __launch_bounds__(256) void k_gru_seq_fwd(const float* __restrict__ gi, const float* __restrict__ wh, const float* __restrict__ bh,
+__global__ __launch_bounds__(256) void k_gru_seq_fwd(const GruParts gi, const float* __restrict__ wh, const float* __restrict__ bh,
                                                      float* __restrict__ hs, float* __restrict__ rzn, float* __restrict__ ghn, int T, int G,
                                                      int B, int tiles) {
     __shared__ __attribute__((aligned(16))) _Float16 hx[2][2][16][HSH];   // [buffer][term][row][feature]
@@ -84,8 +99,9 @@ __global__ __launch_bounds__(256) void k_gru_seq_fwd(const float* __restrict__ g
     // a distance of one step the recurrence would wait for every step's stores; at PF steps the stores have long landed.
     constexpr int PF = 4;
     f32x4 gbuf[PF][3];
+    const float* gbase = gru_part_base(gi, g) + (size_t)rc * G3 + fo;
     auto load_gi = [&](int t, f32x4 (&d)[3]) {
-        const float* gir = gi + (((size_t)t * G + g) * B + rc) * G3 + fo;
+        const float* gir = gbase + (size_t)t * gi.t_stride;
         d[0] = *reinterpret_cast<const f32x4*>(gir); d[1] = *reinterpret_cast<const f32x4*>(gir + GH); d[2] = *reinterpret_cast<const f32x4*>(gir + 2 * GH);
     };
 #pragma unroll
@@ -167,7 +183,7 @@ __device__ __forceinline__ void split3(float x, __bf16& t1, __bf16& t2, __bf16& 
 }
 
 __global__ __launch_bounds__(256) void k_gru_seq_bwd(const float* __restrict__ dhs, const float* __restrict__ hs, const float* __restrict__ rzn,
-                                                     const float* __restrict__ ghn, const float* __restrict__ wh, float* __restrict__ d_gi,
+                                                     const float* __restrict__ ghn, const float* __restrict__ wh, const GruParts d_gi,
                                                      float* __restrict__ dgh, float* __restrict__ d_bh_part, int T, int G, int B, int tiles) {
     __shared__ __attribute__((aligned(16))) __bf16 dgb[2][3][16][DSB];   // dL/dgh of the step: [buffer][term][row][192]
     const int tid = threadIdx.x, lane = tid & 63, ft = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,6 +191,7 @@ __global__ __launch_bounds__(256) void k_gru_seq_bwd(const float* __restrict__ d
     const int g = blockIdx.x / tiles, tile = blockIdx.x - g * tiles;
     const int row = tile * 16 + m, rc = row;                          // B is a multiple of 16 (the host pads): see k_gru_seq_fwd
     const int fo = 16 * ft + 4 * q;
+    float* dgbase = gru_part_base(d_gi, g) + (size_t)row * G3 + fo;
     // resident A fragments of W_h: lane (q, m) = hidden feature 16 ft + m, reduction indices (gate outputs) k = 32 s + 8 q + j
     u32x4 wa[6][3];
 #pragma unroll
@@ -209,7 +226,6 @@ __global__ __launch_bounds__(256) void k_gru_seq_bwd(const float* __restrict__ d
         if (T - 1 - d >= 0) load_step(T - 1 - d, buf[d]);
     auto step = [&](int t, StepIn& in) {
         const int pb = t & 1;
-        const size_t tr = ((size_t)t * G + g) * B + rc;
         const f32x4 dout = in.dout, rg = in.rg, zg = in.zg, ng = in.ng, gn = in.gn, hprev = in.hprev;
         if (t - PF >= 0) load_step(t - PF, in);
         f32x4 d_r, d_z, d_n, d_hn, direct;
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(256) void k_gru_seq_bwd(const float* __restrict__ d
             }
         }
         {
-            float* o = d_gi + tr * G3 + fo;
+            float* o = dgbase + (size_t)t * d_gi.t_stride;
             *reinterpret_cast<f32x4*>(o) = d_r; *reinterpret_cast<f32x4*>(o + GH) = d_z; *reinterpret_cast<f32x4*>(o + 2 * GH) = d_n;
             float* o2 = dgh + (((size_t)g * T + t) * B + row) * G3 + fo;
             *reinterpret_cast<f32x4*>(o2) = d_r; *reinterpret_cast<f32x4*>(o2 + GH) = d_z; *reinterpret_cast<f32x4*>(o2 + 2 * GH) = d_hn;
@@ -277,15 +293,30 @@ __global__ __launch_bounds__(256) void k_gru_seq_bwd(const float* __restrict__ d
         }
 }
 
-void launch_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T, int G, int B, hipStream_t s) {
-    const int tiles = (B + 15) / 16;
-    if (rzn) hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(G * tiles), dim3(256), 0, s, gi, wh, bh, hs, rzn, ghn, T, G, B, tiles);
-    else hipLaunchKernelGGL(k_gru_seq_fwd<false>, dim3(G * tiles), dim3(256), 0, s, gi, wh, bh, hs, rzn, ghn, T, G, B, tiles);
+static GruParts gru_parts(float* const* parts, int n_parts, int T, int G, int B) {
+    GruParts P;
+    for (int k = 0; k < 4; ++k) P.p[k] = parts[k < n_parts ? k : 0];
+    if (n_parts <= 0) {            // one time-major tensor [T, G, B, 192]
+        P.spp = G; P.set_stride = (long)B * G3; P.t_stride = (long)G * B * G3;
+    } else {                       // n_parts set-major tensors [G / n_parts, T, B, 192]
+        P.spp = G / n_parts; P.set_stride = (long)T * B * G3; P.t_stride = (long)B * G3;
+    }
+    return P;
 }
-void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* dgh,
-                        float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s) {
+
+// n_parts 0: gi_parts[0] is one time-major tensor; else set-major parts (see GruParts)
+void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T,
+                        int G, int B, hipStream_t s) {
     const int tiles = (B + 15) / 16;
-    hipLaunchKernelGGL(k_gru_seq_bwd, dim3(G * tiles), dim3(256), 0, s, dhs, hs, rzn, ghn, wh, d_gi, dgh, d_bh_part, T, G, B, tiles);
+    const GruParts P = gru_parts(const_cast<float* const*>(reinterpret_cast<const float* const*>(gi_parts)), n_parts, T, G, B);
+    if (rzn) hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(G * tiles), dim3(256), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles);
+    else hipLaunchKernelGGL(k_gru_seq_fwd<false>, dim3(G * tiles), dim3(256), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles);
+}
+void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* const* d_gi_parts,
+                        int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s) {
+    const int tiles = (B + 15) / 16;
+    const GruParts P = gru_parts(d_gi_parts, n_parts, T, G, B);
+    hipLaunchKernelGGL(k_gru_seq_bwd, dim3(G * tiles), dim3(256), 0, s, dhs, hs, rzn, ghn, wh, P, dgh, d_bh_part, T, G, B, tiles);
     // dL/dW_h[g] = sum_{t >= 1, b} h_{t-1}[b]^T dL/dgh_t[b]: rows (t, b) of hs [G, T, B, 64] against rows (t + 1, b) of dgh [G, T, B, 192] --
     // the x^T g role of the per-agent-layer kernel (csrc/ssd_bmm.hip: K = (T - 1) B rows split over 16 waves per tile, exact f32)
     if (T > 1) launch_bias_bmm_bwd(dgh + (size_t)B * G3, hs, nullptr, nullptr, d_wh, nullptr, nullptr, G, (T - 1) * B, GH, G3, s, (long)T * B * GH, (long)T * B * G3);

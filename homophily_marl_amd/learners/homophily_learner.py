@@ -104,8 +104,9 @@ class HomophilyLearner:
         gi, wh, bh = mac.unroll_pre(batch, shared)
         with th.no_grad():
             gi_t, wh_t, bh_t = tgt.unroll_pre(batch, shared)
-        G = gi.shape[1]
-        hs = ops.gru_sequence(th.cat([gi, gi_t], dim=1), th.cat([wh, wh_t], dim=0), th.cat([bh, bh_t], dim=0))
+        G = wh.shape[0]
+        # live env / inc, target env / inc: the four projection outputs go to the sequence kernel as they are (no concatenation)
+        hs = ops.gru_sequence_parts(list(gi) + list(gi_t), batch.max_seq_length, batch.batch_size, th.cat([wh, wh_t], dim=0), th.cat([bh, bh_t], dim=0))
         q_env, q_inc = mac.agent.unroll_post(hs[:G], shared["other"])
         with th.no_grad():
             tq_env, tq_inc = tgt.agent.unroll_post(hs[G:].detach(), shared["other"])

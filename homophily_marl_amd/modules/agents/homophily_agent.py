@@ -165,13 +165,14 @@ class HomophilyAgent(nn.Module):
         the input-side GRU projections, both dueling heads) runs ONCE over all T; the recurrence itself (h @ W_h and the gate
         arithmetic, env and inc head together as 2n weight sets) is one sequence kernel per direction on the GPU.
         = unroll_pre -> ops.gru_sequence -> unroll_post (the learner runs the live and the target net through ONE sequence launch)."""
-        gi, wh, bh = self.unroll_pre(inputs, act_onehot)
-        hs = ops.gru_sequence(gi, wh, bh)                                              # [2n, T, B, H]: one launch for the T steps
+        parts, wh, bh = self.unroll_pre(inputs, act_onehot)
+        hs = ops.gru_sequence_parts(parts, inputs.shape[1], inputs.shape[0], wh, bh)   # [2n, T, B, H]: one launch for the T steps
         return self.unroll_post(hs, self.unroll_other(act_onehot, agent_pos, agent_orientation, reward, clean_num, apple_den, inputs.dtype))
 
     def unroll_pre(self, inputs, act_onehot):
-        """fc1 + the input-side GRU projections of both heads over all T: gi [T, 2n, B, 3H], and the recurrence weights
-        wh [2n, H, 3H], bh [2n, 1, 3H] (env sets first)."""
+        """fc1 + the input-side GRU projections of both heads over all T: [gi_env, gi_inc], each [n, T * B, 3H] (set-major, rows
+        t * B + b: ops.gru_sequence_parts takes them as they are), and the recurrence weights wh [2n, H, 3H], bh [2n, 1, 3H] (env sets
+        first)."""
         B, T, n = inputs.shape[0], inputs.shape[1], self.n_agents
         H = self.hidden
         tm = lambda x: x.permute(2, 1, 0, 3).reshape(n, T * B, x.shape[-1])          # time-major rows [n, T*B, f]
@@ -179,9 +180,7 @@ class HomophilyAgent(nn.Module):
         xe = F.leaky_relu(ops.bias_bmm(x, self._w("fc1_env_w"), self._b("fc1_env_b")))
         xi = F.leaky_relu(ops.bias_bmm(th.cat([x, act], dim=-1), self._w("fc1_inc_w"), self._b("fc1_inc_b")))
         (wie, whe, bie, bhe), (wii, whi, bii, bhi) = self._gru_weights_both()
-        gi = th.cat([ops.bias_bmm(xe, wie, bie), ops.bias_bmm(xi, wii, bii)], dim=0).reshape(2 * n, T, B, 3 * H)
-        gi = gi.transpose(0, 1).contiguous()                                           # [T, 2n, B, 3H]: gi[t] is one contiguous block
-        return gi, th.cat([whe, whi], dim=0), th.cat([bhe, bhi], dim=0)
+        return [ops.bias_bmm(xe, wie, bie), ops.bias_bmm(xi, wii, bii)], th.cat([whe, whi], dim=0), th.cat([bhe, bhi], dim=0)
 
     @staticmethod
     def unroll_other(act_onehot, agent_pos, agent_orientation, reward, clean_num, apple_den, dtype):

@@ -480,6 +480,59 @@ class _GruSeq(th.autograd.Function):
         return d_gi, d_wh, (d_bh.sum(1) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)
 
 
+class _GruSeqParts(th.autograd.Function):
+    """_GruSeq with the input-side projections given as separately allocated set-major parts [sets, T * B, 3H] (the per-agent affine
+    layers' outputs as they are: ssd_gru_seq_fwd_parts / _bwd_parts) -- no concatenation / transpose copies, and the gradients come back
+    per part, contiguous.  B is a multiple of 16 here (gru_sequence_parts falls back otherwise)."""
+
+    @staticmethod
+    def forward(ctx, T, B, wh, bh, *parts):
+        lib = abi.load_library()
+        parts = [p.contiguous() for p in parts]
+        wh, bh = wh.contiguous(), bh.contiguous()
+        G, H3 = sum(p.shape[0] for p in parts), parts[0].shape[-1]
+        H = H3 // 3
+        dev = parts[0].device
+        hs = th.empty(G, T, B, H, dtype=th.float32, device=dev)
+        need = any(ctx.needs_input_grad)
+        rzn = th.empty(T, G, B, H3, dtype=th.float32, device=dev) if need else None
+        ghn = th.empty(T, G, B, H, dtype=th.float32, device=dev) if need else None
+        ptrs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+        abi.check(lib, lib.ssd_gru_seq_fwd_parts(ptrs, len(parts), wh.data_ptr(), bh.data_ptr(), hs.data_ptr(), None if rzn is None else rzn.data_ptr(),
+                                                 None if ghn is None else ghn.data_ptr(), T, G, B, _stream(hs)))
+        if need:
+            ctx.save_for_backward(hs, rzn, ghn, wh)
+            ctx.shapes = [p.shape for p in parts]
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        lib = abi.load_library()
+        hs, rzn, ghn, wh = ctx.saved_tensors
+        T, G, B, H3 = rzn.shape
+        dhs = dhs.contiguous()
+        d_parts = [th.empty(sh, dtype=th.float32, device=rzn.device) for sh in ctx.shapes]      # parts without a gradient: scratch
+        dgh = th.empty(G, T, B, H3, dtype=th.float32, device=rzn.device)
+        d_wh = th.empty(G, H3 // 3, H3, dtype=th.float32, device=rzn.device)
+        tiles = B // 16
+        d_bh = th.empty(G, tiles, H3, dtype=th.float32, device=rzn.device)
+        ptrs = (C.c_void_p * len(d_parts))(*[p.data_ptr() for p in d_parts])
+        abi.check(lib, lib.ssd_gru_seq_bwd_parts(dhs.data_ptr(), hs.data_ptr(), rzn.data_ptr(), ghn.data_ptr(), wh.data_ptr(), ptrs, len(d_parts),
+                                                 dgh.data_ptr(), d_wh.data_ptr(), d_bh.data_ptr(), T, G, B, _stream(rzn)))
+        need = ctx.needs_input_grad
+        return (None, None, d_wh, (d_bh.sum(1) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)) + tuple(d if need[4 + k] else None for k, d in enumerate(d_parts))
+
+
+def gru_sequence_parts(parts, T, B, wh, bh):
+    """gru_sequence for projections held as equally sized set-major parts [sets, T * B, 3H] (rows t * B + b); wh [G, H, 3H], bh [G, 1, 3H]
+    over all sets in part order.  hs [G, T, B, H]."""
+    H3 = parts[0].shape[-1]
+    if (parts[0].is_cuda and H3 == 192 and B % 16 == 0 and 1 <= len(parts) <= 4 and all(p.shape == parts[0].shape and p.dtype == th.float32 for p in parts)):
+        return _GruSeqParts.apply(T, B, wh, bh, *parts)
+    gi = th.cat([p.reshape(p.shape[0], T, B, H3) for p in parts], dim=0).transpose(0, 1).contiguous()      # [T, G, B, 3H]
+    return gru_sequence(gi, wh, bh)
+
+
 def gru_sequence(gi, wh, bh):
     """hs [G, T, B, H]: the GRU states h_1..h_T for the input-side projections gi [T, G, B, 3H] from a zero initial state."""
     T, G, B, H3 = gi.shape

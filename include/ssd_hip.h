@@ -352,6 +352,14 @@ int ssd_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs
                     void* stream);
 int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* dgh,
                     float* d_wh, float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream);
+/* The same two launches with the input-side projections given as n_parts (1..4) separately allocated SET-MAJOR tensors
+ * gi_parts[k] f32 [G / n_parts, T, B, 192] (what ssd_bias_bmm_fwd leaves for a group of weight sets; the learner passes live / target net
+ * x env / inc head as they are -- no concatenation, no transpose to time-major), and their gradients written into d_gi_parts[k] of the
+ * same shape (every part must be valid memory; a part that needs no gradient is scratch).  hs, rzn, ghn, dgh, d_wh, d_bh_part as above. */
+int ssd_gru_seq_fwd_parts(const float* const* gi_parts, int32_t n_parts, const float* wh, const float* bh, float* hs, float* rzn, float* ghn,
+                          int32_t T, int32_t G, int32_t B, void* stream);
+int ssd_gru_seq_bwd_parts(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* const* d_gi_parts,
+                          int32_t n_parts, float* dgh, float* d_wh, float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream);
 
 /* ---- the learner's per-agent affine layers (csrc/ssd_bmm.hip) ---------------------------------------------------------------
  * th.baddbmm(b, x, w) over the agent axis (homophily_agent.py:154-208: fc1, GRU input projections, dueling heads) and its backward,

@@ -605,3 +605,26 @@ def test_clip_adam_kernel_equals_the_tensor_op_optimiser_tail(name):
             for k in ("exp_avg", "exp_avg_sq"):
                 # after the first step the two runs' parameters differ in the last bits, hence their gradients: 1e-4 of the largest moment
                 assert (sa[k] - sb[k]).abs().max() <= 1e-4 * max(1e-12, float(sa[k].abs().max())), k
+
+
+@pytest.mark.parametrize("T,n,B,k", [(7, 5, 16, 4), (5, 3, 32, 2), (9, 5, 16, 1), (4, 2, 7, 2)])
+def test_gru_sequence_parts_equals_the_time_major_launch(T, n, B, k):
+    """ops.gru_sequence_parts (ssd_gru_seq_fwd_parts / _bwd_parts: the projections as k separately allocated set-major tensors
+    [n, T * B, 3H], two of them without a gradient like the target net's) against ops.gru_sequence on their time-major concatenation:
+    states and gradients bit for bit.  B = 7: the ragged batch falls back to the padded time-major launch."""
+    from homophily_marl_amd import ops
+    g = th.Generator(device="cuda").manual_seed(T * 100 + B)
+    H = 64
+    parts = [(th.randn(n, T * B, 3 * H, generator=g, device="cuda") * 0.5).requires_grad_(i < max(1, k // 2)) for i in range(k)]
+    wh = (th.randn(k * n, H, 3 * H, generator=g, device="cuda") * 0.1).requires_grad_()
+    bh = (th.randn(k * n, 1, 3 * H, generator=g, device="cuda") * 0.1).requires_grad_()
+    w = th.randn(k * n, T, B, H, generator=g, device="cuda")
+    hs = ops.gru_sequence_parts(parts, T, B, wh, bh)
+    gi = th.cat([p.reshape(n, T, B, 3 * H) for p in parts], dim=0).transpose(0, 1).contiguous()
+    ref = ops.gru_sequence(gi, wh, bh)
+    assert th.equal(hs, ref)
+    live = [p for p in parts if p.requires_grad]
+    got = th.autograd.grad((hs * w).sum(), live + [wh, bh])
+    exp = th.autograd.grad((ref * w).sum(), live + [wh, bh])
+    for a, b in zip(got, exp):
+        assert a.is_contiguous() and th.equal(a, b)
