@@ -119,6 +119,11 @@ COPY_BLOCKS_MAX = 32
 ADAM_MAX_JOBS = 64
 
 
+class SsdRowGather(C.Structure):
+    """ssd_row_gather (include/ssd_hip.h): one field of ssd_gather_rows."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64)]
+
+
 class SsdAdamJob(C.Structure):
     """ssd_adam_job (include/ssd_hip.h): one parameter tensor of ssd_clip_adam_step."""
     _fields_ = [("param", C.c_void_p), ("offset", C.c_int64), ("numel", C.c_int32), ("segment", C.c_int32),
@@ -218,6 +223,7 @@ HIP_SIGNATURES["ssd_build_inputs_width"] = (C.c_int, [C.c_int32, C.c_int32, C.c_
 HIP_SIGNATURES["ssd_build_inputs_flags"] = (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_clip_adam_step"] = (C.c_int, [C.POINTER(SsdClipAdamArgs), C.c_void_p])
+HIP_SIGNATURES["ssd_gather_rows"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_copy_blocks"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_fwd_parts"] = (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_bwd_parts"] = (C.c_int, [C.c_void_p] * 6 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p])

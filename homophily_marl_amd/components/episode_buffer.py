@@ -7,6 +7,8 @@ from types import SimpleNamespace
 import numpy as np
 import torch as th
 
+from .. import ops
+
 
 def _count(idx, size):
     if isinstance(idx, slice):
@@ -202,8 +204,10 @@ class ReplayBuffer(EpisodeBatch):
         ep_ids = np.random.choice(self.episodes_in_buffer, batch_size, replace=False)   # episode_buffer.py:243
         if out is not None and out.batch_size == batch_size and out.max_seq_length == self.max_seq_length and not self.data.episode_data:
             ids = th.as_tensor(ep_ids, dtype=th.long, device=self.device)
-            for k, v in self.data.transition_data.items():
-                th.index_select(v, 0, ids, out=out.data.transition_data[k])
+            pairs = [(v, out.data.transition_data[k]) for k, v in self.data.transition_data.items()]
+            if not (ids.is_cuda and ops.gather_rows(pairs, ids)):       # device buffers: one launch for all fields
+                for v, dst in pairs:
+                    th.index_select(v, 0, ids, out=dst)
             return out
         return self[ep_ids]
 

@@ -369,6 +369,14 @@ int ssd_clip_adam_step(const ssd_clip_adam_args* a, void* stream) {
     return launched();
 }
 
+int ssd_gather_rows(const ssd_row_gather* fields, int32_t count, const int64_t* ids, int32_t n_ids, void* stream) {
+    if (!fields || count < 1 || count > SSD_COPY_BLOCKS_MAX || !ids || n_ids < 1 || n_ids > 65535) return fail(SSD_ERR_INVALID, "ssd_gather_rows: bad argument");
+    for (int i = 0; i < count; ++i)
+        if (!fields[i].src || !fields[i].dst || fields[i].row_bytes < 1) return fail(SSD_ERR_INVALID, "ssd_gather_rows: bad field");
+    launch_gather_rows(fields, count, ids, n_ids, (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_copy_blocks(const ssd_block_copy* blocks, int32_t count, void* stream) {
     if (!blocks || count < 1 || count > SSD_COPY_BLOCKS_MAX) return fail(SSD_ERR_INVALID, "ssd_copy_blocks: 1..SSD_COPY_BLOCKS_MAX blocks");
     for (int i = 0; i < count; ++i) {

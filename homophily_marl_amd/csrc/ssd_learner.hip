@@ -293,6 +293,33 @@ __global__ __launch_bounds__(256) void k_copy_blocks(CopyTable t) {
     }
 }
 
+// k_gather_rows: rows ids[e] of up to SSD_COPY_BLOCKS_MAX fields into consecutive rows of their destinations (blockIdx.y = field,
+// blockIdx.z = e); 4-byte accesses at any alignment for the bulk of a row, bytes for its tail.
+struct GatherTable { ssd_row_gather f[SSD_COPY_BLOCKS_MAX]; };
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+__global__ __launch_bounds__(256) void k_gather_rows(GatherTable t, const int64_t* __restrict__ ids) {
+    const ssd_row_gather f = t.f[blockIdx.y];
+    const uint8_t* src = static_cast<const uint8_t*>(f.src) + (size_t)ids[blockIdx.z] * f.row_bytes;
+    uint8_t* dst = static_cast<uint8_t*>(f.dst) + (size_t)blockIdx.z * f.row_bytes;
+    const long words = f.row_bytes >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long)gridDim.x * 256)
+        *reinterpret_cast<u32_unaligned*>(dst + 4 * i) = *reinterpret_cast<const u32_unaligned*>(src + 4 * i);
+    if (blockIdx.x == 0 && (long)threadIdx.x < (f.row_bytes & 3)) dst[4 * words + threadIdx.x] = src[4 * words + threadIdx.x];
+}
+
+void launch_gather_rows(const ssd_row_gather* fields, int count, const int64_t* ids, int n_ids, hipStream_t stream) {
+    GatherTable t;
+    int64_t most = 4;
+    for (int i = 0; i < SSD_COPY_BLOCKS_MAX; ++i) {
+        t.f[i] = fields[i < count ? i : 0];
+        if (i < count && fields[i].row_bytes > most) most = fields[i].row_bytes;
+    }
+    int gx = (int)((most / 4 + 1023) / 1024);                             // 4 words per thread for the longest row
+    if (gx < 1) gx = 1;
+    if (gx > 32) gx = 32;
+    hipLaunchKernelGGL(k_gather_rows, dim3(gx, count, n_ids), dim3(256), 0, stream, t, ids);
+}
+
 void launch_copy_blocks(const ssd_block_copy* blocks, int count, hipStream_t stream) {
     CopyTable t;
     int most = 1;

@@ -173,6 +173,24 @@ def _copy_blocks(entries, like):
     abi.check(lib, lib.ssd_copy_blocks(tab, len(entries), _stream(like)))
 
 
+def gather_rows(pairs, ids):
+    """dst[e] = src[ids[e]] along axis 0 for every (src, dst) pair of contiguous device tensors, as ONE launch (ssd_gather_rows).
+    ids: int64 device tensor.  Returns False (nothing done) when a pair does not qualify -- the caller indexes field by field."""
+    if not pairs or len(pairs) > abi.COPY_BLOCKS_MAX or not ids.is_cuda or ids.dtype != th.long:
+        return False
+    n = ids.numel()
+    for src, dst in pairs:
+        if not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype
+                and dst.shape[0] == n and dst.shape[1:] == src.shape[1:] and src[0].numel() > 0):
+            return False
+    lib = abi.load_library()
+    tab = (abi.SsdRowGather * len(pairs))()
+    for e, (src, dst) in zip(tab, pairs):
+        e.src, e.dst, e.row_bytes = src.data_ptr(), dst.data_ptr(), src[0].numel() * src.element_size()
+    abi.check(lib, lib.ssd_gather_rows(tab, len(pairs), ids.contiguous().data_ptr(), n, _stream(ids)))
+    return True
+
+
 class _CatGroups(th.autograd.Function):
     """Several last-axis concatenations as ONE launch (ssd_copy_blocks), their gradients split again by ONE launch into contiguous
     per-input tensors -- what th.cat + CatBackward + the flattening of its strided gradient views do with one launch per tensor."""

@@ -212,6 +212,17 @@ int ssd_column_sums(const float* x, float* out, int32_t groups, int32_t rows, in
  * HOST array read during the call.  The learner packs the r / z / n blocks of the GRU parameters of both heads side by side with it
  * (homophily_agent.py:83-112 keeps them as 24 separate tensors) and splits the gradients again: 2 launches instead of 8 concatenations
  * and 24 strided copies per train step. */
+/* ssd_gather_rows: dst_f[e] = src_f[ids[e]] for e < n_ids and every field f < count (1..SSD_COPY_BLOCKS_MAX) as ONE launch; a field is
+ * a dense array of rows of row_bytes bytes (any alignment).  ReplayBuffer.sample (episode_buffer.py:240-244) draws 16 episodes out of
+ * thirteen storage fields with it: one launch instead of one indexing kernel per field.  `fields` is a HOST array read during the call,
+ * ids a DEVICE array of n_ids int64 (each within the fields' rows: the caller checks). */
+typedef struct ssd_row_gather {
+    const void* src;
+    void* dst;
+    int64_t row_bytes;
+} ssd_row_gather;
+int ssd_gather_rows(const ssd_row_gather* fields, int32_t count, const int64_t* ids, int32_t n_ids, void* stream);
+
 #define SSD_COPY_BLOCKS_MAX 32
 typedef struct ssd_block_copy {
     const float* src;

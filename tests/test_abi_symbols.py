@@ -32,14 +32,14 @@ def test_struct_sizes_match_the_header(tmp_path):
     """sizeof() of every ABI struct as seen by a C compiler == the ctypes mirror."""
     import subprocess
     c = tmp_path / "s.c"
-    c.write_text('#include <stdio.h>\n#include "ssd_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ssd_config),'
+    c.write_text('#include <stdio.h>\n#include "ssd_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ssd_config),'
                  'sizeof(ssd_tape), sizeof(ssd_step_out), sizeof(ssd_obs_out), sizeof(ssd_state), sizeof(ssd_info),'
-                 'sizeof(ssd_store_step), sizeof(ssd_policy_head), sizeof(ssd_policy_encode_args), sizeof(ssd_block_copy), sizeof(ssd_adam_job), sizeof(ssd_clip_adam_args));return 0;}')
+                 'sizeof(ssd_store_step), sizeof(ssd_policy_head), sizeof(ssd_policy_encode_args), sizeof(ssd_block_copy), sizeof(ssd_adam_job), sizeof(ssd_clip_adam_args), sizeof(ssd_row_gather));return 0;}')
     exe = tmp_path / "s"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert sizes == [ctypes.sizeof(t) for t in (abi.SsdConfig, abi.SsdTape, abi.SsdStepOut, abi.SsdObsOut, abi.SsdState, abi.SsdInfo,
-                                                    abi.SsdStoreStep, abi.SsdPolicyHead, abi.SsdPolicyEncodeArgs, abi.SsdBlockCopy, abi.SsdAdamJob, abi.SsdClipAdamArgs)]
+                                                    abi.SsdStoreStep, abi.SsdPolicyHead, abi.SsdPolicyEncodeArgs, abi.SsdBlockCopy, abi.SsdAdamJob, abi.SsdClipAdamArgs, abi.SsdRowGather)]
 
 
 def test_oracle_is_not_reachable_from_the_product_package():
