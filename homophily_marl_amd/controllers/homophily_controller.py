@@ -184,18 +184,26 @@ class HomophilyMAC(nn.Module):
         acts = batch["actions"].squeeze(-1)                                            # [B, T, n]
         # history features of step t come from t - 1; at t = 0 they are zero: action -1 has an all-zero one-hot
         prev = lambda x, fill: th.cat([th.full_like(x[:, :1], fill), x[:, :-1]], dim=1)
-        hist = (prev(acts, -1).reshape(B * T, n), prev(batch["reward"], 0).reshape(B * T, n),
-                prev(batch["actions_inc"].squeeze(-1), 0).reshape(B * T, n, n), batch["agent_pos"].reshape(B * T, n, 2))
+        on_dev = batch["reward"].is_cuda
+        kernel_tail = (self.shipped_flags or on_dev) and a.rgb_input and self.input_shape > a.obs_dim_net
+        # the device kernel shifts the history itself (seq_len = T); the tensor-op assembly takes shifted copies
+        hist = None if (kernel_tail and on_dev) else (
+            prev(acts, -1).reshape(B * T, n), prev(batch["reward"], 0).reshape(B * T, n),
+            prev(batch["actions_inc"].squeeze(-1), 0).reshape(B * T, n, n), batch["agent_pos"].reshape(B * T, n, 2))
         onehot = F.one_hot(acts, num_classes=a.n_actions)
         sh = dict(obs=None if codes is not None else (obs.float() if a.rgb_input else obs), codes=codes, hist=hist, onehot=onehot, tail=None,
                   other=self.agent.unroll_other(onehot, batch["agent_pos"] / self.pos_scale, batch["agent_orientation"], batch["reward"],
                                                 batch["clean_num"], batch["apple_den"], th.float32))
-        on_dev = batch["reward"].is_cuda
-        if (self.shipped_flags or on_dev) and a.rgb_input and self.input_shape > a.obs_dim_net:
+        if kernel_tail:
             # the non-visual input columns do not depend on the weights either
             tail = th.empty(B * T * n, self.input_shape - a.obs_dim_net, dtype=th.float32, device=batch["obs"].device)
-            ops.build_inputs_tail(tail, 0, hist[0], hist[1], hist[2], hist[3], self.pos_scale, a.n_actions, False,
-                                  flags=None if self.shipped_flags else self.input_flags_all)
+            flags = None if self.shipped_flags else self.input_flags_all
+            if hist is None:
+                ops.build_inputs_tail(tail, 0, acts.reshape(B * T, n), batch["reward"].reshape(B * T, n),
+                                      batch["actions_inc"].squeeze(-1).reshape(B * T, n, n), batch["agent_pos"].reshape(B * T, n, 2),
+                                      self.pos_scale, a.n_actions, False, flags=flags, seq_len=T)
+            else:
+                ops.build_inputs_tail(tail, 0, hist[0], hist[1], hist[2], hist[3], self.pos_scale, a.n_actions, False, flags=flags)
             sh["tail"] = tail
         return sh
 

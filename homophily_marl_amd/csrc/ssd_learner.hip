@@ -18,19 +18,23 @@ __global__ void k_build_inputs(int32_t rows, int32_t n, int32_t A, int32_t t0, c
         const int row = (int)(idx / width), k = (int)(idx - (size_t)row * width);
         const int b = row / n, i = row - b * n;
         const int agent_major = t0 & 2;
-        const int t_zero = t0 & 1;
+        // t0 >> 8 = T > 0: the rows are [batch, T] and the three history tensors hold every step's OWN values -- the previous step is
+        // row b - 1, none at the first step of an episode (the learner's time-batched assembly, no shifted copies)
+        const int hist_T = t0 >> 8;
+        const int t_zero = (t0 & 1) || (hist_T && b % hist_T == 0);
+        const size_t pb = hist_T ? (size_t)b - 1 : (size_t)b, prow = pb * n + i;
         float v;
-        if (k < A) v = (!t_zero && last_actions[row] == k) ? 1.f : 0.f;                  // one-hot of the last action (:137-141)
+        if (k < A) v = (!t_zero && last_actions[prow] == k) ? 1.f : 0.f;                 // one-hot of the last action (:137-141)
         else if (k < A + n) v = (k - A == i) ? 1.f : 0.f;                            // agent id (:142-143)
         else if (k == A + n) {                                                       // sign(last reward) (:145-150)
-            const float r = t_zero ? 0.f : last_reward[row];
+            const float r = t_zero ? 0.f : last_reward[prow];
             v = (float)((r > 0.f) - (r < 0.f));
         } else if (k == A + n + 1) {                                                 // sign(#recv+ - #recv-) (:152-164)
             int recv = 0;
             if (!t_zero)
                 for (int g = 0; g < n; ++g) {
                     if (g == i) continue;                                            // inc_mask_actions: no self incentive
-                    const int64_t x = last_actions_inc[((size_t)b * n + g) * n + i];
+                    const int64_t x = last_actions_inc[(pb * n + g) * n + i];
                     recv += (x == 1) - (x == 2);
                 }
             v = (float)((recv > 0) - (recv < 0));
@@ -47,28 +51,30 @@ __global__ void k_build_inputs_flags(int32_t rows, int32_t n, int32_t A, int32_t
                                      float* __restrict__ out, int32_t out_stride, int32_t out_offset) {
     const int width = L.width;
     const size_t total = (size_t)rows * width;
-    const int agent_major = t0 & 2, t_zero = t0 & 1;
+    const int agent_major = t0 & 2, hist_T = t0 >> 8;                    // hist_T: see k_build_inputs
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(idx / width), k = (int)(idx - (size_t)row * width);
         const int b = row / n, i = row - b * n;
+        const int t_zero = (t0 & 1) || (hist_T && b % hist_T == 0);
+        const size_t pb = hist_T ? (size_t)b - 1 : (size_t)b, prow = pb * n + i;
         float v = 0.f;
-        if (L.o_act >= 0 && k >= L.o_act && k < L.o_act + A) v = (!t_zero && last_actions[row] == k - L.o_act) ? 1.f : 0.f;   // (:137-141)
+        if (L.o_act >= 0 && k >= L.o_act && k < L.o_act + A) v = (!t_zero && last_actions[prow] == k - L.o_act) ? 1.f : 0.f;  // (:137-141)
         else if (L.o_id >= 0 && k >= L.o_id && k < L.o_id + n) v = (k - L.o_id == i) ? 1.f : 0.f;                              // (:142-143)
         else if (k == L.o_r) {                                                                                                   // (:145-150)
-            const float r = t_zero ? 0.f : last_reward[row];
+            const float r = t_zero ? 0.f : last_reward[prow];
             v = (float)((r > 0.f) - (r < 0.f));
         } else if (k == L.o_i) {                                                                                                 // (:152-164)
             int recv = 0;
             if (!t_zero)
                 for (int g = 0; g < n; ++g) {
                     if (g == i) continue;
-                    const int64_t x = last_actions_inc[((size_t)b * n + g) * n + i];
+                    const int64_t x = last_actions_inc[(pb * n + g) * n + i];
                     recv += (x == 1) - (x == 2);
                 }
             v = (float)((recv > 0) - (recv < 0));
         } else if (L.o_oth >= 0 && k >= L.o_oth && k < L.o_oth + n * A) {          // everybody's last action, agent order (:166-173)
             const int g = (k - L.o_oth) / A, a = (k - L.o_oth) - g * A;
-            v = (!t_zero && last_actions[(size_t)b * n + g] == a) ? 1.f : 0.f;
+            v = (!t_zero && last_actions[pb * n + g] == a) ? 1.f : 0.f;
         } else if (L.o_dist >= 0 && k >= L.o_dist && k < L.o_dist + n) {           // 1 - |pos_i - pos_g| / ||(H, W)|| (:174-178)
             const int g = k - L.o_dist;
             const float dx = pos[(size_t)row * 2] - pos[((size_t)b * n + g) * 2], dy = pos[(size_t)row * 2 + 1] - pos[((size_t)b * n + g) * 2 + 1];

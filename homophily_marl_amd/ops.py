@@ -15,14 +15,16 @@ def _stream(t):
     return th.cuda.current_stream(t.device).cuda_stream
 
 
-def build_inputs_tail(out, offset, last_actions, last_reward, last_actions_inc, pos, pos_scale, n_actions, t0, flags=None):
+def build_inputs_tail(out, offset, last_actions, last_reward, last_actions_inc, pos, pos_scale, n_actions, t0, flags=None, seq_len=0):
     """Fill out[:, offset : offset + A + n + 4] with the non-visual agent-input features of
     HomophilyMAC._build_inputs (controllers/homophily_controller.py:137-184):
     onehot(last action) | onehot(agent id) | sign(last reward) | sign(#recv+ - #recv-) | pos / ||(H, W)||.
     out: f32 [B * n, stride]; last_actions i64 [B, n]; last_reward f32 [B, n]; last_actions_inc i64 [B, n, n];
     pos f32 [B, n, 2].  t0: the t == 0 branch (the three history terms are zero, their tensors may be None).
     flags (device tensors only): abi.INPUT_* bits of any other flag set -- the blocks present, in the reference's order, incl.
-    everybody's last action (obs_others_last_action) and 1 - distances (obs_distance); out must be that wide."""
+    everybody's last action (obs_others_last_action) and 1 - distances (obs_distance); out must be that wide.
+    seq_len = T > 0 (device tensors only): B counts [episodes, T] rows and the history tensors hold every step's OWN values -- the
+    kernel reads the previous timestep's row itself (no shifted copies)."""
     B, n = pos.shape[0], pos.shape[1]
     A = n_actions
     if out.is_cuda:
@@ -31,14 +33,15 @@ def build_inputs_tail(out, offset, last_actions, last_reward, last_actions_inc, 
         la, lr, li, p = cont(last_actions), cont(last_reward), cont(last_actions_inc), pos.contiguous()
         assert out.is_contiguous() and out.dtype == th.float32
         ptr = lambda x: None if x is None else x.data_ptr()
+        word = (1 if t0 else 0) | (int(seq_len) << 8)
         if flags is not None:       # any _build_inputs flag set (abi.INPUT_* bits), blocks in the reference's order
-            abi.check(lib, lib.ssd_build_inputs_flags(B, n, A, 1 if t0 else 0, abi.INPUT_EXPLICIT | int(flags), ptr(la), ptr(lr), ptr(li),
+            abi.check(lib, lib.ssd_build_inputs_flags(B, n, A, word, abi.INPUT_EXPLICIT | int(flags), ptr(la), ptr(lr), ptr(li),
                                                       p.data_ptr(), float(pos_scale), out.data_ptr(), out.shape[1], offset, _stream(out)))
             return out
-        abi.check(lib, lib.ssd_build_inputs(B, n, A, 1 if t0 else 0, ptr(la), ptr(lr), ptr(li), p.data_ptr(), float(pos_scale),
+        abi.check(lib, lib.ssd_build_inputs(B, n, A, word, ptr(la), ptr(lr), ptr(li), p.data_ptr(), float(pos_scale),
                                             out.data_ptr(), out.shape[1], offset, _stream(out)))
         return out
-    assert flags is None, "CPU tensors: only the shipped flag set has a tensor-op statement here (HomophilyMAC.assemble_inputs has all)"
+    assert flags is None and not seq_len, "CPU tensors: only the shipped flag set has a tensor-op statement here (HomophilyMAC.assemble_inputs has all)"
     o = out.view(B, n, -1)
     if t0:
         o[..., offset:offset + A] = 0

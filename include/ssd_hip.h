@@ -187,7 +187,10 @@ int ssd_get_info(const ssd_env* env, ssd_info* out);
 /* HomophilyMAC._build_inputs tail (controllers/homophily_controller.py:137-184): everything except the conv
  * encoder.  Writes [B*n, A + n + 1 + 1 + 2] = onehot(last action) | onehot(id) | sign(last reward) |
  * sign(#recv+ - #recv-) | pos/||(H,W)||.  t0 is a flag word: bit 0 selects the t == 0 branch (zeros for the three history
- * terms; a last action of -1 has the same effect per row), bit 1 writes agent-major rows (i * batch + b) instead of (b * n + i). */
+ * terms; a last action of -1 has the same effect per row), bit 1 writes agent-major rows (i * batch + b) instead of (b * n + i);
+ * bits 8.. = T > 0: `batch` counts [episodes, T] rows and the three history tensors hold every step's OWN action / reward / incentives
+ * -- the kernel reads the row of the previous timestep and takes the t == 0 branch at the first step of each episode (the learner's
+ * time-batched assembly without shifted copies of the tensors). */
 int ssd_build_inputs(int32_t batch, int32_t n_agents, int32_t n_actions, int32_t t0,
                      const int64_t* last_actions /*[B,n]*/, const float* last_reward /*[B,n]*/,
                      const int64_t* last_actions_inc /*[B,n,n]*/, const float* pos /*[B,n,2]*/,
