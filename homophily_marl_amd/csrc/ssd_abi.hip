@@ -369,6 +369,17 @@ int ssd_clip_adam_step(const ssd_clip_adam_args* a, void* stream) {
     return launched();
 }
 
+int ssd_dueling_q_fwd(const float* a, const float* v, float* q, int32_t n, int32_t T, int32_t B, int32_t inner, int32_t K, void* stream) {
+    if (!a || !v || !q || n < 1 || T < 1 || B < 1 || inner < 1 || K < 1 || K > 16) return fail(SSD_ERR_INVALID, "ssd_dueling_q_fwd: bad argument");
+    launch_dueling_q(a, v, q, nullptr, nullptr, nullptr, n, T, B, inner, K, (hipStream_t)stream);
+    return launched();
+}
+int ssd_dueling_q_bwd(const float* dq, float* da, float* dv, int32_t n, int32_t T, int32_t B, int32_t inner, int32_t K, void* stream) {
+    if (!dq || !da || !dv || n < 1 || T < 1 || B < 1 || inner < 1 || K < 1 || K > 16) return fail(SSD_ERR_INVALID, "ssd_dueling_q_bwd: bad argument");
+    launch_dueling_q(nullptr, nullptr, nullptr, dq, da, dv, n, T, B, inner, K, (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_gather_rows(const ssd_row_gather* fields, int32_t count, const int64_t* ids, int32_t n_ids, void* stream) {
     if (!fields || count < 1 || count > SSD_COPY_BLOCKS_MAX || !ids || n_ids < 1 || n_ids > 65535) return fail(SSD_ERR_INVALID, "ssd_gather_rows: bad argument");
     for (int i = 0; i < count; ++i)

@@ -299,6 +299,40 @@ __global__ __launch_bounds__(256) void k_copy_blocks(CopyTable t) {
     }
 }
 
+static int grid_for(size_t total);
+// k_dueling_q: q = v + a - mean_k a per (agent, row) of the learner's time-batched heads, output in the batch layout [B, T, n, inner, K];
+// BWD: da = dq - mean_k dq, dv = sum_k dq.  One thread per (agent, row); K <= 16.
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_dueling_q(const float* __restrict__ a, const float* __restrict__ v, float* __restrict__ q,
+                                                   const float* __restrict__ dq, float* __restrict__ da, float* __restrict__ dv, int n, int T, int B,
+                                                   int inner, int K) {
+    const long rows = (long)T * B * inner, total = rows * n;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int i = (int)(idx / rows);
+        const long r = idx - (long)i * rows;
+        const long tb = r / inner;
+        const int j = (int)(r - tb * inner), t = (int)(tb / B), b = (int)(tb - (long)t * B);
+        const size_t qo = ((((size_t)b * T + t) * n + i) * inner + j) * K, ao = ((size_t)i * rows + r) * K;
+        float x[16], sum = 0.f;
+        for (int k = 0; k < K; ++k) { x[k] = BWD ? dq[qo + k] : a[ao + k]; sum += x[k]; }
+        if (BWD) {
+            const float mean = sum / (float)K;
+            for (int k = 0; k < K; ++k) da[ao + k] = x[k] - mean;
+            dv[(size_t)i * rows + r] = sum;
+        } else {
+            const float vv = v[(size_t)i * rows + r], mean = sum / (float)K;
+            for (int k = 0; k < K; ++k) q[qo + k] = (vv + x[k]) - mean;               // v + a - mean(a), in the reference's order
+        }
+    }
+}
+
+void launch_dueling_q(const float* a, const float* v, float* q, const float* dq, float* da, float* dv, int n, int T, int B, int inner, int K,
+                      hipStream_t stream) {
+    const size_t total = (size_t)n * T * B * inner;
+    if (dq) hipLaunchKernelGGL(k_dueling_q<true>, dim3(grid_for(total)), dim3(256), 0, stream, a, v, q, dq, da, dv, n, T, B, inner, K);
+    else hipLaunchKernelGGL(k_dueling_q<false>, dim3(grid_for(total)), dim3(256), 0, stream, a, v, q, dq, da, dv, n, T, B, inner, K);
+}
+
 // k_gather_rows: rows ids[e] of up to SSD_COPY_BLOCKS_MAX fields into consecutive rows of their destinations (blockIdx.y = field,
 // blockIdx.z = e); 4-byte accesses at any alignment for the bulk of a row, bytes for its tail.
 struct GatherTable { ssd_row_gather f[SSD_COPY_BLOCKS_MAX]; };

@@ -198,14 +198,14 @@ class HomophilyAgent(nn.Module):
         he, hi = hs[:n].reshape(n, T * B, H), hs[n:].reshape(n, T * B, H)
         a = ops.bias_bmm(he, self._w("fc2_env_w"), self._b("fc2_env_b"))
         v = ops.bias_bmm(he, self._w("fc2_env_v_w"), self._b("fc2_env_v_b"))
-        q_env = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, T, B, A).permute(2, 1, 0, 3)
+        q_env = ops.dueling_q(a, v, B, T, 1)                                           # v + a - mean(a) as [B, T, n, A]
         # inc head: per ordered pair (i -> j) [h_i | other_j]
         E = other.shape[-1]
         cat = th.cat([hi.unsqueeze(2).expand(n, T * B, n, H), other.unsqueeze(0).expand(n, T * B, n, E)], dim=-1)
         cat = cat.reshape(n, T * B * n, H + E)
         a = ops.bias_bmm(cat, self._w("fc2_inc_w"), self._b("fc2_inc_b"))
         v = ops.bias_bmm(cat, self._w("fc2_inc_v_w"), self._b("fc2_inc_v_b"))
-        q_inc = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, T, B, n, -1).permute(2, 1, 0, 3, 4)
+        q_inc = ops.dueling_q(a, v, B, T, n)                                           # [B, T, n(i), n(j), 3]
         return q_env, q_inc
 
     # ---- heads --------------------------------------------------------------------------------------------------

@@ -176,6 +176,42 @@ def _copy_blocks(entries, like):
     abi.check(lib, lib.ssd_copy_blocks(tab, len(entries), _stream(like)))
 
 
+class _DuelingQ(th.autograd.Function):
+    """q = v + a - mean_k a (homophily_agent.py:168-170, 203-207) from the layers' time-major rows straight into the batch layout
+    [B, T, n, inner, K], one launch forward and one backward (ssd_dueling_q_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, a, v, B, T, inner):
+        lib = abi.load_library()
+        a, v = a.contiguous(), v.contiguous()
+        n, K = a.shape[0], a.shape[-1]
+        q = th.empty(B, T, n, inner, K, dtype=th.float32, device=a.device)
+        abi.check(lib, lib.ssd_dueling_q_fwd(a.data_ptr(), v.data_ptr(), q.data_ptr(), n, T, B, inner, K, _stream(a)))
+        ctx.dims = (n, T, B, inner, K)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        lib = abi.load_library()
+        n, T, B, inner, K = ctx.dims
+        dq = dq.contiguous()
+        da = th.empty(n, T * B * inner, K, dtype=th.float32, device=dq.device)
+        dv = th.empty(n, T * B * inner, 1, dtype=th.float32, device=dq.device)
+        abi.check(lib, lib.ssd_dueling_q_bwd(dq.data_ptr(), da.data_ptr(), dv.data_ptr(), n, T, B, inner, K, _stream(dq)))
+        return da, dv, None, None, None
+
+
+def dueling_q(a, v, B, T, inner):
+    """a [n, T * B * inner, K] (rows (t * B + b) * inner + j), v [n, T * B * inner, 1] -> q = v + a - mean_k a as [B, T, n, K]
+    (inner = 1) or [B, T, n, inner, K]."""
+    n, K = a.shape[0], a.shape[-1]
+    if a.is_cuda and a.dtype == th.float32 and K <= 16:
+        q = _DuelingQ.apply(a, v, B, T, inner)
+    else:
+        q = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, T, B, inner, K).permute(2, 1, 0, 3, 4)
+    return q.reshape(B, T, n, K) if inner == 1 else q
+
+
 def gather_rows(pairs, ids):
     """dst[e] = src[ids[e]] along axis 0 for every (src, dst) pair of contiguous device tensors, as ONE launch (ssd_gather_rows).
     ids: int64 device tensor.  Returns False (nothing done) when a pair does not qualify -- the caller indexes field by field."""

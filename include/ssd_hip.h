@@ -215,6 +215,13 @@ int ssd_column_sums(const float* x, float* out, int32_t groups, int32_t rows, in
  * HOST array read during the call.  The learner packs the r / z / n blocks of the GRU parameters of both heads side by side with it
  * (homophily_agent.py:83-112 keeps them as 24 separate tensors) and splits the gradients again: 2 launches instead of 8 concatenations
  * and 24 strided copies per train step. */
+/* ssd_dueling_q: the dueling combination of the learner's time-batched heads (homophily_agent.py:168-170, 203-207: q = v + a - mean_k a)
+ * written straight in the batch layout the loss reads -- a f32 [n, rows, K], v f32 [n, rows, 1] with rows = T * B * inner in time-major
+ * order r = (t * B + b) * inner + j (what ssd_bias_bmm_fwd leaves) -> q f32 [B, T, n, inner, K] (inner = 1: q_env; inner = n: q_inc) --
+ * and its backward dq -> (da, dv) in the layers' layout: one launch each instead of mean / sub / add / permuted copy and their autograd. */
+int ssd_dueling_q_fwd(const float* a, const float* v, float* q, int32_t n, int32_t T, int32_t B, int32_t inner, int32_t K, void* stream);
+int ssd_dueling_q_bwd(const float* dq, float* da, float* dv, int32_t n, int32_t T, int32_t B, int32_t inner, int32_t K, void* stream);
+
 /* ssd_gather_rows: dst_f[e] = src_f[ids[e]] for e < n_ids and every field f < count (1..SSD_COPY_BLOCKS_MAX) as ONE launch; a field is
  * a dense array of rows of row_bytes bytes (any alignment).  ReplayBuffer.sample (episode_buffer.py:240-244) draws 16 episodes out of
  * thirteen storage fields with it: one launch instead of one indexing kernel per field.  `fields` is a HOST array read during the call,

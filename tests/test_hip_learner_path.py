@@ -655,3 +655,22 @@ def test_replay_sample_into_a_batch_is_one_gather_launch_with_the_same_episodes(
     dst = th.zeros(4, T, 3, dtype=th.uint8, device="cuda")
     assert ops.gather_rows([(buf["odd"], dst)], ids) and th.equal(dst, buf["odd"][ids])      # 303-byte rows: unaligned words + a byte tail
     assert not ops.gather_rows([(buf["odd"], dst[:3])], ids)                                  # shapes that do not fit are refused
+
+
+@pytest.mark.parametrize("n,T,B,inner,K", [(5, 101, 16, 1, 9), (5, 101, 16, 5, 3), (3, 7, 5, 3, 3), (10, 4, 9, 1, 8)])
+def test_dueling_q_kernels_match_the_tensor_expression(n, T, B, inner, K):
+    """ops.dueling_q (ssd_dueling_q_fwd / _bwd: v + a - mean(a) of the time-batched heads, written in the batch layout the loss reads)
+    against the tensor expression of homophily_agent.py:168-170 / 203-207 and its autograd."""
+    from homophily_marl_amd import ops
+    g = th.Generator(device="cuda").manual_seed(n * 1000 + T)
+    a = th.randn(n, T * B * inner, K, generator=g, device="cuda").requires_grad_()
+    v = th.randn(n, T * B * inner, 1, generator=g, device="cuda").requires_grad_()
+    q = ops.dueling_q(a, v, B, T, inner)
+    ref = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, T, B, inner, K).permute(2, 1, 0, 3, 4)
+    ref = ref.reshape(B, T, n, K) if inner == 1 else ref
+    assert q.shape == ref.shape and q.is_contiguous() and (q - ref).abs().max() < 1e-6
+    w = th.randn(q.shape, generator=g, device="cuda")
+    got = th.autograd.grad((q * w).sum(), [a, v])
+    exp = th.autograd.grad((ref * w).sum(), [a, v])
+    for x, y in zip(got, exp):
+        assert x.shape == y.shape and (x - y).abs().max() < 2e-6
