@@ -6,7 +6,7 @@ The native library is REQUIRED: there is no CPU fallback on the product path.  `
 import ctypes as C
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_AGENTS = 10
 MAX_CELLS = 1024
 MAX_SITES = 256

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSD_ABI_VERSION 2
+#define SSD_ABI_VERSION 3
 
 #define SSD_MAX_AGENTS 10   /* maps hold at most 10 spawn points; agent ids >= 10 break the reference (map_env.py:370) */
 #define SSD_MAX_CELLS 1024  /* H*W upper bound (largest reference map is 48x18 = 864) */
