@@ -7,10 +7,12 @@ mechanics that make a timestep capturable and replayable for every t:
     finished batch moves no data.  Everything that holds pointers into a storage lives in a per-storage bundle;
   * the controller state (hidden states, previous action / reward / incentives) lives in static tensors; the t == 0 history
     features are zeros because the previous action is -1 (all-zero one-hot);
-  * with FastPolicy's fused kernels (default) a timestep is 4 launches: k_encode reads obs[:, t] where the env kernel wrote it,
-    k_head<env>, the fused env step + observe (writes obs[:, t + 1] of the storage), k_head<inc>; the heads file actions /
-    pose / rewards in slot t and carry the runner state.  Other configurations (non-shipped input flags, fast_policy=False)
-    take the generic torch timestep, captured the same way;
+  * with FastPolicy's fused kernels (default) a timestep is 3 launches (pipelined): k_head<env> on the features the previous
+    timestep's launch left, the fused env step + observe (writes obs[:, t + 1] of the storage), and k_inc_encode = k_head<inc> of
+    t together with k_encode of slot t + 1 (they share no data; the input rows live in a buffer pair indexed by the parity of t);
+    the heads file actions / pose / rewards in slot t, carry the runner state and hand the device-side counters over.  Several env
+    groups or an odd number of timesteps per graph take the four standalone launches (k_encode, k_head<env>, env, k_head<inc>).
+    Other configurations (obs_others_last_action, fast_policy=False) take the generic torch timestep, captured the same way;
   * epsilon is a device scalar; exploration uses the package's counter generator (no multinomial, no host sync).
 The first episode runs eagerly (warm-up of hipBLASLt plans and the allocator); graphs are captured from the second on.
 The returned EpisodeBatch is the persistent storage: consume it (buffer.insert_episode_batch) before the next run(), as the
@@ -191,7 +193,8 @@ class HipGraphRunner(HipVecRunner):
         """The launches of one timestep with the FastPolicy kernels, in order, as (kernel name, key, closure).  Fused path
         (default): k_encode reads obs[:, t] from the storage where the env kernel put it, the two head kernels file actions / pose /
         rewards into slot t and carry the previous-step inputs, return and counters themselves -- a timestep is 4 launches
-        (encode, env head, env step+observe, inc head).  Otherwise one store-step launch writes the nine small fields."""
+        (encode, env head, env step+observe, inc head), or 3 when pipelined (self.pipe: env head, env step+observe, inc head of t +
+        encoder of t + 1 as one launch).  Otherwise one store-step launch writes the nine small fields."""
         st = self.store.data.transition_data
         td = self.t_dev
         obs, pos, orient = self.cur["obs"], self.cur["pos"], self.cur["orient"]
