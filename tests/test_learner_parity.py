@@ -125,3 +125,35 @@ def test_class_code_storage_expands_to_the_reference_observation():
         batch.data.transition_data["obs"] = th.as_tensor(codes)          # the compact form of the same batch
         qe2, qi2 = mac.unroll(batch)
     assert th.equal(qe, qe2) and th.equal(qi, qi2)
+
+
+def test_input_flag_words_and_widths_for_every_flag_combination():
+    """Host logic of the _build_inputs flag sets (homophily_controller.py:137-184, 186-201): for all 128 combinations the controller's
+    flag words (the rollout heads' input_flags: None with obs_others_last_action; the learner kernel's input_flags_all) and the C
+    ABI's layout arithmetic (ssd_build_inputs_width: host code, no launch) agree with the reference's _get_input_shape; FastPolicy
+    accepts exactly the sets whose inputs plus the inc head's one-hot action fit the 64-column weight image."""
+    import itertools
+    from types import SimpleNamespace
+    from homophily_marl_amd import abi
+    from homophily_marl_amd.controllers import REGISTRY as mac_REGISTRY
+    from homophily_marl_amd.fast_policy import FastPolicy
+    z, meta = load_fixture("learner_cleanup5.npz")
+    args, batch, _, _ = build(z, meta)
+    lib = abi.load_library()
+    names = ["obs_last_action", "obs_agent_id", "obs_reward", "obs_inc_reward", "obs_distance", "obs_agent_pos", "obs_others_last_action"]
+    bits = [1, 2, 4, 8, 16, 32, 64]
+    n, A = args.n_agents, args.n_actions
+    widths = [A, n, 1, 1, n, 2, n * A]
+    shipped = 0
+    for combo in itertools.product([False, True], repeat=7):
+        a = SimpleNamespace(**dict(vars(args), **dict(zip(names, combo))))
+        mac = mac_REGISTRY[a.mac](batch.scheme, {"agents": n}, a)
+        word = sum(b for b, on in zip(bits, combo) if on)
+        tail = sum(w for w, on in zip(widths, combo) if on)
+        assert mac.input_shape == a.obs_dim_net + tail
+        assert mac.input_flags_all == word and mac.input_flags == (None if combo[6] else word)
+        assert lib.ssd_build_inputs_width(n, A, abi.INPUT_EXPLICIT | word) == tail
+        fits = (not combo[6]) and a.obs_dim_net + tail + A <= 64
+        assert FastPolicy.supports(mac) == (fits or mac.shipped_flags)
+        shipped += mac.shipped_flags
+    assert shipped == 1 and lib.ssd_build_inputs_width(n, A, 0) == A + n + 4          # 0 = the shipped set
