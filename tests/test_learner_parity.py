@@ -157,3 +157,21 @@ def test_input_flag_words_and_widths_for_every_flag_combination():
         assert FastPolicy.supports(mac) == (fits or mac.shipped_flags)
         shipped += mac.shipped_flags
     assert shipped == 1 and lib.ssd_build_inputs_width(n, A, 0) == A + n + 4          # 0 = the shipped set
+
+
+def test_fused_logs_mapping_reads_the_loss_kernels_sums():
+    """The nine logged scalars of a train step (homophily_learner.py:228-246) as a read-only mapping over the loss kernel's column sums:
+    the quotients are formed when read, from the CURRENT contents of the buffers (a replayed graph refreshes them in place)."""
+    from homophily_marl_amd.learners.homophily_learner import _FusedLogs
+    sums = th.arange(13, dtype=th.float32) + 1.0
+    dens = th.tensor([4.0, 9.0])
+    logs = _FusedLogs(sums, dens, rows=10.0, n=5)
+    assert len(logs) == 9 and set(logs) == set(_FusedLogs.KEYS)
+    assert float(logs["loss_value_env"]) == 3.0 / 4.0 and float(logs["loss_value_inc"]) == 4.0 / 4.0 and float(logs["loss_sim"]) == 5.0 / 10.0
+    assert abs(float(logs["q_env_taken_mean"]) - 6.0 / 10.0) < 1e-7 and abs(float(logs["q_inc_taken_mean"]) - 7.0 / 50.0) < 1e-7
+    assert abs(float(logs["value_give_mean"]) - 8.0 / 10.0) < 1e-7 and abs(float(logs["value_receive_mean"]) - 9.0 / 10.0) < 1e-7
+    assert abs(float(logs["incentives_to_cleanup_per"]) - 10.0 / (11.0 + 1e-6)) < 1e-6
+    sums.mul_(2.0)                                                     # the buffers change (next replay): the mapping follows
+    assert float(logs["loss_value_env"]) == 6.0 / 4.0 and dict(logs.items()).keys() == set(_FusedLogs.KEYS)
+    with pytest.raises(KeyError):
+        logs["nope"]
