@@ -29,6 +29,7 @@ c = CONFIGS[a.config]
 N, n, T = c["n_env"], c["n_agents"], 100
 cfg = load_config(c["env"], overrides=dict(
     runner="hip_graph", rollout_graph=False, batch_size_run=N, batch_size=16, buffer_size=N, buffer_cpu_only=False, store_state=False,
+    pipeline_encode=False,      # the phase stamps are defined per standalone kernel (k_encode, k_head<env>, k_head<inc>)
     env_args=dict(num_agents=n, map=c["map"], episode_limit=T, view_size=c["view_size"], seed=1),
     use_cuda=True, save_model=False, runner_stats=False, learner_log_interval=10 ** 12))
 th.manual_seed(0)
