@@ -2,7 +2,11 @@
 """bench.py -- agent-steps/sec of the SSD hot path on N MI355X GPUs (one process per GPU), BASELINE.json metric.
 
     python bench.py --gpus N --steps K --warmup W [--config cleanup5|harvest5|cleanup10] [--workload e2e|env]
-    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 works both ways: under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env), and as plain `python bench.py --gpus N ...`: without WORLD_SIZE in
+    the env the process starts that launcher itself as a CHILD (before anything touches the GPU; never an exec), relays rank 0's
+    one JSON line and exits with the launcher's return code.  `--launch-dry-run` takes the same front door with gloo ranks that
+    only form the group and count each other (no GPU; the CPU suite runs it).
 
 Configurations (BASELINE.json `configs`; episode_limit 100, default extra_args, COUNTER-mode env RNG seed 1):
   cleanup5  (default, configs[1], the one the metric is quoted on): Cleanup `default5`, 5 agents, 4096 envs per GPU
@@ -117,10 +121,65 @@ def roofline_entry(k):
             ach = a32["flops_per_launch"] / (k["avg_us"] * 1e-6) / 1e12
             e["algorithmic_f32"] = {"achieved": ach, "peak": a32["peak_tf"], "unit": "TFLOP/s", "frac": ach / a32["peak_tf"],
                                     "algorithmic_flops_per_launch": a32["flops_per_launch"]}
+    e["traffic_source"] = k.get("traffic_source")
     e.update(kernel=k["name"], kernel_avg_us=k["avg_us"], kernel_median_us=k.get("median_us", k["avg_us"]))
     if "share_of_timestep" in k:
         e["share_of_timestep"] = k["share_of_timestep"]
     return e
+
+
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a child `torch.distributed.run` job (one process per GPU),
+    pass rank 0's JSON line through and return the job's exit code.  Called before torch is imported: this process never
+    initialises the GPU and never execs."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SSD_SELF_LAUNCHED="1")
+    print("[bench] self-launch: %s" % " ".join(cmd), file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [l for l in p.stdout.read().decode(errors="replace").splitlines() if l.strip()]
+    rc = p.wait()
+    js = [l for l in lines if l.lstrip().startswith("{")]
+    for l in lines:
+        if l not in js[-1:]:
+            print(l, file=sys.stderr)
+    if rc == 0 and not js:
+        print("[bench] the ranks exited 0 without a JSON line", file=sys.stderr)
+        rc = 1
+    if js and rc == 0:
+        sys.stdout.write(js[-1] + "\n")
+        sys.stdout.flush()
+    return rc
+
+
+def dry_run(args):
+    """--launch-dry-run: the ranks form a gloo group, count each other with an all-reduce of ones and rank 0 prints a line with
+    the launch-related fields only (no GPU, no workload)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    seen = 1
+    if os.environ.get("SSD_DRY_RUN_FAIL_RANK") == str(rank):      # test hook: a rank that dies must fail the whole front door
+        raise SystemExit(7)
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "agent_steps_per_sec", "value": None, "n_gpus": world, "dry_run": True,
+                          "config": {"world_size": world, "ranks_seen": seen, "backend": "gloo" if world > 1 else "none",
+                                     "self_launched": os.environ.get("SSD_SELF_LAUNCHED") == "1"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if seen == world == args.gpus else 1
 
 
 def main():
@@ -135,7 +194,7 @@ def main():
     ap.add_argument("--train-graph", type=int, default=1, help="e2e: capture the train step as hipGraphs")
     ap.add_argument("--steps-per-graph", type=int, default=10, help="e2e: timesteps captured per rollout hipGraph")
     ap.add_argument("--qnet-dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="e2e: arithmetic of the ROLLOUT controller kernels: fp32 (split-bf16 MFMA products, f32-equivalent; the headline) "
+                    help="e2e: arithmetic of the ROLLOUT controller kernels: fp32 (two-term f16 split MFMA products, f32-equivalent; the headline) "
                          "or bf16 (single bf16 products; a second, labelled line -- the learner stays fp32)")
     ap.add_argument("--train-steps-per-rollout", type=int, default=1, help="e2e: learner.train calls per rollout (reference cadence: 1)")
     ap.add_argument("--obs-storage", default="code", choices=["f32", "code"],
@@ -147,7 +206,12 @@ def main():
                          "exercises apple spawning; 0 = start from the map's reset state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=None)
+    ap.add_argument("--launch-dry-run", action="store_true", help="form the process group (gloo), count the ranks, print the launch fields; no GPU")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.launch_dry_run:
+        sys.exit(dry_run(args))
     # stdout carries exactly ONE line, the JSON: libraries that print banners to fd 1 (RCCL's version header at communicator
     # creation) are sent to stderr for the lifetime of the process
     sys.stdout.flush()
@@ -172,7 +236,8 @@ def main():
     backend = "none"
     force_dist = os.environ.get("SSD_FORCE_DIST") == "1"      # rehearsal: a 1-rank process group still runs every collective
     if args.gpus > 1 or world > 1 or force_dist:
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        if world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N` or torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
         backend = os.environ.get("SSD_DIST_BACKEND", "nccl")     # "nccl" = RCCL; "gloo" only for rehearsing >1 rank on one GPU
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
@@ -183,6 +248,12 @@ def main():
     in_group = dist.is_initialized()
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    ranks_seen = 1
+    if in_group:       # how many ranks the collective really joins: an all-reduce of ones on the job's own backend
+        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world, "process group joins %d ranks, WORLD_SIZE is %d" % (ranks_seen, world)
 
     n, N, T, V = c["n_agents"], c["n_env"], 100, 2 * c["view_size"] + 1
     if args.workload == "e2e":
@@ -261,6 +332,7 @@ def main():
                 rec = tr.get("kernels", {}).get("%s@%s%s" % (k["name"], args.config, suffix))
                 if rec and rec.get("n_env") == N:
                     k["traffic"] = rec.get("hbm_bytes_per_launch")
+                    k["traffic_source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes of %s; not measured in this run)" % tr.get("collected", "an earlier collection")
         entries = [roofline_entry(k) for k in kernels]
         dominant = max(entries, key=lambda e: e["kernel_avg_us"])
         line = {
@@ -269,7 +341,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": result["dtype"], "data": "synthetic",
             "config": dict({"workload": result["workload"], "name": args.config, "env": c["env"], "map": c["map"], "n_agents": n,
                             "n_env_per_gpu": N, "episode_limit": T, "view_size": c["view_size"], "rng": "counter(philox4x32-10, seed 1)",
-                            "world_size": world, "backend": {"nccl": "nccl(RCCL)"}.get(backend, backend),
+                            "world_size": world, "ranks_seen": ranks_seen, "backend": {"nccl": "nccl(RCCL)"}.get(backend, backend),
+                            "self_launched": os.environ.get("SSD_SELF_LAUNCHED") == "1",
                             "parallelism": ("dp%d: env shards, no collective in the rollout" % world) +
                                            ("; 1 flat-gradient all-reduce + 2 scalars per train step" if args.workload == "e2e" else "")},
                            **result["extra"]),

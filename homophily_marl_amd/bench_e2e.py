@@ -183,7 +183,7 @@ def run_e2e(args, c, rank, world, local_rank):
     return dict(elapsed=elapsed, kernels=kernels, dtype="fp32" if qnet == "fp32" else "bf16",
                 workload="%s_rollout_plus_homophily_train" % args.config,
                 extra=dict(obs_format=("u8 class codes [n_env,n,%d,%d] (format C)" % (V, V)) if code else "f32[n_env,n,3,%d,%d]" % (V, V),
-                           qnet_dtype=("fp32 (rollout: split-bf16 MFMA products, f32-equivalent; learner: fp32)" if qnet == "fp32"
+                           qnet_dtype=("fp32 (rollout: two-term f16 split MFMA products, f32-equivalent; learner: fp32)" if qnet == "fp32"
                                        else "bf16 rollout inference (single bf16 MFMA products), fp32 learner"),
                            step="1 bench step = 1 iteration: reset + %d timesteps + slot-T pass + replay insert + sample + %d learner.train" % (T, tspr),
                            timesteps_timed=timed["timesteps"], train_steps_timed=timed["trains"], rollouts_timed=args.steps,

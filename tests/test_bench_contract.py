@@ -55,3 +55,29 @@ def test_roofline_bytes_follow_the_survey_formula():
     assert algorithmic_bytes_per_env_step(10, 10, 3, 15) == 8444        # Cleanup-3
     assert algorithmic_bytes_per_env_step(48, 18, 10, 15) == 29208      # Cleanup-10
     assert algorithmic_bytes_per_env_step(9, 38, 5, 31) == 58584        # Harvest-5
+
+
+def test_bench_front_door_starts_its_own_ranks_for_n_gt_1():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command form) starts two ranks as a child
+    torch.distributed.run job, the ranks count each other with an all-reduce, and exactly one JSON line comes back on stdout."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-dry-run"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["world_size"] == 2 and d["config"]["self_launched"] is True
+
+
+def test_bench_front_door_propagates_a_failing_rank():
+    """a rank that dies makes the self-launched job exit non-zero and print no JSON line."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SSD_DRY_RUN_FAIL_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-dry-run"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and not p.stdout.decode().strip()
