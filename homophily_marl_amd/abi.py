@@ -226,6 +226,8 @@ HIP_SIGNATURES["ssd_clip_adam_step"] = (C.c_int, [C.POINTER(SsdClipAdamArgs), C.
 HIP_SIGNATURES["ssd_dueling_q_fwd"] = (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_void_p])
 HIP_SIGNATURES["ssd_dueling_q_bwd"] = (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_void_p])
 HIP_SIGNATURES["ssd_gather_rows"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p])
+HIP_SIGNATURES["ssd_sample_ids"] = (C.c_int, [C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p])
+SAMPLE_IDS_MAX = 1024
 HIP_SIGNATURES["ssd_copy_blocks"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_fwd_parts"] = (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_bwd_parts"] = (C.c_int, [C.c_void_p] * 6 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p])

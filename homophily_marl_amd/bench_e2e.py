@@ -58,27 +58,21 @@ def run_e2e(args, c, rank, world, local_rank):
         obs_storage=getattr(args, "obs_storage", "f32"), buffer_cpu_only=False, store_state=False, qnet_dtype=qnet,
         train_steps_per_rollout=tspr,
         env_args=dict(num_agents=n, map=c["map"], episode_limit=T, view_size=c["view_size"], seed=1), use_cuda=True, save_model=False,
-        device_index=local_rank, env_id_base=rank * N, runner_stats=False, learner_log_interval=10 ** 12))
+        device_index=local_rank, env_id_base=rank * N, strict_device_ops=True))       # runner / learner statistics on, at the shipped log intervals
     th.manual_seed(0)                     # fixed-seed random-init weights, identical on every rank
     ctx = setup(cfg)
     runner, learner, buf = ctx.runner, ctx.learner, ctx.buffer
     a = ctx.args
     state = dict(episode=0, trains=0, timesteps=0)
 
+    from .run import train_iteration
+
     def iteration():
-        runner.begin_episode(False)
-        for _ in range(T):
-            runner.step_once()
+        # the shipped driver loop body itself (run.train_iteration = run.py:181-210: runner.run, insert, sample, learner.train)
+        before = ctx.train_steps
+        state["episode"] = train_iteration(ctx, state["episode"])
         state["timesteps"] += T
-        batch = runner.finish_episode()
-        buf.insert_episode_batch(batch)
-        if buf.can_sample(a.batch_size):
-            for _ in range(tspr):
-                sample = buf.sample(a.batch_size, out=learner.sample_out())[:, :T + 1]
-                learner.train(sample, runner.t_env, ctx.train_steps if a.schedule_unit == "rollouts" else state["episode"])
-                ctx.train_steps += 1
-                state["trains"] += 1
-        state["episode"] += a.batch_size_run
+        state["trains"] += ctx.train_steps - before
 
     # Setup (not warm-up): build the hipGraphs.  The rollout graph of a replay slab is captured at the start of the 2nd episode
     # that lands in it and the two train-step graphs at the 3rd learner.train call, so every slab is visited twice before the W

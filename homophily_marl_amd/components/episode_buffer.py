@@ -160,6 +160,12 @@ class ReplayBuffer(EpisodeBatch):
         self.buffer_size = buffer_size
         self.buffer_index = 0
         self.episodes_in_buffer = 0
+        # device-resident buffers draw their sample indices on the device (ops.sample_ids: counter generator keyed by a seed taken
+        # from numpy's global generator at the first device sample -- np.random.seed still makes a run reproducible -- and the
+        # number of the sample call); host buffers keep the reference's np.random.choice and consume nothing else
+        self._sample_seed = None
+        self._sample_calls = 0
+        self._sample_ids = None
 
     def reserve(self, n):
         """A view over the next n episode slots, for producers that write whole episodes in place (vectorised runners): hand
@@ -197,19 +203,31 @@ class ReplayBuffer(EpisodeBatch):
     def sample(self, batch_size, out=None):
         """batch_size episodes drawn without replacement (episode_buffer.py:240-244).  out: an EpisodeBatch of batch_size whole
         episodes (a learner's static copy of the sampled batch) that receives the episodes directly -- one gather per field
-        instead of a gather into fresh tensors and a second copy into the consumer's buffers."""
+        instead of a gather into fresh tensors and a second copy into the consumer's buffers; taken only when it lives on the
+        buffer's device.  A device-resident buffer draws the indices on the device (ssd_sample_ids): no host draw, no H2D copy."""
         assert self.can_sample(batch_size)
         if self.episodes_in_buffer == batch_size:
             return self[:batch_size]
-        ep_ids = np.random.choice(self.episodes_in_buffer, batch_size, replace=False)   # episode_buffer.py:243
-        if out is not None and out.batch_size == batch_size and out.max_seq_length == self.max_seq_length and not self.data.episode_data:
+        on_device = th.device(self.device).type == "cuda"
+        if on_device and batch_size <= ops.abi.SAMPLE_IDS_MAX:
+            if self._sample_seed is None:
+                self._sample_seed = int(np.random.randint(0, 2 ** 31 - 1)) | (int(np.random.randint(0, 2 ** 31 - 1)) << 32)
+            if self._sample_ids is None or self._sample_ids.numel() != batch_size:
+                self._sample_ids = th.empty(batch_size, dtype=th.long, device=self.device)
+            ids = ops.sample_ids(self._sample_seed, self._sample_calls, self.episodes_in_buffer, batch_size, self._sample_ids)
+            self._sample_calls += 1
+        else:
+            ep_ids = np.random.choice(self.episodes_in_buffer, batch_size, replace=False)   # episode_buffer.py:243
             ids = th.as_tensor(ep_ids, dtype=th.long, device=self.device)
+        if (out is not None and out.batch_size == batch_size and out.max_seq_length == self.max_seq_length and not self.data.episode_data
+                and all(out.data.transition_data[k].device == v.device for k, v in self.data.transition_data.items())):
             pairs = [(v, out.data.transition_data[k]) for k, v in self.data.transition_data.items()]
             if not (ids.is_cuda and ops.gather_rows(pairs, ids)):       # device buffers: one launch for all fields
+                ops._leaving_kernels("gather_rows", ids, "fields that do not qualify for ssd_gather_rows")
                 for v, dst in pairs:
                     th.index_select(v, 0, ids, out=dst)
             return out
-        return self[ep_ids]
+        return self[ids]
 
     def sample_latest(self, batch_size):
         ep_ids = np.arange(self.buffer_index - batch_size, self.buffer_index) % self.buffer_size

@@ -180,6 +180,7 @@ class HomophilyMAC(nn.Module):
             if a.rgb_input and self.agent.encoder_kernel_shape and ops.encode_codes_supported(obs):
                 codes = obs                        # the encoder kernel reads the codes themselves (ops.encode_codes)
             else:
+                ops._leaving_kernels("encode_codes", obs, "no encoder kernel for %s windows" % (tuple(obs.shape[-2:]),))
                 obs = self.expand_codes(obs)
         acts = batch["actions"].squeeze(-1)                                            # [B, T, n]
         # history features of step t come from t - 1; at t = 0 they are zero: action -1 has an all-zero one-hot

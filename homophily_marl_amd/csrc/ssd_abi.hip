@@ -388,6 +388,12 @@ int ssd_gather_rows(const ssd_row_gather* fields, int32_t count, const int64_t* 
     return launched();
 }
 
+int ssd_sample_ids(uint64_t seed, uint32_t call, int32_t population, int32_t count, int64_t* ids, void* stream) {
+    if (!ids || count < 1 || count > SSD_SAMPLE_IDS_MAX || population < count) return fail(SSD_ERR_INVALID, "ssd_sample_ids: 1 <= count <= min(population, SSD_SAMPLE_IDS_MAX)");
+    launch_sample_ids(seed, call, population, count, ids, (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_copy_blocks(const ssd_block_copy* blocks, int32_t count, void* stream) {
     if (!blocks || count < 1 || count > SSD_COPY_BLOCKS_MAX) return fail(SSD_ERR_INVALID, "ssd_copy_blocks: 1..SSD_COPY_BLOCKS_MAX blocks");
     for (int i = 0; i < count; ++i) {

@@ -127,6 +127,7 @@ void launch_column_sums(const float* x, float* out, int G, int R, int C, float* 
 void launch_copy_blocks(const ssd_block_copy* blocks, int count, hipStream_t stream);
 void launch_clip_adam(const ssd_clip_adam_args* a, hipStream_t stream);
 void launch_dueling_q(const float* a, const float* v, float* q, const float* dq, float* da, float* dv, int n, int T, int B, int inner, int K, hipStream_t stream);
+void launch_sample_ids(uint64_t seed, uint32_t call, int population, int count, int64_t* out, hipStream_t stream);
 void launch_gather_rows(const ssd_row_gather* fields, int count, const int64_t* ids, int n_ids, hipStream_t stream);
 void launch_td_sim_loss(const ssd_td_loss_args* a, int mode, hipStream_t stream);
 void launch_encoder(const float* obs, int rows, int V, const float* cw, const float* cb, const float* lw, const float* lb, float* out,

@@ -360,6 +360,35 @@ void launch_gather_rows(const ssd_row_gather* fields, int count, const int64_t* 
     hipLaunchKernelGGL(k_gather_rows, dim3(gx, count, n_ids), dim3(256), 0, stream, t, ids);
 }
 
+// k_sample_ids: `count` distinct episode ids out of [0, population), uniformly, from a counter generator keyed by (seed, call) --
+// ReplayBuffer.sample's np.random.choice(replace = False) (episode_buffer.py:240-244) without a host draw or an H2D copy.  Floyd's
+// subset sampling (a uniform count-subset with count draws, no population-sized permutation), then a Fisher-Yates pass over the
+// count picks.  One thread: count is a batch size (16 in the shipped configuration; the ABI bounds it at SSD_SAMPLE_IDS_MAX).
+__device__ __forceinline__ uint32_t sample_draw(uint32_t s0, uint32_t s1, uint32_t call, uint32_t i) {
+    uint32_t x = s0 ^ (call * 0x9E3779B9u);
+    x ^= x >> 17; x *= 0xed5ad4bbu; x ^= x >> 11; x *= 0xac4c1b51u; x ^= x >> 15; x *= 0x31848babu; x ^= x >> 14;
+    x ^= s1 + i * 0x85EBCA6Bu;
+    x ^= x >> 17; x *= 0xed5ad4bbu; x ^= x >> 11; x *= 0xac4c1b51u; x ^= x >> 15; x *= 0x31848babu; x ^= x >> 14;
+    return x;
+}
+__global__ __launch_bounds__(64) void k_sample_ids(uint32_t s0, uint32_t s1, uint32_t call, int population, int count, int64_t* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < count; ++i) {
+        const int j = population - count + i;
+        const int t = (int)(((uint64_t)sample_draw(s0, s1, call, (uint32_t)i) * (uint32_t)(j + 1)) >> 32);
+        bool taken = false;
+        for (int k = 0; k < i; ++k) taken |= out[k] == (int64_t)t;
+        out[i] = taken ? j : t;
+    }
+    for (int i = count - 1; i > 0; --i) {
+        const int k = (int)(((uint64_t)sample_draw(s0, s1, call, (uint32_t)(count + i)) * (uint32_t)(i + 1)) >> 32);
+        const int64_t a = out[i]; out[i] = out[k]; out[k] = a;
+    }
+}
+void launch_sample_ids(uint64_t seed, uint32_t call, int population, int count, int64_t* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sample_ids, dim3(1), dim3(64), 0, stream, (uint32_t)seed, (uint32_t)(seed >> 32), call, population, count, out);
+}
+
 void launch_copy_blocks(const ssd_block_copy* blocks, int count, hipStream_t stream) {
     CopyTable t;
     int most = 1;

@@ -48,6 +48,13 @@ class _FusedLogs(Mapping):
     def __len__(self):
         return len(self.KEYS)
 
+    def synced(self):
+        """Under data parallelism the kernel sums are this rank's share while the denominators are global: the logger reads the
+        sums added over the group (one small all-reduce per log interval, issued by every rank at the same train step)."""
+        s = self.sums.detach().clone()
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        return _FusedLogs(s, self.dens, self.rows * dist.get_world_size(), self.n)
+
 
 class HomophilyLearner:
     def __init__(self, mac, scheme, logger, args):
@@ -86,6 +93,11 @@ class HomophilyLearner:
         for p in self.target_mac.parameters():
             p.requires_grad_(False)
         self.log_stats_t = -self.args.learner_log_interval - 1
+        # log_clock: the clock learner_log_interval is measured on (None: t_env, the reference's).  run.setup sets it to the
+        # runner's schedule clock under schedule_unit "rollouts" (episode_limit per rollout of ALL envs), so that the vectorised loop
+        # logs -- and synchronises with the host -- every learner_log_interval / episode_limit rollouts like the reference does,
+        # not after every train step (one rollout of 4096 envs advances t_env by 409 600)
+        self.log_clock = None
         # SSD_FORCE_DIST=1: a process group of ONE rank still issues every collective (RCCL rehearsal on a one-GPU box)
         self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or
                                                                                os.environ.get("SSD_FORCE_DIST") == "1")
@@ -406,12 +418,15 @@ class HomophilyLearner:
         if (episode_num - self.last_target_update_episode) / self.args.target_update_interval >= 1.0:
             self._update_targets()
             self.last_target_update_episode = episode_num
-        if t_env - self.log_stats_t >= self.args.learner_log_interval:
+        clock = self.log_clock() if self.log_clock is not None else t_env
+        if clock - self.log_stats_t >= self.args.learner_log_interval:
             self.logger.log_stat("clean_num_mean", batch["clean_num"][:, :-1].mean().item(), t_env)
             self.logger.log_stat("apple_den_mean", batch["apple_den"][:, :-1].mean().item(), t_env)
+            if self.distributed and isinstance(logs, _FusedLogs):
+                logs = logs.synced()
             for k, v in logs.items():
                 self.logger.log_stat(k, v.item(), t_env)
-            self.log_stats_t = t_env
+            self.log_stats_t = clock
 
     def _update_targets(self):
         self.target_mac.load_state(self.mac)

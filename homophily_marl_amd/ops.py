@@ -15,6 +15,25 @@ def _stream(t):
     return th.cuda.current_stream(t.device).cuda_stream
 
 
+# strict_device_ops: raise where a DEVICE tensor would leave the HIP kernels for a tensor-op statement (shapes / dtypes an operator's
+# kernel is not instantiated for).  bench.py, smoke() and the GPU suite switch it on (config key `strict_device_ops`, or
+# SSD_STRICT_DEVICE_OPS=1): a silent torch branch on a GPU run is a failure there, not a fallback.
+import os as _os
+STRICT = _os.environ.get("SSD_STRICT_DEVICE_OPS") == "1"
+
+
+def set_strict(on=True):
+    global STRICT
+    STRICT = bool(on)
+
+
+def _leaving_kernels(op, t, why):
+    """called on every branch that evaluates an operator with tensor ops: fine for host tensors, an error for device tensors under
+    strict_device_ops."""
+    if STRICT and t is not None and t.is_cuda:
+        raise RuntimeError("strict_device_ops: ops.%s would take the tensor-op branch for a device tensor (%s)" % (op, why))
+
+
 def build_inputs_tail(out, offset, last_actions, last_reward, last_actions_inc, pos, pos_scale, n_actions, t0, flags=None, seq_len=0):
     """Fill out[:, offset : offset + A + n + 4] with the non-visual agent-input features of
     HomophilyMAC._build_inputs (controllers/homophily_controller.py:137-184):
@@ -208,8 +227,44 @@ def dueling_q(a, v, B, T, inner):
     if a.is_cuda and a.dtype == th.float32 and K <= 16:
         q = _DuelingQ.apply(a, v, B, T, inner)
     else:
+        _leaving_kernels("dueling_q", a, "K = %d > 16 or dtype %s" % (K, a.dtype))
         q = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, T, B, inner, K).permute(2, 1, 0, 3, 4)
     return q.reshape(B, T, n, K) if inner == 1 else q
+
+
+def _mix32p(x):
+    x &= 0xFFFFFFFF
+    x ^= x >> 17; x = (x * 0xed5ad4bb) & 0xFFFFFFFF; x ^= x >> 11; x = (x * 0xac4c1b51) & 0xFFFFFFFF
+    x ^= x >> 15; x = (x * 0x31848bab) & 0xFFFFFFFF; x ^= x >> 14
+    return x
+
+
+def _sample_draw(seed, call, i):
+    s0, s1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    x = _mix32p(s0 ^ ((call * 0x9E3779B9) & 0xFFFFFFFF))
+    return _mix32p(x ^ ((s1 + i * 0x85EBCA6B) & 0xFFFFFFFF))
+
+
+def sample_ids(seed, call, population, count, out):
+    """out[0 .. count) (int64) = `count` distinct indices drawn uniformly from [0, population): the replay buffer's
+    np.random.choice(population, count, replace=False) (episode_buffer.py:240-244) as a counter generator keyed by (seed, call).
+    Device tensor: one launch (ssd_sample_ids), nothing crosses the host boundary.  Host tensor: the same arithmetic restated
+    (Floyd's subset sampling, then Fisher-Yates over the picks), so both give the same ids."""
+    assert out.dtype == th.long and out.numel() >= count and 1 <= count <= population
+    if out.is_cuda:
+        lib = abi.load_library()
+        abi.check(lib, lib.ssd_sample_ids(seed & (2 ** 64 - 1), call & 0xFFFFFFFF, population, count, out.data_ptr(), _stream(out)))
+        return out
+    ids = []
+    for i in range(count):
+        j = population - count + i
+        t = (_sample_draw(seed, call & 0xFFFFFFFF, i) * (j + 1)) >> 32
+        ids.append(j if t in ids else t)
+    for i in range(count - 1, 0, -1):
+        k = (_sample_draw(seed, call & 0xFFFFFFFF, count + i) * (i + 1)) >> 32
+        ids[i], ids[k] = ids[k], ids[i]
+    out[:count] = th.tensor(ids, dtype=th.long)
+    return out
 
 
 def gather_rows(pairs, ids):
@@ -218,6 +273,8 @@ def gather_rows(pairs, ids):
     if not pairs or len(pairs) > abi.COPY_BLOCKS_MAX or not ids.is_cuda or ids.dtype != th.long:
         return False
     n = ids.numel()
+    if n < 1 or n > 65535:                      # the launch's grid-z limit: the caller indexes field by field
+        return False
     for src, dst in pairs:
         if not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype
                 and dst.shape[0] == n and dst.shape[1:] == src.shape[1:] and src[0].numel() > 0):
@@ -288,6 +345,7 @@ def cat_groups(groups):
     if (flat[0].is_cuda and len(flat) <= abi.COPY_BLOCKS_MAX and all(t.dtype == th.float32 and t.is_cuda for t in flat)
             and all(t.shape[:-1] == g[0].shape[:-1] for g in groups for t in g)):
         return list(_CatGroups.apply(tuple(len(g) for g in groups), *flat))
+    _leaving_kernels("cat_groups", flat[0], "%d tensors / dtypes / leading axes" % len(flat))
     return [th.cat(list(g), dim=-1) for g in groups]
 
 
@@ -338,6 +396,7 @@ def bias_bmm(x, w, b):
         if th.is_grad_enabled() and (w.requires_grad or b.requires_grad or x.requires_grad):
             return _BiasBmm.apply(x, w, b)
         return _bias_bmm_fwd(x, w, b)
+    _leaving_kernels("bias_bmm", x, "dtype / rank")
     return th.baddbmm(b, x, w)
 
 
@@ -368,7 +427,8 @@ class _ChannelBias(th.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         R, C = g.shape[0], g.shape[1]
-        db = column_sums(g.reshape(R, -1)).view(C, -1).sum(1) if ctx.needs_input_grad[1] else None
+        # rows first (k_column_sums), then the H x W positions of a channel as the rows of a second k_column_sums: no ATen reduction
+        db = column_sums(column_sums(g.reshape(R, -1)).view(C, -1).t().contiguous()) if ctx.needs_input_grad[1] else None
         return g, db
 
 
@@ -534,7 +594,7 @@ class _GruSeq(th.autograd.Function):
                                            dgh.data_ptr(), d_wh.data_ptr(), d_bh.data_ptr(), T, G, Bp, _stream(rzn)))
         if Bp != B:
             d_gi = d_gi[:, :, :B].contiguous()
-        return d_gi, d_wh, (d_bh.sum(1) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)
+        return d_gi, d_wh, (column_sums(d_bh) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)      # per-tile bias sums: k_column_sums (no ATen reduction)
 
 
 class _GruSeqParts(th.autograd.Function):
@@ -577,7 +637,7 @@ class _GruSeqParts(th.autograd.Function):
         abi.check(lib, lib.ssd_gru_seq_bwd_parts(dhs.data_ptr(), hs.data_ptr(), rzn.data_ptr(), ghn.data_ptr(), wh.data_ptr(), ptrs, len(d_parts),
                                                  dgh.data_ptr(), d_wh.data_ptr(), d_bh.data_ptr(), T, G, B, _stream(rzn)))
         need = ctx.needs_input_grad
-        return (None, None, d_wh, (d_bh.sum(1) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)) + tuple(d if need[4 + k] else None for k, d in enumerate(d_parts))
+        return (None, None, d_wh, (column_sums(d_bh) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)) + tuple(d if need[4 + k] else None for k, d in enumerate(d_parts))
 
 
 def gru_sequence_parts(parts, T, B, wh, bh):
@@ -586,6 +646,9 @@ def gru_sequence_parts(parts, T, B, wh, bh):
     H3 = parts[0].shape[-1]
     if (parts[0].is_cuda and H3 == 192 and B % 16 == 0 and 1 <= len(parts) <= 4 and all(p.shape == parts[0].shape and p.dtype == th.float32 for p in parts)):
         return _GruSeqParts.apply(T, B, wh, bh, *parts)
+    if H3 != 192 or parts[0].dtype != th.float32:
+        _leaving_kernels("gru_sequence_parts", parts[0], "hidden size %d / dtype" % (H3 // 3))
+    # ragged batches (B % 16) and other part counts: the time-major launch (it pads the batch itself); still the HIP recurrence
     gi = th.cat([p.reshape(p.shape[0], T, B, H3) for p in parts], dim=0).transpose(0, 1).contiguous()      # [T, G, B, 3H]
     return gru_sequence(gi, wh, bh)
 
@@ -595,6 +658,7 @@ def gru_sequence(gi, wh, bh):
     T, G, B, H3 = gi.shape
     if gi.is_cuda and H3 == 192:
         return _GruSeq.apply(gi, wh, bh)
+    _leaving_kernels("gru_sequence", gi, "hidden size %d: the sequence kernels are instantiated for 64" % (H3 // 3))
     h = gi.new_zeros(G, B, H3 // 3)
     hs = []
     for t in range(T):

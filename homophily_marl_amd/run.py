@@ -72,6 +72,9 @@ def setup(config, logger=None):
     if getattr(args, "schedule_unit", None) not in ("env_steps", "rollouts"):
         args.schedule_unit = "env_steps" if args.batch_size_run == 1 else "rollouts"
     args.train_steps_per_rollout = max(1, int(getattr(args, "train_steps_per_rollout", 1) or 1))
+    if getattr(args, "strict_device_ops", False):
+        from . import ops
+        ops.set_strict(True)
     logger = logger or Logger()
     runner = r_REGISTRY[args.runner](args=args, logger=logger)
     env_info = runner.get_env_info()
@@ -87,6 +90,8 @@ def setup(config, logger=None):
     learner = le_REGISTRY[args.learner](mac, buffer.scheme, logger, args)
     if args.use_cuda:
         learner.cuda()
+    if args.schedule_unit == "rollouts":       # the log intervals run on the schedule clock too (see HomophilyLearner.log_clock)
+        learner.log_clock = lambda: runner.sched_t
     if getattr(args, "replay_in_place", True) and hasattr(runner, "set_replay_buffer"):
         runner.set_replay_buffer(buffer)        # hip_graph: rollouts land in the replay buffer's own slots when the sizes allow
     return SimpleNamespace(args=args, logger=logger, runner=runner, buffer=buffer, mac=mac, learner=learner, train_steps=0)
@@ -102,7 +107,10 @@ def train_iteration(ctx, episode):
     if ctx.buffer.can_sample(a.batch_size):
         for _ in range(a.train_steps_per_rollout):
             sample = ctx.buffer.sample(a.batch_size, out=ctx.learner.sample_out() if hasattr(ctx.learner, "sample_out") else None)
-            sample = sample[:, :sample.max_t_filled()]
+            # run.py:188-189 trims the sample to its longest episode; the vectorised runners always write episode_limit + 1 slots
+            # (`filled` is all ones), so the trim is the identity there and the device -> host read of max_t_filled() is skipped
+            if not getattr(ctx.runner, "fixed_length_episodes", False):
+                sample = sample[:, :sample.max_t_filled()]
             if str(sample.device) != str(a.device):
                 sample.to(a.device)
             ctx.learner.train(sample, ctx.runner.t_env, ctx.train_steps if a.schedule_unit == "rollouts" else episode)

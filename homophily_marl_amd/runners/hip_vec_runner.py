@@ -18,6 +18,7 @@ from ..envs import REGISTRY as env_REGISTRY
 
 class HipVecRunner:
     single_env_only = False
+    fixed_length_episodes = True       # the SSD envs terminate at episode_limit only: every stored episode fills all T + 1 slots
 
     def __init__(self, args, logger):
         self.args, self.logger = args, logger
@@ -33,7 +34,7 @@ class HipVecRunner:
         self.t = 0
         self.t_env = 0
         self.rollouts = 0          # training rollouts finished (schedule_unit "rollouts": the epsilon clock, see sched_t)
-        self.train_returns, self.test_returns = [], []
+        self.train_returns, self.test_returns = [], []          # reference attributes; the statistics live on the device (_finish_stats)
         self.train_stats, self.test_stats = {}, {}
         self.log_train_stats_t = -1000000
         # obs_storage: "code" keeps observations as u8 class codes (simplified palette; 12x fewer bytes in the storage and the
@@ -115,31 +116,42 @@ class HipVecRunner:
         return self._finish_stats()
 
     def _finish_stats(self):
+        """Episode statistics of episode_runner.py:121-152 (collective_return / equality_metric / ep_length sums over the episodes,
+        mean and standard deviation of the per-agent returns), accumulated ON THE DEVICE: a rollout adds its sums to a small f64
+        tensor with a handful of device ops and no host synchronisation; the host reads the tensor once per log interval (_log)."""
         test_mode = self._test_mode
         out, ep_return = self._out, self._ep_return
         stats = self.test_stats if test_mode else self.train_stats
-        returns = self.test_returns if test_mode else self.train_returns
         prefix = "test_" if test_mode else ""
         if getattr(self.args, "runner_stats", True):
-            env_info = {"collective_return": float(out["collective_return"].sum().item()),
-                        "equality_metric": float(out["equality"].sum().item())}
-            for k, v in env_info.items():
-                stats[k] = stats.get(k, 0) + v
+            acc = self._stat_acc(test_mode)
+            r = ep_return.to(th.float64)
+            acc += th.stack([out["collective_return"].sum(dtype=th.float64), out["equality"].sum(dtype=th.float64), r.sum(), (r * r).sum()])
             stats["n_episodes"] = self.batch_size + stats.get("n_episodes", 0)
             stats["ep_length"] = self.t * self.batch_size + stats.get("ep_length", 0)
-            returns.extend(ep_return.cpu().numpy())
+            stats["n_returns"] = ep_return.numel() + stats.get("n_returns", 0)
         if not test_mode:
             self.t_env += self.t * self.batch_size
             self.rollouts += 1
         if getattr(self.args, "runner_stats", True):
-            if test_mode and len(self.test_returns) >= self.args.test_nepisode:
-                self._log(returns, stats, prefix)
-            elif not test_mode and self.t_env - self.log_train_stats_t >= self.args.runner_log_interval:
-                self._log(returns, stats, prefix)
+            if test_mode and stats["n_episodes"] >= self.args.test_nepisode:
+                self._log(stats, prefix, test_mode)
+            # runner_log_interval is measured on the schedule clock: under schedule_unit "rollouts" a rollout of all envs advances it
+            # by episode_limit, so the host reads the device sums every runner_log_interval / episode_limit rollouts (the reference's
+            # cadence) instead of after every rollout (4096 envs advance t_env by 409 600)
+            elif not test_mode and self.sched_t - self.log_train_stats_t >= self.args.runner_log_interval:
+                self._log(stats, prefix, test_mode)
                 if hasattr(self.mac.action_selector, "epsilon"):
                     self.logger.log_stat("epsilon", self.mac.action_selector.epsilon, self.t_env)
-                self.log_train_stats_t = self.t_env
+                self.log_train_stats_t = self.sched_t
         return self.batch
+
+    def _stat_acc(self, test_mode):
+        """device accumulator [sum collective_return, sum equality_metric, sum of returns, sum of squared returns]"""
+        key = "_acc_test" if test_mode else "_acc_train"
+        if getattr(self, key, None) is None:
+            setattr(self, key, th.zeros(4, dtype=th.float64, device=self.env.device))
+        return getattr(self, key)
 
     def run(self, test_mode=False):
         self.begin_episode(test_mode)
@@ -147,14 +159,16 @@ class HipVecRunner:
             pass
         return self.finish_episode()
 
-    def _log(self, returns, stats, prefix):
-        import numpy as np
-        self.logger.log_stat(prefix + "return_mean", float(np.mean(returns)), self.t_env)
-        self.logger.log_stat(prefix + "return_std", float(np.std(returns)), self.t_env)
-        returns.clear()
-        for k, v in stats.items():
-            if k != "n_episodes":
-                self.logger.log_stat(prefix + k + "_mean", v / stats["n_episodes"], self.t_env)
+    def _log(self, stats, prefix, test_mode):
+        acc = self._stat_acc(test_mode)
+        coll, eq, rs, rss = acc.cpu().tolist()          # the one device -> host read of the log interval
+        acc.zero_()
+        n_ep, n_ret = stats["n_episodes"], max(1, stats.get("n_returns", 0))
+        mean = rs / n_ret
+        self.logger.log_stat(prefix + "return_mean", mean, self.t_env)
+        self.logger.log_stat(prefix + "return_std", max(0.0, rss / n_ret - mean * mean) ** 0.5, self.t_env)    # np.std: population
+        for k, v in (("collective_return", coll), ("equality_metric", eq), ("ep_length", stats.get("ep_length", 0))):
+            self.logger.log_stat(prefix + k + "_mean", v / n_ep, self.t_env)
         stats.clear()
 
 

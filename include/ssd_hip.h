@@ -233,6 +233,14 @@ typedef struct ssd_row_gather {
 } ssd_row_gather;
 int ssd_gather_rows(const ssd_row_gather* fields, int32_t count, const int64_t* ids, int32_t n_ids, void* stream);
 
+/* ssd_sample_ids: ids[0 .. count) = `count` DISTINCT episode indices drawn uniformly from [0, population) on the device --
+ * ReplayBuffer.sample's `np.random.choice(episodes_in_buffer, batch_size, replace=False)` (episode_buffer.py:240-244) without a host
+ * draw or an H2D copy of the indices.  Counter generator keyed by (seed, call): the caller advances `call` per sample; the same
+ * (seed, call, population, count) gives the same ids on every device (a restatement for host tensors: ops.sample_ids).  Floyd's
+ * subset sampling + a Fisher-Yates pass over the picks; a bounded draw is floor(u32 * m / 2^32) (bias < m / 2^32).  ids: DEVICE int64. */
+#define SSD_SAMPLE_IDS_MAX 1024
+int ssd_sample_ids(uint64_t seed, uint32_t call, int32_t population, int32_t count, int64_t* ids, void* stream);
+
 #define SSD_COPY_BLOCKS_MAX 32
 typedef struct ssd_block_copy {
     const float* src;

@@ -646,7 +646,7 @@ def test_replay_sample_into_a_batch_is_one_gather_launch_with_the_same_episodes(
     out = EpisodeBatch(scheme, {}, 16, T, device="cuda")
     np.random.seed(11)
     ref = buf.sample(16)
-    np.random.seed(11)
+    buf._sample_calls = 0                     # the same draw again (device-side counter generator: seed, call number)
     got = buf.sample(16, out=out)
     assert got is out
     for k in ref.data.transition_data:
@@ -655,6 +655,36 @@ def test_replay_sample_into_a_batch_is_one_gather_launch_with_the_same_episodes(
     dst = th.zeros(4, T, 3, dtype=th.uint8, device="cuda")
     assert ops.gather_rows([(buf["odd"], dst)], ids) and th.equal(dst, buf["odd"][ids])      # 303-byte rows: unaligned words + a byte tail
     assert not ops.gather_rows([(buf["odd"], dst[:3])], ids)                                  # shapes that do not fit are refused
+
+
+def test_replay_indices_are_drawn_on_the_device():
+    """ssd_sample_ids (ReplayBuffer.sample of a device-resident buffer, episode_buffer.py:240-244): bit for bit the host restatement
+    (ops.sample_ids on a host tensor), distinct and in range at the bench's sizes, and sample() neither consumes numpy's generator
+    after its seed is taken nor moves anything across the host boundary that depends on the draw."""
+    from homophily_marl_amd import abi, ops
+    from homophily_marl_amd.components.episode_buffer import ReplayBuffer
+    for seed, call, pop, cnt in [(0x1234567890ABCDEF, 0, 8192, 16), (7, 3, 4096, 16), (2 ** 63 + 5, 2 ** 31 + 1, 17, 16), (1, 1, 64, 64),
+                                 (5, 9, 5000, 1024), (11, 0, 1, 1)]:
+        dev = ops.sample_ids(seed, call, pop, cnt, th.empty(cnt, dtype=th.long, device="cuda")).cpu()
+        host = ops.sample_ids(seed, call, pop, cnt, th.empty(cnt, dtype=th.long))
+        assert th.equal(dev, host), (seed, call, pop, cnt)
+        assert len(set(dev.tolist())) == cnt and 0 <= int(dev.min()) and int(dev.max()) < pop
+    lib = abi.load_library()
+    for pop, cnt in [(8, 16), (100, 0), (100, 1025)]:
+        with pytest.raises(abi.SsdError):
+            abi.check(lib, lib.ssd_sample_ids(1, 0, pop, cnt, th.empty(2048, dtype=th.long, device="cuda").data_ptr(), 0))
+    scheme = {"reward": {"vshape": (5,)}}
+    buf = ReplayBuffer(scheme, {}, 64, 8, device="cuda")
+    buf["reward"].copy_(th.arange(64, device="cuda").view(64, 1, 1).expand(64, 8, 5))
+    buf.buffer_index, buf.episodes_in_buffer = 0, 64
+    np.random.seed(3)
+    a = buf.sample(16)
+    state = np.random.get_state()[1].copy()
+    b = buf.sample(16)
+    assert (np.random.get_state()[1] == state).all()                    # no host draw per sample
+    ra, rb = a["reward"][:, 0, 0].cpu(), b["reward"][:, 0, 0].cpu()
+    assert len(set(ra.tolist())) == 16 and len(set(rb.tolist())) == 16 and not th.equal(ra, rb)
+    assert th.equal(ra.long(), ops.sample_ids(buf._sample_seed, 0, 64, 16, th.empty(16, dtype=th.long)))
 
 
 @pytest.mark.parametrize("n,T,B,inner,K", [(5, 101, 16, 1, 9), (5, 101, 16, 5, 3), (3, 7, 5, 3, 3), (10, 4, 9, 1, 8)])

@@ -68,3 +68,39 @@ def test_sample_into_a_given_batch_draws_the_same_episodes():
     for k in ref.data.transition_data:
         assert th.equal(ref[k], got[k]), k
     assert buf.sample(5, out=EpisodeBatch(_scheme(), {"agents": 2}, 4, 4)).batch_size == 5      # a batch of another size is not used
+
+
+def test_sample_with_an_out_batch_on_another_device_falls_back_to_indexing():
+    """a host buffer (buffer_cpu_only) asked to sample into a batch that lives elsewhere (the learner's device-resident
+    static batch) must not gather across devices: it returns a fresh host batch, as without `out`."""
+    buf = ReplayBuffer(_scheme(), {"agents": 2}, 12, 4)
+    for seed in (1, 2, 3):
+        buf.insert_episode_batch(_episodes(4, 4, seed))
+    elsewhere = EpisodeBatch(_scheme(), {"agents": 2}, 5, 4, device="meta")
+    np.random.seed(7)
+    ref = buf.sample(5)
+    np.random.seed(7)
+    got = buf.sample(5, out=elsewhere)
+    assert got is not elsewhere and got["obs"].device.type == "cpu"
+    for k in ref.data.transition_data:
+        assert th.equal(ref[k], got[k]), k
+
+
+def test_sample_ids_restatement_draws_distinct_uniform_ids():
+    """ops.sample_ids on host tensors = the arithmetic of ssd_sample_ids (the GPU suite compares the two bit for bit): count distinct
+    ids in range, a pure function of (seed, call), every id when count == population, and uniform inclusion frequencies."""
+    from homophily_marl_amd import ops
+    out = th.empty(16, dtype=th.long)
+    a = ops.sample_ids(0x1234567890ABCDEF, 5, 8192, 16, out).clone()
+    assert len(set(a.tolist())) == 16 and 0 <= int(a.min()) and int(a.max()) < 8192
+    assert th.equal(ops.sample_ids(0x1234567890ABCDEF, 5, 8192, 16, th.empty(16, dtype=th.long)), a)
+    assert not th.equal(ops.sample_ids(0x1234567890ABCDEF, 6, 8192, 16, th.empty(16, dtype=th.long)), a)
+    assert sorted(ops.sample_ids(3, 0, 16, 16, th.empty(16, dtype=th.long)).tolist()) == list(range(16))
+    hits = np.zeros(40)
+    first = np.zeros(40)
+    for call in range(4000):
+        ids = ops.sample_ids(99, call, 40, 8, th.empty(8, dtype=th.long)).numpy()
+        hits[ids] += 1
+        first[ids[0]] += 1
+    assert abs(hits / 4000 - 0.2).max() < 0.03          # inclusion probability 8 / 40 for every id (sd 0.0063)
+    assert abs(first / 4000 - 1 / 40).max() < 0.012     # and every id equally likely in a given position (sd 0.0025)
