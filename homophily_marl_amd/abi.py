@@ -6,7 +6,7 @@ The native library is REQUIRED: there is no CPU fallback on the product path.  `
 import ctypes as C
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_AGENTS = 10
 MAX_CELLS = 1024
 MAX_SITES = 256
@@ -237,7 +237,9 @@ HIP_SIGNATURES["ssd_conv_wgrad_partial_rows"] = (C.c_int, [C.c_int32])
 HIP_SIGNATURES["ssd_conv_wgrad_codes"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_policy_encode"] = (C.c_int, [C.POINTER(SsdPolicyEncodeArgs), C.c_void_p])
 HIP_SIGNATURES["ssd_policy_head_inc_encode"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.POINTER(SsdPolicyEncodeArgs), C.c_void_p])
-HIP_SIGNATURES["ssd_policy_pack_encoder"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])
+HIP_SIGNATURES["ssd_policy_pack_encoder"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])
+HIP_SIGNATURES["ssd_numeric_status"] = (C.c_int, [C.POINTER(C.c_int32)])
+ERRBIT_F16_RANGE = 32
 HIP_SIGNATURES["ssd_column_sums"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p])
 COLSUM_CHUNK = 64
 HIP_SIGNATURES["ssd_td_sim_loss"] = (C.c_int, [C.POINTER(SsdTdLossArgs), C.c_int32, C.c_void_p])

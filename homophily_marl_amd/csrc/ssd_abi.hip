@@ -165,6 +165,7 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
     if (e == hipSuccess) e = hipMemset(E->st.ep_step, 0, N * 4);
     if (e == hipSuccess) e = hipMemset(E->st.epoch, 0, N * 4);
     if (e == hipSuccess) e = hipMemset(E->st.err, 0, 4);
+    if (e == hipSuccess && !numeric_err_word()) e = hipErrorOutOfMemory;      // exists before anything captures a graph
     if (e == hipSuccess) {
         // a fresh handle holds the reset image with agents on their spawn cells (the reference constructor
         // also builds agents before the first reset, map_env.py:149)
@@ -247,6 +248,22 @@ static int make_oo(const ssd_env* E, const ssd_obs_out* o, DevObsOut* d) {
     d->stamps = E->st.stamps;
     return SSD_OK;
 }
+}   // extern "C" (reopened below): the numeric-status word is a C++ helper of namespace ssd
+namespace ssd {
+int32_t* numeric_err_word() {
+    static int32_t* word[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!word[dev]) {
+        int32_t* w = nullptr;
+        if (hipMalloc((void**)&w, 64) != hipSuccess || hipMemset(w, 0, 64) != hipSuccess) return nullptr;
+        word[dev] = w;
+    }
+    return word[dev];
+}
+}  // namespace ssd
+extern "C" {
+
 static int launched(void) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SSD_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
@@ -297,6 +314,19 @@ int ssd_poll_error(ssd_env* E, int32_t* bits) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(bits, E->st.err, 4, hipMemcpyDeviceToHost));
     if (*bits) HIP_TRY(hipMemset(E->st.err, 0, 4));
+    int32_t num = 0;                                                   // + the device's numeric status (SSD_ERRBIT_F16_RANGE)
+    if (int rc = ssd_numeric_status(&num)) return rc;
+    *bits |= num;
+    return SSD_OK;
+}
+
+int ssd_numeric_status(int32_t* bits) {
+    if (!bits) return fail(SSD_ERR_INVALID, "null argument");
+    int32_t* w = numeric_err_word();
+    if (!w) return fail(SSD_ERR_DEVICE, "numeric status word: allocation failed");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(bits, w, 4, hipMemcpyDeviceToHost));
+    if (*bits) HIP_TRY(hipMemset(w, 0, 4));
     return SSD_OK;
 }
 
@@ -566,12 +596,12 @@ int ssd_policy_encode(const ssd_policy_encode_args* a, void* stream) {
     return launched();
 }
 
-int ssd_policy_pack_encoder(const float* conv_w, const float* lin_w, int32_t view_edge, int32_t precision, void* conv_frags,
+int ssd_policy_pack_encoder(const float* conv_w, const float* conv_b, const float* lin_w, int32_t view_edge, int32_t precision, void* conv_frags,
                             void* lin_frags, void* stream) {
-    if (!conv_w || !lin_w || !conv_frags || !lin_frags) return fail(SSD_ERR_INVALID, "null argument");
+    if (!conv_w || !conv_b || !lin_w || !conv_frags || !lin_frags) return fail(SSD_ERR_INVALID, "null argument");
     if (precision != 1 && precision != 2) return fail(SSD_ERR_INVALID, "precision must be 1 or 2");
     if ((reinterpret_cast<uintptr_t>(conv_frags) | reinterpret_cast<uintptr_t>(lin_frags)) & 15) return fail(SSD_ERR_INVALID, "fragment images must be 16-byte aligned");
-    if (launch_pack_encoder(conv_w, lin_w, view_edge, precision, conv_frags, lin_frags, (hipStream_t)stream))
+    if (launch_pack_encoder(conv_w, conv_b, lin_w, view_edge, precision, conv_frags, lin_frags, (hipStream_t)stream))
         return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_pack_encoder: view_edge must be 15 or 31");
     return launched();
 }

@@ -90,7 +90,12 @@ struct DevObsOut {
     unsigned long long* stamps;  // diagnostic builds only
 };
 
-enum : int { ERR_BAD_ACTION = 1, ERR_BAD_TAPE = 2, ERR_KEYERROR = 4, ERR_TAPE_OVERRUN = 8, ERR_SLOT_OVERRUN = 16 };
+enum : int { ERR_BAD_ACTION = 1, ERR_BAD_TAPE = 2, ERR_KEYERROR = 4, ERR_TAPE_OVERRUN = 8, ERR_SLOT_OVERRUN = 16, ERR_F16_RANGE = 32 };
+// The sticky numeric-status word of the current device (ssd_numeric_status): bit ERR_F16_RANGE is set by the pack kernels, the
+// rollout heads and the learner's recurrence when a SCALED value of a two-term f16 split product leaves f16's range (65 504) -- the
+// product would silently carry inf / NaN.  Allocated on first use (ssd_create and the pack entry points call it outside any capture).
+int32_t* numeric_err_word();
+constexpr float F16_MAX = 65504.f;
 
 // LDS bytes one wave needs: grid | agent overlay | padded class map | output planes (+16 alignment slack) | colour lut.
 // The class map + planes region doubles as scratch for the tape-mode waste ranks (2 * 256 bytes) during the step.
@@ -141,7 +146,7 @@ void launch_gru_fwd_train(const float* gi, const float* gh, const float* h, floa
 void launch_gru_bwd(const float* dh, const float* rzn, const float* gh, const float* h, float* d_gi, float* d_gh, float* dh_prev, int R,
                     int H, hipStream_t s);
 int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s);
-int launch_pack_encoder(const float* cw, const float* lw, int V, int prec, void* conv_frags, void* lin_frags, hipStream_t s);
+int launch_pack_encoder(const float* cw, const float* cb, const float* lw, int V, int prec, void* conv_frags, void* lin_frags, hipStream_t s);
 void launch_pack_head(const ssd_policy_head_params* p, int prec, void* image, hipStream_t s);
 void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T,
                         int G, int B, hipStream_t s);

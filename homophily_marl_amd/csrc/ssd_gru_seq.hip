@@ -68,7 +68,7 @@ __device__ __forceinline__ float* gru_part_base(const GruParts& P, int g) {
 template <bool TRAIN>
 __global__ __launch_bounds__(256) void k_gru_seq_fwd(const GruParts gi, const float* __restrict__ wh, const float* __restrict__ bh,
                                                      float* __restrict__ hs, float* __restrict__ rzn, float* __restrict__ ghn, int T, int G,
-                                                     int B, int tiles) {
+                                                     int B, int tiles, int32_t* __restrict__ err) {
     __shared__ __attribute__((aligned(16))) _Float16 hx[2][2][16][HSH];   // [buffer][term][row][feature]
     const int tid = threadIdx.x, lane = tid & 63, ft = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void k_gru_seq_fwd(const GruParts gi, const fl
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float w = wh[((size_t)g * GH + 32 * s + 8 * q + j) * G3 + gate * GH + 16 * ft + m] * GRU_WS;
+                if (!(fabsf(w) <= F16_MAX) && err) atomicOr(err, ERR_F16_RANGE);      // |W_h| >= 1 023.5 (or NaN): outside the split's range; |h| < 1 needs no check
                 h[j] = (_Float16)w; l[j] = (_Float16)(w - (float)h[j]);
             }
             ah[gate][s] = __builtin_bit_cast(u32x4, h); al[gate][s] = __builtin_bit_cast(u32x4, l);
@@ -309,8 +310,9 @@ void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* 
                         int G, int B, hipStream_t s) {
     const int tiles = (B + 15) / 16;
     const GruParts P = gru_parts(const_cast<float* const*>(reinterpret_cast<const float* const*>(gi_parts)), n_parts, T, G, B);
-    if (rzn) hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(G * tiles), dim3(256), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles);
-    else hipLaunchKernelGGL(k_gru_seq_fwd<false>, dim3(G * tiles), dim3(256), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles);
+    int32_t* err = numeric_err_word();
+    if (rzn) hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(G * tiles), dim3(256), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles, err);
+    else hipLaunchKernelGGL(k_gru_seq_fwd<false>, dim3(G * tiles), dim3(256), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles, err);
 }
 void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* const* d_gi_parts,
                         int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s) {

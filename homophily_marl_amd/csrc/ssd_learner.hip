@@ -476,8 +476,12 @@ __global__ __launch_bounds__(256) void k_clip_adam(ssd_clip_adam_args a, int chu
         for (int c = t; c < chunks; c += 256) v += a.partials[(size_t)c * 3 + k];
         S[k] = block_sum_256(v, red);
     }
-    const float c_inc = fminf(1.f, a.clip / (sqrtf(S[0] + S[2]) + 1e-6f));
-    const float c_env = fminf(1.f, a.clip / (sqrtf(c_inc * c_inc * S[0] + S[1]) + 1e-6f));
+    // torch.clamp(clip_coef, max = 1) keeps a NaN coefficient (clip_grad_norm_ then spreads it over every gradient of the group);
+    // fminf alone would return 1 and hide a non-finite norm
+    const float r_inc = a.clip / (sqrtf(S[0] + S[2]) + 1e-6f);
+    const float c_inc = r_inc != r_inc ? r_inc : fminf(1.f, r_inc);
+    const float r_env = a.clip / (sqrtf(c_inc * c_inc * S[0] + S[1]) + 1e-6f);
+    const float c_env = r_env != r_env ? r_env : fminf(1.f, r_env);
     if (t < a.n_jobs) {
         const ssd_adam_job j = a.jobs[t];
         j_off[t] = j.offset;

@@ -78,8 +78,10 @@ __device__ __forceinline__ void leaky_split8(const f32x4& t0, const f32x4& t1, u
 #endif
 }
 
-template <int PREC> __device__ __forceinline__ void store_term(uint8_t* dst, float v, size_t term_stride) {
+// err: the device's numeric-status word (ssd_numeric_status); a scaled term outside f16's range (or NaN) raises ERR_F16_RANGE
+template <int PREC> __device__ __forceinline__ void store_term(uint8_t* dst, float v, size_t term_stride, int32_t* err) {
     if constexpr (PREC == 2) {
+        if (!(fabsf(v) <= F16_MAX) && err) atomicOr(err, ERR_F16_RANGE);
         const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
         *reinterpret_cast<_Float16*>(dst) = h; *reinterpret_cast<_Float16*>(dst + term_stride) = l;
     } else {
@@ -151,6 +153,7 @@ struct HeadCold {
     float *p_rew, *ep_ret;
     int64_t* next_t;
     int64_t *next_step, *t_copy, *step_copy;   // inc head: *next_step = *step + 1; env head: *t_copy = *t_index, *step_copy = *step
+    int32_t* numeric_err;          // the device's numeric-status word (ERR_F16_RANGE)
     uint64_t tail_layout;          // env head: first tail column of each _build_inputs block as 6 signed bytes (TAIL_ABSENT = not present):
                                    // last action | agent id | sign(r) | sign(received incentives) | 1 - distances | pos
 };
@@ -227,6 +230,24 @@ __device__ __forceinline__ void operand(const f32x4 (&x)[4], float scale, u32x4 
         for (int j = 0; j < 8; ++j) v[j] = x[2 * s + (j >> 2)][j & 3] * scale;
         split8<PREC>(v, bh[s], bl[s]);
     }
+}
+
+// running max |x| over result tiles (one v_max3_f32 with |.| source modifiers per two values): the range guard of the activations that
+// are about to be scaled and split (the fc1 operand and fc1's output; hidden states are < 1 by construction)
+__device__ __forceinline__ float amax2(float acc, float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+    return r;
+#else
+    return fmaxf(acc, fmaxf(fabsf(a), fabsf(b)));
+#endif
+}
+template <int NT>
+__device__ __forceinline__ float amax_tiles(float acc, const f32x4 (&x)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc = amax2(acc, x[t][0], x[t][1]); acc = amax2(acc, x[t][2], x[t][3]); }
+    return acc;
 }
 
 // sigmoid / tanh on v_exp_f32 + v_rcp_f32 (1 ulp each)
@@ -337,6 +358,14 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
     const bool file = slot_t < (long)a.slots;                          // never file past the episode storage
     const uint32_t avail_bits = INC ? 0xFFFFFFFFu : avail_to_bits(a.avail, A);
     u32x4 bh[2], bl[2];                                                // the fc1 operand of the current tile
+    // range guard of the activations that get scaled by XS and split (PREC 2): checked where they are produced (no state carried
+    // through the tile chain -- the env head has no register to spare); the branch is never taken on a healthy network
+    auto range_check = [&](float amax) {
+        if (!(amax * XS <= F16_MAX)) {
+            int32_t* nerr = COLD(int32_t, numeric_err);
+            if (nerr) atomicOr(nerr, ERR_F16_RANGE);
+        }
+    };
     // Everything of a tile that only needs its inputs -- the input tail (controller :137-184), the by-product stores, the split
     // of the fc1 operand -- is done as soon as the loads land: for the first tile while the weight image is still in flight.
     auto prepare = [&](int tl) {
@@ -420,6 +449,7 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
                 }
             }
         }
+        if (PREC == 2) range_check(amax_tiles<4>(0.f, x));
         operand<PREC>(x, XS, bh, bl);
     };
     {   // stage this agent's image (already in LDS layout): every load in flight before the first LDS write
@@ -486,6 +516,7 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
         for (int ot = 0; ot < 16; ++ot) g[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
         {   // the six GRU products as 12 K-steps, each step's fragments requested one step ahead
             u32x4 xh[2], xl[2], hh[2], hl[2];
+            if (PREC == 2) range_check(amax_tiles<4>(0.f, x1));
             operand<PREC>(x1, XS, xh, xl);
             operand<PREC>(hp, XS, hh, hl);
             frag4_load<PREC>(img, HF_WI, 1, lane, fb);       frag4_mma<PREC>(fa, xh[0], xl[0], g);
@@ -660,6 +691,7 @@ static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c) {
         c.tail_layout = lay;
     }
     c.next_step = p->next_step_out; c.t_copy = p->t_copy_out; c.step_copy = p->step_copy_out;
+    c.numeric_err = numeric_err_word();
     PSTAMP_SET(k);
     const int tiles = (k.N + 15) / 16;
     int bpa = 256 / k.n;                                               // one workgroup per CU (the image fills most of the LDS)
@@ -707,7 +739,7 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
 
 // ---- pack: reference-shaped f32 parameters -> the per-agent head image --------------------------------------------------------
 template <int PREC>
-__global__ __launch_bounds__(256) void k_pack_head(ssd_policy_head_params p, uint8_t* image) {
+__global__ __launch_bounds__(256) void k_pack_head(ssd_policy_head_params p, uint8_t* image, int32_t* err) {
     constexpr size_t TERM = (size_t)HF_TOT * 1024, IMAGE_BYTES = PREC * TERM + HT_TOT * 4;
     constexpr float WS = PREC == 2 ? HEAD_WSCALE : 1.f;
     const int agent = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
@@ -728,7 +760,7 @@ __global__ __launch_bounds__(256) void k_pack_head(ssd_policy_head_params p, uin
             if (m < p.fc2_out) w = p.fc2_w[((size_t)agent * p.fc2_in + k) * p.fc2_out + m];
             else if (m == p.fc2_out) w = p.fc2_v_w[(size_t)agent * p.fc2_in + k];
         }
-        store_term<PREC>(img + ((size_t)F * 64 + lane) * 16 + 2 * j, w * WS, TERM);
+        store_term<PREC>(img + ((size_t)F * 64 + lane) * 16 + 2 * j, w * WS, TERM, err);
     }
     if (e < HT_TOT) {
         float v = 0.f;
@@ -751,8 +783,9 @@ __global__ __launch_bounds__(256) void k_pack_head(ssd_policy_head_params p, uin
 
 void launch_pack_head(const ssd_policy_head_params* p, int prec, void* image, hipStream_t s) {
     const dim3 grid((HF_TOT * 512 + 255) / 256, p->n_agents);
-    if (prec == 2) hipLaunchKernelGGL(k_pack_head<2>, grid, dim3(256), 0, s, *p, static_cast<uint8_t*>(image));
-    else hipLaunchKernelGGL(k_pack_head<1>, grid, dim3(256), 0, s, *p, static_cast<uint8_t*>(image));
+    int32_t* err = numeric_err_word();
+    if (prec == 2) hipLaunchKernelGGL(k_pack_head<2>, grid, dim3(256), 0, s, *p, static_cast<uint8_t*>(image), err);
+    else hipLaunchKernelGGL(k_pack_head<1>, grid, dim3(256), 0, s, *p, static_cast<uint8_t*>(image), err);
 }
 
 // ===========================================================================================================================
@@ -1140,12 +1173,25 @@ int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s) {
 
 // ---- pack: conv_w f32 [6, 3, 3, 3], lin_w f32 [32, 6 P] -> fragment images ------------------------------------------------------
 template <int V, int PREC>
-__global__ __launch_bounds__(256) void k_pack_encoder(const float* __restrict__ cw, const float* __restrict__ lw, uint8_t* conv_frags, uint8_t* lin_frags) {
+__global__ __launch_bounds__(256) void k_pack_encoder(const float* __restrict__ cw, const float* __restrict__ cb, const float* __restrict__ lw, uint8_t* conv_frags,
+                                                      uint8_t* lin_frags, int32_t* err) {
     using G = Geo<V>;
     constexpr int O = G::O, XTP = G::XTP, P = O * O, UNITS = SSD_ENCODE_UNITS(V);
     constexpr int NCONV = 9 * 512, NLIN = UNITS * 2 * 512;
     constexpr float CS = PREC == 2 ? ENC_CSCALE : 2.f, LS = PREC == 2 ? ENC_LSCALE : 1.f;   // PREC 1: the plane value is 0.5
     const int e = blockIdx.x * 256 + threadIdx.x;
+    if (PREC == 2 && e < 6 && err) {
+        // The conv ACTIVATIONS are split at the scale CS inside the encoder's loop, where a range check per value would cost ~4 % of
+        // the kernel: they are bounded here instead.  A window cell lights at most one plane, so for output channel e
+        // |conv| <= |b| + 255/256 * sum over the 9 taps of max_ch |w[e, ch, dy, dx]| -- the exact worst case over all observations.
+        float bound = fabsf(cb[e]);
+        for (int tap = 0; tap < 9; ++tap) {
+            float mx = 0.f;
+            for (int ch = 0; ch < 3; ++ch) mx = fmaxf(mx, fabsf(cw[(e * 3 + ch) * 9 + tap]));
+            bound += mx * (255.f / 256.f);
+        }
+        if (!(bound * CS <= F16_MAX)) atomicOr(err, ERR_F16_RANGE);
+    }
     if (e < NCONV) {
         // fragment (s, dy): row m = (o2 = m >> 3, position p = m & 7); quarter q < 3: plane q, cells 0..7; quarter 3: the tail
         // [R 8, R 9, G 8, G 9, B 8, B 9, 0, 0]; the tap index is d = cell - p
@@ -1154,23 +1200,24 @@ __global__ __launch_bounds__(256) void k_pack_encoder(const float* __restrict__ 
         const int ch = q < 3 ? q : j >> 1, cell = q < 3 ? j : 8 + (j & 1), d = cell - pp;
         float w = 0.f;
         if ((q < 3 || j < 6) && d >= 0 && d <= 2) w = (float)((double)cw[((oc * 3 + ch) * 3 + dy) * 3 + d] * (255.0 / 256.0) * (double)CS);
-        store_term<PREC>(conv_frags + ((size_t)sd * 64 + lane) * 16 + 2 * j, w, (size_t)9 * 1024);
+        store_term<PREC>(conv_frags + ((size_t)sd * 64 + lane) * 16 + 2 * j, w, (size_t)9 * 1024, err);
     } else if (e < NCONV + NLIN) {
         const int i = e - NCONV, mt = (i >> 9) & 1, u = i >> 10, lane = (i >> 3) & 63, j = i & 7, q = lane >> 4, m = lane & 15;
         const int s = u % 3, xtp = (u / 3) % XTP, y = u / (3 * XTP);
         const int r = 4 * q + (j & 3);                                 // row of conv result tile (j >> 2) of the pair
         const int oc = 2 * s + (r >> 3), x = 8 * (2 * xtp + (j >> 2)) + (r & 7);
         const float w = x < O ? lw[(size_t)(16 * mt + m) * (6 * P) + oc * P + y * O + x] * LS : 0.f;
-        store_term<PREC>(lin_frags + (((size_t)(u * 2 + mt) * PREC) * 64 + lane) * 16 + 2 * j, w, (size_t)64 * 16);
+        store_term<PREC>(lin_frags + (((size_t)(u * 2 + mt) * PREC) * 64 + lane) * 16 + 2 * j, w, (size_t)64 * 16, err);
     }
 }
 
-int launch_pack_encoder(const float* cw, const float* lw, int V, int prec, void* conv_frags, void* lin_frags, hipStream_t s) {
+int launch_pack_encoder(const float* cw, const float* cb, const float* lw, int V, int prec, void* conv_frags, void* lin_frags, hipStream_t s) {
     uint8_t *c = static_cast<uint8_t*>(conv_frags), *l = static_cast<uint8_t*>(lin_frags);
+    int32_t* err = numeric_err_word();
 #define SSD_PACK(V_, P_)                                                                                                     \
     do {                                                                                                                     \
         const int total = 9 * 512 + SSD_ENCODE_UNITS(V_) * 2 * 512;                                  \
-        hipLaunchKernelGGL((k_pack_encoder<V_, P_>), dim3((total + 255) / 256), dim3(256), 0, s, cw, lw, c, l);              \
+        hipLaunchKernelGGL((k_pack_encoder<V_, P_>), dim3((total + 255) / 256), dim3(256), 0, s, cw, cb, lw, c, l, err);     \
     } while (0)
     if (V == 15) { if (prec == 2) SSD_PACK(15, 2); else SSD_PACK(15, 1); return 0; }
     if (V == 31) { if (prec == 2) SSD_PACK(31, 2); else SSD_PACK(31, 1); return 0; }

@@ -129,7 +129,7 @@ class FastPolicy:
                 hp = self._head_params(head)
                 abi.check(self.lib, self.lib.ssd_policy_pack_head(C.byref(hp), self.precision, self.p["img_" + head].data_ptr(), st))
         if self.fused_enc:
-            abi.check(self.lib, self.lib.ssd_policy_pack_encoder(ag.conv_to_fc[0].weight.data_ptr(), lin.data_ptr(), self.V, self.precision,
+            abi.check(self.lib, self.lib.ssd_policy_pack_encoder(ag.conv_to_fc[0].weight.data_ptr(), ag.conv_to_fc[0].bias.data_ptr(), lin.data_ptr(), self.V, self.precision,
                                                                  self.p["conv_frags"].data_ptr(), self.p["lin_frags"].data_ptr(), st))
 
     @staticmethod

@@ -22,6 +22,15 @@ import os as _os
 STRICT = _os.environ.get("SSD_STRICT_DEVICE_OPS") == "1"
 
 
+def numeric_status():
+    """Sticky numeric-status bits of the current device, cleared on read (ssd_numeric_status; abi.ERRBIT_F16_RANGE: a scaled value of
+    a two-term f16 split product left f16's range in a pack kernel, a rollout head or the learner's recurrence).  Synchronises."""
+    lib = abi.load_library()
+    bits = C.c_int32(0)
+    abi.check(lib, lib.ssd_numeric_status(C.byref(bits)))
+    return bits.value
+
+
 def set_strict(on=True):
     global STRICT
     STRICT = bool(on)
@@ -474,7 +483,7 @@ class _EncodeCodes(th.autograd.Function):
         cb, lb = conv_b.detach().contiguous(), lin_b.detach().contiguous()
         cbytes, lbytes = abi.encode_frag_bytes(V, 2)
         cf, lf = th.empty(cbytes, dtype=th.uint8, device=dev), th.empty(lbytes, dtype=th.uint8, device=dev)
-        abi.check(lib, lib.ssd_policy_pack_encoder(cw.data_ptr(), lw.data_ptr(), V, 2, cf.data_ptr(), lf.data_ptr(), st))
+        abi.check(lib, lib.ssd_policy_pack_encoder(cw.data_ptr(), cb.data_ptr(), lw.data_ptr(), V, 2, cf.data_ptr(), lf.data_ptr(), st))
         need = any(ctx.needs_input_grad[1:])
         act = th.empty(R, 6, O, O, dtype=th.float32, device=dev) if need else None
         bands = abi.encode_bands(V)

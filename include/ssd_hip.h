@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSD_ABI_VERSION 3
+#define SSD_ABI_VERSION 4
 
 #define SSD_MAX_AGENTS 10   /* maps hold at most 10 spawn points; agent ids >= 10 break the reference (map_env.py:370) */
 #define SSD_MAX_CELLS 1024  /* H*W upper bound (largest reference map is 48x18 = 864) */
@@ -595,8 +595,19 @@ int ssd_policy_encode(const ssd_policy_encode_args* args, void* stream);
  * t + 1 and must write a DIFFERENT `inputs` buffer / `part`), so one launch-to-launch gap of the timestep disappears.  enc_args: no
  * act, no slot_t_copy / counter_inc (the heads hand the counters over, see ssd_policy_head); same precision as inc_args. */
 int ssd_policy_head_inc_encode(const ssd_policy_head* inc_args, const ssd_policy_encode_args* enc_args, void* stream);
-int ssd_policy_pack_encoder(const float* conv_w, const float* lin_w, int32_t view_edge, int32_t precision, void* conv_frags,
+/* conv_b (f32 [6]): read only for the range bound of the conv activations (see SSD_ERRBIT_F16_RANGE). */
+int ssd_policy_pack_encoder(const float* conv_w, const float* conv_b, const float* lin_w, int32_t view_edge, int32_t precision, void* conv_frags,
                             void* lin_frags, void* stream);
+
+/* Range guard of the two-term f16 split products (precision 2; homophily_agent.py:154-208 computed in f32 by the reference).  The
+ * splits use fixed power-of-two scales: head weights x 64, head activations x 16, conv weights / conv activations / Linear weights
+ * x 256, the learner's recurrence W_h x 64.  A scaled value beyond f16's 65 504 would turn the product into inf / NaN silently, so
+ * the kernels raise the sticky bit SSD_ERRBIT_F16_RANGE in the device's numeric-status word instead: the pack kernels for every
+ * weight term and -- from the weights alone -- for the worst-case conv activation; the rollout heads for the activations they scale
+ * (the fc1 operand and fc1's output; hidden states are < 1); the recurrence kernel for W_h.  ssd_numeric_status returns and
+ * clears the word (it synchronises the device); ssd_poll_error ORs it into an env's bits. */
+#define SSD_ERRBIT_F16_RANGE 32
+int ssd_numeric_status(int32_t* bits);
 
 /* ---- COUNTER-mode generator (shared definition) ---------------------------------------------
  * Two levels, so that the expensive part is computed once per EPISODE (by the reset call) and kept in the env state:

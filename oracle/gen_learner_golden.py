@@ -8,7 +8,7 @@ reference env (Cleanup default5, 5 agents, short episodes), then records:
   * learning_logs of two consecutive cal_loss_and_step calls and checksums of every parameter after each step.
 pyclustering is absent: its two entry points are stubbed with the documented exact-value rule
 (cluster id = 2 * rewards_t + clean_num_t), so `loss_sim` is parity-pinned only relative to that rule.
-Output: tests/golden/learner_cleanup5.npz
+Output: tests/golden/learner_cleanup5.npz, learner_harvest5.npz, learner_cleanup5_w4.npz (the same at 4 x the initial weights)
 """
 import contextlib
 import io
@@ -59,7 +59,7 @@ def merge(d, u):
     return d
 
 
-def main(env_name, env_over, out_name, seed):
+def main(env_name, env_over, out_name, seed, wscale=1.0):
     OUT = os.path.join(GOLDEN, out_name)
     RH.import_reference()
     install_cluster_stub()
@@ -95,6 +95,13 @@ def main(env_name, env_over, out_name, seed):
     preprocess = {"actions": ("actions_onehot", [OneHot(out_dim=args.n_actions)])}
     buffer = ReplayBuffer(scheme, groups, args.buffer_size, env_info["episode_limit"] + 1, preprocess=preprocess, device="cpu")
     mac = mac_REGISTRY[args.mac](buffer.scheme, groups, args)
+    if wscale != 1.0:
+        # "trained-magnitude" fixture: every parameter of the freshly initialised reference controller times wscale before anything
+        # is computed (the soak runs' parameter norm grows 47 -> 155 over 8 000 rollouts: x 3.3), so that the reference's Q-values,
+        # losses and steps are recorded at the magnitudes a trained network has
+        with th.no_grad():
+            for prm in mac.parameters():
+                prm.mul_(wscale)
     runner.setup(scheme=scheme, groups=groups, preprocess=preprocess, mac=mac)
     learner = le_REGISTRY[args.learner](mac, buffer.scheme, logger, args)
     init_sd = {k: v.detach().clone().numpy() for k, v in mac.agent.state_dict().items()}
@@ -136,7 +143,7 @@ def main(env_name, env_over, out_name, seed):
         out["param_names"] = np.array(names)
     out["meta_seq_len"] = np.int64(batch.max_seq_length)
     import json
-    out["meta"] = np.frombuffer(json.dumps(dict(env=env_name, env_args=cfg["env_args"])).encode(), np.uint8)
+    out["meta"] = np.frombuffer(json.dumps(dict(env=env_name, env_args=cfg["env_args"], wscale=wscale)).encode(), np.uint8)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KB;",
           {k[6:]: float(out[k]) for k in out if k.startswith("step0_loss") or k.startswith("step1_loss")},
@@ -144,5 +151,7 @@ def main(env_name, env_over, out_name, seed):
 
 
 if __name__ == "__main__":
-    main("cleanup", dict(num_agents=5, map="default5", episode_limit=12), "learner_cleanup5.npz", 3)
-    main("harvest", dict(num_agents=5, map="default10", episode_limit=12, view_size=7), "learner_harvest5.npz", 4)
+    if "--w4-only" not in sys.argv:
+        main("cleanup", dict(num_agents=5, map="default5", episode_limit=12), "learner_cleanup5.npz", 3)
+        main("harvest", dict(num_agents=5, map="default10", episode_limit=12, view_size=7), "learner_harvest5.npz", 4)
+    main("cleanup", dict(num_agents=5, map="default5", episode_limit=12), "learner_cleanup5_w4.npz", 5, wscale=4.0)

@@ -56,18 +56,30 @@ LOG_KEYS = ("loss_value_env", "loss_value_inc", "loss_sim", "value_give_mean", "
 
 
 @pytest.mark.parametrize("train_graph,storage", [(False, "f32"), (True, "f32"), (False, "code"), (True, "code")])
-@pytest.mark.parametrize("name", ["learner_cleanup5.npz", "learner_harvest5.npz"])
+@pytest.mark.parametrize("name", ["learner_cleanup5.npz", "learner_harvest5.npz", "learner_cleanup5_w4.npz"])
 def test_learner_on_device_matches_reference_fixture(name, train_graph, storage):
     """Same fixtures as the CPU suite, network + HIP kernels on the GPU (fused loss kernel, sequence GRU kernels): inputs, Q-values,
     every logged value of two optimisation steps within 1e-5 (fp32) and every parameter after each step (pins the two-Adam /
     double-clip order on the device) -- eagerly and with the train step captured as hipGraphs (the captured step is compared with
     the REFERENCE's numbers, not only with the eager step).  storage "code": the sampled batch holds the observations as u8 class
     codes (obs_storage: code) and both networks' encoders run through the matrix-core encoder kernel (ops.encode_codes: forward
-    in the kernel, backward from the activations it emits) -- against the same reference numbers."""
+    in the kernel, backward from the activations it emits) -- against the same reference numbers.  `_w4`: the reference run at
+    4 x the initial weights (|q| up to 2, the magnitudes of a trained network) -- the split products hold the same absolute bar.
+    With code storage every operator must stay on the HIP kernels (strict_device_ops)."""
+    from homophily_marl_amd import ops
     from tests.learner_util import build, load_fixture, param_checksums
     th.backends.cuda.matmul.allow_tf32 = False
     z, meta = load_fixture(name)
     args, batch, mac, learner = build(z, meta, device="cuda:0", overrides=dict(train_graph=train_graph), code_obs=storage == "code")
+    ops.set_strict(storage == "code")
+    try:
+        _learner_fixture_body(z, args, batch, mac, learner, train_graph, storage)
+    finally:
+        ops.set_strict(False)
+
+
+def _learner_fixture_body(z, args, batch, mac, learner, train_graph, storage):
+    from tests.learner_util import param_checksums
     assert learner._fused(batch) and learner.use_graph == train_graph
     assert (batch["obs"].dtype == th.uint8) == (storage == "code")
     with th.no_grad():
@@ -380,6 +392,125 @@ def test_fast_graph_runner_stores_a_consistent_batch(groups, kind, n, view, stor
     ctx.runner.close_env()
 
 
+@pytest.mark.parametrize("kind,n,view,N", [("cleanup", 5, 7, 4096), ("harvest", 5, 15, 4096)])
+def test_the_benched_configuration_at_its_own_size(kind, n, view, N, monkeypatch):
+    """Exactly what bench.py times (BASELINE configs 2 / 3), at its own size: hip_graph runner, 4096 envs x 100 timesteps, 10 timesteps
+    per rollout hipGraph (the pipelined 3-launch timestep), class-code storage, episodes written in place into an 8 192-slot replay
+    buffer (two slabs of 4 096), train step captured as hipGraphs, device-side replay sampling and runner statistics, strict_device_ops.
+    Five iterations, so that both slabs are written by pure graph replays (slab 0: eager, captured, replayed; slab 1: captured,
+    replayed).  EVERY rollout is replayed on the CPU oracle with the stored actions (the waste permutation persists across episodes):
+    rewards / clean_num / apple_den / terminated of every step, pose and observation every 25 steps and at slot T.  Every captured
+    train step is compared, gradient by gradient, with an eager evaluation on the same sampled batch (SSD_GRAPH_CHECK)."""
+    from homophily_marl_amd import ops
+    from homophily_marl_amd.run import load_config, setup
+    from oracle.oracle_py import OracleEnv
+    T = 100
+    mp = "default10" if kind == "harvest" else "default5"
+    th.manual_seed(0)
+    np.random.seed(0)
+    monkeypatch.setenv("SSD_GRAPH_CHECK", "1")
+    cfg = load_config(kind, overrides=dict(
+        runner="hip_graph", train_graph=1, steps_per_graph=10, batch_size_run=N, batch_size=16, buffer_size=2 * N, obs_storage="code",
+        buffer_cpu_only=False, store_state=False, strict_device_ops=True,
+        env_args=dict(num_agents=n, map=mp, episode_limit=T, seed=1, view_size=view), use_cuda=True, save_model=False))
+    ctx = setup(cfg)
+    runner, buf, learner = ctx.runner, ctx.buffer, ctx.learner
+    orc = OracleEnv(kind, map=mp, num_agents=n, n_env=N, view_size=view, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=1)
+    ok_actions = th.nonzero(runner.env.avail_actions_batch[0, 0]).squeeze(-1).cpu().numpy()
+    ret_sums, ret_sq = [], []
+    try:
+        for it in range(5):
+            batch = runner.run(test_mode=False)
+            assert runner.pipe and runner.fold_store and runner.fast.fused_enc and runner._replay is buf
+            assert batch["obs"].data_ptr() == buf["obs"][(it % 2) * N:].data_ptr()               # written in place, slab it % 2
+            assert it == 0 or (runner._graph is not None and runner._graph_steps == 10)
+            orc.reset()
+            acts = batch["actions"].squeeze(-1).cpu().numpy()
+            rew, cln, den = (batch[k].cpu().numpy() for k in ("reward", "clean_num", "apple_den"))
+            term = batch["terminated"][:, :, 0].cpu().numpy()
+            ep_ret = rew[:, :T].astype(np.float64).sum(1)
+            ret_sums.append(ep_ret.sum()); ret_sq.append((ep_ret * ep_ret).sum())
+            for t in range(T):
+                if t % 25 == 0:
+                    ob = orc.observe(abi.OBS_CODE)
+                    assert (batch["obs"][:, t].cpu().numpy() == ob["obs"]).all(), (it, t)
+                    assert (batch["agent_pos"][:, t].cpu().numpy() == ob["pos"]).all() and (batch["agent_orientation"][:, t].cpu().numpy() == ob["orient"]).all()
+                o = orc.step(acts[:, t])
+                assert (rew[:, t] == o["reward"]).all() and (cln[:, t] == o["clean_num"]).all() and (den[:, t] == o["apple_den"]).all(), (it, t)
+                assert (term[:, t] == o["terminated"]).all()
+            assert (batch["obs"][:, T].cpu().numpy() == orc.observe(abi.OBS_CODE)["obs"]).all()
+            assert np.isin(acts, ok_actions).all() and int(batch["filled"].sum()) == N * (T + 1)
+            ai = batch["actions_inc"].squeeze(-1)
+            assert (ai.diagonal(dim1=2, dim2=3) == 0).all() and int(ai.max()) <= 2 and int(ai.min()) >= 0
+            buf.insert_episode_batch(batch)
+            assert buf.episodes_in_buffer == min(2, it + 1) * N
+            sample = buf.sample(16, out=learner.sample_out())
+            assert (learner.sample_out() is None) or sample is learner.sample_out()
+            learner.train(sample, runner.t_env, ctx.train_steps)          # replays are checked against the eager step inside (SystemExit)
+            ctx.train_steps += 1
+        assert learner._graph is not None and learner._check_n >= 2
+        assert all(bool(th.isfinite(p).all()) for p in ctx.mac.parameters())
+        assert runner.env.native.poll_error() == 0                        # no slot overrun, no f16 range flag
+        # device-side runner statistics (episode_runner.py:121-152): the first rollout was logged and cleared (log clock), the other
+        # four are still accumulated on the device -- against the stored batches' own sums
+        acc = runner._acc_train.cpu().numpy()
+        assert runner.train_stats["n_episodes"] == 4 * N and runner.train_stats["n_returns"] == 4 * N * n
+        assert abs(acc[2] - sum(ret_sums[1:])) < 1e-6 * max(1.0, abs(acc[2])) and abs(acc[3] - sum(ret_sq[1:])) < 1e-6 * max(1.0, acc[3])
+    finally:
+        ops.set_strict(False)
+        runner.close_env()
+
+
+def test_host_replay_buffer_with_a_captured_train_step():
+    """the shipped default buffer_cpu_only: True with use_cuda and train_graph = 1.  From the 4th learner.train on the
+    learner offers its device-resident static batch as `out`; a HOST buffer must not gather into it across devices but hand back a
+    host sample that train_iteration moves over, as the reference loop does (run.py:207-208)."""
+    from homophily_marl_amd.run import load_config, setup, train_iteration
+    N, T = 32, 12
+    cfg = load_config("cleanup", overrides=dict(
+        runner="hip_graph", train_graph=1, batch_size_run=N, batch_size=8, buffer_size=64, buffer_cpu_only=True, store_state=False,
+        obs_storage="code", env_args=dict(num_agents=5, map="default5", episode_limit=T, seed=5), use_cuda=True, save_model=False))
+    th.manual_seed(0)
+    np.random.seed(0)
+    ctx = setup(cfg)
+    assert str(ctx.buffer.device) == "cpu"
+    ep = 0
+    for _ in range(7):
+        ep = train_iteration(ctx, ep)
+    assert ctx.train_steps == 7 and ctx.learner._graph is not None
+    assert all(bool(th.isfinite(p).all()) for p in ctx.mac.parameters())
+    ctx.runner.close_env()
+
+
+def test_captured_train_step_equals_the_eager_step_at_batch_64(monkeypatch):
+    """batch_size 64: four 16-row tiles per weight set, so the per-tile bias sums of the recurrence (and every other row reduction of
+    the step) are added inside the captured graph -- by k_column_sums, not by an ATen multi-block reduction.
+    Every replay is compared with an eager evaluation of the same step while another learner trains eagerly in between."""
+    from types import SimpleNamespace
+    from homophily_marl_amd import ops
+    from homophily_marl_amd.controllers import REGISTRY as mac_REGISTRY
+    from homophily_marl_amd.learners import REGISTRY as le_REGISTRY
+    batch, eager, _ = _random_learner_batch(64, 40, 5, "cleanup", seed=5)
+    a = SimpleNamespace(**vars(eager.args)); a.train_graph = True
+    mac = mac_REGISTRY[a.mac](batch.scheme, {"agents": 5}, a).cuda()
+    mac.agent.load_state_dict(eager.mac.agent.state_dict())
+    graph = le_REGISTRY[a.learner](mac, batch.scheme, SimpleNamespace(log_stat=lambda *x, **k: None, console_logger=None), a)
+    graph.cuda()
+    monkeypatch.setenv("SSD_GRAPH_CHECK", "1")
+    g = th.Generator(device="cuda").manual_seed(0)
+    ops.set_strict(True)
+    try:
+        for step in range(40):
+            r = (th.rand(batch["reward"].shape, generator=g, device="cuda") < 0.05).float()
+            batch.data.transition_data["reward"].copy_(r)
+            graph.train(batch, 0, step)
+            eager.train(batch, 0, step)
+    finally:
+        ops.set_strict(False)
+    assert graph._graph is not None and graph._check_n >= 36
+    assert all(bool(th.isfinite(p).all()) for p in mac.parameters())
+
+
 def test_fused_gru_gate_kernels_forward_and_backward():
     """ops.gru_gates on the GPU (one fused forward + one fused backward kernel) against the torch expression + autograd."""
     from homophily_marl_amd import ops
@@ -605,6 +736,26 @@ def test_clip_adam_kernel_equals_the_tensor_op_optimiser_tail(name):
             for k in ("exp_avg", "exp_avg_sq"):
                 # after the first step the two runs' parameters differ in the last bits, hence their gradients: 1e-4 of the largest moment
                 assert (sa[k] - sb[k]).abs().max() <= 1e-4 * max(1e-12, float(sa[k].abs().max())), k
+
+
+def test_clip_adam_kernel_spreads_a_non_finite_norm_like_clip_grad_norm():
+    """one NaN gradient makes clip_grad_norm_'s coefficient NaN, which torch multiplies into EVERY gradient of the group
+    (and through the once-clipped encoder into the other group): the fused tail does the same instead of stepping unclipped."""
+    from tests.learner_util import build, load_fixture
+    z, meta = load_fixture("learner_cleanup5.npz")
+    outs = []
+    for fused_opt in (False, True):
+        args, batch, mac, learner = build(z, meta, device="cuda:0", overrides=dict(train_graph=False, fused_optimiser=fused_opt))
+        for _ in range(2):                                              # the first step creates the optimiser state
+            learner.cal_loss_and_step(batch)
+        dens = learner.denominators(batch)
+        learner.forward_backward(batch, dens)
+        inc_only = next(p for p in learner.params_inc if all(p is not q for q in learner.params_env))
+        inc_only.grad.view(-1)[0] = float("nan")
+        learner.clip_and_step()
+        assert (learner._opt_plan not in (None, False)) == fused_opt
+        outs.append([bool(th.isnan(p).all()) for p in learner.params])
+    assert outs[0] == outs[1] and all(outs[1])
 
 
 @pytest.mark.parametrize("T,n,B,k", [(7, 5, 16, 4), (5, 3, 32, 2), (9, 5, 16, 1), (4, 2, 7, 2)])

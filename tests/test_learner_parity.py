@@ -9,7 +9,7 @@ import os
 
 from tests.learner_util import GOLDEN, build, load_fixture, param_checksums
 
-FIXTURES = ["learner_cleanup5.npz", "learner_harvest5.npz"]
+FIXTURES = ["learner_cleanup5.npz", "learner_harvest5.npz", "learner_cleanup5_w4.npz"]      # _w4: 4 x the initial weights ("trained magnitude")
 LOSS_TOL = 1e-5
 
 
