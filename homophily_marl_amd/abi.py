@@ -197,8 +197,25 @@ TD_LOSS_PARTIALS = 16
 POLICY_HEAD_FRAGS, POLICY_HEAD_TAIL_FLOATS = 58, 464 + 64
 
 
+POLICY_TAIL_PIECES = 3
+
+
 def policy_image_bytes(precision):
-    return precision * POLICY_HEAD_FRAGS * 1024 + POLICY_HEAD_TAIL_FLOATS * 4
+    """SSD_POLICY_IMAGE_BYTES: 3 tail pieces + 58 fragments per term, in whole 8 KiB chunks."""
+    return (120 if precision == 2 else 64) * 1024
+
+
+def policy_frag_piece(precision, F, term):
+    """1 KiB piece of fragment F (the numbering of csrc: 2 ot + s fc1; 8 + 2 ot + s GRU input side, 12 tiles; 32 + 2 ot + s hidden
+    side; 56 + s fc2) and split term `term` inside a head image (include/ssd_hip.h: consumption order)."""
+    if F < 8:
+        c, ot = F & 1, F >> 1
+    elif F < 56:
+        G = (F - 8) % 24
+        c, ot = (8 if F >= 32 else 2) + 2 * (G >> 3) + (G & 1), (G & 7) >> 1
+    else:
+        return POLICY_TAIL_PIECES + 56 * precision + 2 * term + (F - 56)
+    return POLICY_TAIL_PIECES + 4 * precision * c + 4 * term + ot
 
 
 def encode_bands(V):

@@ -113,10 +113,56 @@ constexpr float ENC_CSCALE = 256.f, ENC_LSCALE = 256.f;                  // conv
 // ===========================================================================================================================
 // heads
 // ===========================================================================================================================
-constexpr int HF_FC1 = 0, HF_WI = 8, HF_WH = 32, HF_FC2 = 56, HF_TOT = SSD_POLICY_HEAD_FRAGS;
+constexpr int HF_WI = 8, HF_WH = 32, HF_FC2 = 56, HF_TOT = SSD_POLICY_HEAD_FRAGS;
 constexpr int HT_B1 = 0, HT_BI = 64, HT_BH = 256, HT_B2 = 448, HT_W2O = 464, HT_TOT = SSD_POLICY_HEAD_TAIL_FLOATS;
 constexpr int HEAD_WAVES = 8;
 constexpr int SCRATCH = 16 * 16;               // per wave: fc2 output tile [row 16][out 16]
+// The image is laid out in the order the head consumes it (include/ssd_hip.h), in 1 KiB pieces: the f32 tail (3 pieces), then per
+// K-STEP c of the chain (fc1: c = s; GRU input side: 2 + 2 g + s; hidden side: 8 + 2 g + s) its [term][output tile] fragments, then
+// fc2's [term][s].  A CHUNK is 8 consecutive pieces: one LDS-DMA wave instruction per wave of the workgroup.
+constexpr int HEAD_STEPS = 14, TAIL_PIECES = SSD_POLICY_TAIL_PIECES;
+template <int PREC> constexpr int head_pieces() { return SSD_POLICY_IMAGE_PIECES(PREC); }
+template <int PREC> constexpr int head_chunks() { return head_pieces<PREC>() / HEAD_WAVES; }
+template <int PREC> constexpr int step_piece(int c, int t, int ot) { return TAIL_PIECES + 4 * PREC * c + 4 * t + ot; }
+template <int PREC> constexpr int fc2_piece(int t, int s2) { return TAIL_PIECES + 4 * PREC * HEAD_STEPS + 2 * t + s2; }
+template <int PREC> constexpr int need_chunk(int c) { return (step_piece<PREC>(c, PREC - 1, 3)) >> 3; }   // last chunk K-step c reads
+// chunks requested before the tile's inputs (they cover fc1, K-steps 0 and 1); the rest streams in behind the chain
+template <int PREC> constexpr int first_chunks() { return need_chunk<PREC>(1) + 1; }
+static_assert(head_pieces<2>() % HEAD_WAVES == 0 && head_pieces<1>() % HEAD_WAVES == 0, "whole chunks");
+static_assert(fc2_piece<2>(1, 1) < head_pieces<2>() && fc2_piece<1>(0, 1) < head_pieces<1>(), "image holds every piece");
+static_assert(need_chunk<2>(HEAD_STEPS - 1) == head_chunks<2>() - 1 && need_chunk<1>(HEAD_STEPS - 1) == head_chunks<1>() - 1,
+              "the last K-step's wait retires the whole image (fc2's fragments included)");
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from each lane's global address into 1 KiB of LDS at the wave-uniform byte address lds_dst
+// (global_load_lds_dwordx4: no VGPR destination; M0 carries the LDS address and is restored).  hipcc does not count it: completion is
+// waited for with wait_vm<N> below, then a workgroup barrier, then the ds_reads.
+__device__ __forceinline__ void dma_piece(const uint8_t* gsrc_lane, uint32_t lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
+#else
+    (void)gsrc_lane; (void)lds_dst;
+#endif
+}
+template <int N> __device__ __forceinline__ void wait_vm() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+#endif
+}
+// Before the fragments of K-step C are read for the first time: this wave's pieces of every chunk up to need_chunk(C) have landed
+// (counted wait: the younger chunks stay in flight), then the workgroup barrier makes the other waves' pieces readable.  Steps whose
+// chunks were covered by an earlier wait need nothing.  Waves with and without a tile execute the same sequence (idle_sync).
+template <int PREC, int C> __device__ __forceinline__ void step_sync() {
+    constexpr int need = need_chunk<PREC>(C), before = C == 0 ? first_chunks<PREC>() - 1 : need_chunk<PREC>(C - 1);
+    if constexpr (need >= first_chunks<PREC>() && need > before) {
+        wait_vm<head_chunks<PREC>() - 1 - need>();
+        __builtin_amdgcn_s_barrier();
+    }
+}
+template <int PREC, int C = 0> __device__ __forceinline__ void idle_sync() {
+    if constexpr (C < HEAD_STEPS) { step_sync<PREC, C>(); idle_sync<PREC, C + 1>(); }
+}
 
 // Kernel arguments.  HeadK is what the main path reads; HeadCold holds the ~20 pointers only the epilogue touches (results, filing
 // into the episode storage, runner state).  hipcc loads every by-value kernel argument into SGPRs at kernel entry -- 100+ SGPRs
@@ -169,43 +215,18 @@ __device__ __forceinline__ T* cold_ptr(int field_offset) {
 #define COLD(T, field) cold_ptr<T>((int)offsetof(HeadCold, field))
 #define COLD_U64(field) reinterpret_cast<uint64_t>(cold_ptr<void>((int)offsetof(HeadCold, field)))
 
-// acc[ot] += (W^T tile ot of the block starting at fragment F0) x B for OT output tiles, both K-steps; small terms first
-template <int PREC, int OT>
-__device__ __forceinline__ void gemm_t(const uint8_t* img, int F0, const u32x4 (&bh)[2], const u32x4 (&bl)[2], f32x4* acc, int lane) {
-    constexpr size_t TERM = (size_t)HF_TOT * 1024;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        u32x4 ah[OT], al[OT];
-#pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-            const uint8_t* p = img + ((size_t)(F0 + 2 * ot + s) * 64 + lane) * 16;
-            ah[ot] = *reinterpret_cast<const u32x4*>(p);
-            if (PREC == 2) al[ot] = *reinterpret_cast<const u32x4*>(p + TERM);
-        }
-        if (PREC == 2) {
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) acc[ot] = mma<PREC>(al[ot], bh[s], acc[ot]);
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) acc[ot] = mma<PREC>(ah[ot], bl[s], acc[ot]);
-        }
-#pragma unroll
-        for (int ot = 0; ot < OT; ++ot) acc[ot] = mma<PREC>(ah[ot], bh[s], acc[ot]);
-    }
-}
-
-// One K-step (s) of a 4-output-tile product as two halves, so that a SEQUENCE of products can request the next step's A fragments
+// One K-step (c) of a 4-output-tile product as two halves, so that a SEQUENCE of products can request the next step's A fragments
 // from LDS before the current step's MFMAs issue (a wave that is alone on its SIMD has nothing else to hide the ds_read latency):
-// frag4_load fetches the 4 (PREC 2: 8) fragments of tiles F0 + 2 ot + s, frag4_mma adds their products.
+// frag4_load fetches the 4 (PREC 2: 8) fragments of K-step c, frag4_mma adds their products.
 template <int PREC>
 struct Frag4 { u32x4 h[4], l[4]; };
 template <int PREC>
-__device__ __forceinline__ void frag4_load(const uint8_t* img, int F0, int s, int lane, Frag4<PREC>& f) {
-    constexpr size_t TERM = (size_t)HF_TOT * 1024;
+__device__ __forceinline__ void frag4_load(const uint8_t* img, int c, int lane, Frag4<PREC>& f) {
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) {
-        const uint8_t* p = img + ((size_t)(F0 + 2 * ot + s) * 64 + lane) * 16;
+        const uint8_t* p = img + (size_t)step_piece<PREC>(c, 0, ot) * 1024 + lane * 16;
         f.h[ot] = *reinterpret_cast<const u32x4*>(p);
-        if (PREC == 2) f.l[ot] = *reinterpret_cast<const u32x4*>(p + TERM);
+        if (PREC == 2) f.l[ot] = *reinterpret_cast<const u32x4*>(p + 4 * 1024);
     }
 }
 template <int PREC>
@@ -339,7 +360,7 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
 // compile-time columns -- the register allocation of the tuned kernel is left as it was.
 template <int INC, int PREC, int AT, int GEN>
 __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, const int block) {
-    constexpr int FRAG_BYTES = PREC * HF_TOT * 1024, IMAGE_BYTES = FRAG_BYTES + HT_TOT * 4;
+    constexpr int IMAGE_BYTES = SSD_POLICY_IMAGE_BYTES(PREC), NCHUNK = head_chunks<PREC>(), B1 = first_chunks<PREC>();
     constexpr float XS = PREC == 2 ? HEAD_XSCALE : 1.f, INV = PREC == 2 ? 1.f / (HEAD_WSCALE * HEAD_XSCALE) : 1.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int agent = block / a.bpa, bia = block - agent * a.bpa;
@@ -348,10 +369,18 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
     constexpr int A = AT;
     PSTAMP(0);
     PSTAMP_REAL(14);
-    const int tiles = (N + 15) >> 4, tstep = a.bpa * HEAD_WAVES;
-    int tile = wave * a.bpa + bia;                                     // consecutive tiles go to different CUs
+    const int tiles = (N + 15) >> 4;
+    const int tile = wave * a.bpa + bia;                               // consecutive tiles go to different CUs; bpa * 8 >= tiles
     TileIn<INC> in;
-    if (tile < tiles) load_tile<INC>(a, tile, agent, lane, in);        // in flight while the image is staged
+    // The agent's image streams into LDS behind the kernel's own arithmetic (it is stored in consumption order): every wave requests
+    // one 1 KiB piece per 8 KiB chunk by LDS-DMA -- the first B1 chunks (tail + fc1) now, the others once the tile's inputs have
+    // landed -- and the chain below waits, K-step by K-step, for just the chunks it is about to read (step_sync).  Staging the
+    // whole 118 KB before the first MFMA took 40 % of a head launch (a CU takes in ~12 bytes per cycle).
+    const uint8_t* img_src = a.weights + (size_t)agent * IMAGE_BYTES + (size_t)wave * 1024 + lane * 16;
+    const uint32_t img_dst = (uint32_t)(uintptr_t)lds_raw + (uint32_t)wave * 1024u;
+#pragma unroll
+    for (int ch = 0; ch < B1; ++ch) dma_piece(img_src + (size_t)ch * 8192, img_dst + (uint32_t)ch * 8192u);
+    if (tile < tiles) load_tile<INC>(a, tile, agent, lane, in);        // queued behind the first chunks
     const float eps = *a.eps;
     const uint32_t step = (uint32_t)*a.step;
     const long slot_t = a.t_index ? (long)*a.t_index : 0;
@@ -452,23 +481,6 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
         if (PREC == 2) range_check(amax_tiles<4>(0.f, x));
         operand<PREC>(x, XS, bh, bl);
     };
-    {   // stage this agent's image (already in LDS layout): every load in flight before the first LDS write
-        const u32x4* src = reinterpret_cast<const u32x4*>(a.weights + (size_t)agent * IMAGE_BYTES);
-        u32x4* dst = reinterpret_cast<u32x4*>(lds_raw);
-        constexpr int NV = IMAGE_BYTES / 16, PER = (NV + HEAD_WAVES * 64 - 1) / (HEAD_WAVES * 64);
-        u32x4 tmp[PER];
-#pragma unroll
-        for (int j = 0; j < PER; ++j) { const int e = tid + j * HEAD_WAVES * 64; if (e < NV) tmp[j] = src[e]; }
-        if (tile < tiles) prepare(tile);
-#pragma unroll
-        for (int j = 0; j < PER; ++j) { const int e = tid + j * HEAD_WAVES * 64; if (e < NV) dst[e] = tmp[j]; }
-    }
-    __syncthreads();
-    PSTAMP(1);
-    bool first = true;
-    const uint8_t* img = lds_raw;
-    const float* tail = reinterpret_cast<const float*>(lds_raw + FRAG_BYTES);
-    float* scratch = reinterpret_cast<float*>(lds_raw + IMAGE_BYTES) + wave * SCRATCH;
     // Device-side counters advance by ping-pong copies, never by a kernel incrementing a scalar it (or a workgroup of the same
     // launch) also reads: the inc head reads the copies and writes the masters' next values, the env head (pipelined rollout) reads
     // the masters and writes the copies.
@@ -483,7 +495,38 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
             if (step_copy) *step_copy = *a.step;
         }
     }
-    while (tile < tiles) {
+    if (tile < tiles) prepare(tile);
+#if defined(__HIP_DEVICE_COMPILE__)
+    {   // every compiler-issued load of this wave is consumed (or pinned) here, BEFORE the second batch of LDS-DMA: hipcc does not count
+        // the DMA pieces, so a wait it placed later for one of its own loads would drain them (vmcnt retires in issue order)
+        uint32_t ab = avail_bits;
+        asm volatile("" : "+s"(ab));
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) asm volatile("" : "+v"(in.hp[ct]));
+        if (INC) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                asm volatile("" : "+v"(in.aj[k]));
+#pragma unroll
+                for (int e = 0; e < 7; ++e) asm volatile("" : "+v"(in.f[k][e]));
+            }
+        }
+    }
+#endif
+#pragma unroll
+    for (int ch = B1; ch < NCHUNK; ++ch) dma_piece(img_src + (size_t)ch * 8192, img_dst + (uint32_t)ch * 8192u);
+    wait_vm<NCHUNK - B1>();                                            // all but the second batch: the first chunks and every older access
+    __builtin_amdgcn_s_barrier();                                      // ... of every wave: chunks < B1 are readable
+    PSTAMP(1);
+    bool first = true;
+    const uint8_t* img = lds_raw;
+    const float* tail = reinterpret_cast<const float*>(lds_raw);
+    float* scratch = reinterpret_cast<float*>(lds_raw + IMAGE_BYTES) + wave * SCRATCH;
+    // The wave's 16-row tile through the chain; the K-steps synchronise with the image still streaming in (step_sync).  A wave has
+    // AT MOST ONE tile (the host sizes the grid for it: bpa = ceil(tiles per agent / 8)): with a loop over further tiles in the
+    // kernel every argument and pointer of the input phase stayed live through the chain -- 118 scalar registers spilled and the
+    // vector file full (256, against 150 now).
+    auto run_tile = [&]() {
         const int b = tile * 16 + m;
         const bool valid = b < N;
         const int bc = valid ? b : N - 1;
@@ -494,10 +537,11 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) x1[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
         Frag4<PREC> fa, fb;                                            // fragment double buffer of the whole tile chain
-        frag4_load<PREC>(img, HF_FC1, 0, lane, fa);
-        frag4_load<PREC>(img, HF_FC1, 1, lane, fb);
+#define SSD_LOAD_STEP(c_, f_) do { step_sync<PREC, c_>(); frag4_load<PREC>(img, c_, lane, f_); } while (0)
+        SSD_LOAD_STEP(0, fa);
+        SSD_LOAD_STEP(1, fb);
         frag4_mma<PREC>(fa, bh[0], bl[0], x1);
-        frag4_load<PREC>(img, HF_WI, 0, lane, fa);                     // the GRU's first step: in flight under fc1's second half
+        SSD_LOAD_STEP(2, fa);                                          // the GRU's first step: in flight under fc1's second half
         frag4_mma<PREC>(fb, bh[1], bl[1], x1);
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
@@ -519,26 +563,26 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
             if (PREC == 2) range_check(amax_tiles<4>(0.f, x1));
             operand<PREC>(x1, XS, xh, xl);
             operand<PREC>(hp, XS, hh, hl);
-            frag4_load<PREC>(img, HF_WI, 1, lane, fb);       frag4_mma<PREC>(fa, xh[0], xl[0], g);
-            frag4_load<PREC>(img, HF_WI + 8, 0, lane, fa);   frag4_mma<PREC>(fb, xh[1], xl[1], g);
-            frag4_load<PREC>(img, HF_WI + 8, 1, lane, fb);   frag4_mma<PREC>(fa, xh[0], xl[0], g + 4);
-            frag4_load<PREC>(img, HF_WI + 16, 0, lane, fa);  frag4_mma<PREC>(fb, xh[1], xl[1], g + 4);
-            frag4_load<PREC>(img, HF_WI + 16, 1, lane, fb);  frag4_mma<PREC>(fa, xh[0], xl[0], g + 8);
-            frag4_load<PREC>(img, HF_WH, 0, lane, fa);       frag4_mma<PREC>(fb, xh[1], xl[1], g + 8);
-            frag4_load<PREC>(img, HF_WH, 1, lane, fb);       frag4_mma<PREC>(fa, hh[0], hl[0], g);
-            frag4_load<PREC>(img, HF_WH + 8, 0, lane, fa);   frag4_mma<PREC>(fb, hh[1], hl[1], g);
-            frag4_load<PREC>(img, HF_WH + 8, 1, lane, fb);   frag4_mma<PREC>(fa, hh[0], hl[0], g + 4);
-            frag4_load<PREC>(img, HF_WH + 16, 0, lane, fa);  frag4_mma<PREC>(fb, hh[1], hl[1], g + 4);
-            frag4_load<PREC>(img, HF_WH + 16, 1, lane, fb);  frag4_mma<PREC>(fa, hh[0], hl[0], g + 12);
+            SSD_LOAD_STEP(3, fb);   frag4_mma<PREC>(fa, xh[0], xl[0], g);          // K-steps 2 .. 7: input side (r, z, n)
+            SSD_LOAD_STEP(4, fa);   frag4_mma<PREC>(fb, xh[1], xl[1], g);
+            SSD_LOAD_STEP(5, fb);   frag4_mma<PREC>(fa, xh[0], xl[0], g + 4);
+            SSD_LOAD_STEP(6, fa);   frag4_mma<PREC>(fb, xh[1], xl[1], g + 4);
+            SSD_LOAD_STEP(7, fb);   frag4_mma<PREC>(fa, xh[0], xl[0], g + 8);
+            SSD_LOAD_STEP(8, fa);   frag4_mma<PREC>(fb, xh[1], xl[1], g + 8);
+            SSD_LOAD_STEP(9, fb);   frag4_mma<PREC>(fa, hh[0], hl[0], g);          // K-steps 8 .. 13: hidden side
+            SSD_LOAD_STEP(10, fa);  frag4_mma<PREC>(fb, hh[1], hl[1], g);
+            SSD_LOAD_STEP(11, fb);  frag4_mma<PREC>(fa, hh[0], hl[0], g + 4);
+            SSD_LOAD_STEP(12, fa);  frag4_mma<PREC>(fb, hh[1], hl[1], g + 4);
+            SSD_LOAD_STEP(13, fb);  frag4_mma<PREC>(fa, hh[0], hl[0], g + 12);
             frag4_mma<PREC>(fb, hh[1], hl[1], g + 12);
         }
         if (first) PSTAMP(4);
         u32x4 f2h[2], f2l[2];                                          // fc2's fragments: in flight under the gate arithmetic
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const uint8_t* p2 = img + ((size_t)(HF_FC2 + s2) * 64 + lane) * 16;
+            const uint8_t* p2 = img + (size_t)fc2_piece<PREC>(0, s2) * 1024 + lane * 16;
             f2h[s2] = *reinterpret_cast<const u32x4*>(p2);
-            if (PREC == 2) f2l[s2] = *reinterpret_cast<const u32x4*>(p2 + (size_t)HF_TOT * 1024);
+            if (PREC == 2) f2l[s2] = *reinterpret_cast<const u32x4*>(p2 + 2 * 1024);
         }
         f32x4 hn[4];
 #pragma unroll
@@ -649,9 +693,9 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
         __builtin_amdgcn_wave_barrier();                               // scratch is reused by the next tile
         if (first) PSTAMP(6);
         first = false;
-        tile += tstep;
-        if (tile < tiles) { load_tile<INC>(a, tile, agent, lane, in); prepare(tile); }
-    }
+#undef SSD_LOAD_STEP
+    };
+    if (tile < tiles) run_tile(); else idle_sync<PREC>();               // the same waits and barriers on either side
     PSTAMP(7);
     PSTAMP_REAL(15);
 }
@@ -694,10 +738,7 @@ static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c) {
     c.numeric_err = numeric_err_word();
     PSTAMP_SET(k);
     const int tiles = (k.N + 15) / 16;
-    int bpa = 256 / k.n;                                               // one workgroup per CU (the image fills most of the LDS)
-    if (bpa > tiles) bpa = tiles;
-    if (bpa < 1) bpa = 1;
-    k.bpa = bpa;
+    k.bpa = (tiles + HEAD_WAVES - 1) / HEAD_WAVES;                     // workgroups per agent: every wave owns at most one 16-row tile
 }
 
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
@@ -740,27 +781,31 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
 // ---- pack: reference-shaped f32 parameters -> the per-agent head image --------------------------------------------------------
 template <int PREC>
 __global__ __launch_bounds__(256) void k_pack_head(ssd_policy_head_params p, uint8_t* image, int32_t* err) {
-    constexpr size_t TERM = (size_t)HF_TOT * 1024, IMAGE_BYTES = PREC * TERM + HT_TOT * 4;
+    constexpr size_t IMAGE_BYTES = SSD_POLICY_IMAGE_BYTES(PREC);
     constexpr float WS = PREC == 2 ? HEAD_WSCALE : 1.f;
     const int agent = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
     uint8_t* img = image + (size_t)agent * IMAGE_BYTES;
     if (e < HF_TOT * 512) {
         const int F = e >> 9, lane = (e >> 3) & 63, j = e & 7, q = lane >> 4, m = lane & 15;
         float w = 0.f;
+        int piece, term_pieces = 4;                                    // hi term's piece; the lo term sits term_pieces further
         if (F < HF_WI) {
             const int ot = F >> 1, s = F & 1, out = 16 * ot + m, k = 32 * s + 16 * (j >> 2) + 4 * q + (j & 3);
             if (k < p.fc1_in) w = p.fc1_w[((size_t)agent * p.fc1_in + k) * 64 + out];
+            piece = step_piece<PREC>(s, 0, ot);
         } else if (F < HF_FC2) {
             const bool hid = F >= HF_WH;
             const int G = F - (hid ? HF_WH : HF_WI), ot = G >> 1, s = G & 1, out = 16 * ot + m, k = 32 * s + 16 * (j >> 2) + 4 * q + (j & 3);
             const float* W = (hid ? p.w_h : p.w_i)[out >> 6];
             w = W[((size_t)agent * 64 + k) * 64 + (out & 63)];
+            piece = step_piece<PREC>((hid ? 8 : 2) + 2 * (ot >> 2) + s, 0, ot & 3);    // gate g = ot >> 2 (r, z, n), its 4 output tiles
         } else {
             const int s = F - HF_FC2, k = 32 * s + 16 * (j >> 2) + 4 * q + (j & 3);   // the h part of fc2: rows 0..63 of [fc2_in, out]
             if (m < p.fc2_out) w = p.fc2_w[((size_t)agent * p.fc2_in + k) * p.fc2_out + m];
             else if (m == p.fc2_out) w = p.fc2_v_w[(size_t)agent * p.fc2_in + k];
+            piece = fc2_piece<PREC>(0, s); term_pieces = 2;
         }
-        store_term<PREC>(img + ((size_t)F * 64 + lane) * 16 + 2 * j, w * WS, TERM, err);
+        store_term<PREC>(img + ((size_t)piece * 64 + lane) * 16 + 2 * j, w * WS, (size_t)term_pieces * 1024, err);
     }
     if (e < HT_TOT) {
         float v = 0.f;
@@ -777,7 +822,7 @@ __global__ __launch_bounds__(256) void k_pack_head(ssd_policy_head_params p, uin
                 else if (o == p.fc2_out) v = p.fc2_v_w[(size_t)agent * p.fc2_in + 64 + ee];
             }
         }
-        reinterpret_cast<float*>(img + PREC * TERM)[e] = v;
+        reinterpret_cast<float*>(img)[e] = v;                          // the tail opens the image (pieces 0 .. 2)
     }
 }
 

@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n-env", type=int, default=4096)
 ap.add_argument("--mode", default="step_observe")
 ap.add_argument("--dest", default="dense", choices=["dense", "storage"])
+ap.add_argument("--fmt", default="f32", choices=["f32", "code"], help="observation format: f32 planes (format R) or u8 class codes (format C, the rollout's)")
 a = ap.parse_args()
 out = os.path.join(ROOT, "gpurun_out", "libssd_hip_stamps.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
@@ -33,14 +34,16 @@ env.lib.ssd_debug_set_stamps(env.h, stamps.data_ptr())
 avail = torch.tensor([0, 1, 2, 3, 4, 8], dtype=torch.int32, device="cuda")
 env.reset()
 out = None
+FMT = abi.OBS_CODE if a.fmt == "code" else abi.OBS_F32
 if a.dest == "storage":      # the rollout's destination: slot ep_step of an episode storage (every launch lands in fresh HBM lines)
-    out = env.storage_obs_buffers(torch.empty(N, 101, n, 3, 15, 15, device="cuda"), abi.OBS_F32)
+    store = torch.empty(N, 101, n, 15, 15, dtype=torch.uint8, device="cuda") if a.fmt == "code" else torch.empty(N, 101, n, 3, 15, 15, device="cuda")
+    out = env.storage_obs_buffers(store, FMT)
 names = ["load", "moves", "consume+paint", "beams", "spawn", "scalars", "writeback", "obs pass0", "obs pass1", "obs pass2"]
 acc = []
 for t in range(40):
     acts = avail[torch.randint(0, 6, (N, n), device="cuda")].contiguous()
     if a.mode == "step_observe":
-        env.step_observe(acts, out=out)
+        env.step_observe(acts, fmt=FMT, out=out)
     else:
         env.step(acts)
     torch.cuda.synchronize()
