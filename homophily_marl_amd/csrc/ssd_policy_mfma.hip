@@ -99,11 +99,14 @@ void set_policy_stamps(unsigned long long* buf) { g_policy_stamps = buf; }
 #define PSTAMP_AT(i, v) do { if (a.stamps && lane == 0) a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave) * 16 + (i)] = (v); } while (0)
 #define PSTAMP(i) PSTAMP_AT(i, __builtin_amdgcn_s_memtime())
 #define PSTAMP_REAL(i) PSTAMP_AT(i, __builtin_amdgcn_s_memrealtime())      // chip-wide 100 MHz clock: comparable across XCDs
+// stamp AFTER every outstanding memory operation of the wave has completed (prices a load phase; perturbs what follows)
+#define PSTAMP_DRAINED(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); PSTAMP(i); } while (0)
 #else
 #define PSTAMP_DECL
 #define PSTAMP_SET(k)
 #define PSTAMP(i)
 #define PSTAMP_REAL(i)
+#define PSTAMP_DRAINED(i)
 #endif
 
 // exact power-of-two scales (PREC 2; PREC 1 needs none: bf16 has the f32 exponent range)
@@ -285,31 +288,37 @@ template <int INC>
 struct TileIn {
     f32x4 x[4];                    // env: x[0..1] = encoder features (final, or lin_b + the band sums); inc: the 64 stored inputs
     f32x4 hp[4];                   // previous hidden state
-    int pa, recv, act;             // env: last action, #recv+ - #recv-; inc: the env action just taken
+    int pa, act;                   // env: last action; inc: the env action just taken
+    int32_t inc[SSD_MAX_AGENTS];   // env: the incentive action every giver g sent this agent at the previous step (0 / 1 / 2)
     float pr, p0, p1, o0, o1;      // env: last reward, pose
     int aj[3];                     // inc epilogue items (row, j) = lane + 64 k: action of j and its 7 features
     float f[3][7];
 };
 
+// Addresses are 32-bit element offsets from the (scalar) base pointers -- every array here has far fewer than 2^31 elements (the ABI
+// checks n_env * n_agents^2 * 64) -- so a load is `global_load v, v_offset, s[base]` instead of a chain of 64-bit multiplies per lane,
+// and nothing in here branches: a branch the compiler makes out of a predicated load waits for EVERY outstanding load of the wave,
+// the image's first chunks included (measured: 5 300 of the prologue's 12 000 cycles).
+template <typename T>
+__device__ __forceinline__ T ld32(const T* base, uint32_t idx) { return *reinterpret_cast<const T*>(reinterpret_cast<const uint8_t*>(base) + (size_t)(idx * (uint32_t)sizeof(T))); }
 template <int INC>
 __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, int lane, TileIn<INC>& in) {
     const int m = lane & 15, q = lane >> 4, N = a.N, n = a.n;
     const int b = tile * 16 + m, bc = b < N ? b : N - 1;
-    const size_t arow = (size_t)agent * N + bc;
-    const float* in_row = a.inputs + arow * 64;
-    const float* h_row = a.h + arow * 64;
+    const uint32_t arow = (uint32_t)agent * (uint32_t)N + (uint32_t)bc;
+    const uint32_t ro = arow * 64u + 4u * (uint32_t)q;                 // this lane's first float of the agent-major row
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) in.hp[ct] = *reinterpret_cast<const f32x4*>(h_row + 16 * ct + 4 * q);
+    for (int ct = 0; ct < 4; ++ct) in.hp[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.h) + (size_t)((ro + 16u * ct) * 4u));
     if (!INC) {
-        if (a.feat_part) {          // the encoder left per-band partial sums: lin_b + sum over the bands, band order
-            const size_t rows = (size_t)n * N;
+        if (a.feat_part) {          // the encoder left per-band partial sums: lin_b + sum over the bands, band order (wave-uniform branch)
+            const uint32_t rows = (uint32_t)n * (uint32_t)N;
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 f32x4 part[6];
 #pragma unroll
                 for (int bd = 0; bd < 6; ++bd) {   // branch-free: bands past the last re-read the last one and are masked out
                     const int bdc = bd < a.feat_bands ? bd : a.feat_bands - 1;
-                    part[bd] = *reinterpret_cast<const f32x4*>(a.feat_part + ((size_t)bdc * rows + arow) * 32 + 16 * ct + 4 * q);
+                    part[bd] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.feat_part) + (size_t)((((uint32_t)bdc * rows + arow) * 32u + 16u * ct + 4u * q) * 4u));
                 }
                 f32x4 s = *reinterpret_cast<const f32x4*>(a.lin_b + 16 * ct + 4 * q);
 #pragma unroll
@@ -317,40 +326,48 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
                 in.x[ct] = s;
             }
         } else {
-            in.x[0] = *reinterpret_cast<const f32x4*>(in_row + 4 * q);
-            in.x[1] = *reinterpret_cast<const f32x4*>(in_row + 16 + 4 * q);
+            in.x[0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)(ro * 4u));
+            in.x[1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)((ro + 16u) * 4u));
         }
-        const size_t er = (size_t)bc * n + agent;                      // env-major row
-        in.pa = (int)a.prev_actions[er];
-        in.pr = a.prev_reward[er];
-        int64_t v[SSD_MAX_AGENTS];
+        const uint32_t er = (uint32_t)bc * (uint32_t)n + (uint32_t)agent;     // env-major row
+        in.pa = (int)ld32(reinterpret_cast<const int32_t*>(a.prev_actions), 2u * er);   // low word of the int64 (little endian; -1 .. A - 1)
+        in.pr = ld32(a.prev_reward, er);
+        // received incentives: prev_inc[bc, g, agent] for every giver g (values 0 / 1 / 2: the low word); givers past n re-read giver
+        // n - 1 and count nothing
+        const int32_t* pi = reinterpret_cast<const int32_t*>(a.prev_inc);
 #pragma unroll
-        for (int g = 0; g < SSD_MAX_AGENTS; ++g) v[g] = a.prev_inc[((size_t)bc * n + (g < n ? g : agent)) * n + agent];   // branch-free: clamped index
-        int recv = 0;
+        for (int g = 0; g < SSD_MAX_AGENTS; ++g) in.inc[g] = 0;
 #pragma unroll
-        for (int g = 0; g < SSD_MAX_AGENTS; ++g) recv += (g < n && g != agent) ? (v[g] == 1) - (v[g] == 2) : 0;   // inc_mask_actions: no self incentive
-        in.recv = recv;
-        in.p0 = a.pos[er * 2]; in.p1 = a.pos[er * 2 + 1];
-        in.o0 = in.o1 = 0.f;
-        if (a.orient) { in.o0 = a.orient[er * 2]; in.o1 = a.orient[er * 2 + 1]; }
+        for (int g = 0; g < 5; ++g) {                                  // (counted in prepare: nothing here waits for a load)
+            const uint32_t gc = (uint32_t)(g < n ? g : n - 1);
+            in.inc[g] = ld32(pi, 2u * (((uint32_t)bc * (uint32_t)n + gc) * (uint32_t)n + (uint32_t)agent));
+        }
+        if (n > 5) {                                                   // wave-uniform: no load waits inside
+#pragma unroll
+            for (int g = 5; g < SSD_MAX_AGENTS; ++g) {
+                const uint32_t gc = (uint32_t)(g < n ? g : n - 1);
+                in.inc[g] = ld32(pi, 2u * (((uint32_t)bc * (uint32_t)n + gc) * (uint32_t)n + (uint32_t)agent));
+            }
+        }
+        in.p0 = ld32(a.pos, 2u * er); in.p1 = ld32(a.pos, 2u * er + 1u);
+        const float* orient = a.orient ? a.orient : a.pos;             // no orientation given: read something valid, use zeros
+        const float ok = a.orient ? 1.f : 0.f;
+        in.o0 = ld32(orient, 2u * er) * ok; in.o1 = ld32(orient, 2u * er + 1u) * ok;
     } else {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) in.x[ct] = *reinterpret_cast<const f32x4*>(in_row + 16 * ct + 4 * q);
-        in.act = (int)a.actions[(size_t)bc * n + agent];
+        for (int ct = 0; ct < 4; ++ct) in.x[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)((ro + 16u * ct) * 4u));
+        in.act = (int)ld32(reinterpret_cast<const int32_t*>(a.actions), 2u * ((uint32_t)bc * (uint32_t)n + (uint32_t)agent));
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int it = lane + 64 * k, row = it / n, j = it - row * n, bb = tile * 16 + row;
-            in.aj[k] = 0;
-#pragma unroll
-            for (int e = 0; e < 7; ++e) in.f[k][e] = 0.f;
-            if (it < 16 * n && bb < N) {
-                // other_j = [one-hot(a_j), pos_j / scale, orient_j, r_j, clean_j, apple_den_j] (homophily_agent.py:194-201)
-                const size_t ej = (size_t)bb * n + j;
-                in.aj[k] = (int)a.actions[ej];
-                in.f[k][0] = a.pos_pre[ej * 2]; in.f[k][1] = a.pos_pre[ej * 2 + 1];
-                in.f[k][2] = a.orient_pre[ej * 2]; in.f[k][3] = a.orient_pre[ej * 2 + 1];
-                in.f[k][4] = a.reward[ej]; in.f[k][5] = a.clean[ej]; in.f[k][6] = a.den[ej];
-            }
+            // other_j = [one-hot(a_j), pos_j / scale, orient_j, r_j, clean_j, apple_den_j] (homophily_agent.py:194-201); items past the
+            // tile (or the batch) read the batch's last row and are never used
+            const bool live = it < 16 * n && bb < N;
+            const uint32_t ej = live ? (uint32_t)bb * (uint32_t)n + (uint32_t)j : (uint32_t)N * (uint32_t)n - 1u;
+            in.aj[k] = (int)ld32(reinterpret_cast<const int32_t*>(a.actions), 2u * ej);
+            in.f[k][0] = ld32(a.pos_pre, 2u * ej); in.f[k][1] = ld32(a.pos_pre, 2u * ej + 1u);
+            in.f[k][2] = ld32(a.orient_pre, 2u * ej); in.f[k][3] = ld32(a.orient_pre, 2u * ej + 1u);
+            in.f[k][4] = ld32(a.reward, ej); in.f[k][5] = ld32(a.clean, ej); in.f[k][6] = ld32(a.den, ej);
         }
     }
 }
@@ -378,14 +395,24 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
     // whole 118 KB before the first MFMA took 40 % of a head launch (a CU takes in ~12 bytes per cycle).
     const uint8_t* img_src = a.weights + (size_t)agent * IMAGE_BYTES + (size_t)wave * 1024 + lane * 16;
     const uint32_t img_dst = (uint32_t)(uintptr_t)lds_raw + (uint32_t)wave * 1024u;
+    if (!INC) PSTAMP_DRAINED(8);                                       // (diagnostic builds: kernel arguments fetched)
+#ifndef SSD_HEAD_EARLY
+#define SSD_HEAD_EARLY 1
+#endif
+#if SSD_HEAD_EARLY
 #pragma unroll
     for (int ch = 0; ch < B1; ++ch) dma_piece(img_src + (size_t)ch * 8192, img_dst + (uint32_t)ch * 8192u);
+#endif
+    if (!INC) PSTAMP(9);
     if (tile < tiles) load_tile<INC>(a, tile, agent, lane, in);        // queued behind the first chunks
-    const float eps = *a.eps;
-    const uint32_t step = (uint32_t)*a.step;
-    const long slot_t = a.t_index ? (long)*a.t_index : 0;
-    const bool file = slot_t < (long)a.slots;                          // never file past the episode storage
+    if (!INC) PSTAMP(10);
+    float eps = *a.eps;
+    int64_t step64 = *a.step;
+    long slot_t = a.t_index ? (long)*a.t_index : 0;
+    uint32_t step = 0;                                                 // (both assigned once the loads above are pinned, see below)
+    bool file = false;
     const uint32_t avail_bits = INC ? 0xFFFFFFFFu : avail_to_bits(a.avail, A);
+    if (!INC) PSTAMP_DRAINED(11);
     u32x4 bh[2], bl[2];                                                // the fc1 operand of the current tile
     // range guard of the activations that get scaled by XS and split (PREC 2): checked where they are produced (no state carried
     // through the tile chain -- the env head has no register to spare); the branch is never taken on a healthy network
@@ -395,14 +422,16 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
             if (nerr) atomicOr(nerr, ERR_F16_RANGE);
         }
     };
-    // Everything of a tile that only needs its inputs -- the input tail (controller :137-184), the by-product stores, the split
-    // of the fc1 operand -- is done as soon as the loads land: for the first tile while the weight image is still in flight.
+    // Everything of a tile that only needs its inputs -- the input tail (controller :137-184) and the split of the fc1 operand -- is
+    // done as soon as the loads land, while the rest of the weight image is in flight.  It issues NO store: vmcnt retires loads, stores
+    // and LDS-DMA pieces in issue order, so a store issued behind the image's pieces could not complete before all of them -- and a
+    // counted wait for the next chunk would wait for the whole image.  The by-product stores (file_inputs) follow the last K-step.
+    f32x4 xk[4];                                                       // the tile's input row, kept for file_inputs
     auto prepare = [&](int tl) {
         const int b = tl * 16 + m;
         const bool valid = b < N;
         const int bc = valid ? b : N - 1;
-        float* in_row = a.inputs + ((size_t)agent * N + bc) * 64;
-        f32x4 x[4];
+        f32x4 (&x)[4] = xk;
         if (!INC) {
             x[0] = in.x[0]; x[1] = in.x[1];
             if (a.feat_part) {      // finish the encoder: LeakyReLU of (lin_b + band sums); the inc head reads them from `inputs`
@@ -410,20 +439,6 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
                 for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) x[ct][r] = leaky(x[ct][r]);
-                    if (valid) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = x[ct];
-                }
-            }
-            const size_t er = (size_t)bc * n + agent;                  // env-major row
-            {   // the pose BEFORE the env step (inc head input, storage slot t)
-                float *pos_copy = COLD(float, pos_copy), *d_pos = COLD(float, d_pos);
-                if (valid && q == 0 && pos_copy) {
-                    float* orient_copy = COLD(float, orient_copy);
-                    pos_copy[er * 2] = in.p0; pos_copy[er * 2 + 1] = in.p1; orient_copy[er * 2] = in.o0; orient_copy[er * 2 + 1] = in.o1;
-                }
-                if (valid && q == 0 && d_pos && file) {
-                    float* d_orient = COLD(float, d_orient);
-                    const size_t sr = (((size_t)bc * a.slots + slot_t) * n + agent) * 2;
-                    d_pos[sr] = in.p0; d_pos[sr + 1] = in.p1; d_orient[sr] = in.o0; d_orient[sr + 1] = in.o1;
                 }
             }
             // tail columns (controller :137-184, each block present iff its flag is set): one-hot(last action) | one-hot(agent id)
@@ -436,7 +451,13 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
                 o_dist = (int8_t)(lay >> 32); o_pos = (int8_t)(lay >> 40);
             }
             const float px = in.p0 / a.pos_scale, py = in.p1 / a.pos_scale;
-            const float sg_r = (float)((in.pr > 0.f) - (in.pr < 0.f)), sg_i = (float)((in.recv > 0) - (in.recv < 0));
+            int recv = 0;                                              // #rewards - #punishments received (controller :150-157)
+#pragma unroll
+            for (int g = 0; g < SSD_MAX_AGENTS; ++g) {
+                const int on = (g < n && g != agent) ? 1 : 0;          // inc_mask_actions: no self incentive (wave-uniform)
+                recv += on * ((in.inc[g] == 1) - (in.inc[g] == 2));
+            }
+            const float sg_r = (float)((in.pr > 0.f) - (in.pr < 0.f)), sg_i = (float)((recv > 0) - (recv < 0));
             const int c_pa = o_act + in.pa, c_id = o_id + agent;       // pa in [-1, A): -1 (no previous step) lands left of the block
 #pragma unroll
             for (int ct = 2; ct < 4; ++ct) {
@@ -461,10 +482,6 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
                         for (int r = 0; r < 4; ++r) x[ct][r] = (16 * ct + 4 * q + r - 32 == o_dist + g) ? d : x[ct][r];
                 }
             }
-#pragma unroll
-            for (int ct = 2; ct < 4; ++ct) {
-                if (valid) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = x[ct];   // the inc head reads the full row
-            }
         } else {
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
@@ -478,45 +495,82 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
                 }
             }
         }
-        if (PREC == 2) range_check(amax_tiles<4>(0.f, x));
         operand<PREC>(x, XS, bh, bl);
+        (void)valid; (void)bc;
+    };
+    // the env head's by-products of the input phase: the finished encoder features (31 x 31 windows) and the tail columns into the
+    // agent's input row (the inc head reads the full row), the pose BEFORE the env step (inc head input, storage slot t)
+    auto file_inputs = [&](int tl) {
+        if (INC) return;
+        const int b = tl * 16 + m;
+        if (b >= N) return;
+        float* in_row = a.inputs + ((size_t)agent * N + b) * 64;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            if (ct >= 2 || a.feat_part) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = xk[ct];
+        if (q == 0) {
+            const size_t er = (size_t)b * n + agent;                   // env-major row
+            float *pos_copy = COLD(float, pos_copy), *d_pos = COLD(float, d_pos);
+            if (pos_copy) {
+                float* orient_copy = COLD(float, orient_copy);
+                pos_copy[er * 2] = in.p0; pos_copy[er * 2 + 1] = in.p1; orient_copy[er * 2] = in.o0; orient_copy[er * 2 + 1] = in.o1;
+            }
+            if (d_pos && file) {
+                float* d_orient = COLD(float, d_orient);
+                const size_t sr = (((size_t)b * a.slots + slot_t) * n + agent) * 2;
+                d_pos[sr] = in.p0; d_pos[sr + 1] = in.p1; d_orient[sr] = in.o0; d_orient[sr + 1] = in.o1;
+            }
+        }
     };
     // Device-side counters advance by ping-pong copies, never by a kernel incrementing a scalar it (or a workgroup of the same
     // launch) also reads: the inc head reads the copies and writes the masters' next values, the env head (pipelined rollout) reads
-    // the masters and writes the copies.
-    if (block == 0 && tid == 0) {
+    // the masters and writes the copies.  (Stores: after the last K-step, like file_inputs.)
+    auto hand_counters = [&]() {
+      if (block == 0 && tid == 0) {
         if (INC) {
             int64_t *next_t = COLD(int64_t, next_t), *next_step = COLD(int64_t, next_step);
             if (next_t) *next_t = slot_t + 1;
-            if (next_step) *next_step = *a.step + 1;
+            if (next_step) *next_step = step64 + 1;
         } else {
             int64_t *t_copy = COLD(int64_t, t_copy), *step_copy = COLD(int64_t, step_copy);
             if (t_copy) *t_copy = slot_t;
-            if (step_copy) *step_copy = *a.step;
+            if (step_copy) *step_copy = step64;
         }
-    }
-    if (tile < tiles) prepare(tile);
+      }
+    };
+    PSTAMP(12);
 #if defined(__HIP_DEVICE_COMPILE__)
-    {   // every compiler-issued load of this wave is consumed (or pinned) here, BEFORE the second batch of LDS-DMA: hipcc does not count
-        // the DMA pieces, so a wait it placed later for one of its own loads would drain them (vmcnt retires in issue order)
+    {   // Every compiler-issued load of this wave is pinned here -- its data has landed -- BEFORE the rest of the image is requested:
+        // hipcc does not count the DMA pieces, so a wait it placed later for one of its own loads would drain them (vmcnt retires in
+        // issue order).  From here to the last K-step the wave issues no global load and no store.
         uint32_t ab = avail_bits;
         asm volatile("" : "+s"(ab));
+        asm volatile("" : "+v"(eps), "+v"(step64), "+v"(slot_t));      // the device scalars arrive through the vector memory path too
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) asm volatile("" : "+v"(in.hp[ct]));
+        for (int ct = 0; ct < 4; ++ct) { asm volatile("" : "+v"(in.hp[ct])); asm volatile("" : "+v"(in.x[ct])); }
         if (INC) {
+            asm volatile("" : "+v"(in.act));
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 asm volatile("" : "+v"(in.aj[k]));
 #pragma unroll
                 for (int e = 0; e < 7; ++e) asm volatile("" : "+v"(in.f[k][e]));
             }
+        } else {
+            asm volatile("" : "+v"(in.pa), "+v"(in.pr), "+v"(in.p0), "+v"(in.p1), "+v"(in.o0), "+v"(in.o1));
+#pragma unroll
+            for (int g = 0; g < SSD_MAX_AGENTS; ++g) asm volatile("" : "+v"(in.inc[g]));
         }
     }
 #endif
+    step = (uint32_t)step64;
+    file = slot_t < (long)a.slots;                                     // never file past the episode storage
 #pragma unroll
-    for (int ch = B1; ch < NCHUNK; ++ch) dma_piece(img_src + (size_t)ch * 8192, img_dst + (uint32_t)ch * 8192u);
-    wait_vm<NCHUNK - B1>();                                            // all but the second batch: the first chunks and every older access
-    __builtin_amdgcn_s_barrier();                                      // ... of every wave: chunks < B1 are readable
+    for (int ch = SSD_HEAD_EARLY ? B1 : 0; ch < NCHUNK; ++ch) dma_piece(img_src + (size_t)ch * 8192, img_dst + (uint32_t)ch * 8192u);
+    if (tile < tiles) prepare(tile);                                   // arithmetic only, under the image's second batch
+    PSTAMP(13);
+    wait_vm<NCHUNK - B1>();                                            // all but the second batch: the first chunks have landed
+    __builtin_amdgcn_s_barrier();                                      // ... those of every wave: chunks < B1 are readable
     PSTAMP(1);
     bool first = true;
     const uint8_t* img = lds_raw;
@@ -527,6 +581,7 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
     // kernel every argument and pointer of the input phase stayed live through the chain -- 118 scalar registers spilled and the
     // vector file full (256, against 150 now).
     auto run_tile = [&]() {
+        if (PREC == 2) range_check(amax_tiles<4>(0.f, xk));
         const int b = tile * 16 + m;
         const bool valid = b < N;
         const int bc = valid ? b : N - 1;
@@ -575,6 +630,8 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
             SSD_LOAD_STEP(12, fa);  frag4_mma<PREC>(fb, hh[1], hl[1], g + 4);
             SSD_LOAD_STEP(13, fb);  frag4_mma<PREC>(fa, hh[0], hl[0], g + 12);
             frag4_mma<PREC>(fb, hh[1], hl[1], g + 12);
+            file_inputs(tile);                                         // the whole image has landed: stores may follow
+            hand_counters();
         }
         if (first) PSTAMP(4);
         u32x4 f2h[2], f2l[2];                                          // fc2's fragments: in flight under the gate arithmetic
@@ -695,7 +752,7 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
         first = false;
 #undef SSD_LOAD_STEP
     };
-    if (tile < tiles) run_tile(); else idle_sync<PREC>();               // the same waits and barriers on either side
+    if (tile < tiles) run_tile(); else { idle_sync<PREC>(); hand_counters(); }   // the same waits and barriers on either side
     PSTAMP(7);
     PSTAMP_REAL(15);
 }

@@ -82,6 +82,13 @@ for name, key, fn in r.timestep_launches():
     print("   us after the first wave's start (min / p10 / median / p90 / max): start %s | end %s | kernel span %.2f us" % (
         " ".join("%.2f" % (x / 100) for x in th.quantile(t0 - base, q).tolist()),
         " ".join("%.2f" % (x / 100) for x in th.quantile(t1 - base, q).tolist()), (t1.max() - base).item() / 100))
+    if key in ("head_env", "head_inc"):      # the prologue: scalars + issue of the tile's loads | their landing + input assembly | first chunks
+        pro = ((0, 8, "start -> kernargs"), (8, 9, "1st DMA batch issued"), (9, 10, "tile loads issued"), (10, 11, "scalars + avail + ALL landed"), (11, 12, "-> prepare"))
+        for a_, b_, nm in (pro if key == "head_env" else ()) + ((0, 12, "start -> loads issued"), (12, 13, "loads landed + prepare"), (13, 1, "2nd DMA batch + wait + barrier")):
+            ok = (s[:, a_] > 0) & (s[:, b_] > 0)
+            d = (s[ok, b_] - s[ok, a_]).double()
+            if d.numel():
+                print("   %-32s waves %5d  median %7d  p90 %7d" % (nm, d.numel(), int(d.median()), int(th.quantile(d, th.tensor(0.9, dtype=th.double)))))
     if key == "head_inc":
         for a_, b_, nm in ((4, 5, "gru mfma -> gates"), (5, 8, "gates -> fc2 + scratch"), (8, 9, "cold pointer loads"), (9, 10, "items k = 0"), (10, 11, "items k = 1"), (11, 6, "k = 2 (empty) -> tile done")):
             ok = (s[:, a_] > 0) & (s[:, b_] > 0)
