@@ -201,8 +201,13 @@ POLICY_TAIL_PIECES = 3
 
 
 def policy_image_bytes(precision):
-    """SSD_POLICY_IMAGE_BYTES: 3 tail pieces + 58 fragments per term, in whole 8 KiB chunks."""
-    return (120 if precision == 2 else 64) * 1024
+    """SSD_POLICY_IMAGE_BYTES: 14 K-steps of 4 * precision pieces + the resident chunk (fc2, tail, padding), 1 KiB pieces."""
+    return (56 * precision + 8) * 1024
+
+
+def policy_tail_piece(precision):
+    """first 1 KiB piece of the f32 tail (biases, pair part of fc2) inside a head image"""
+    return 56 * precision + 2 * precision
 
 
 def policy_frag_piece(precision, F, term):
@@ -214,8 +219,8 @@ def policy_frag_piece(precision, F, term):
         G = (F - 8) % 24
         c, ot = (8 if F >= 32 else 2) + 2 * (G >> 3) + (G & 1), (G & 7) >> 1
     else:
-        return POLICY_TAIL_PIECES + 56 * precision + 2 * term + (F - 56)
-    return POLICY_TAIL_PIECES + 4 * precision * c + 4 * term + ot
+        return 56 * precision + 2 * term + (F - 56)
+    return 4 * precision * c + 4 * term + ot
 
 
 def encode_bands(V):

@@ -118,23 +118,27 @@ constexpr float ENC_CSCALE = 256.f, ENC_LSCALE = 256.f;                  // conv
 // ===========================================================================================================================
 constexpr int HF_WI = 8, HF_WH = 32, HF_FC2 = 56, HF_TOT = SSD_POLICY_HEAD_FRAGS;
 constexpr int HT_B1 = 0, HT_BI = 64, HT_BH = 256, HT_B2 = 448, HT_W2O = 464, HT_TOT = SSD_POLICY_HEAD_TAIL_FLOATS;
-constexpr int HEAD_WAVES = 8;
 constexpr int SCRATCH = 16 * 16;               // per wave: fc2 output tile [row 16][out 16]
-// The image is laid out in the order the head consumes it (include/ssd_hip.h), in 1 KiB pieces: the f32 tail (3 pieces), then per
-// K-STEP c of the chain (fc1: c = s; GRU input side: 2 + 2 g + s; hidden side: 8 + 2 g + s) its [term][output tile] fragments, then
-// fc2's [term][s].  A CHUNK is 8 consecutive pieces: one LDS-DMA wave instruction per wave of the workgroup.
-constexpr int HEAD_STEPS = 14, TAIL_PIECES = SSD_POLICY_TAIL_PIECES;
-template <int PREC> constexpr int head_pieces() { return SSD_POLICY_IMAGE_PIECES(PREC); }
-template <int PREC> constexpr int head_chunks() { return head_pieces<PREC>() / HEAD_WAVES; }
-template <int PREC> constexpr int step_piece(int c, int t, int ot) { return TAIL_PIECES + 4 * PREC * c + 4 * t + ot; }
-template <int PREC> constexpr int fc2_piece(int t, int s2) { return TAIL_PIECES + 4 * PREC * HEAD_STEPS + 2 * t + s2; }
-template <int PREC> constexpr int need_chunk(int c) { return (step_piece<PREC>(c, PREC - 1, 3)) >> 3; }   // last chunk K-step c reads
-// chunks requested before the tile's inputs (they cover fc1, K-steps 0 and 1); the rest streams in behind the chain
-template <int PREC> constexpr int first_chunks() { return need_chunk<PREC>(1) + 1; }
-static_assert(head_pieces<2>() % HEAD_WAVES == 0 && head_pieces<1>() % HEAD_WAVES == 0, "whole chunks");
-static_assert(fc2_piece<2>(1, 1) < head_pieces<2>() && fc2_piece<1>(0, 1) < head_pieces<1>(), "image holds every piece");
-static_assert(need_chunk<2>(HEAD_STEPS - 1) == head_chunks<2>() - 1 && need_chunk<1>(HEAD_STEPS - 1) == head_chunks<1>() - 1,
-              "the last K-step's wait retires the whole image (fc2's fragments included)");
+// The image is laid out in the order the head consumes it (include/ssd_hip.h), in 1 KiB pieces, 8 pieces to a CHUNK: per K-STEP c of
+// the chain (fc1: c = s; GRU input side: 2 + 2 g + s; hidden side: 8 + 2 g + s) its [term][output tile] fragments (PREC 2: one chunk
+// per K-step; PREC 1: two K-steps per chunk), then the RESIDENT chunk: fc2's [term][s] fragments, the f32 tail (3 pieces), padding.
+// The image is brought in by a dedicated LOADER wave (the last wave of the workgroup; it owns no tile): vmcnt retires a wave's
+// loads, stores and LDS-DMA pieces in issue order, so a wave that requested the image could not have its tile's inputs before all of
+// it -- with the loader the compute waves' own memory traffic is untouched and hipcc's wait counts stay exact.  The loader requests
+// chunk after chunk with 6 chunks (48 KiB) in flight, whatever the compute waves are doing -- the ingest (~11 bytes per cycle and CU
+// from the Infinity Cache) runs under their input phase -- and publishes its progress in an LDS word; a compute wave looks at that word
+// before the first read of a chunk and only waits when the stream is behind it.  No workgroup barrier anywhere: the waves of a
+// workgroup share nothing but the image.
+constexpr int HEAD_STEPS = 14;
+template <int PREC> constexpr int stream_chunks() { return HEAD_STEPS * 4 * PREC / 8; }                       // 14 / 7
+template <int PREC> constexpr int step_piece(int c, int t, int ot) { return 4 * PREC * c + 4 * t + ot; }
+template <int PREC> constexpr int res_piece() { return stream_chunks<PREC>() * 8; }                         // first piece of the resident chunk
+template <int PREC> constexpr int fc2_piece(int t, int s2) { return res_piece<PREC>() + 2 * t + s2; }
+template <int PREC> constexpr int tail_piece() { return res_piece<PREC>() + 2 * PREC; }
+static_assert(res_piece<2>() + 8 == SSD_POLICY_IMAGE_PIECES(2) && res_piece<1>() + 8 == SSD_POLICY_IMAGE_PIECES(1), "image = stream chunks + resident chunk");
+static_assert(tail_piece<2>() + SSD_POLICY_TAIL_PIECES <= SSD_POLICY_IMAGE_PIECES(2) && tail_piece<1>() + SSD_POLICY_TAIL_PIECES <= SSD_POLICY_IMAGE_PIECES(1), "tail fits");
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from each lane's global address into 1 KiB of LDS at the wave-uniform byte address lds_dst
 // (global_load_lds_dwordx4: no VGPR destination; M0 carries the LDS address and is restored).  hipcc does not count it: completion is
@@ -153,18 +157,42 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
 #endif
 }
-// Before the fragments of K-step C are read for the first time: this wave's pieces of every chunk up to need_chunk(C) have landed
-// (counted wait: the younger chunks stay in flight), then the workgroup barrier makes the other waves' pieces readable.  Steps whose
-// chunks were covered by an earlier wait need nothing.  Waves with and without a tile execute the same sequence (idle_sync).
-template <int PREC, int C> __device__ __forceinline__ void step_sync() {
-    constexpr int need = need_chunk<PREC>(C), before = C == 0 ? first_chunks<PREC>() - 1 : need_chunk<PREC>(C - 1);
-    if constexpr (need >= first_chunks<PREC>() && need > before) {
-        wait_vm<head_chunks<PREC>() - 1 - need>();
-        __builtin_amdgcn_s_barrier();
+constexpr int STREAM_AHEAD = 6;                // chunks in flight behind the one being waited for (x 8 pieces < the 64 vmcnt can count)
+constexpr int head_lds_bytes(int waves, int prec) { return SSD_POLICY_IMAGE_BYTES(prec) + waves * SCRATCH * 4 + 16; }
+// the loader wave's whole program: LDS image = the global image, piece for piece (chunk j at byte 8192 j, the resident chunk last)
+template <int PREC>
+__device__ __forceinline__ void stream_image(const uint8_t* src_lane, uint32_t lds_dst, volatile uint32_t* landed) {
+    constexpr int NK = stream_chunks<PREC>(), NC = NK + 1;            // + the resident chunk, requested FIRST (fc1's biases are in it)
+    auto issue = [&](int k) {                                          // k-th request: resident chunk, then stream chunks 0 .. NK - 1
+        const int j = k == 0 ? NK : k - 1;
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) dma_piece(src_lane + (size_t)j * 8192 + pc * 1024, lds_dst + (uint32_t)j * 8192u + (uint32_t)pc * 1024u);
+    };
+#pragma unroll
+    for (int k = 0; k < cmin(STREAM_AHEAD + 1, NC); ++k) issue(k);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {                                     // request k has landed (everything older too) -> publish, request the next
+        if (k + STREAM_AHEAD < NC) wait_vm<8 * STREAM_AHEAD>();
+        else if (k == NC - 1) wait_vm<0>();
+        else if (k == NC - 2) wait_vm<8>();
+        else if (k == NC - 3) wait_vm<16>();
+        else if (k == NC - 4) wait_vm<24>();
+        else if (k == NC - 5) wait_vm<32>();
+        else wait_vm<40>();
+        *landed = (uint32_t)k;                                         // = stream chunks 0 .. k - 1 (and the resident chunk) are readable
+        if (k + STREAM_AHEAD + 1 < NC) issue(k + STREAM_AHEAD + 1);
     }
 }
-template <int PREC, int C = 0> __device__ __forceinline__ void idle_sync() {
-    if constexpr (C < HEAD_STEPS) { step_sync<PREC, C>(); idle_sync<PREC, C + 1>(); }
+// a compute wave, before the first read of K-step C's chunk j: the loader must have published `landed` > j (chunks 0 .. j readable;
+// seen caches the last value read, so a wave that runs behind the stream reads the word once)
+template <int PREC, int C> __device__ __forceinline__ void chunk_ready(volatile const uint32_t* landed, uint32_t& seen) {
+    constexpr int first_piece = step_piece<PREC>(C, 0, 0), j = first_piece >> 3;
+    if constexpr ((first_piece & 7) == 0) {
+        while (seen <= (uint32_t)j) {
+            seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)*landed);
+            if (seen <= (uint32_t)j) __builtin_amdgcn_s_sleep(1);
+        }
+    }
 }
 
 // Kernel arguments.  HeadK is what the main path reads; HeadCold holds the ~20 pointers only the epilogue touches (results, filing
@@ -375,9 +403,11 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
 // AT: the env's action count (9 Cleanup, 8 Harvest) at compile time: the one-hot / dueling loops unroll.  GEN (env head): the
 // tail blocks sit where HeadCold::tail_layout says (any _build_inputs flag set that fits); GEN = 0 is the shipped layout with
 // compile-time columns -- the register allocation of the tuned kernel is left as it was.
-template <int INC, int PREC, int AT, int GEN>
+// WAVES: compute waves per workgroup = 16-row tiles per workgroup (the host sizes the grid: bpa = ceil(tiles per agent / WAVES)); the
+// workgroup has WAVES + 1 waves, the last one is the loader.
+template <int INC, int PREC, int AT, int GEN, int WAVES>
 __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, const int block) {
-    constexpr int IMAGE_BYTES = SSD_POLICY_IMAGE_BYTES(PREC), NCHUNK = head_chunks<PREC>(), B1 = first_chunks<PREC>();
+    constexpr int IMAGE_BYTES = SSD_POLICY_IMAGE_BYTES(PREC);
     constexpr float XS = PREC == 2 ? HEAD_XSCALE : 1.f, INV = PREC == 2 ? 1.f / (HEAD_WSCALE * HEAD_XSCALE) : 1.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int agent = block / a.bpa, bia = block - agent * a.bpa;
@@ -387,22 +417,17 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
     PSTAMP(0);
     PSTAMP_REAL(14);
     const int tiles = (N + 15) >> 4;
-    const int tile = wave * a.bpa + bia;                               // consecutive tiles go to different CUs; bpa * 8 >= tiles
+    const int tile = wave < WAVES ? wave * a.bpa + bia : tiles;        // consecutive tiles go to different CUs; bpa * WAVES >= tiles; the loader has none
     TileIn<INC> in;
-    // The agent's image streams into LDS behind the kernel's own arithmetic (it is stored in consumption order): every wave requests
-    // one 1 KiB piece per 8 KiB chunk by LDS-DMA -- the first B1 chunks (tail + fc1) now, the others once the tile's inputs have
-    // landed -- and the chain below waits, K-step by K-step, for just the chunks it is about to read (step_sync).  Staging the
-    // whole 118 KB before the first MFMA took 40 % of a head launch (a CU takes in ~12 bytes per cycle).
-    const uint8_t* img_src = a.weights + (size_t)agent * IMAGE_BYTES + (size_t)wave * 1024 + lane * 16;
-    const uint32_t img_dst = (uint32_t)(uintptr_t)lds_raw + (uint32_t)wave * 1024u;
+    // LDS: the image (as in global memory) | per-wave scratch | the loader's progress word
+    volatile uint32_t* landed = reinterpret_cast<volatile uint32_t*>(lds_raw + IMAGE_BYTES + WAVES * SCRATCH * 4);
+    if (wave == WAVES) *landed = 0u;                                   // LDS holds garbage at launch: the word is valid behind this barrier
+    __builtin_amdgcn_s_barrier();                                      // (the only one: every wave is still at its first instructions)
+    if (wave == WAVES) {                                               // the loader wave: nothing but the image stream
+        stream_image<PREC>(a.weights + (size_t)agent * IMAGE_BYTES + lane * 16, (uint32_t)(uintptr_t)lds_raw, landed);
+        return;
+    }
     if (!INC) PSTAMP_DRAINED(8);                                       // (diagnostic builds: kernel arguments fetched)
-#ifndef SSD_HEAD_EARLY
-#define SSD_HEAD_EARLY 1
-#endif
-#if SSD_HEAD_EARLY
-#pragma unroll
-    for (int ch = 0; ch < B1; ++ch) dma_piece(img_src + (size_t)ch * 8192, img_dst + (uint32_t)ch * 8192u);
-#endif
     if (!INC) PSTAMP(9);
     if (tile < tiles) load_tile<INC>(a, tile, agent, lane, in);        // queued behind the first chunks
     if (!INC) PSTAMP(10);
@@ -565,17 +590,14 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
 #endif
     step = (uint32_t)step64;
     file = slot_t < (long)a.slots;                                     // never file past the episode storage
-#pragma unroll
-    for (int ch = SSD_HEAD_EARLY ? B1 : 0; ch < NCHUNK; ++ch) dma_piece(img_src + (size_t)ch * 8192, img_dst + (uint32_t)ch * 8192u);
-    if (tile < tiles) prepare(tile);                                   // arithmetic only, under the image's second batch
+    if (tile < tiles) prepare(tile);                                   // arithmetic only
     PSTAMP(13);
-    wait_vm<NCHUNK - B1>();                                            // all but the second batch: the first chunks have landed
-    __builtin_amdgcn_s_barrier();                                      // ... those of every wave: chunks < B1 are readable
     PSTAMP(1);
     bool first = true;
     const uint8_t* img = lds_raw;
-    const float* tail = reinterpret_cast<const float*>(lds_raw);
+    const float* tail = reinterpret_cast<const float*>(img + (size_t)tail_piece<PREC>() * 1024);
     float* scratch = reinterpret_cast<float*>(lds_raw + IMAGE_BYTES) + wave * SCRATCH;
+    uint32_t seen = 0;                                                 // last value read from the loader's progress word
     // The wave's 16-row tile through the chain; the K-steps synchronise with the image still streaming in (step_sync).  A wave has
     // AT MOST ONE tile (the host sizes the grid for it: bpa = ceil(tiles per agent / 8)): with a loop over further tiles in the
     // kernel every argument and pointer of the input phase stayed live through the chain -- 118 scalar registers spilled and the
@@ -592,7 +614,7 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) x1[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
         Frag4<PREC> fa, fb;                                            // fragment double buffer of the whole tile chain
-#define SSD_LOAD_STEP(c_, f_) do { step_sync<PREC, c_>(); frag4_load<PREC>(img, c_, lane, f_); } while (0)
+#define SSD_LOAD_STEP(c_, f_) do { chunk_ready<PREC, c_>(landed, seen); frag4_load<PREC>(img, c_, lane, f_); } while (0)
         SSD_LOAD_STEP(0, fa);
         SSD_LOAD_STEP(1, fb);
         frag4_mma<PREC>(fa, bh[0], bl[0], x1);
@@ -752,18 +774,20 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
         first = false;
 #undef SSD_LOAD_STEP
     };
-    if (tile < tiles) run_tile(); else { idle_sync<PREC>(); hand_counters(); }   // the same waits and barriers on either side
+    if (tile < tiles) run_tile(); else hand_counters();
     PSTAMP(7);
     PSTAMP_REAL(15);
 }
 
+// the standalone heads: 6 tiles per workgroup + the loader wave (Cleanup-5 x 4096 envs: 256 tiles per agent -> 43 workgroups per agent, 215 in all)
+constexpr int HEAD_WAVES = 6;
 template <int INC, int PREC, int AT, int GEN = 0>
-__global__ __launch_bounds__(HEAD_WAVES * 64) void k_head(HeadK a, HeadCold cold_unused) {
+__global__ __launch_bounds__((HEAD_WAVES + 1) * 64) void k_head(HeadK a, HeadCold cold_unused) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    head_body<INC, PREC, AT, GEN>(a, lds_raw, (int)blockIdx.x);
+    head_body<INC, PREC, AT, GEN, HEAD_WAVES>(a, lds_raw, (int)blockIdx.x);
 }
 
-static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c) {
+static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c, int waves = HEAD_WAVES) {
     k.N = p->n_env; k.n = p->n_agents; k.A = p->n_actions; k.inp = p->input_shape;
     k.pos_scale = p->pos_scale; k.seed = p->seed; k.env_id_base = p->env_id_base;
     k.inputs = p->inputs; k.h = p->h; k.weights = static_cast<const uint8_t*>(p->weights); k.avail = p->avail; k.eps = p->epsilon; k.step = p->step;
@@ -795,7 +819,7 @@ static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c) {
     c.numeric_err = numeric_err_word();
     PSTAMP_SET(k);
     const int tiles = (k.N + 15) / 16;
-    k.bpa = (tiles + HEAD_WAVES - 1) / HEAD_WAVES;                     // workgroups per agent: every wave owns at most one 16-row tile
+    k.bpa = (tiles + waves - 1) / waves;                               // workgroups per agent: every wave owns at most one 16-row tile
 }
 
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
@@ -804,7 +828,7 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     head_args(p, k, c);
     const int prec = p->precision == 1 ? 1 : 2;
     const int bpa = k.bpa;
-    const size_t lds = (size_t)SSD_POLICY_IMAGE_BYTES(prec) + HEAD_WAVES * SCRATCH * sizeof(float);
+    const size_t lds = (size_t)head_lds_bytes(HEAD_WAVES, prec);
     if (k.A != 9 && k.A != 8) return -3;                               // instantiated for Cleanup (9 actions) and Harvest (8)
     static bool attr_done_dev[64] = {};                               // the attribute is per device
     int dev = 0;
@@ -814,7 +838,7 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
                           reinterpret_cast<const void*>(&k_head<0, 2, 8>), reinterpret_cast<const void*>(&k_head<1, 2, 8>),
                           reinterpret_cast<const void*>(&k_head<0, 1, 8>), reinterpret_cast<const void*>(&k_head<1, 1, 8>)};
     if (!attr_done_dev[dev]) {
-        const size_t l2 = (size_t)SSD_POLICY_IMAGE_BYTES(2) + HEAD_WAVES * SCRATCH * sizeof(float);
+        const size_t l2 = (size_t)head_lds_bytes(HEAD_WAVES, 2);
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess) return -1;
         attr_done_dev[dev] = true;
@@ -824,14 +848,14 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     static bool gen_attr_done_dev[64] = {};
     const bool gen = !inc && p->input_flags && (p->input_flags & ~SSD_INPUT_EXPLICIT) != (uint32_t)SSD_INPUT_FLAGS_SHIPPED;
     if (gen && !gen_attr_done_dev[dev]) {
-        const size_t l2 = (size_t)SSD_POLICY_IMAGE_BYTES(2) + HEAD_WAVES * SCRATCH * sizeof(float);
+        const size_t l2 = (size_t)head_lds_bytes(HEAD_WAVES, 2);
         for (const void* f : gen_fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess) return -1;
         gen_attr_done_dev[dev] = true;
     }
     void* args[2] = {&k, &c};
     const void* fn = gen ? gen_fns[(k.A == 8 ? 2 : 0) + (prec == 1 ? 1 : 0)] : fns[(k.A == 8 ? 4 : 0) + (prec == 1 ? 2 : 0) + (inc ? 1 : 0)];
-    if (hipLaunchKernel(fn, dim3(k.n * bpa), dim3(HEAD_WAVES * 64), args, lds, s) != hipSuccess) return -1;
+    if (hipLaunchKernel(fn, dim3(k.n * bpa), dim3((HEAD_WAVES + 1) * 64), args, lds, s) != hipSuccess) return -1;
     return 0;
 }
 
@@ -879,7 +903,7 @@ __global__ __launch_bounds__(256) void k_pack_head(ssd_policy_head_params p, uin
                 else if (o == p.fc2_out) v = p.fc2_v_w[(size_t)agent * p.fc2_in + 64 + ee];
             }
         }
-        reinterpret_cast<float*>(img)[e] = v;                          // the tail opens the image (pieces 0 .. 2)
+        reinterpret_cast<float*>(img + (size_t)tail_piece<PREC>() * 1024)[e] = v;      // the tail follows fc2 in the resident chunk
     }
 }
 
@@ -1184,13 +1208,13 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
 // starts on each CU the moment its head workgroup retires.  Workgroups [0, heads) run head_body, the rest encode_body with the
 // (x, band) index unfolded; EncK sits behind the two head arguments (the heads' cold-argument offsets are unchanged).
 // ---------------------------------------------------------------------------------------------------------------------------
-static_assert(HEAD_WAVES == ENC_WAVES, "k_inc_encode: one block size for both bodies");
+constexpr int FUSED_WAVES = ENC_WAVES;          // k_inc_encode: one block size for both bodies
 template <int PREC, int AT, int V>
-__global__ __launch_bounds__(HEAD_WAVES * 64) void k_inc_encode(HeadK a, HeadCold cold_unused, EncK e, int heads, int enc_groups) {
+__global__ __launch_bounds__(FUSED_WAVES * 64) void k_inc_encode(HeadK a, HeadCold cold_unused, EncK e, int heads, int enc_groups) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int b = (int)blockIdx.x;
     if (b < heads) {
-        head_body<1, PREC, AT, 0>(a, lds_raw, b);
+        head_body<1, PREC, AT, 0, FUSED_WAVES - 1>(a, lds_raw, b);    // 7 compute waves + the loader
     } else {
         const int i = b - heads, by = i / enc_groups;
         encode_body<V, PREC, false>(e, lds_raw, i - by * enc_groups, by);
@@ -1225,7 +1249,7 @@ static void encode_args(const ssd_policy_encode_args* p, EncK& k) {
 
 template <int PREC, int AT, int V>
 static int launch_inc_encode_t(HeadK& k, HeadCold& c, EncK& e, hipStream_t s) {
-    const size_t lh = (size_t)SSD_POLICY_IMAGE_BYTES(PREC) + HEAD_WAVES * SCRATCH * sizeof(float), le = enc_lds_bytes<V, PREC>();
+    const size_t lh = (size_t)head_lds_bytes(FUSED_WAVES - 1, PREC), le = enc_lds_bytes<V, PREC>();
     const size_t lds = lh > le ? lh : le;
     static bool done[64] = {};
     int dev = 0;
@@ -1237,7 +1261,7 @@ static int launch_inc_encode_t(HeadK& k, HeadCold& c, EncK& e, hipStream_t s) {
     }
     int heads = k.n * k.bpa, groups = (e.rows + ENC_BT * 16 - 1) / (ENC_BT * 16);
     void* args[5] = {&k, &c, &e, &heads, &groups};
-    if (hipLaunchKernel(fn, dim3(heads + groups * Geo<V>::NB), dim3(HEAD_WAVES * 64), args, lds, s) != hipSuccess) return -1;
+    if (hipLaunchKernel(fn, dim3(heads + groups * Geo<V>::NB), dim3(FUSED_WAVES * 64), args, lds, s) != hipSuccess) return -1;
     return 0;
 }
 
@@ -1246,7 +1270,7 @@ int launch_policy_inc_encode(const ssd_policy_head* ph, const ssd_policy_encode_
     HeadK k;
     HeadCold c;
     EncK e;
-    head_args(ph, k, c);
+    head_args(ph, k, c, FUSED_WAVES - 1);
     encode_args(pe, e);
     const int prec = ph->precision == 1 ? 1 : 2, V = pe->view_edge;
     if (k.A != 9 && k.A != 8) return -3;

@@ -434,14 +434,13 @@ int ssd_conv_wgrad_codes(const uint8_t* codes, const float* d_conv, float* parti
  * any lane movement (fc1 -> GRU -> dueling chain in registers).
  *
  * Head image (per agent, SSD_POLICY_IMAGE_BYTES(precision) bytes, 16-byte aligned), stored IN THE ORDER THE HEAD KERNEL CONSUMES IT in
- * pieces of 1 KiB (one LDS-DMA wave instruction each), so that the kernel streams it into LDS behind its own arithmetic instead of
- * staging all of it before the first MFMA:
- *   pieces 0 .. 2: the f32 tail -- biases fc1[64] gru_i[192] gru_h[192] fc2[16], then (inc) the pair part of fc2 f32 [16 extra
- *     features][4] -- zero-padded to 3 KiB;
- *   then, per K-STEP c < 14 of the chain, [term t < precision][output tile ot < 4] fragments (piece 3 + 4 precision c + 4 t + ot):
+ * pieces of 1 KiB (one LDS-DMA wave instruction each), 8 pieces to a chunk: the kernel STREAMS the image through a small ring in LDS
+ * behind its own arithmetic (a head workgroup holds 48 KiB of it at a time, not 118 KB):
+ *   per K-STEP c < 14 of the chain, [term t < precision][output tile ot < 4] fragments at piece 4 precision c + 4 t + ot:
  *     c = s: fc1 (s = the 32-deep half of the reduction); c = 2 + 2 g + s: GRU input side, gate g = r, z, n; c = 8 + 2 g + s: hidden side;
- *   then fc2's [term t][s < 2] fragments (advantage rows, then the value row; inc: the h part) at piece 3 + 56 precision + 2 t + s;
- *   zero padding to a whole number of 8 KiB chunks (SSD_POLICY_IMAGE_PIECES).
+ *   then the resident chunk (8 pieces from piece 56 precision): fc2's [term t][s < 2] fragments (advantage rows, then the value row;
+ *     inc: the h part) at + 2 t + s; the f32 tail at + 2 precision -- biases fc1[64] gru_i[192] gru_h[192] fc2[16], then (inc) the pair
+ *     part of fc2 f32 [16 extra features][4] -- zero-padded to SSD_POLICY_TAIL_PIECES pieces; zero padding to the end of the chunk.
  * Activations are agent-major: inputs f32 [n, n_env, 64] (columns 0..31 = encoder output; the env head fills 32..63: tail then
  * zeros), h f32 [n, n_env, 64] updated in place. q_out (nullable): env f32 [n, n_env, n_actions]; inc f32 [n, n_env, n, 3].
  * Exploration draws: the package's counter generator keyed by (seed, *step, GLOBAL env id = env_id_base + env, agent[, j]) --
@@ -449,7 +448,7 @@ int ssd_conv_wgrad_codes(const uint8_t* codes, const float* d_conv, float* parti
 #define SSD_POLICY_HEAD_FRAGS 58
 #define SSD_POLICY_HEAD_TAIL_FLOATS (464 + 64)
 #define SSD_POLICY_TAIL_PIECES 3
-#define SSD_POLICY_IMAGE_PIECES(precision) ((precision) == 2 ? 120 : 64)      /* 3 + 58 precision, rounded up to 8 */
+#define SSD_POLICY_IMAGE_PIECES(precision) (56 * (precision) + 8)              /* 14 K-steps x 4 precision pieces + the resident chunk */
 #define SSD_POLICY_IMAGE_BYTES(precision) (SSD_POLICY_IMAGE_PIECES(precision) * 1024)
 typedef struct ssd_policy_head {
     int32_t n_env, n_agents, n_actions, input_shape;
