@@ -217,23 +217,24 @@ struct HeadK {
     const float *pos_pre, *orient_pre, *reward, *clean, *den;
     const int64_t* t_index;
     const float *feat_part, *lin_b;
+    const float* ep_ret;           // inc head: the episode return so far (read with the tile's inputs, written back in the epilogue)
+    const uint8_t* term;           // inc head: the env step's terminated flags
     PSTAMP_DECL
 };
 struct HeadCold {
-    int64_t* out_actions;
-    float* q_out;
-    int32_t* out_actions_i32;
-    float *pos_copy, *orient_copy;
-    float *d_pos, *d_orient, *d_onehot, *d_reward, *d_clean, *d_den;
-    uint8_t* d_term; const uint8_t* term;
-    int64_t *d_actions, *d_actions_inc, *p_act, *p_inc;
-    float *p_rew, *ep_ret;
+    // block A (64 bytes): what both epilogues write first, then the env head's results and by-products
+    int64_t* out_actions; float* q_out; int32_t* out_actions_i32; int64_t* p_act; int64_t* d_actions; float* d_onehot; float *pos_copy, *orient_copy;
+    // block B (64 bytes): the inc head's filing
+    int64_t *p_inc, *d_actions_inc; float *d_reward, *p_rew, *ep_ret, *d_clean, *d_den; uint8_t* d_term;
+    // block C (16 bytes): the env head's pose filing
+    float *d_pos, *d_orient;
+    int32_t* numeric_err;          // the device's numeric-status word (ERR_F16_RANGE)
     int64_t* next_t;
     int64_t *next_step, *t_copy, *step_copy;   // inc head: *next_step = *step + 1; env head: *t_copy = *t_index, *step_copy = *step
-    int32_t* numeric_err;          // the device's numeric-status word (ERR_F16_RANGE)
     uint64_t tail_layout;          // env head: first tail column of each _build_inputs block as 6 signed bytes (TAIL_ABSENT = not present):
                                    // last action | agent id | sign(r) | sign(received incentives) | 1 - distances | pos
 };
+static_assert(offsetof(HeadCold, p_inc) == 64 && offsetof(HeadCold, d_pos) == 128, "cold argument blocks");
 constexpr int TAIL_ABSENT = -64;
 constexpr int HEAD_COLD_OFFSET = (int)((sizeof(HeadK) + alignof(HeadCold) - 1) / alignof(HeadCold) * alignof(HeadCold));   // second kernel argument
 template <typename T>
@@ -242,6 +243,29 @@ __device__ __forceinline__ T* cold_ptr(int field_offset) {
     uint64_t v;
     asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "s"(HEAD_COLD_OFFSET + field_offset) : "memory");
     return reinterpret_cast<T*>(v);
+}
+// Several cold pointers at once: ONE scalar-load burst and ONE wait instead of a load + wait per pointer (~150 cycles each on a wave
+// that is alone on its SIMD).  cold_blocks: block A [+ block B] [+ block C] of HeadCold.
+typedef uint32_t u32x16s __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+struct ColdA { int64_t* out_actions; float* q_out; int32_t* out_actions_i32; int64_t* p_act; int64_t* d_actions; float* d_onehot; float *pos_copy, *orient_copy; };
+struct ColdB { int64_t *p_inc, *d_actions_inc; float *d_reward, *p_rew, *ep_ret, *d_clean, *d_den; uint8_t* d_term; };
+struct ColdC { float *d_pos, *d_orient; };
+__device__ __forceinline__ void cold_blocks(ColdA& A, ColdB* B, ColdC* C) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    u32x16s a, b = {};
+    u32x4s c = {};
+    if (B && C) asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx4 %2, %3, %6\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(ka), "s"(HEAD_COLD_OFFSET), "s"(HEAD_COLD_OFFSET + 64), "s"(HEAD_COLD_OFFSET + 128) : "memory");
+    else if (B) asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(ka), "s"(HEAD_COLD_OFFSET), "s"(HEAD_COLD_OFFSET + 64) : "memory");
+    else if (C) asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(c) : "s"(ka), "s"(HEAD_COLD_OFFSET), "s"(HEAD_COLD_OFFSET + 128) : "memory");
+    else asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(ka), "s"(HEAD_COLD_OFFSET) : "memory");
+    A = __builtin_bit_cast(ColdA, a);
+    if (B) *B = __builtin_bit_cast(ColdB, b);
+    if (C) *C = __builtin_bit_cast(ColdC, c);
+#else
+    (void)A; (void)B; (void)C;
+#endif
 }
 #define COLD(T, field) cold_ptr<T>((int)offsetof(HeadCold, field))
 #define COLD_U64(field) reinterpret_cast<uint64_t>(cold_ptr<void>((int)offsetof(HeadCold, field)))
@@ -321,6 +345,8 @@ struct TileIn {
     float pr, p0, p1, o0, o1;      // env: last reward, pose
     int aj[3];                     // inc epilogue items (row, j) = lane + 64 k: action of j and its 7 features
     float f[3][7];
+    float own[3], ep;              // inc, lanes < 16 (row = lane): this agent's reward / clean_num / apple_den of the step, its return so far
+    int term;                      // inc, agent 0: the env's terminated flag
 };
 
 // Addresses are 32-bit element offsets from the (scalar) base pointers -- every array here has far fewer than 2^31 elements (the ABI
@@ -396,6 +422,13 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
             in.f[k][0] = ld32(a.pos_pre, 2u * ej); in.f[k][1] = ld32(a.pos_pre, 2u * ej + 1u);
             in.f[k][2] = ld32(a.orient_pre, 2u * ej); in.f[k][3] = ld32(a.orient_pre, 2u * ej + 1u);
             in.f[k][4] = ld32(a.reward, ej); in.f[k][5] = ld32(a.clean, ej); in.f[k][6] = ld32(a.den, ej);
+        }
+        {   // once per (env, agent) -- lanes < 16, row = lane: what the epilogue files for the agent itself
+            const int br = tile * 16 + (lane & 15), brc = br < N ? br : N - 1;
+            const uint32_t ea = (uint32_t)brc * (uint32_t)n + (uint32_t)agent;
+            in.own[0] = ld32(a.reward, ea); in.own[1] = ld32(a.clean, ea); in.own[2] = ld32(a.den, ea);
+            in.ep = ld32(a.ep_ret ? a.ep_ret : a.reward, ea);
+            in.term = (int)ld32(a.term ? a.term : reinterpret_cast<const uint8_t*>(a.reward), (uint32_t)brc);
         }
     }
 }
@@ -535,15 +568,14 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
             if (ct >= 2 || a.feat_part) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = xk[ct];
         if (q == 0) {
             const size_t er = (size_t)b * n + agent;                   // env-major row
-            float *pos_copy = COLD(float, pos_copy), *d_pos = COLD(float, d_pos);
-            if (pos_copy) {
-                float* orient_copy = COLD(float, orient_copy);
-                pos_copy[er * 2] = in.p0; pos_copy[er * 2 + 1] = in.p1; orient_copy[er * 2] = in.o0; orient_copy[er * 2 + 1] = in.o1;
+            ColdA ca; ColdC cc;
+            cold_blocks(ca, nullptr, &cc);
+            if (ca.pos_copy) {
+                ca.pos_copy[er * 2] = in.p0; ca.pos_copy[er * 2 + 1] = in.p1; ca.orient_copy[er * 2] = in.o0; ca.orient_copy[er * 2 + 1] = in.o1;
             }
-            if (d_pos && file) {
-                float* d_orient = COLD(float, d_orient);
+            if (cc.d_pos && file) {
                 const size_t sr = (((size_t)b * a.slots + slot_t) * n + agent) * 2;
-                d_pos[sr] = in.p0; d_pos[sr + 1] = in.p1; d_orient[sr] = in.o0; d_orient[sr + 1] = in.o1;
+                cc.d_pos[sr] = in.p0; cc.d_pos[sr + 1] = in.p1; cc.d_orient[sr] = in.o0; cc.d_orient[sr + 1] = in.o1;
             }
         }
     };
@@ -574,7 +606,7 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) { asm volatile("" : "+v"(in.hp[ct])); asm volatile("" : "+v"(in.x[ct])); }
         if (INC) {
-            asm volatile("" : "+v"(in.act));
+            asm volatile("" : "+v"(in.act), "+v"(in.own[0]), "+v"(in.own[1]), "+v"(in.own[2]), "+v"(in.ep), "+v"(in.term));
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 asm volatile("" : "+v"(in.aj[k]));
@@ -697,9 +729,11 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
         __builtin_amdgcn_wave_barrier();
         if (!INC) {
             const int bb = tile * 16 + lane;
-            int64_t *out_actions = COLD(int64_t, out_actions), *p_act = COLD(int64_t, p_act), *d_actions = COLD(int64_t, d_actions);
-            int32_t* out_i32 = COLD(int32_t, out_actions_i32);
-            float *q_out = COLD(float, q_out), *d_onehot = COLD(float, d_onehot);
+            ColdA ca;
+            cold_blocks(ca, nullptr, nullptr);
+            int64_t *out_actions = ca.out_actions, *p_act = ca.p_act, *d_actions = ca.d_actions;
+            int32_t* out_i32 = ca.out_actions_i32;
+            float *q_out = ca.q_out, *d_onehot = ca.d_onehot;
             if (lane < 16 && bb < N) {
                 float av[16];
 #pragma unroll
@@ -724,15 +758,18 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
         } else {
             if (first) PSTAMP(8);
             const float* w2o = tail + HT_W2O;                          // [E][4]: 3 advantages + value per extra feature
-            int64_t *out_actions = COLD(int64_t, out_actions), *p_inc = COLD(int64_t, p_inc), *d_actions_inc = COLD(int64_t, d_actions_inc);
-            float *q_out = COLD(float, q_out), *d_reward = COLD(float, d_reward), *p_rew = COLD(float, p_rew), *ep_ret = COLD(float, ep_ret);
+            ColdA ca; ColdB cb;
+            cold_blocks(ca, &cb, nullptr);
+            int64_t *out_actions = ca.out_actions, *p_inc = cb.p_inc, *d_actions_inc = cb.d_actions_inc;
+            float* q_out = ca.q_out;
             if (first) PSTAMP(9);
+            const uint32_t n_magic = (65536u + (uint32_t)n - 1u) / (uint32_t)n;      // it / n for it < 192, n <= 10
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (first && k == 1) PSTAMP(10);
                 if (first && k == 2) PSTAMP(11);
                 const int it = lane + 64 * k;
-                const int row = it / n, j = it - row * n, bb = tile * 16 + row;
+                const int row = (int)(((uint32_t)it * n_magic) >> 16), j = it - row * n, bb = tile * 16 + row;
                 if (it >= 16 * n || bb >= N) continue;
                 const int aj = in.aj[k];
                 float f[7];
@@ -754,19 +791,19 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
                 const uint32_t rk = ((a.env_id_base + (uint32_t)bb) * (uint32_t)n + (uint32_t)agent) * (uint32_t)n + (uint32_t)j;
                 int act = dueling_pick_bits<3>(av, av[3], 3, 0xFFFFFFFFu, eps, step, a.seed, rk, q_out ? q_out + (size_t)rq * 3 : nullptr);
                 if (j == agent) act = 0;                               // no self incentive (homophily_controller.py:44-46)
-                out_actions[((size_t)bb * n + agent) * n + j] = act;
-                if (p_inc) p_inc[((size_t)bb * n + agent) * n + j] = act;
-                const size_t sr = ((size_t)bb * a.slots + slot_t) * n + agent;
-                if (d_actions_inc && file) d_actions_inc[sr * n + j] = act;
-                if (j == agent && d_reward) {                          // once per (env, agent): this step's outcome (f[4..6] are agent's own)
-                    const size_t ea = (size_t)bb * n + agent;
-                    const float rw = f[4];
-                    if (file) { d_reward[sr] = rw; COLD(float, d_clean)[sr] = f[5]; COLD(float, d_den)[sr] = f[6]; }
-                    if (p_rew) p_rew[ea] = rw;
-                    if (ep_ret) ep_ret[ea] += rw;
-                    uint8_t* d_term = COLD(uint8_t, d_term);
-                    if (agent == 0 && d_term && file) d_term[(size_t)bb * a.slots + slot_t] = COLD(const uint8_t, term)[bb];
-                }
+                const size_t pair = ((size_t)bb * n + agent) * n + j;
+                out_actions[pair] = act;
+                if (p_inc) p_inc[pair] = act;
+                if (d_actions_inc && file) d_actions_inc[(((size_t)bb * a.slots + slot_t) * n + agent) * n + j] = act;
+            }
+            // once per (env, agent), lanes < 16 (row = lane): this step's outcome of the agent itself, read with the tile's inputs
+            const int br = tile * 16 + lane;
+            if (lane < 16 && br < N && cb.d_reward) {
+                const size_t ea = (size_t)br * n + agent, sr = ((size_t)br * a.slots + slot_t) * n + agent;
+                if (file) { cb.d_reward[sr] = in.own[0]; cb.d_clean[sr] = in.own[1]; cb.d_den[sr] = in.own[2]; }
+                if (cb.p_rew) cb.p_rew[ea] = in.own[0];
+                if (cb.ep_ret) cb.ep_ret[ea] = in.ep + in.own[0];
+                if (agent == 0 && cb.d_term && file) cb.d_term[(size_t)br * a.slots + slot_t] = (uint8_t)in.term;
             }
         }
         __builtin_amdgcn_wave_barrier();                               // scratch is reused by the next tile
@@ -796,9 +833,10 @@ static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c, int waves
     k.den = p->apple_den;
     k.t_index = p->t_index; k.slots = p->t_index ? p->t_slots : 1;
     k.feat_part = p->feat_part; k.feat_bands = p->feat_bands; k.lin_b = p->lin_b;
+    k.ep_ret = p->ep_return; k.term = p->terminated;
     c.out_actions = p->out_actions; c.q_out = p->q_out; c.out_actions_i32 = p->out_actions_i32; c.pos_copy = p->pos_copy; c.orient_copy = p->orient_copy;
     c.d_pos = p->dst_pos; c.d_orient = p->dst_orient; c.d_onehot = p->dst_actions_onehot; c.d_reward = p->dst_reward;
-    c.d_clean = p->dst_clean_num; c.d_den = p->dst_apple_den; c.d_term = p->dst_terminated; c.term = p->terminated;
+    c.d_clean = p->dst_clean_num; c.d_den = p->dst_apple_den; c.d_term = p->dst_terminated;
     c.d_actions = p->dst_actions; c.d_actions_inc = p->dst_actions_inc; c.p_act = p->prev_actions_out; c.p_inc = p->prev_actions_inc_out;
     c.p_rew = p->prev_reward_out; c.ep_ret = p->ep_return; c.next_t = p->next_t_out;
     {   // first tail column of each block, reference order (homophily_controller.py:137-184); input_flags 0 = the shipped set
