@@ -208,7 +208,8 @@ def main():
     ap.add_argument("--cpu-sample-steps", type=int, default=None)
     ap.add_argument("--launch-dry-run", action="store_true", help="form the process group (gloo), count the ranks, print the launch fields; no GPU")
     args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # SSD_FORCE_DIST=1 (rehearsal of the collective path on a one-GPU box): a 1-rank job goes through the same front door
+    if (args.gpus > 1 or os.environ.get("SSD_FORCE_DIST") == "1") and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
     if args.launch_dry_run:
         sys.exit(dry_run(args))

@@ -963,7 +963,10 @@ template <int V> struct Geo;
 template <> struct Geo<15> { static constexpr int O = 13, CP = 16, NXT = 2, XTP = 1, R = 13, NB = 1; };
 template <> struct Geo<31> { static constexpr int O = 29, CP = 32, NXT = 4, XTP = 2, R = 10, NB = 3; };
 constexpr int ENC_BT = 5;                      // batch tiles (16 rows each) per workgroup: Linear weights are fetched once per 80 rows
-constexpr int ENC_WAVES = 8;                     // 2 per SIMD: one wave's LDS / VALU work overlaps its partner's MFMAs
+#ifndef SSD_ENC_WAVES
+#define SSD_ENC_WAVES 8
+#endif
+constexpr int ENC_WAVES = SSD_ENC_WAVES;                     // 2 per SIMD: one wave's LDS / VALU work overlaps its partner's MFMAs
 // LDS record of (batch row, input row): [plane R: CP one-hot bytes][plane G][plane B][tail: NXT x 8 bytes].  tail[k] = cells 8 (k + 1)
 // and 8 (k + 1) + 1 of the three planes (+ 2 zero bytes): the 4th K-quarter of position tile k, so that every lane's B operand is
 // ONE 8-byte LDS read.  The per-batch-row stride is padded to 8 * odd (mod 256): the 16 rows of a read hit 16 different bank pairs.

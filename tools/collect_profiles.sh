@@ -12,8 +12,10 @@ python3 bench.py --config cleanup10 --steps 10 --warmup 3 > $OUT/bench_e2e_clean
 python3 bench.py --no-cpu-baseline --qnet-dtype bf16 > $OUT/bench_e2e_cleanup5_bf16.json 2> $OUT/bf16.err || exit 1
 python3 bench.py --no-cpu-baseline --obs-storage f32 > $OUT/bench_e2e_cleanup5_f32storage.json 2> $OUT/f32.err || exit 1
 python3 bench.py --workload env > $OUT/bench_env_cleanup5.json 2> $OUT/env.err || exit 1
-SSD_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_e2e_1rank_rccl_rehearsal.json 2> $OUT/rccl1.err || exit 1
-SSD_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 --n-env 1024 --no-cpu-baseline > $OUT/bench_e2e_2rank_gloo_rehearsal.json 2> $OUT/gloo.err || exit 1
+python3 bench.py --no-cpu-baseline --train-steps-per-rollout 8 > $OUT/bench_e2e_cleanup5_tspr8.json 2> $OUT/tspr8.err || exit 1
+# the multi-rank front door (python bench.py --gpus N starts its own ranks): a 1-rank RCCL group and a 2-rank gloo group on this one GPU
+SSD_FORCE_DIST=1 python3 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_e2e_1rank_rccl_rehearsal.json 2> $OUT/rccl1.err || exit 1
+SSD_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 3 --warmup 1 --n-env 1024 --no-cpu-baseline > $OUT/bench_e2e_2rank_gloo_rehearsal.json 2> $OUT/gloo.err || exit 1
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bp -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/$OUT/bench_e2e_under_rocprof.json 2> $R/$OUT/rocprof.err; cp /tmp/bp/*/*kernel_stats.csv $R/$OUT/e2e_kernel_stats.csv)
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/be && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/be -- python3 $R/bench.py --workload env --no-cpu-baseline > $R/$OUT/bench_env_under_rocprof.json 2> $R/$OUT/rocprof_env.err; cp /tmp/be/*/*kernel_stats.csv $R/$OUT/env_kernel_stats.csv)
 # HBM traffic of the env workload's kernel (separate --pmc passes, nothing else traced)
