@@ -438,7 +438,9 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
 // compile-time columns -- the register allocation of the tuned kernel is left as it was.
 // WAVES: compute waves per workgroup = 16-row tiles per workgroup (the host sizes the grid: bpa = ceil(tiles per agent / WAVES)); the
 // workgroup has WAVES + 1 waves, the last one is the loader.
-template <int INC, int PREC, int AT, int GEN, int WAVES>
+// LOOP: a wave walks tiles tile, tile + bpa * WAVES, ... (grids larger than the chip: Cleanup-10 x 8192 has 512 tiles per agent); with
+// LOOP = false the host guarantees at most one tile per wave and the kernel has no back edge (see run_tile).
+template <int INC, int PREC, int AT, int GEN, int WAVES, bool LOOP = false>
 __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, const int block) {
     constexpr int IMAGE_BYTES = SSD_POLICY_IMAGE_BYTES(PREC);
     constexpr float XS = PREC == 2 ? HEAD_XSCALE : 1.f, INV = PREC == 2 ? 1.f / (HEAD_WSCALE * HEAD_XSCALE) : 1.f;
@@ -450,7 +452,7 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
     PSTAMP(0);
     PSTAMP_REAL(14);
     const int tiles = (N + 15) >> 4;
-    const int tile = wave < WAVES ? wave * a.bpa + bia : tiles;        // consecutive tiles go to different CUs; bpa * WAVES >= tiles; the loader has none
+    int tile = wave < WAVES ? wave * a.bpa + bia : tiles;              // consecutive tiles go to different CUs; the loader has none
     TileIn<INC> in;
     // LDS: the image (as in global memory) | per-wave scratch | the loader's progress word
     volatile uint32_t* landed = reinterpret_cast<volatile uint32_t*>(lds_raw + IMAGE_BYTES + WAVES * SCRATCH * 4);
@@ -596,35 +598,12 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
       }
     };
     PSTAMP(12);
-#if defined(__HIP_DEVICE_COMPILE__)
-    {   // Every compiler-issued load of this wave is pinned here -- its data has landed -- BEFORE the rest of the image is requested:
-        // hipcc does not count the DMA pieces, so a wait it placed later for one of its own loads would drain them (vmcnt retires in
-        // issue order).  From here to the last K-step the wave issues no global load and no store.
-        uint32_t ab = avail_bits;
-        asm volatile("" : "+s"(ab));
-        asm volatile("" : "+v"(eps), "+v"(step64), "+v"(slot_t));      // the device scalars arrive through the vector memory path too
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { asm volatile("" : "+v"(in.hp[ct])); asm volatile("" : "+v"(in.x[ct])); }
-        if (INC) {
-            asm volatile("" : "+v"(in.act), "+v"(in.own[0]), "+v"(in.own[1]), "+v"(in.own[2]), "+v"(in.ep), "+v"(in.term));
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                asm volatile("" : "+v"(in.aj[k]));
-#pragma unroll
-                for (int e = 0; e < 7; ++e) asm volatile("" : "+v"(in.f[k][e]));
-            }
-        } else {
-            asm volatile("" : "+v"(in.pa), "+v"(in.pr), "+v"(in.p0), "+v"(in.p1), "+v"(in.o0), "+v"(in.o1));
-#pragma unroll
-            for (int g = 0; g < SSD_MAX_AGENTS; ++g) asm volatile("" : "+v"(in.inc[g]));
-        }
-    }
-#endif
     step = (uint32_t)step64;
     file = slot_t < (long)a.slots;                                     // never file past the episode storage
     if (tile < tiles) prepare(tile);                                   // arithmetic only
     PSTAMP(13);
     PSTAMP(1);
+    const bool had_tile = tile < tiles;
     bool first = true;
     const uint8_t* img = lds_raw;
     const float* tail = reinterpret_cast<const float*>(img + (size_t)tail_piece<PREC>() * 1024);
@@ -811,19 +790,37 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
         first = false;
 #undef SSD_LOAD_STEP
     };
-    if (tile < tiles) run_tile(); else hand_counters();
+    if (tile < tiles) run_tile();
+    if constexpr (LOOP) {
+        for (tile += a.bpa * WAVES; tile < tiles; tile += a.bpa * WAVES) {     // the image is resident by now (seen == every chunk)
+            load_tile<INC>(a, tile, agent, lane, in);
+            prepare(tile);
+            run_tile();
+        }
+    }
+    if (!had_tile) hand_counters();
     PSTAMP(7);
     PSTAMP_REAL(15);
 }
 
 // the standalone heads: 6 tiles per workgroup + the loader wave (Cleanup-5 x 4096 envs: 256 tiles per agent -> 43 workgroups per agent, 215 in all)
 constexpr int HEAD_WAVES = 6;
-template <int INC, int PREC, int AT, int GEN = 0>
+template <int INC, int PREC, int AT, int GEN = 0, bool LOOP = false>
 __global__ __launch_bounds__((HEAD_WAVES + 1) * 64) void k_head(HeadK a, HeadCold cold_unused) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    head_body<INC, PREC, AT, GEN, HEAD_WAVES>(a, lds_raw, (int)blockIdx.x);
+    head_body<INC, PREC, AT, GEN, HEAD_WAVES, LOOP>(a, lds_raw, (int)blockIdx.x);
 }
 
+static int chip_cus() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int v = 0;
+        cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return cus[dev];
+}
 static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c, int waves = HEAD_WAVES) {
     k.N = p->n_env; k.n = p->n_agents; k.A = p->n_actions; k.inp = p->input_shape;
     k.pos_scale = p->pos_scale; k.seed = p->seed; k.env_id_base = p->env_id_base;
@@ -856,9 +853,13 @@ static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c, int waves
     c.next_step = p->next_step_out; c.t_copy = p->t_copy_out; c.step_copy = p->step_copy_out;
     c.numeric_err = numeric_err_word();
     PSTAMP_SET(k);
+    // workgroups per agent: one 16-row tile per wave while that grid fits the chip (no back edge in the kernel); larger jobs get one
+    // workgroup per CU and waves that walk several tiles (the LOOP instantiations)
     const int tiles = (k.N + 15) / 16;
-    k.bpa = (tiles + waves - 1) / waves;                               // workgroups per agent: every wave owns at most one 16-row tile
+    k.bpa = (tiles + waves - 1) / waves;
+    if (k.n * k.bpa > chip_cus()) { k.bpa = chip_cus() / k.n; if (k.bpa < 1) k.bpa = 1; }
 }
+static bool head_loops(const HeadK& k, int waves) { return k.bpa * waves < (k.N + 15) / 16; }
 
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     HeadK k;
@@ -871,18 +872,22 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     static bool attr_done_dev[64] = {};                               // the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
-    const void* fns[8] = {reinterpret_cast<const void*>(&k_head<0, 2, 9>), reinterpret_cast<const void*>(&k_head<1, 2, 9>),
-                          reinterpret_cast<const void*>(&k_head<0, 1, 9>), reinterpret_cast<const void*>(&k_head<1, 1, 9>),
-                          reinterpret_cast<const void*>(&k_head<0, 2, 8>), reinterpret_cast<const void*>(&k_head<1, 2, 8>),
-                          reinterpret_cast<const void*>(&k_head<0, 1, 8>), reinterpret_cast<const void*>(&k_head<1, 1, 8>)};
+    const void* fns[16] = {reinterpret_cast<const void*>(&k_head<0, 2, 9>), reinterpret_cast<const void*>(&k_head<1, 2, 9>),
+                           reinterpret_cast<const void*>(&k_head<0, 1, 9>), reinterpret_cast<const void*>(&k_head<1, 1, 9>),
+                           reinterpret_cast<const void*>(&k_head<0, 2, 8>), reinterpret_cast<const void*>(&k_head<1, 2, 8>),
+                           reinterpret_cast<const void*>(&k_head<0, 1, 8>), reinterpret_cast<const void*>(&k_head<1, 1, 8>),
+                           reinterpret_cast<const void*>(&k_head<0, 2, 9, 0, true>), reinterpret_cast<const void*>(&k_head<1, 2, 9, 0, true>),
+                           reinterpret_cast<const void*>(&k_head<0, 1, 9, 0, true>), reinterpret_cast<const void*>(&k_head<1, 1, 9, 0, true>),
+                           reinterpret_cast<const void*>(&k_head<0, 2, 8, 0, true>), reinterpret_cast<const void*>(&k_head<1, 2, 8, 0, true>),
+                           reinterpret_cast<const void*>(&k_head<0, 1, 8, 0, true>), reinterpret_cast<const void*>(&k_head<1, 1, 8, 0, true>)};
     if (!attr_done_dev[dev]) {
         const size_t l2 = (size_t)head_lds_bytes(HEAD_WAVES, 2);
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess) return -1;
         attr_done_dev[dev] = true;
     }
-    const void* gen_fns[4] = {reinterpret_cast<const void*>(&k_head<0, 2, 9, 1>), reinterpret_cast<const void*>(&k_head<0, 1, 9, 1>),
-                              reinterpret_cast<const void*>(&k_head<0, 2, 8, 1>), reinterpret_cast<const void*>(&k_head<0, 1, 8, 1>)};
+    const void* gen_fns[4] = {reinterpret_cast<const void*>(&k_head<0, 2, 9, 1, true>), reinterpret_cast<const void*>(&k_head<0, 1, 9, 1, true>),
+                              reinterpret_cast<const void*>(&k_head<0, 2, 8, 1, true>), reinterpret_cast<const void*>(&k_head<0, 1, 8, 1, true>)};      // (any grid)
     static bool gen_attr_done_dev[64] = {};
     const bool gen = !inc && p->input_flags && (p->input_flags & ~SSD_INPUT_EXPLICIT) != (uint32_t)SSD_INPUT_FLAGS_SHIPPED;
     if (gen && !gen_attr_done_dev[dev]) {
@@ -892,7 +897,8 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
         gen_attr_done_dev[dev] = true;
     }
     void* args[2] = {&k, &c};
-    const void* fn = gen ? gen_fns[(k.A == 8 ? 2 : 0) + (prec == 1 ? 1 : 0)] : fns[(k.A == 8 ? 4 : 0) + (prec == 1 ? 2 : 0) + (inc ? 1 : 0)];
+    const void* fn = gen ? gen_fns[(k.A == 8 ? 2 : 0) + (prec == 1 ? 1 : 0)]
+                         : fns[(head_loops(k, HEAD_WAVES) ? 8 : 0) + (k.A == 8 ? 4 : 0) + (prec == 1 ? 2 : 0) + (inc ? 1 : 0)];
     if (hipLaunchKernel(fn, dim3(k.n * bpa), dim3((HEAD_WAVES + 1) * 64), args, lds, s) != hipSuccess) return -1;
     return 0;
 }
@@ -1250,12 +1256,12 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
 // (x, band) index unfolded; EncK sits behind the two head arguments (the heads' cold-argument offsets are unchanged).
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int FUSED_WAVES = ENC_WAVES;          // k_inc_encode: one block size for both bodies
-template <int PREC, int AT, int V>
+template <int PREC, int AT, int V, bool LOOP = false>
 __global__ __launch_bounds__(FUSED_WAVES * 64) void k_inc_encode(HeadK a, HeadCold cold_unused, EncK e, int heads, int enc_groups) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int b = (int)blockIdx.x;
     if (b < heads) {
-        head_body<1, PREC, AT, 0, FUSED_WAVES - 1>(a, lds_raw, b);    // 7 compute waves + the loader
+        head_body<1, PREC, AT, 0, FUSED_WAVES - 1, LOOP>(a, lds_raw, b);    // 7 compute waves + the loader
     } else {
         const int i = b - heads, by = i / enc_groups;
         encode_body<V, PREC, false>(e, lds_raw, i - by * enc_groups, by);
@@ -1288,14 +1294,14 @@ static void encode_args(const ssd_policy_encode_args* p, EncK& k) {
     PSTAMP_SET(k);
 }
 
-template <int PREC, int AT, int V>
+template <int PREC, int AT, int V, bool LOOP>
 static int launch_inc_encode_t(HeadK& k, HeadCold& c, EncK& e, hipStream_t s) {
     const size_t lh = (size_t)head_lds_bytes(FUSED_WAVES - 1, PREC), le = enc_lds_bytes<V, PREC>();
     const size_t lds = lh > le ? lh : le;
     static bool done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
-    const void* fn = reinterpret_cast<const void*>(&k_inc_encode<PREC, AT, V>);
+    const void* fn = reinterpret_cast<const void*>(&k_inc_encode<PREC, AT, V, LOOP>);
     if (!done[dev]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         done[dev] = true;
@@ -1316,7 +1322,8 @@ int launch_policy_inc_encode(const ssd_policy_head* ph, const ssd_policy_encode_
     const int prec = ph->precision == 1 ? 1 : 2, V = pe->view_edge;
     if (k.A != 9 && k.A != 8) return -3;
     if (V != 15 && V != 31) return -2;
-#define SSD_IE(P_, A_, V_) if (prec == P_ && k.A == A_ && V == V_) return launch_inc_encode_t<P_, A_, V_>(k, c, e, s)
+    const bool loops = head_loops(k, FUSED_WAVES - 1);
+#define SSD_IE(P_, A_, V_) if (prec == P_ && k.A == A_ && V == V_) return loops ? launch_inc_encode_t<P_, A_, V_, true>(k, c, e, s) : launch_inc_encode_t<P_, A_, V_, false>(k, c, e, s)
     SSD_IE(2, 9, 15); SSD_IE(2, 9, 31); SSD_IE(2, 8, 15); SSD_IE(2, 8, 31);
     SSD_IE(1, 9, 15); SSD_IE(1, 9, 31); SSD_IE(1, 8, 15); SSD_IE(1, 8, 31);
 #undef SSD_IE
