@@ -107,7 +107,7 @@ def run_e2e(args, c, rank, world, local_rank):
     _, bd["rollout_100_steps_ms"] = timed_ms(lambda: [runner.step_once() for _ in range(T)])
     batch, bd["finish_episode_ms"] = timed_ms(runner.finish_episode)
     _, bd["replay_insert_ms"] = timed_ms(lambda: buf.insert_episode_batch(batch))
-    sample, bd["sample_ms"] = timed_ms(lambda: buf.sample(a.batch_size)[:, :T + 1])
+    sample, bd["sample_ms"] = timed_ms(lambda: buf.sample(a.batch_size, out=learner.sample_out())[:, :T + 1])      # as run.train_iteration calls it
     _, bd["learner_train_ms"] = timed_ms(lambda: learner.train(sample, runner.t_env, ctx.train_steps if a.schedule_unit == "rollouts" else state["episode"]))
     bd = {k: round(v, 3) for k, v in bd.items()}
 
