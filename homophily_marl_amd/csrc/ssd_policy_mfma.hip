@@ -803,8 +803,12 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
     PSTAMP_REAL(15);
 }
 
-// the standalone heads: 6 tiles per workgroup + the loader wave (Cleanup-5 x 4096 envs: 256 tiles per agent -> 43 workgroups per agent, 215 in all)
-constexpr int HEAD_WAVES = 6;
+// the standalone heads: 8 tiles per workgroup + the loader wave (Cleanup-5 x 4096 envs: 256 tiles per agent -> 32 workgroups per agent, 160 in
+// all; measured 4 / 6 / 8 / 11 compute waves: 19.1 / 14.8 / 14.2 / 17.4 us)
+#ifndef SSD_HEAD_WAVES
+#define SSD_HEAD_WAVES 8
+#endif
+constexpr int HEAD_WAVES = SSD_HEAD_WAVES;
 template <int INC, int PREC, int AT, int GEN = 0, bool LOOP = false>
 __global__ __launch_bounds__((HEAD_WAVES + 1) * 64) void k_head(HeadK a, HeadCold cold_unused) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
