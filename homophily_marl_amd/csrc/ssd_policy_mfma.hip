@@ -809,10 +809,12 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
 #define SSD_HEAD_WAVES 8
 #endif
 constexpr int HEAD_WAVES = SSD_HEAD_WAVES;
+constexpr int HEAD_WAVES_LOOP = 6;             // the looped instantiations need the whole register file: 7 waves = 2 per SIMD at 256 registers
+constexpr int head_waves(bool loop) { return loop ? HEAD_WAVES_LOOP : HEAD_WAVES; }
 template <int INC, int PREC, int AT, int GEN = 0, bool LOOP = false>
-__global__ __launch_bounds__((HEAD_WAVES + 1) * 64) void k_head(HeadK a, HeadCold cold_unused) {
+__global__ __launch_bounds__((head_waves(LOOP) + 1) * 64) void k_head(HeadK a, HeadCold cold_unused) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    head_body<INC, PREC, AT, GEN, HEAD_WAVES, LOOP>(a, lds_raw, (int)blockIdx.x);
+    head_body<INC, PREC, AT, GEN, head_waves(LOOP), LOOP>(a, lds_raw, (int)blockIdx.x);
 }
 
 static int chip_cus() {
@@ -864,14 +866,22 @@ static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c, int waves
     if (k.n * k.bpa > chip_cus()) { k.bpa = chip_cus() / k.n; if (k.bpa < 1) k.bpa = 1; }
 }
 static bool head_loops(const HeadK& k, int waves) { return k.bpa * waves < (k.N + 15) / 16; }
+// the standalone heads: 8 compute waves when one tile per wave fits the chip, else the looped kernel with 6
+static int head_plan(const ssd_policy_head* p, HeadK& k, HeadCold& c, bool gen) {
+    head_args(p, k, c, gen ? HEAD_WAVES_LOOP : HEAD_WAVES);
+    if (!gen && !head_loops(k, HEAD_WAVES)) return HEAD_WAVES;
+    head_args(p, k, c, HEAD_WAVES_LOOP);
+    return HEAD_WAVES_LOOP;
+}
 
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     HeadK k;
     HeadCold c;
-    head_args(p, k, c);
+    const bool gen = !inc && p->input_flags && (p->input_flags & ~SSD_INPUT_EXPLICIT) != (uint32_t)SSD_INPUT_FLAGS_SHIPPED;
+    const int waves = head_plan(p, k, c, gen);                         // (the generic-layout kernels exist as looped instantiations only)
     const int prec = p->precision == 1 ? 1 : 2;
     const int bpa = k.bpa;
-    const size_t lds = (size_t)head_lds_bytes(HEAD_WAVES, prec);
+    const size_t lds = (size_t)head_lds_bytes(waves, prec);
     if (k.A != 9 && k.A != 8) return -3;                               // instantiated for Cleanup (9 actions) and Harvest (8)
     static bool attr_done_dev[64] = {};                               // the attribute is per device
     int dev = 0;
@@ -893,7 +903,6 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     const void* gen_fns[4] = {reinterpret_cast<const void*>(&k_head<0, 2, 9, 1, true>), reinterpret_cast<const void*>(&k_head<0, 1, 9, 1, true>),
                               reinterpret_cast<const void*>(&k_head<0, 2, 8, 1, true>), reinterpret_cast<const void*>(&k_head<0, 1, 8, 1, true>)};      // (any grid)
     static bool gen_attr_done_dev[64] = {};
-    const bool gen = !inc && p->input_flags && (p->input_flags & ~SSD_INPUT_EXPLICIT) != (uint32_t)SSD_INPUT_FLAGS_SHIPPED;
     if (gen && !gen_attr_done_dev[dev]) {
         const size_t l2 = (size_t)head_lds_bytes(HEAD_WAVES, 2);
         for (const void* f : gen_fns)
@@ -902,8 +911,8 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     }
     void* args[2] = {&k, &c};
     const void* fn = gen ? gen_fns[(k.A == 8 ? 2 : 0) + (prec == 1 ? 1 : 0)]
-                         : fns[(head_loops(k, HEAD_WAVES) ? 8 : 0) + (k.A == 8 ? 4 : 0) + (prec == 1 ? 2 : 0) + (inc ? 1 : 0)];
-    if (hipLaunchKernel(fn, dim3(k.n * bpa), dim3((HEAD_WAVES + 1) * 64), args, lds, s) != hipSuccess) return -1;
+                         : fns[(waves == HEAD_WAVES_LOOP ? 8 : 0) + (k.A == 8 ? 4 : 0) + (prec == 1 ? 2 : 0) + (inc ? 1 : 0)];
+    if (hipLaunchKernel(fn, dim3(k.n * bpa), dim3((waves + 1) * 64), args, lds, s) != hipSuccess) return -1;
     return 0;
 }
 
@@ -972,7 +981,9 @@ void launch_pack_head(const ssd_policy_head_params* p, int prec, void* image, hi
 template <int V> struct Geo;
 template <> struct Geo<15> { static constexpr int O = 13, CP = 16, NXT = 2, XTP = 1, R = 13, NB = 1; };
 template <> struct Geo<31> { static constexpr int O = 29, CP = 32, NXT = 4, XTP = 2, R = 10, NB = 3; };
-constexpr int ENC_BT = 5;                      // batch tiles (16 rows each) per workgroup: Linear weights are fetched once per 80 rows
+// (a template parameter BT of the kernels: 4 for 15 x 15 windows at up to 32 768 rows -- Cleanup-5 x 4096: 320 workgroups balance the
+// chip better behind the inc heads, k_inc_encode 32.4 -> 30.5 us -- else 5, which moves fewer Linear fragments per row)
+constexpr int ENC_BT_MAX = 5;                      // batch tiles (16 rows each) per workgroup: Linear weights are fetched once per 80 rows
 #ifndef SSD_ENC_WAVES
 #define SSD_ENC_WAVES 8
 #endif
@@ -986,9 +997,9 @@ template <int V> constexpr int enc_batch_row_bytes() {
     while ((b & 255) % 16 != 8) b += 8;
     return b;
 }
-template <int V, int PREC> constexpr size_t enc_lds_bytes() {
-    const size_t work = (size_t)ENC_BT * 16 * enc_batch_row_bytes<V>() + (size_t)PREC * 9 * 1024;
-    const size_t red = (size_t)ENC_WAVES * ENC_BT * 2 * 1024;           // the reduction scratch aliases planes + fragments
+template <int V, int PREC, int BT = ENC_BT_MAX> constexpr size_t enc_lds_bytes() {
+    const size_t work = (size_t)BT * 16 * enc_batch_row_bytes<V>() + (size_t)PREC * 9 * 1024;
+    const size_t red = (size_t)ENC_WAVES * BT * 2 * 1024;           // the reduction scratch aliases planes + fragments
     return work > red ? work : red;
 }
 
@@ -1006,10 +1017,10 @@ struct EncK {
     PSTAMP_DECL
 };
 
-template <int V, int PREC, bool ACT>
+template <int V, int PREC, bool ACT, int BT>
 __device__ __forceinline__ void encode_body(const EncK& a, uint8_t* lds_raw, const int block_x, const int block_y) {
     using G = Geo<V>;
-    constexpr int O = G::O, CP = G::CP, XTP = G::XTP, R = G::R, BT = ENC_BT;
+    constexpr int O = G::O, CP = G::CP, XTP = G::XTP, R = G::R;
     constexpr int RB = enc_row_bytes<V>(), PR = enc_batch_row_bytes<V>();   // bytes of an input-row record / of a batch row (this band)
     constexpr int PLANES = BT * 16 * PR, CONV_BYTES = PREC * 9 * 1024;
     constexpr uint32_t ON = PREC == 2 ? 0x3Cu : 0x3Fu;                 // f16 0x3C00 = 1.0;  bf16 0x3F00 = 0.5 (the conv weights carry the 2)
@@ -1245,11 +1256,12 @@ __device__ __forceinline__ void encode_body(const EncK& a, uint8_t* lds_raw, con
     PSTAMP_REAL(15);
 }
 
-template <int V, int PREC, bool ACT>
+template <int V, int PREC, bool ACT, int BT>
 __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    encode_body<V, PREC, ACT>(a, lds_raw, (int)blockIdx.x, (int)blockIdx.y);
+    encode_body<V, PREC, ACT, BT>(a, lds_raw, (int)blockIdx.x, (int)blockIdx.y);
 }
+static int enc_bt(int V, int rows) { return (V == 15 && rows <= 32768) ? 4 : 5; }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_inc_encode: the inc head of timestep t and the encoder of timestep t + 1 as ONE launch (pipelined rollout).  Both follow the env
@@ -1260,32 +1272,41 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
 // (x, band) index unfolded; EncK sits behind the two head arguments (the heads' cold-argument offsets are unchanged).
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int FUSED_WAVES = ENC_WAVES;          // k_inc_encode: one block size for both bodies
-template <int PREC, int AT, int V, bool LOOP = false>
+template <int PREC, int AT, int V, bool LOOP, int BT>
 __global__ __launch_bounds__(FUSED_WAVES * 64) void k_inc_encode(HeadK a, HeadCold cold_unused, EncK e, int heads, int enc_groups) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const int b = (int)blockIdx.x;
+#ifndef SSD_ENC_FIRST
+#define SSD_ENC_FIRST 0
+#endif
+    const int total = (int)gridDim.x;
+    const int b = SSD_ENC_FIRST ? ((int)blockIdx.x + heads) % total : (int)blockIdx.x;      // (which body the first workgroups run)
     if (b < heads) {
         head_body<1, PREC, AT, 0, FUSED_WAVES - 1, LOOP>(a, lds_raw, b);    // 7 compute waves + the loader
     } else {
         const int i = b - heads, by = i / enc_groups;
-        encode_body<V, PREC, false>(e, lds_raw, i - by * enc_groups, by);
+        encode_body<V, PREC, false, BT>(e, lds_raw, i - by * enc_groups, by);
     }
 }
 
-template <int V, int PREC, bool ACT>
-static int launch_encode_t(const EncK& k, hipStream_t s) {
+template <int V, int PREC, bool ACT, int BT>
+static int launch_encode_bt(const EncK& k, hipStream_t s) {
     using G = Geo<V>;
-    constexpr size_t lds = enc_lds_bytes<V, PREC>();
+    constexpr size_t lds = enc_lds_bytes<V, PREC, BT>();
     static bool done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
     if (!done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode<V, PREC, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode<V, PREC, ACT, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         done[dev] = true;
     }
-    const int groups = (k.rows + ENC_BT * 16 - 1) / (ENC_BT * 16);
-    hipLaunchKernelGGL((k_encode<V, PREC, ACT>), dim3(groups, G::NB), dim3(ENC_WAVES * 64), lds, s, k);
+    const int groups = (k.rows + BT * 16 - 1) / (BT * 16);
+    hipLaunchKernelGGL((k_encode<V, PREC, ACT, BT>), dim3(groups, G::NB), dim3(ENC_WAVES * 64), lds, s, k);
     return 0;
+}
+template <int V, int PREC, bool ACT>
+static int launch_encode_t(const EncK& k, hipStream_t s) {
+    if constexpr (V == 15) { if (enc_bt(V, k.rows) == 4) return launch_encode_bt<V, PREC, ACT, 4>(k, s); }
+    return launch_encode_bt<V, PREC, ACT, 5>(k, s);
 }
 
 static void encode_args(const ssd_policy_encode_args* p, EncK& k) {
@@ -1298,22 +1319,27 @@ static void encode_args(const ssd_policy_encode_args* p, EncK& k) {
     PSTAMP_SET(k);
 }
 
-template <int PREC, int AT, int V, bool LOOP>
-static int launch_inc_encode_t(HeadK& k, HeadCold& c, EncK& e, hipStream_t s) {
-    const size_t lh = (size_t)head_lds_bytes(FUSED_WAVES - 1, PREC), le = enc_lds_bytes<V, PREC>();
+template <int PREC, int AT, int V, bool LOOP, int BT>
+static int launch_inc_encode_bt(HeadK& k, HeadCold& c, EncK& e, hipStream_t s) {
+    const size_t lh = (size_t)head_lds_bytes(FUSED_WAVES - 1, PREC), le = enc_lds_bytes<V, PREC, BT>();
     const size_t lds = lh > le ? lh : le;
     static bool done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
-    const void* fn = reinterpret_cast<const void*>(&k_inc_encode<PREC, AT, V, LOOP>);
+    const void* fn = reinterpret_cast<const void*>(&k_inc_encode<PREC, AT, V, LOOP, BT>);
     if (!done[dev]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         done[dev] = true;
     }
-    int heads = k.n * k.bpa, groups = (e.rows + ENC_BT * 16 - 1) / (ENC_BT * 16);
+    int heads = k.n * k.bpa, groups = (e.rows + BT * 16 - 1) / (BT * 16);
     void* args[5] = {&k, &c, &e, &heads, &groups};
     if (hipLaunchKernel(fn, dim3(heads + groups * Geo<V>::NB), dim3(FUSED_WAVES * 64), args, lds, s) != hipSuccess) return -1;
     return 0;
+}
+template <int PREC, int AT, int V, bool LOOP>
+static int launch_inc_encode_t(HeadK& k, HeadCold& c, EncK& e, hipStream_t s) {
+    if constexpr (V == 15) { if (enc_bt(V, e.rows) == 4) return launch_inc_encode_bt<PREC, AT, V, LOOP, 4>(k, c, e, s); }
+    return launch_inc_encode_bt<PREC, AT, V, LOOP, 5>(k, c, e, s);
 }
 
 // inc head (timestep t) + encoder (timestep t + 1) as one launch; -2: no instance for this window size, -3: for this action count
