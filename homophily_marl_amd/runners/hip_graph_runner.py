@@ -139,7 +139,8 @@ class HipGraphRunner(HipVecRunner):
         if b is None:
             st["filled"].fill_(1)                                       # fixed-length episodes: every slot is filled
             st["avail_actions"].copy_(self.env.avail_actions_batch.unsqueeze(1).expand(-1, self.episode_limit + 1, -1, -1))
-            b = SimpleNamespace(graph=None, cur=self._dense_cur, ss=None, ss_last=None, file_env=None, file_inc=None, file_inc_last=None)
+            b = SimpleNamespace(graph=None, cur=self._dense_cur, ss=None, ss_last=None, file_env=None, file_inc=None, file_inc_last=None,
+                                begin_graph=None, finish_graph=None)
             if self.fast is not None:
                 if self.direct_obs:
                     b.cur = self.env.native.storage_obs_buffers(st["obs"], self.obs_fmt, want_code=self._want_code)
@@ -365,25 +366,23 @@ class HipGraphRunner(HipVecRunner):
             store = self._own_store
         self._bind_store(store)
         self.batch = self.store
-        self.env.reset_batch()
-        self.env.observe_batch(self.obs_fmt, out=self.cur if getattr(self, "direct_obs", False) else None)   # fills self.cur (or obs[:, 0])
-        self.t = 0
-        self.t_dev.zero_()
-        self.prev_actions.fill_(-1); self.prev_reward.zero_(); self.prev_inc.zero_()
-        self.ep_return.zero_()
-        if self.fast is None:
-            self.h_env.zero_(); self.h_inc.zero_()       # the generic timestep's hidden states (FastPolicy keeps its own)
-        if self.fast is not None:
-            for fp in self.fasts:
-                fp.reset()
-            self.fast.pack()          # the learner may have stepped the weights since the last episode (packs are shared)
         sel = self.mac.action_selector
         sel.epsilon = 0.0 if test_mode else sel.schedule.eval(self.sched_t)
         zero_after = getattr(self.args, "epsilon_zero", None)
         if zero_after is not None and self.t_env > zero_after:
             sel.epsilon = 0.0
-        self.eps.fill_(sel.epsilon)
+        self.t = 0
         self._episodes += 1
+        b = self._bundle
+        # The episode's opening launches (env reset + first observation, the runner state's fills, the weight packs, the encoder of
+        # slot 0) and its closing ones (slot-T pass, statistics) are ~25 small launches the host issues one by one while the GPU waits
+        # for them (0.4 of a 7.5 ms iteration); from the third episode of a storage on they are two more hipGraph replays.
+        if b.begin_graph is not None:
+            self.eps.fill_(sel.epsilon)
+            b.begin_graph.replay()
+            return
+        self._begin_launches()
+        self.eps.fill_(sel.epsilon)
         if self._graph is None and self._episodes >= 2 and getattr(self.args, "rollout_graph", True):
             th.cuda.synchronize()
             g = th.cuda.CUDAGraph()
@@ -398,6 +397,32 @@ class HipGraphRunner(HipVecRunner):
             self._graph = self._bundle.graph = g
             # capture records but does not run: re-establish the episode start state
             self.t_dev.zero_()
+        elif (self._graph is not None and self.fast is not None and getattr(self.fast, "_pack_graph", None) is not None
+              and getattr(self.args, "rollout_graph", True) and getattr(self.args, "episode_edge_graphs", True)):
+            # third episode of this storage: everything is warm (the pack graph exists) -- capture the opening launches; they were
+            # just run eagerly for THIS episode, the capture itself runs nothing
+            th.cuda.synchronize()
+            g = th.cuda.CUDAGraph()
+            with th.no_grad(), th.cuda.graph(g, capture_error_mode="thread_local"):
+                self._begin_launches(in_capture=True)
+            b.begin_graph = g
+
+    def _begin_launches(self, in_capture=False):
+        """the device work that opens an episode on the bound storage (everything but the epsilon scalar, which the host computes)"""
+        self.env.reset_batch()
+        self.env.observe_batch(self.obs_fmt, out=self.cur if getattr(self, "direct_obs", False) else None)   # fills self.cur (or obs[:, 0])
+        self.t_dev.zero_()
+        self.prev_actions.fill_(-1); self.prev_reward.zero_(); self.prev_inc.zero_()
+        self.ep_return.zero_()
+        if self.fast is None:
+            self.h_env.zero_(); self.h_inc.zero_()       # the generic timestep's hidden states (FastPolicy keeps its own)
+        if self.fast is not None:
+            for fp in self.fasts:
+                fp.reset()
+            if in_capture:
+                self.fast._pack_eager()   # the learner may have stepped the weights since the last episode (packs are shared)
+            else:
+                self.fast.pack()
         if self.pipe:       # the encoder runs one timestep ahead of the heads: the observation of slot 0 is encoded here
             with th.no_grad():
                 codes = self.store.data.transition_data["obs"] if self.obs_fmt == abi.OBS_CODE else self.cur["code"]
@@ -419,7 +444,25 @@ class HipGraphRunner(HipVecRunner):
     @th.no_grad()
     def finish_episode(self):
         self._par = self.t & 1
-        self._select(False)
+        b = self._bundle
         self._out = dict(collective_return=self.env.native.out["collective_return"], equality=self.env.native.out["equality"])
         self._ep_return = self.ep_return
+        stats_on = bool(getattr(self.args, "runner_stats", True))
+        if b.finish_graph is not None and not self._test_mode:
+            b.finish_graph.replay()                                     # the slot-T pass + this rollout's statistics
+            self._stats_on_device_done = stats_on
+            return self._finish_stats()
+        self._select(False)
+        if (b.begin_graph is not None and b.finish_graph is None and not self._test_mode and self._par == 0
+                and getattr(self.args, "episode_edge_graphs", True)):
+            # the closing launches of a training episode on this storage as a graph (captured after they ran eagerly for this episode)
+            if stats_on:
+                self._stat_acc(False)                                   # the accumulator exists before the capture
+            th.cuda.synchronize()
+            g = th.cuda.CUDAGraph()
+            with th.cuda.graph(g, capture_error_mode="thread_local"):
+                self._select(False)
+                if stats_on:
+                    self._stats_device(self._out, self._ep_return, False)
+            b.finish_graph = g
         return self._finish_stats()

@@ -124,9 +124,9 @@ class HipVecRunner:
         stats = self.test_stats if test_mode else self.train_stats
         prefix = "test_" if test_mode else ""
         if getattr(self.args, "runner_stats", True):
-            acc = self._stat_acc(test_mode)
-            r = ep_return.to(th.float64)
-            acc += th.stack([out["collective_return"].sum(dtype=th.float64), out["equality"].sum(dtype=th.float64), r.sum(), (r * r).sum()])
+            if not getattr(self, "_stats_on_device_done", False):
+                self._stats_device(out, ep_return, test_mode)
+            self._stats_on_device_done = False
             stats["n_episodes"] = self.batch_size + stats.get("n_episodes", 0)
             stats["ep_length"] = self.t * self.batch_size + stats.get("ep_length", 0)
             stats["n_returns"] = ep_return.numel() + stats.get("n_returns", 0)
@@ -145,6 +145,13 @@ class HipVecRunner:
                     self.logger.log_stat("epsilon", self.mac.action_selector.epsilon, self.t_env)
                 self.log_train_stats_t = self.sched_t
         return self.batch
+
+    def _stats_device(self, out, ep_return, test_mode):
+        """the device side of _finish_stats: this rollout's sums added to the accumulator (a handful of launches, no synchronisation;
+        the graph runner replays them as part of its episode-closing graph)"""
+        acc = self._stat_acc(test_mode)
+        r = ep_return.to(th.float64)
+        acc += th.stack([out["collective_return"].sum(dtype=th.float64), out["equality"].sum(dtype=th.float64), r.sum(), (r * r).sum()])
 
     def _stat_acc(self, test_mode):
         """device accumulator [sum collective_return, sum equality_metric, sum of returns, sum of squared returns]"""
