@@ -25,11 +25,12 @@ def _check_roofline(r):
 
 
 @pytest.mark.parametrize("name", ["r02_bench_e2e_cleanup5.json", "r02_bench_e2e_harvest5.json", "r02_bench_e2e_cleanup10.json",
-                                  "r02_bench_env_cleanup5.json"])
+                                  "r02_bench_env_cleanup5.json", "r03_bench_e2e_cleanup5.json", "r03_bench_e2e_harvest5.json",
+                                  "r03_bench_e2e_cleanup10.json", "r03_bench_env_cleanup5.json", "r03_bench_e2e_cleanup5_tspr8.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     d = json.load(open(os.path.join(ROOT, "profiles", name)))
     for k in REQUIRED:
-        assert k in d or (k == "cpu_baseline" and "env" in name), k        # the env-only line was taken with --no-cpu-baseline
+        assert k in d or (k == "cpu_baseline" and ("r02_bench_env" in name or "tspr8" in name)), k      # lines taken with --no-cpu-baseline
     assert d["metric"] == "agent_steps_per_sec" and d["unit"] == "agent-steps/s" and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     _check_roofline(d["roofline"])
