@@ -341,7 +341,8 @@ struct TileIn {
     f32x4 x[4];                    // env: x[0..1] = encoder features (final, or lin_b + the band sums); inc: the 64 stored inputs
     f32x4 hp[4];                   // previous hidden state
     int pa, act;                   // env: last action; inc: the env action just taken
-    int32_t inc[SSD_MAX_AGENTS];   // env: the incentive action every giver g sent this agent at the previous step (0 / 1 / 2)
+    int32_t inc[3];                // env: the incentive action giver g = q + 4 k sent this agent at the previous step (0 / 1 / 2), k = 0 .. 2:
+                                   // the four lane quarters of a row share the givers between them (summed over q in prepare)
     float pr, p0, p1, o0, o1;      // env: last reward, pose
     int aj[3];                     // inc epilogue items (row, j) = lane + 64 k: action of j and its 7 features
     float f[3][7];
@@ -390,23 +391,18 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
         // n - 1 and count nothing
         const int32_t* pi = reinterpret_cast<const int32_t*>(a.prev_inc);
 #pragma unroll
-        for (int g = 0; g < SSD_MAX_AGENTS; ++g) in.inc[g] = 0;
-#pragma unroll
-        for (int g = 0; g < 5; ++g) {                                  // (counted in prepare: nothing here waits for a load)
+        for (int k = 0; k < 3; ++k) {                                  // (counted in prepare: nothing here waits for a load)
+            const int g = q + 4 * k;
             const uint32_t gc = (uint32_t)(g < n ? g : n - 1);
-            in.inc[g] = ld32(pi, 2u * (((uint32_t)bc * (uint32_t)n + gc) * (uint32_t)n + (uint32_t)agent));
+            in.inc[k] = (k == 0 || n > 4 * k) ? ld32(pi, 2u * (((uint32_t)bc * (uint32_t)n + gc) * (uint32_t)n + (uint32_t)agent)) : 0;   // wave-uniform predicate
         }
-        if (n > 5) {                                                   // wave-uniform: no load waits inside
-#pragma unroll
-            for (int g = 5; g < SSD_MAX_AGENTS; ++g) {
-                const uint32_t gc = (uint32_t)(g < n ? g : n - 1);
-                in.inc[g] = ld32(pi, 2u * (((uint32_t)bc * (uint32_t)n + gc) * (uint32_t)n + (uint32_t)agent));
-            }
-        }
-        in.p0 = ld32(a.pos, 2u * er); in.p1 = ld32(a.pos, 2u * er + 1u);
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
+        const f32x2v pp = ld32(reinterpret_cast<const f32x2v*>(a.pos), er);      // one 8-byte load per pair
+        in.p0 = pp.x; in.p1 = pp.y;
         const float* orient = a.orient ? a.orient : a.pos;             // no orientation given: read something valid, use zeros
         const float ok = a.orient ? 1.f : 0.f;
-        in.o0 = ld32(orient, 2u * er) * ok; in.o1 = ld32(orient, 2u * er + 1u) * ok;
+        const f32x2v oo = ld32(reinterpret_cast<const f32x2v*>(orient), er);
+        in.o0 = oo.x * ok; in.o1 = oo.y * ok;
     } else {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) in.x[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)((ro + 16u * ct) * 4u));
@@ -419,8 +415,9 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
             const bool live = it < 16 * n && bb < N;
             const uint32_t ej = live ? (uint32_t)bb * (uint32_t)n + (uint32_t)j : (uint32_t)N * (uint32_t)n - 1u;
             in.aj[k] = (int)ld32(reinterpret_cast<const int32_t*>(a.actions), 2u * ej);
-            in.f[k][0] = ld32(a.pos_pre, 2u * ej); in.f[k][1] = ld32(a.pos_pre, 2u * ej + 1u);
-            in.f[k][2] = ld32(a.orient_pre, 2u * ej); in.f[k][3] = ld32(a.orient_pre, 2u * ej + 1u);
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
+            const f32x2v pj = ld32(reinterpret_cast<const f32x2v*>(a.pos_pre), ej), oj = ld32(reinterpret_cast<const f32x2v*>(a.orient_pre), ej);
+            in.f[k][0] = pj.x; in.f[k][1] = pj.y; in.f[k][2] = oj.x; in.f[k][3] = oj.y;
             in.f[k][4] = ld32(a.reward, ej); in.f[k][5] = ld32(a.clean, ej); in.f[k][6] = ld32(a.den, ej);
         }
         {   // once per (env, agent) -- lanes < 16, row = lane: what the epilogue files for the agent itself
@@ -513,10 +510,13 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
             const float px = in.p0 / a.pos_scale, py = in.p1 / a.pos_scale;
             int recv = 0;                                              // #rewards - #punishments received (controller :150-157)
 #pragma unroll
-            for (int g = 0; g < SSD_MAX_AGENTS; ++g) {
-                const int on = (g < n && g != agent) ? 1 : 0;          // inc_mask_actions: no self incentive (wave-uniform)
-                recv += on * ((in.inc[g] == 1) - (in.inc[g] == 2));
+            for (int k = 0; k < 3; ++k) {
+                const int g = q + 4 * k;
+                const int on = (g < n && g != agent) ? 1 : 0;          // inc_mask_actions: no self incentive
+                recv += on * ((in.inc[k] == 1) - (in.inc[k] == 2));
             }
+            recv += __shfl_xor(recv, 16);                              // the row's four quarters hold different givers
+            recv += __shfl_xor(recv, 32);
             const float sg_r = (float)((in.pr > 0.f) - (in.pr < 0.f)), sg_i = (float)((recv > 0) - (recv < 0));
             const int c_pa = o_act + in.pa, c_id = o_id + agent;       // pa in [-1, A): -1 (no previous step) lands left of the block
 #pragma unroll
