@@ -7,7 +7,8 @@
 // (one batched GEMM); what is left per step is a [B, 64] x [64, 192] product and the gate arithmetic -- at the learner's batch
 // (B = 16 episodes) a latency chain of ~10 tiny launches per step and direction.  Here one workgroup owns one (weight set g,
 // 16-row tile) and walks the whole sequence:
-//   * 4 waves, wave w owns hidden features 16 w .. 16 w + 15 (all three gates); its slice of W_h lives in registers for all T as
+//   * 4 compute waves (+ a writer wave that takes each step's results from an LDS staging image to HBM, so that no compute wave
+//     ever waits for a store); wave w owns hidden features 16 w .. 16 w + 15 (all three gates); its slice of W_h lives in registers for all T as
 //     MFMA A operands, products are computed in the transposed form of ssd_policy_mfma.hip (activation row on the lane, 4
 //     consecutive features in the lane's registers), so the gate arithmetic is lane-local;
 //   * forward: v_mfma_f32_16x16x32_f16 on two-term f16 splits (f32-equivalent; |h| < 1), the new state crosses the waves through a
@@ -39,17 +40,36 @@ __device__ __forceinline__ float tanh_fast_(float x) {
     const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * ax) + 1.f);
     return copysignf(t, x);
 }
+// The workgroup barrier of a recurrence step orders LDS traffic only: wait for this wave's LDS operations and join.
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+// Results leave through a WRITER wave.  gfx950 retires a wave's loads and stores through one in-order counter: a compute wave that
+// stores its step's results waits, at its next counted wait for a prefetched input, for those stores to be acknowledged by memory as
+// well (measured: 5 result stores per step cost the forward walk 33 us of 90, the backward walk 56 us of 165).  So the compute waves
+// put a step's results into an LDS staging image next to the state image (same barrier), and wave 4 -- which never waits for
+// memory -- copies the image of step t to HBM in 1 KiB pieces while the compute waves are in step t + 1.  Rows of the staging image
+// are padded to 16 * odd bytes (mod 256): b128 accesses of 16 lanes with different rows fall on different banks.
+constexpr int GRU_COMPUTE_WAVES = 4, GRU_THREADS = (GRU_COMPUTE_WAVES + 1) * 64;
+// piece i (1 KiB) of a [16, ROWF] f32 tile, lane l: the lane's 16 bytes lie in row (1024 i + 16 l) / (4 ROWF) at byte column (..) % (4 ROWF)
+template <int ROWF>
+__device__ __forceinline__ void piece_rc(int i, int lane, int& row, int& colf) {
+    const int off = 1024 * i + 16 * lane;
+    row = off / (4 * ROWF); colf = (off - row * 4 * ROWF) >> 2;
+}
 __device__ __forceinline__ f32x4 mma16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
 
 // gi [T, G, B, 192], wh [G, 64, 192], bh [G, 192] -> hs [G, T, B, 64]; optional (training) rzn [T, G, B, 192], ghn [T, G, B, 64]
-// One workgroup per (weight set g, 16-row tile), 4 waves; wave ft owns hidden features 16 ft .. 16 ft + 15 of the three gates.
+// One workgroup per (weight set g, 16-row tile), 4 compute waves + the writer; wave ft owns hidden features 16 ft .. 16 ft + 15 of the three gates.
 // Per step: gh^T = W_h^T h^T as 18 v_mfma_f32_16x16x32_f16 (3 gates x 2 K-steps x 3 split products; the W_h slice stays in
 // registers as hi / lo fragments for all T), lane-local gate arithmetic, and the new state goes to the other waves through a
 // double-buffered LDS image that already holds the hi / lo f16 terms (one barrier per step; each lane splits only its own 4 values).
 // B is a multiple of 16 (the host pads): no row predicate and no branch inside the steps, so that the compiler's vmcnt accounting
-// stays exact and the prefetched loads are never waited for together with younger stores.
+// stays exact.
 // Where the input-side projections (forward) / their gradients (backward) live: up to 4 separately allocated parts of G / n_parts
 // weight sets each.  Time-major [T, G, B, 192] (one part) is t_stride = G B 192, set_stride = B 192; the per-agent affine layers'
 // own output [sets, T, B, 192] (set-major) is set_stride = T B 192, t_stride = B 192 -- the learner hands its four projection outputs
@@ -65,17 +85,47 @@ __device__ __forceinline__ float* gru_part_base(const GruParts& P, int g) {
     return b + (size_t)(g - part * P.spp) * P.set_stride;
 }
 
+constexpr int FST = 324;            // staging row stride (floats): [hs 64 | r 64 | z 64 | n 64 | gh_n 64] + pad, 1296 B = 16 * 81
 template <bool TRAIN>
-__global__ __launch_bounds__(256) void k_gru_seq_fwd(const GruParts gi, const float* __restrict__ wh, const float* __restrict__ bh,
-                                                     float* __restrict__ hs, float* __restrict__ rzn, float* __restrict__ ghn, int T, int G,
-                                                     int B, int tiles, int32_t* __restrict__ err) {
+__global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_fwd(const GruParts gi, const float* __restrict__ wh, const float* __restrict__ bh,
+                                                             float* __restrict__ hs, float* __restrict__ rzn, float* __restrict__ ghn, int T, int G,
+                                                             int B, int tiles, int32_t* __restrict__ err) {
     __shared__ __attribute__((aligned(16))) _Float16 hx[2][2][16][HSH];   // [buffer][term][row][feature]
+    __shared__ __attribute__((aligned(16))) float st[2][16][FST];         // [buffer][row][staged results of the step]
     const int tid = threadIdx.x, lane = tid & 63, ft = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 15, q = lane >> 4;
     const int g = blockIdx.x / tiles, tile = blockIdx.x - g * tiles;
+    if (ft == GRU_COMPUTE_WAVES) {                                     // the writer wave
+        float* hs_t = hs + (((size_t)g * T) * B + tile * 16) * GH + 4 * lane;          // + t * B * GH
+        float* rzn_t = TRAIN ? rzn + ((size_t)g * B + tile * 16) * G3 + 4 * lane : nullptr;   // + t * G * B * G3
+        float* ghn_t = TRAIN ? ghn + ((size_t)g * B + tile * 16) * GH + 4 * lane : nullptr;   // + t * G * B * GH
+        for (int t = 0; t < T; ++t) {
+            lds_barrier();                                             // the step's image is complete
+            const float* im = &st[t & 1][0][0];
+            f32x4 vh[4], vr[TRAIN ? 12 : 1], vn[TRAIN ? 4 : 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { int r, c; piece_rc<GH>(i, lane, r, c); vh[i] = *reinterpret_cast<const f32x4*>(im + r * FST + c); }
+            if constexpr (TRAIN) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) { int r, c; piece_rc<G3>(i, lane, r, c); vr[i] = *reinterpret_cast<const f32x4*>(im + r * FST + GH + c); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { int r, c; piece_rc<GH>(i, lane, r, c); vn[i] = *reinterpret_cast<const f32x4*>(im + r * FST + 4 * GH + c); }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(hs_t + (size_t)t * B * GH + 256 * i) = vh[i];
+            if constexpr (TRAIN) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) *reinterpret_cast<f32x4*>(rzn_t + (size_t)t * G * B * G3 + 256 * i) = vr[i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(ghn_t + (size_t)t * G * B * GH + 256 * i) = vn[i];
+            }
+        }
+        return;
+    }
+    const int m = lane & 15, q = lane >> 4;
     const int row = tile * 16 + m, rc = row;
     // resident A fragments: lane (q, m) = output feature gate * 64 + 16 ft + m, reduction indices k = 32 s + 8 q + j
     u32x4 ah[3][2], al[3][2];
+    bool out_of_range = false;                                        // ONE test after the 48 loads: a branch per value made each load wait for the one before (14 us)
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
@@ -84,20 +134,20 @@ __global__ __launch_bounds__(256) void k_gru_seq_fwd(const GruParts gi, const fl
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float w = wh[((size_t)g * GH + 32 * s + 8 * q + j) * G3 + gate * GH + 16 * ft + m] * GRU_WS;
-                if (!(fabsf(w) <= F16_MAX) && err) atomicOr(err, ERR_F16_RANGE);      // |W_h| >= 1 023.5 (or NaN): outside the split's range; |h| < 1 needs no check
+                out_of_range |= !(fabsf(w) <= F16_MAX);                // |W_h| >= 1 023.5 (or NaN): outside the split's range; |h| < 1 needs no check
                 h[j] = (_Float16)w; l[j] = (_Float16)(w - (float)h[j]);
             }
             ah[gate][s] = __builtin_bit_cast(u32x4, h); al[gate][s] = __builtin_bit_cast(u32x4, l);
         }
+    if (out_of_range && err) atomicOr(err, ERR_F16_RANGE);
     f32x4 bias[3];
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) bias[gate] = *reinterpret_cast<const f32x4*>(bh + (size_t)g * G3 + gate * GH + 16 * ft + 4 * q);
     const int fo = 16 * ft + 4 * q;                                   // this lane's 4 features
     f32x4 hown = {0.f, 0.f, 0.f, 0.f};                                // h_{t-1}[row m][fo .. fo + 3]
     u32x4 xh[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, xl[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};   // B operand: h_0 = 0
-    // The step's input-side projections are requested PF steps ahead.  gfx950 retires loads and stores through one in-order
-    // counter (vmcnt): a load issued after a step's result stores cannot be waited for before those stores have completed, so with
-    // a distance of one step the recurrence would wait for every step's stores; at PF steps the stores have long landed.
+    // The step's input-side projections are requested PF steps ahead; the compute waves issue no stores, so a counted wait for a
+    // prefetched projection waits for nothing younger.
     constexpr int PF = 4;
     f32x4 gbuf[PF][3];
     const float* gbase = gru_part_base(gi, g) + (size_t)rc * G3 + fo;
@@ -109,7 +159,6 @@ __global__ __launch_bounds__(256) void k_gru_seq_fwd(const GruParts gi, const fl
     for (int d = 0; d < PF; ++d)
         if (d < T) load_gi(d, gbuf[d]);
     auto step = [&](int t, f32x4 (&gb)[3]) {
-        const size_t tr = ((size_t)t * G + g) * B + rc;                // row of the [T, G, B, .] tensors
         const f32x4 gr = gb[0], gz = gb[1], gn = gb[2];
         if (t + PF < T) load_gi(t + PF, gb);
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -141,13 +190,15 @@ __global__ __launch_bounds__(256) void k_gru_seq_fwd(const GruParts gi, const fl
             *reinterpret_cast<u32x2*>(&hx[t & 1][0][m][fo]) = __builtin_bit_cast(u32x2, h);
             *reinterpret_cast<u32x2*>(&hx[t & 1][1][m][fo]) = __builtin_bit_cast(u32x2, l);
         }
-        *reinterpret_cast<f32x4*>(hs + (((size_t)g * T + t) * B + row) * GH + fo) = hn;
-        if constexpr (TRAIN) {
-            float* s = rzn + tr * G3 + fo;
-            *reinterpret_cast<f32x4*>(s) = rg; *reinterpret_cast<f32x4*>(s + GH) = zg; *reinterpret_cast<f32x4*>(s + 2 * GH) = ng;
-            *reinterpret_cast<f32x4*>(ghn + tr * GH + fo) = an;
+        {   // results of the step -> staging image (the writer wave takes them to hs / rzn / ghn)
+            float* o = &st[t & 1][m][fo];
+            *reinterpret_cast<f32x4*>(o) = hn;
+            if constexpr (TRAIN) {
+                *reinterpret_cast<f32x4*>(o + GH) = rg; *reinterpret_cast<f32x4*>(o + 2 * GH) = zg; *reinterpret_cast<f32x4*>(o + 3 * GH) = ng;
+                *reinterpret_cast<f32x4*>(o + 4 * GH) = an;
+            }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             xh[s] = *reinterpret_cast<const u32x4*>(&hx[t & 1][0][m][32 * s + 8 * q]);
@@ -183,16 +234,39 @@ __device__ __forceinline__ void split3(float x, __bf16& t1, __bf16& t2, __bf16& 
     t3 = (__bf16)r2;
 }
 
-__global__ __launch_bounds__(256) void k_gru_seq_bwd(const float* __restrict__ dhs, const float* __restrict__ hs, const float* __restrict__ rzn,
-                                                     const float* __restrict__ ghn, const float* __restrict__ wh, const GruParts d_gi,
-                                                     float* __restrict__ dgh, float* __restrict__ d_bh_part, int T, int G, int B, int tiles) {
-    __shared__ __attribute__((aligned(16))) __bf16 dgb[2][3][16][DSB];   // dL/dgh of the step: [buffer][term][row][192]
+constexpr int BST = 260;            // staging row stride (floats): [d_r 64 | d_z 64 | d_n 64 | d_hn 64] + pad, 1040 B = 16 * 65
+constexpr int GRU_BWD_LDS = 2 * 3 * 16 * DSB * 2 + 2 * 16 * BST * 4;   // bf16 operand image + f32 staging image: 71 680 B (dynamic)
+__global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_bwd(const float* __restrict__ dhs, const float* __restrict__ hs, const float* __restrict__ rzn,
+                                                             const float* __restrict__ ghn, const float* __restrict__ wh, const GruParts d_gi,
+                                                             float* __restrict__ dgh, float* __restrict__ d_bh_part, int T, int G, int B, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gru_lds[];
+    __bf16 (*dgb)[3][16][DSB] = reinterpret_cast<__bf16 (*)[3][16][DSB]>(gru_lds);                    // dL/dgh of the step: [buffer][term][row][192]
+    float (*st)[16][BST] = reinterpret_cast<float (*)[16][BST]>(gru_lds + 2 * 3 * 16 * DSB * 2);         // [buffer][row][staged results of the step]
     const int tid = threadIdx.x, lane = tid & 63, ft = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 15, q = lane >> 4;
     const int g = blockIdx.x / tiles, tile = blockIdx.x - g * tiles;
+    if (ft == GRU_COMPUTE_WAVES) {                                     // the writer wave (see k_gru_seq_fwd)
+        float* dgi_t = gru_part_base(d_gi, g) + (size_t)tile * 16 * G3 + 4 * lane;        // + t * t_stride
+        float* dgh_t = dgh + (((size_t)g * T) * B + tile * 16) * G3 + 4 * lane;           // + t * B * G3
+        for (int t = T - 1; t >= 0; --t) {
+            lds_barrier();
+            const float* im = &st[t & 1][0][0];
+            f32x4 vg[12], vh[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                int r, c; piece_rc<G3>(i, lane, r, c);
+                vg[i] = *reinterpret_cast<const f32x4*>(im + r * BST + c);                              // d_r | d_z | d_n
+                vh[i] = *reinterpret_cast<const f32x4*>(im + r * BST + c + (c >= 2 * GH ? GH : 0));     // d_r | d_z | d_hn
+            }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) *reinterpret_cast<f32x4*>(dgi_t + (size_t)t * d_gi.t_stride + 256 * i) = vg[i];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) *reinterpret_cast<f32x4*>(dgh_t + (size_t)t * B * G3 + 256 * i) = vh[i];
+        }
+        return;
+    }
+    const int m = lane & 15, q = lane >> 4;
     const int row = tile * 16 + m, rc = row;                          // B is a multiple of 16 (the host pads): see k_gru_seq_fwd
     const int fo = 16 * ft + 4 * q;
-    float* dgbase = gru_part_base(d_gi, g) + (size_t)row * G3 + fo;
     // resident A fragments of W_h: lane (q, m) = hidden feature 16 ft + m, reduction indices (gate outputs) k = 32 s + 8 q + j
     u32x4 wa[6][3];
 #pragma unroll
@@ -208,9 +282,8 @@ __global__ __launch_bounds__(256) void k_gru_seq_bwd(const float* __restrict__ d
     }
     f32x4 dbh[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 carry = {0.f, 0.f, 0.f, 0.f};                                // dL/dh_t arriving from step t + 1
-    // everything a step reads from global memory is requested PF steps ahead (see k_gru_seq_fwd: one in-order counter for loads and
-    // stores)
-    constexpr int PF = 4;
+    // everything a step reads from global memory is requested PF steps ahead; the compute waves issue no stores (see k_gru_seq_fwd)
+    constexpr int PF = 2;                                              // 2 steps ~ 2 us ahead; 4 would need 48 more registers than the 256 a wave has when 5 waves share 4 SIMDs
     struct StepIn { f32x4 dout, rg, zg, ng, gn, hprev; };
     auto load_step = [&](int t, StepIn& in) {
         const size_t tr = ((size_t)t * G + g) * B + rc;
@@ -251,14 +324,13 @@ __global__ __launch_bounds__(256) void k_gru_seq_bwd(const float* __restrict__ d
                 *reinterpret_cast<u32x2*>(&dgb[pb][2][m][gate * GH + fo]) = __builtin_bit_cast(u32x2, t3);
             }
         }
-        {
-            float* o = dgbase + (size_t)t * d_gi.t_stride;
+        {   // the step's results -> staging image (the writer wave takes them to d_gi and dgh)
+            float* o = &st[pb][m][fo];
             *reinterpret_cast<f32x4*>(o) = d_r; *reinterpret_cast<f32x4*>(o + GH) = d_z; *reinterpret_cast<f32x4*>(o + 2 * GH) = d_n;
-            float* o2 = dgh + (((size_t)g * T + t) * B + row) * G3 + fo;
-            *reinterpret_cast<f32x4*>(o2) = d_r; *reinterpret_cast<f32x4*>(o2 + GH) = d_z; *reinterpret_cast<f32x4*>(o2 + 2 * GH) = d_hn;
+            *reinterpret_cast<f32x4*>(o + 3 * GH) = d_hn;
         }
         dbh[0] += d_r; dbh[1] += d_z; dbh[2] += d_hn;
-        __syncthreads();
+        lds_barrier();
         // dL/dh_{t-1}, matrix part: D[feature 16 ft + 4 q + reg][row m] = sum_k W_h[feature][k] dL/dgh[row][k]; partial products by
         // order of magnitude into three accumulators (smallest first when they are added)
         f32x4 a3 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -311,14 +383,20 @@ void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* 
     const int tiles = (B + 15) / 16;
     const GruParts P = gru_parts(const_cast<float* const*>(reinterpret_cast<const float* const*>(gi_parts)), n_parts, T, G, B);
     int32_t* err = numeric_err_word();
-    if (rzn) hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(G * tiles), dim3(256), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles, err);
-    else hipLaunchKernelGGL(k_gru_seq_fwd<false>, dim3(G * tiles), dim3(256), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles, err);
+    if (rzn) hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(G * tiles), dim3(GRU_THREADS), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles, err);
+    else hipLaunchKernelGGL(k_gru_seq_fwd<false>, dim3(G * tiles), dim3(GRU_THREADS), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles, err);
 }
 void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* const* d_gi_parts,
                         int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s) {
     const int tiles = (B + 15) / 16;
     const GruParts P = gru_parts(d_gi_parts, n_parts, T, G, B);
-    hipLaunchKernelGGL(k_gru_seq_bwd, dim3(G * tiles), dim3(256), 0, s, dhs, hs, rzn, ghn, wh, P, dgh, d_bh_part, T, G, B, tiles);
+    static bool attr_done_dev[64] = {};                                // the attribute is per device
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done_dev[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_seq_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, GRU_BWD_LDS);
+        attr_done_dev[dev] = true;                                     // a refused attribute shows as a launch error (ssd_poll_error / hipGetLastError)
+    }
+    hipLaunchKernelGGL(k_gru_seq_bwd, dim3(G * tiles), dim3(GRU_THREADS), GRU_BWD_LDS, s, dhs, hs, rzn, ghn, wh, P, dgh, d_bh_part, T, G, B, tiles);
     // dL/dW_h[g] = sum_{t >= 1, b} h_{t-1}[b]^T dL/dgh_t[b]: rows (t, b) of hs [G, T, B, 64] against rows (t + 1, b) of dgh [G, T, B, 192] --
     // the x^T g role of the per-agent-layer kernel (csrc/ssd_bmm.hip: K = (T - 1) B rows split over 16 waves per tile, exact f32)
     if (T > 1) launch_bias_bmm_bwd(dgh + (size_t)B * G3, hs, nullptr, nullptr, d_wh, nullptr, nullptr, G, (T - 1) * B, GH, G3, s, (long)T * B * GH, (long)T * B * G3);
