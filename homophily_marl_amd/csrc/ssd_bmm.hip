@@ -28,6 +28,11 @@ struct BmmK {
     long x_set, g_set;         // elements between two weight sets of x / g (default R * I, R * O; larger when the rows are a slice)
 };
 
+// base[idx] with the BYTE offset formed in 32 bits: the load takes the uniform base from scalar registers and one VGPR of offset
+// (no 64-bit multiply-add per lane, and no load destination doubling as the dead half of a 64-bit address temporary)
+__device__ __forceinline__ float ld32(const float* base, uint32_t idx) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(base) + (size_t)(idx * 4u));
+}
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // 4 consecutive floats p[k0 .. k0 + 3] of a row of `len` floats; elements at or past len read as 0
@@ -43,7 +48,9 @@ __device__ __forceinline__ f32x4 load4(const float* p, int k0, int len) {
 // y[g][row][o] = b[g][o] + sum_i x[g][row][i] w[g][i][o].  A wave owns one unit = (16-row tile, group of up to BMM_TPW output tiles);
 // units are dealt to the waves of the grid in order (grid (ceil(units / 4), n), 256 threads).  D[row 4 q + r][col m]; K-step
 // (chunk c, r) uses k = 16 c + 4 q + r for lane quarter q.
+// XV: I is a multiple of 4, a lane's four x values of a chunk come as one 16-byte load (no chunk straddles the end of a row).
 constexpr int BMM_TPW = 3;                      // output tiles per wave
+template <bool XV>
 __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, q = lane >> 4;
@@ -53,7 +60,8 @@ __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
     if (unit >= rtiles * groups) return;
     const int g = blockIdx.y, row0 = (unit / groups) * 16, t0 = (unit % groups) * BMM_TPW;
     const int rowc = row0 + m < R ? row0 + m : R - 1;
-    const float* xr = a.x + ((size_t)g * R + rowc) * I;
+    const float* xs = a.x + (size_t)g * R * I;                        // the weight set's rows (uniform); this lane's row starts at xrow
+    const uint32_t xrow = (uint32_t)rowc * (uint32_t)I;
     const float* wg = a.w + (size_t)g * I * O;
     f32x4 acc[BMM_TPW];
 #pragma unroll
@@ -62,23 +70,51 @@ __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
         const float bv = (t0 + t < otiles && o < O) ? a.b[(size_t)g * O + o] : 0.f;
         acc[t] = f32x4{bv, bv, bv, bv};
     }
+    // Loads never branch (a predicated load makes hipcc wait for everything in flight where the branch joins): addresses are clamped
+    // into the operand and the value is masked when it is used; chunk c + 1 is requested before chunk c is multiplied.
     const int chunks = (I + 15) >> 4;
-    for (int c = 0; c < chunks; ++c) {
+    int oc[BMM_TPW]; bool on[BMM_TPW];
+#pragma unroll
+    for (int t = 0; t < BMM_TPW; ++t) {
+        const int o = 16 * (t0 + t) + m;
+        on[t] = t0 + t < otiles && o < O; oc[t] = on[t] ? o : 0;
+    }
+    struct Chunk { float x[4]; float w[BMM_TPW][4]; };
+    auto fetch = [&](int c, Chunk& d) {
         const int k0 = 16 * c + 4 * q;
-        const f32x4 xa = load4(xr, k0, I);
-        float bs[BMM_TPW][4];
+        if constexpr (XV) {
+            const f32x4 v = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const uint8_t*>(xs) + (size_t)((xrow + (uint32_t)(k0 < I ? k0 : I - 4)) * 4u));
 #pragma unroll
-        for (int t = 0; t < BMM_TPW; ++t) {
-            const int o = 16 * (t0 + t) + m;
-            const bool on = t0 + t < otiles && o < O;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bs[t][r] = (on && k0 + r < I) ? wg[(size_t)(k0 + r) * O + o] : 0.f;
+            for (int r = 0; r < 4; ++r) d.x[r] = v[r];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+            const int k = k0 + r < I ? k0 + r : I - 1;
+            if constexpr (!XV) d.x[r] = ld32(xs, xrow + (uint32_t)k);
+#pragma unroll
+            for (int t = 0; t < BMM_TPW; ++t) d.w[t][r] = ld32(wg, (uint32_t)k * (uint32_t)O + (uint32_t)oc[t]);
+        }
+    };
+    auto use = [&](int c, const Chunk& d) {
+        const int k0 = 16 * c + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool kon = k0 + r < I;
+            const float xv = kon ? d.x[r] : 0.f;
 #pragma unroll
             for (int t = 0; t < BMM_TPW; ++t)
-                if (t0 + t < otiles) acc[t] = mfma4(xa[r], bs[t][r], acc[t]);
+                if (t0 + t < otiles) acc[t] = mfma4(xv, (kon && on[t]) ? d.w[t][r] : 0.f, acc[t]);
+        }
+    };
+    Chunk ca, cb;
+    fetch(0, ca);
+    for (int c = 0; c < chunks; c += 2) {
+        if (c + 1 < chunks) fetch(c + 1, cb);
+        use(c, ca);
+        if (c + 1 < chunks) {
+            if (c + 2 < chunks) fetch(c + 2, ca);
+            use(c + 1, cb);
+        }
     }
 #pragma unroll
     for (int t = 0; t < BMM_TPW; ++t) {
@@ -92,11 +128,13 @@ __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
     }
 }
 
-// One launch, grid (DX + DW, n): blocks [0, DX) compute dx = g w^T, one unit = (16-row tile, 16-input tile) per wave, units dealt to
-// the waves in order; blocks [DX, DX + DW) compute one 16 x 16 tile of dw = x^T g (rows of the batch = K, a sixteenth per wave,
-// partials added in LDS in wave order) and, for input tile 0, the matching 16 entries of db = column sums of g.
+// One launch, grid (DW + DX, n): blocks [0, DW) compute one 16 x 16 tile of dw = x^T g (rows of the batch = K, a sixteenth per wave,
+// partials added in LDS in wave order) and, for input tile 0, the matching 16 entries of db = column sums of g -- the long chains
+// of the launch (up to 127 K-steps of 4 rows per wave), so they are dispatched first; blocks [DW, DW + DX) compute dx = g w^T, one
+// unit = (16-row tile, 16-input tile) per wave, units dealt to the waves in order.
 constexpr int BMM_BWD_WAVES = 16;               // the row axis (K of dw: up to T B n = 8080 rows) is split 16 ways
-__global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int dx_blocks) {
+template <bool OV>                              // O is a multiple of 4: 16-byte operand loads along the output axis in the dx part
+__global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int dw_blocks) {
     __shared__ f32x4 red[BMM_BWD_WAVES][64];
     __shared__ float redb[BMM_BWD_WAVES][16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -105,20 +143,45 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
     const int R = a.R, I = a.I, O = a.O;
     const int itiles = (I + 15) >> 4, otiles = (O + 15) >> 4;
     const float* gg = a.g + (size_t)g * a.g_set;
-    if ((int)blockIdx.x < dx_blocks) {
-        const int unit = blockIdx.x * BMM_BWD_WAVES + wave, rtiles = (R + 15) >> 4;
+    if ((int)blockIdx.x >= dw_blocks) {
+        const int unit = (blockIdx.x - dw_blocks) * BMM_BWD_WAVES + wave, rtiles = (R + 15) >> 4;
         if (unit >= rtiles * itiles) return;
         const int row0 = (unit / itiles) * 16, i = 16 * (unit % itiles) + m;
         const int rowc = row0 + m < R ? row0 + m : R - 1;
-        const float* gr = gg + (size_t)rowc * O;
-        const float* wr = a.w + ((size_t)g * I + (i < I ? i : I - 1)) * O;
+        const float* ws = a.w + (size_t)g * I * O;
+        const uint32_t grow = (uint32_t)rowc * (uint32_t)O, wrow = (uint32_t)(i < I ? i : I - 1) * (uint32_t)O;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int chunks = (O + 15) >> 4;
-        for (int c = 0; c < chunks; ++c) {
-            const int k0 = 16 * c + 4 * q;                             // reduction index = output feature
-            const f32x4 ga = load4(gr, k0, O), wb = load4(wr, k0, O);
+        // reduction index = output feature; branch-free loads (clamped, masked at use), chunk c + 1 requested before chunk c is used
+        struct Pair { f32x4 g, w; };
+        auto fetch = [&](int c, Pair& d) {
+            const int k0 = 16 * c + 4 * q;
+            if constexpr (OV) {
+                const uint32_t kb = (uint32_t)(k0 < O ? k0 : O - 4);
+                d.g = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const uint8_t*>(gg) + (size_t)((grow + kb) * 4u));
+                d.w = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const uint8_t*>(ws) + (size_t)((wrow + kb) * 4u));
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = mfma4(ga[r], wb[r], acc);
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t k = (uint32_t)(k0 + r < O ? k0 + r : O - 1);
+                    d.g[r] = ld32(gg, grow + k); d.w[r] = ld32(ws, wrow + k);
+                }
+            }
+        };
+        auto use = [&](int c, const Pair& d) {
+            const int k0 = 16 * c + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const bool on = k0 + r < O; acc = mfma4(on ? d.g[r] : 0.f, on ? d.w[r] : 0.f, acc); }
+        };
+        Pair pa, pb;
+        fetch(0, pa);
+        for (int c = 0; c < chunks; c += 2) {
+            if (c + 1 < chunks) fetch(c + 1, pb);
+            use(c, pa);
+            if (c + 1 < chunks) {
+                if (c + 2 < chunks) fetch(c + 2, pa);
+                use(c + 1, pb);
+            }
         }
         if (i < I) {
 #pragma unroll
@@ -134,7 +197,7 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
         return;
     }
     // ---- dw / db: tile (it, ot); this wave's rows: part `wave` of the steps of 4 rows ----------------------------------------
-    const int tile = blockIdx.x - dx_blocks, it = tile / otiles, ot = tile - it * otiles;
+    const int tile = blockIdx.x, it = tile / otiles, ot = tile - it * otiles;
     const int i = 16 * it + m, o = 16 * ot + m;
     const bool ion = i < I, oon = o < O;
     const float* xg = a.x + (size_t)g * a.x_set;
@@ -142,25 +205,38 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
     const int s0 = wave * per, s1 = s0 + per < steps ? s0 + per : steps;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-    constexpr int UN = 4;
-    int s = s0;
-    for (; s + UN <= s1; s += UN) {
-        float av[UN], bv[UN];
+    // 2 x UN steps of operands in flight: the chain is load latency, not arithmetic.  Clamped addresses, values masked at use (no
+    // branch around a load); the order of the additions is the step order, as before.
+    constexpr int UN = 8;
+    const uint32_t icol = ion ? i : I - 1, ocol = oon ? o : O - 1;
+    auto fetch = [&](int s, float (&av)[UN], float (&bv)[UN]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int row = 4 * (s + u) + q;
-            const bool rv = row < R;
-            av[u] = (rv && ion) ? xg[(size_t)row * I + i] : 0.f;
-            bv[u] = (rv && oon) ? gg[(size_t)row * O + o] : 0.f;
+            const int su = s + u < s1 ? s + u : s1 - 1;                 // past the wave's part: its last step again (the same cache lines)
+            const int row = 4 * su + q;
+            const uint32_t rc = row < R ? row : R - 1;
+            av[u] = ld32(xg, rc * (uint32_t)I + icol);
+            bv[u] = ld32(gg, rc * (uint32_t)O + ocol);
         }
+    };
+    auto use = [&](int s, const float (&av)[UN], const float (&bv)[UN]) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) { acc = mfma4(av[u], bv[u], acc); bsum += bv[u]; }
-    }
-    for (; s < s1; ++s) {
-        const int row = 4 * s + q;
-        const bool rv = row < R;
-        const float av = (rv && ion) ? xg[(size_t)row * I + i] : 0.f, bv = (rv && oon) ? gg[(size_t)row * O + o] : 0.f;
-        acc = mfma4(av, bv, acc); bsum += bv;
+        for (int u = 0; u < UN; ++u) {
+            const bool rv = 4 * (s + u) + q < R && s + u < s1;
+            const float x = (rv && ion) ? av[u] : 0.f, gv = (rv && oon) ? bv[u] : 0.f;
+            acc = mfma4(x, gv, acc); bsum += gv;
+        }
+    };
+    float a0[UN], b0[UN], a1[UN], b1[UN];
+    if (s0 < s1) fetch(s0, a0, b0);
+    for (int s = s0; s < s1; s += 2 * UN) {
+        const bool second = s + UN < s1;
+        if (second) fetch(s + UN, a1, b1);
+        use(s, a0, b0);
+        if (second) {
+            if (s + 2 * UN < s1) fetch(s + 2 * UN, a0, b0);
+            use(s + UN, a1, b1);
+        }
     }
     bsum += __shfl_xor(bsum, 16); bsum += __shfl_xor(bsum, 32);        // the four row quarters of a step
     red[wave][lane] = acc;
@@ -190,7 +266,9 @@ int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y
     BmmK k = {};
     k.x = x; k.w = w; k.b = b; k.y = y; k.n = n; k.R = R; k.I = I; k.O = O;
     const int otiles = (O + 15) / 16, units = ((R + 15) / 16) * ((otiles + BMM_TPW - 1) / BMM_TPW);
-    hipLaunchKernelGGL(k_bias_bmm_fwd, dim3((units + 3) / 4, n), dim3(256), 0, s, k);
+    if ((long)I * O >= (1L << 30) || (long)R * I >= (1L << 30)) return -2;        // 32-bit byte offsets inside a weight set
+    if ((I & 3) == 0) hipLaunchKernelGGL(k_bias_bmm_fwd<true>, dim3((units + 3) / 4, n), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL(k_bias_bmm_fwd<false>, dim3((units + 3) / 4, n), dim3(256), 0, s, k);
     return 0;
 }
 
@@ -202,7 +280,9 @@ int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* d
     const int dxb = dx ? (((R + 15) / 16) * ((I + 15) / 16) + BMM_BWD_WAVES - 1) / BMM_BWD_WAVES : 0;
     const int dwb = (dw || db) ? ((I + 15) / 16) * ((O + 15) / 16) : 0;
     if (dxb + dwb == 0) return 0;
-    hipLaunchKernelGGL(k_bias_bmm_bwd, dim3(dxb + dwb, n), dim3(BMM_BWD_WAVES * 64), 0, s, k, dxb);
+    if ((long)R * I >= (1L << 30) || (long)R * O >= (1L << 30)) return -2;       // 32-bit byte offsets inside a weight set
+    if ((O & 3) == 0) hipLaunchKernelGGL(k_bias_bmm_bwd<true>, dim3(dwb + dxb, n), dim3(BMM_BWD_WAVES * 64), 0, s, k, dwb);
+    else hipLaunchKernelGGL(k_bias_bmm_bwd<false>, dim3(dwb + dxb, n), dim3(BMM_BWD_WAVES * 64), 0, s, k, dwb);
     return 0;
 }
 
