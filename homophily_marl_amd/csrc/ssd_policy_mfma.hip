@@ -157,11 +157,16 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
 #endif
 }
+// The progress word is accessed as an LDS word (ds_write_b32 / ds_read_b32).  Through a generic pointer the same accesses are FLAT
+// instructions, which count in vmcnt as well: the loader's volatile store was followed by s_waitcnt vmcnt(0) -- every publish waited for
+// ALL chunks in flight, so behind the first burst the image came in one chunk at a time -- and a compute wave's poll waited for its
+// own outstanding global loads.
+using lds_u32 = __attribute__((address_space(3))) uint32_t;
 constexpr int STREAM_AHEAD = 6;                // chunks in flight behind the one being waited for (x 8 pieces < the 64 vmcnt can count)
 constexpr int head_lds_bytes(int waves, int prec) { return SSD_POLICY_IMAGE_BYTES(prec) + waves * SCRATCH * 4 + 16; }
 // the loader wave's whole program: LDS image = the global image, piece for piece (chunk j at byte 8192 j, the resident chunk last)
 template <int PREC>
-__device__ __forceinline__ void stream_image(const uint8_t* src_lane, uint32_t lds_dst, volatile uint32_t* landed) {
+__device__ __forceinline__ void stream_image(const uint8_t* src_lane, uint32_t lds_dst, volatile lds_u32* landed) {
     constexpr int NK = stream_chunks<PREC>(), NC = NK + 1;            // + the resident chunk, requested FIRST (fc1's biases are in it)
     auto issue = [&](int k) {                                          // k-th request: resident chunk, then stream chunks 0 .. NK - 1
         const int j = k == 0 ? NK : k - 1;
@@ -185,7 +190,7 @@ __device__ __forceinline__ void stream_image(const uint8_t* src_lane, uint32_t l
 }
 // a compute wave, before the first read of K-step C's chunk j: the loader must have published `landed` > j (chunks 0 .. j readable;
 // seen caches the last value read, so a wave that runs behind the stream reads the word once)
-template <int PREC, int C> __device__ __forceinline__ void chunk_ready(volatile const uint32_t* landed, uint32_t& seen) {
+template <int PREC, int C> __device__ __forceinline__ void chunk_ready(volatile const lds_u32* landed, uint32_t& seen) {
     constexpr int first_piece = step_piece<PREC>(C, 0, 0), j = first_piece >> 3;
     if constexpr ((first_piece & 7) == 0) {
         while (seen <= (uint32_t)j) {
@@ -452,7 +457,7 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
     int tile = wave < WAVES ? wave * a.bpa + bia : tiles;              // consecutive tiles go to different CUs; the loader has none
     TileIn<INC> in;
     // LDS: the image (as in global memory) | per-wave scratch | the loader's progress word
-    volatile uint32_t* landed = reinterpret_cast<volatile uint32_t*>(lds_raw + IMAGE_BYTES + WAVES * SCRATCH * 4);
+    volatile lds_u32* landed = (volatile lds_u32*)(lds_raw + IMAGE_BYTES + WAVES * SCRATCH * 4);      // generic -> LDS address space
     if (wave == WAVES) *landed = 0u;                                   // LDS holds garbage at launch: the word is valid behind this barrier
     __builtin_amdgcn_s_barrier();                                      // (the only one: every wave is still at its first instructions)
     if (wave == WAVES) {                                               // the loader wave: nothing but the image stream
@@ -1147,6 +1152,11 @@ __device__ __forceinline__ void encode_body(const EncK& a, uint8_t* lds_raw, con
     };
     u32x4 la[2][PREC], la_next[2][PREC];
     if (u_begin < u_end) load_la(u_begin, la_next);
+    // this lane's conv bias for each channel pair, fetched once: a load per unit at the top of the loop was waited for with vmcnt(0) --
+    // a full L2 latency per unit, and the Linear fragments requested a unit ahead were waited for with it
+    float cbq[3];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) cbq[s3] = a.conv_b[2 * s3 + (q >> 1)] * CS;
 #pragma unroll 1
     for (int u = u_begin; u < u_end; ++u) {
         const int s = u % 3, xtp = (u / 3) % XTP, yl = u / (3 * XTP);  // yl: output row inside the band
@@ -1157,7 +1167,7 @@ __device__ __forceinline__ void encode_body(const EncK& a, uint8_t* lds_raw, con
         if (u + 1 < u_end) load_la(u + 1, la_next);
         f32x4 accc[2][BT];                                             // [position tile of the pair][batch tile]: rows (o2 = q >> 1, 8 positions)
         {
-            const float bq = a.conv_b[2 * s + (q >> 1)] * CS;
+            const float bq = s == 0 ? cbq[0] : (s == 1 ? cbq[1] : cbq[2]);
 #pragma unroll
             for (int bt = 0; bt < BT; ++bt) { accc[0][bt] = f32x4{bq, bq, bq, bq}; accc[1][bt] = f32x4{bq, bq, bq, bq}; }
         }
