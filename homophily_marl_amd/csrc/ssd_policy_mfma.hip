@@ -1058,6 +1058,9 @@ __device__ __forceinline__ void encode_body(const EncK& a, uint8_t* lds_raw, con
         // is written.
         constexpr int NQ = CP / 16, ITEMS = BT * 16 * (R + 2), NT = ENC_WAVES * 64, IPT = (ITEMS + NT - 1) / NT;
         typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+        // (addresses formed as integers: say that they are global, or the loads become FLAT instructions, which count in lgkmcnt too)
+        typedef __attribute__((address_space(1))) u32x4_u gl_u32x4_u;
+        typedef __attribute__((address_space(1))) uint32_t gl_u32;
         u32x4 cw[IPT][NQ];
         const uintptr_t cbase = reinterpret_cast<uintptr_t>(a.codes), cend = cbase + (uintptr_t)a.code_bytes;
 #pragma unroll
@@ -1072,16 +1075,16 @@ __device__ __forceinline__ void encode_body(const EncK& a, uint8_t* lds_raw, con
                 const uintptr_t ptr = cbase + (uintptr_t)((long)b * a.env_stride + t_off + (long)i * a.agent_stride + y * V);
                 if (ptr + 16 * NQ <= cend) {
 #pragma unroll
-                    for (int h = 0; h < NQ; ++h) cw[k][h] = *reinterpret_cast<const u32x4_u*>(ptr + 16 * h);
+                    for (int h = 0; h < NQ; ++h) cw[k][h] = *reinterpret_cast<const gl_u32x4_u*>(ptr + 16 * h);
                 } else {                                               // the last rows of the buffer: aligned dwords that hold readable bytes
                     const uintptr_t al = ptr & ~(uintptr_t)3, lim = (cend + 3) & ~(uintptr_t)3;
-                    uint32_t prev = *reinterpret_cast<const uint32_t*>(al);
+                    uint32_t prev = *reinterpret_cast<const gl_u32*>(al);
 #pragma unroll
                     for (int h = 0; h < NQ; ++h)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const uintptr_t nx = al + 4 * (4 * h + e + 1);
-                            const uint32_t next = nx + 4 <= lim ? *reinterpret_cast<const uint32_t*>(nx) : 0u;
+                            const uint32_t next = nx + 4 <= lim ? *reinterpret_cast<const gl_u32*>(nx) : 0u;
                             cw[k][h][e] = __builtin_amdgcn_alignbyte(next, prev, (uint32_t)(ptr & 3));
                             prev = next;
                         }
