@@ -548,7 +548,8 @@ __device__ __forceinline__ void expand_range(const uint8_t* src, T* out, int q0,
 // FMT: SSD_OBS_F32 / BF16 / U8 (three byte planes per agent) or SSD_OBS_CODE (one class plane per agent)
 // WC: also emit the window as one channel-mask byte per cell (bit 0 R, 1 G, 2 B; simplified palette) into the dense side buffer
 // oo.code -- what the rollout-time encoder reads: one extra LDS byte per cell in the gather, one 16-byte store per lane and agent.
-template <bool FULL, int FMT, bool WC>
+// PMC: the class map already holds SSD_OBS_CODE values (observe_phase wrote them: nothing else reads the map in this call)
+template <bool FULL, int FMT, bool WC, bool PMC = false>
 __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut& oo, const uint8_t* lut) {
     typedef typename std::conditional<FMT == SSD_OBS_F32, float, typename std::conditional<FMT == SSD_OBS_BF16, uint16_t, uint8_t>::type>::type T;
     constexpr bool CODE = FMT == SSD_OBS_CODE;
@@ -598,7 +599,7 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { ok[u] = jv && i + u * rpi < V; cls[u] = E.pm[ok[u] ? sidx + u * sstep : 0]; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) E.pl[ok[u] ? d + u * dstep : dumpc] = (uint8_t)((0x30120u >> (4 * cls[u])) & 0xFu);   // class bit 1 / 2 / 4 -> code 2 / 1 / 3
+                for (int u = 0; u < 4; ++u) E.pl[ok[u] ? d + u * dstep : dumpc] = PMC ? (uint8_t)cls[u] : (uint8_t)((0x30120u >> (4 * cls[u])) & 0xFu);   // class bit 1 / 2 / 4 -> code 2 / 1 / 3
             }
         }
         wsync();
@@ -682,6 +683,7 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
     // return_view's zero padding (utility_funcs.py:93-116), so the window gather needs no bounds test
     for (int i = lane * 16; i < h->PMS; i += kWave * 16) *(uint4*)(E.pm + i) = make_uint4(0, 0, 0, 0);
     wsync();
+    const bool codes_in_map = !FULL && oo.obs && oo.fmt == SSD_OBS_CODE && !oo.state;     // (wave-uniform)
     if (!FULL) {
         // simplified palette: 4 cells per lane and trip, classes by byte-SWAR on the packed cell codes (all codes < 0x80):
         // wall or agent -> 4, apple -> 2, waste (Cleanup) -> 1, else 0
@@ -692,7 +694,9 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
             const uint32_t wo = (((o4 + lo) | ~((g4 ^ 0x01010101u) + lo)) & hi);          // byte != 0 in occ, or code == '@'
             const uint32_t ap = ~((g4 ^ 0x02020202u) + lo) & hi & ~wo;                    // code == 'A', nobody on it
             const uint32_t wa = ~((g4 ^ 0x03030303u) + lo) & waste_on & ~wo;              // code == 'H'
-            const uint32_t cls4 = (wo >> 5) | (ap >> 6) | (wa >> 7);
+            // class bits 4 / 2 / 1, or -- when only the class-code windows read the map -- the codes themselves (3 / 1 / 2): the gather
+            // then copies bytes instead of translating each one
+            const uint32_t cls4 = codes_in_map ? ((wo >> 7) | (wo >> 6) | (ap >> 7) | (wa >> 6)) : ((wo >> 5) | (ap >> 6) | (wa >> 7));
             const int r = (int)udiv((uint32_t)i4, h->magic_W);
             int c = i4 - r * W, d = (r + v) * Wp + c + v;
             // cells past H * W (the grid is padded to 16 bytes with code 0, nobody stands there) have class 0 and land in the
@@ -730,10 +734,12 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
             if (oo.fmt == SSD_OBS_F32) observe_windows<FULL, SSD_OBS_F32, true>(E, env, oo, lut);
             else if (oo.fmt == SSD_OBS_BF16) observe_windows<FULL, SSD_OBS_BF16, true>(E, env, oo, lut);
             else if (oo.fmt == SSD_OBS_U8) observe_windows<FULL, SSD_OBS_U8, true>(E, env, oo, lut);
+            else if (codes_in_map) observe_windows<false, SSD_OBS_CODE, false, true>(E, env, oo, lut);
             else observe_windows<false, SSD_OBS_CODE, false>(E, env, oo, lut);
         } else if (oo.fmt == SSD_OBS_F32) observe_windows<FULL, SSD_OBS_F32, false>(E, env, oo, lut);
         else if (oo.fmt == SSD_OBS_BF16) observe_windows<FULL, SSD_OBS_BF16, false>(E, env, oo, lut);
         else if (oo.fmt == SSD_OBS_U8) observe_windows<FULL, SSD_OBS_U8, false>(E, env, oo, lut);
+        else if (codes_in_map) observe_windows<false, SSD_OBS_CODE, false, true>(E, env, oo, lut);
         else observe_windows<false, SSD_OBS_CODE, false>(E, env, oo, lut);
     }
     STAMP_OBS(9);
