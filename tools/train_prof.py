@@ -12,18 +12,21 @@ th.manual_seed(0)
 ctx = setup(cfg)
 batch = ctx.runner.run(False)
 ctx.buffer.insert_episode_batch(batch)
-sample = ctx.buffer.sample(16)[:, :101]
+# the loop body of run.train_iteration without the rollout: device-side sample straight into the captured step's batch, then train; the
+# learner's episode counter is the number of train calls (schedule_unit "rollouts": target sync every 20 calls)
 for i in range(int(os.environ.get("TRAIN_CALLS", 40))):
     if i == 10:
         th.cuda.synchronize(); t0 = time.perf_counter()
-    ctx.learner.train(sample, 100 * N, i * N)
+    sample = ctx.buffer.sample(16, out=ctx.learner.sample_out())
+    ctx.learner.train(sample, 100 * N, i)
 th.cuda.synchronize()
-print("train: %.2f ms/call" % (1e3 * (time.perf_counter() - t0) / (int(os.environ.get("TRAIN_CALLS", 40)) - 10)), flush=True)
+print("sample + train: %.2f ms/call" % (1e3 * (time.perf_counter() - t0) / (int(os.environ.get("TRAIN_CALLS", 40)) - 10)), flush=True)
 
 if os.environ.get("TORCH_PROFILE"):
     # op-level view of ONE eager step: which aten ops the ~500 launches of a train step come from
     from torch.profiler import profile, ProfilerActivity
     ctx.learner.use_graph = False
+    sample = ctx.buffer.sample(16)
     ctx.learner.cal_loss_and_step(sample)
     th.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
