@@ -166,6 +166,7 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
     if (e == hipSuccess) e = hipMemset(E->st.epoch, 0, N * 4);
     if (e == hipSuccess) e = hipMemset(E->st.err, 0, 4);
     if (e == hipSuccess && !numeric_err_word()) e = hipErrorOutOfMemory;      // exists before anything captures a graph
+    if (e == hipSuccess && !bmm_scratch()) e = hipErrorOutOfMemory;           // (the affine layers' backward scratch: same reason)
     if (e == hipSuccess) {
         // a fresh handle holds the reset image with agents on their spawn cells (the reference constructor
         // also builds agents before the first reset, map_env.py:149)

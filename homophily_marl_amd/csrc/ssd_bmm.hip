@@ -26,7 +26,10 @@ struct BmmK {
     const float* slope_of;     // backward, nullable: dx is multiplied by LeakyReLU'(.) taken from the sign of slope_of[g][row][i]
     int n, R, I, O;
     long x_set, g_set;         // elements between two weight sets of x / g (default R * I, R * O; larger when the rows are a slice)
+    float* part;               // backward with row_chunks > 1: per (set, tile, chunk) partial dw tile [64 lanes x 4] + db [16] (BMM_PART floats)
+    int row_chunks;            // the rows (K of dw) are cut into this many chunks, one workgroup each; k_bmm_dw_reduce adds them in order
 };
+constexpr int BMM_PART = 272;                    // floats per partial record: 256 (dw tile) + 16 (db)
 
 // base[idx] with the BYTE offset formed in 32 bits: the load takes the uniform base from scalar registers and one VGPR of offset
 // (no 64-bit multiply-add per lane, and no load destination doubling as the dead half of a 64-bit address temporary)
@@ -132,6 +135,32 @@ __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
 // partials added in LDS in wave order) and, for input tile 0, the matching 16 entries of db = column sums of g -- the long chains
 // of the launch (up to 127 K-steps of 4 rows per wave), so they are dispatched first; blocks [DW, DW + DX) compute dx = g w^T, one
 // unit = (16-row tile, 16-input tile) per wave, units dealt to the waves in order.
+// A dw tile streams its two 64-byte column slabs of ALL rows through one CU's L1 (the cache-line rate of that L1 is the bound: 22 us
+// for 8 080 rows), and jobs with few tiles (the inc head's [80, 3] layer: 5 tiles x 5 sets) leave most CUs idle.  With row_chunks > 1
+// the rows are cut into chunks, DW = tiles x chunks workgroups write partial tiles, and a second, tiny launch (k_bmm_dw_reduce) adds
+// the chunks in order: deterministic, no hand-off between workgroups of one launch.
+__device__ __forceinline__ int gridDim_tiles(const BmmK& a) { return ((a.I + 15) >> 4) * ((a.O + 15) >> 4); }
+// adds the row chunks of every dw tile in chunk order: grid (tiles, n), one wave
+__global__ __launch_bounds__(64) void k_bmm_dw_reduce(BmmK a) {
+    const int lane = threadIdx.x, m = lane & 15, q = lane >> 4, tile = blockIdx.x, g = blockIdx.y, C = a.row_chunks;
+    const int otiles = (a.O + 15) >> 4, it = tile / otiles, ot = tile - it * otiles, o = 16 * ot + m;
+    const float* P = a.part + ((size_t)((size_t)g * gridDim.x + tile) * C) * BMM_PART;
+    f32x4 sum = *reinterpret_cast<const f32x4*>(P + 4 * lane);
+    float sb = q == 0 ? P[256 + m] : 0.f;
+    for (int c = 1; c < C; ++c) {
+        sum += *reinterpret_cast<const f32x4*>(P + (size_t)c * BMM_PART + 4 * lane);
+        if (q == 0) sb += P[(size_t)c * BMM_PART + 256 + m];
+    }
+    if (o >= a.O) return;
+    if (a.dw) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ii = 16 * it + 4 * q + r;
+            if (ii < a.I) a.dw[((size_t)g * a.I + ii) * a.O + o] = sum[r];
+        }
+    }
+    if (a.db && it == 0 && q == 0) a.db[(size_t)g * a.O + o] = sb;
+}
 constexpr int BMM_BWD_WAVES = 16;               // the row axis (K of dw: up to T B n = 8080 rows) is split 16 ways
 template <bool OV>                              // O is a multiple of 4: 16-byte operand loads along the output axis in the dx part
 __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int dw_blocks) {
@@ -197,12 +226,14 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
         return;
     }
     // ---- dw / db: tile (it, ot); this wave's rows: part `wave` of the steps of 4 rows ----------------------------------------
-    const int tile = blockIdx.x, it = tile / otiles, ot = tile - it * otiles;
+    const int C = a.row_chunks, tile = (int)blockIdx.x / C, chunk = (int)blockIdx.x - tile * C, it = tile / otiles, ot = tile - it * otiles;
     const int i = 16 * it + m, o = 16 * ot + m;
     const bool ion = i < I, oon = o < O;
     const float* xg = a.x + (size_t)g * a.x_set;
-    const int steps = (R + 3) >> 2, per = (steps + BMM_BWD_WAVES - 1) / BMM_BWD_WAVES;
-    const int s0 = wave * per, s1 = s0 + per < steps ? s0 + per : steps;
+    const int steps = (R + 3) >> 2, spc = (steps + C - 1) / C;        // steps of 4 rows; per chunk
+    const int c0 = chunk * spc < steps ? chunk * spc : steps, c1 = c0 + spc < steps ? c0 + spc : steps;
+    const int per = (c1 - c0 + BMM_BWD_WAVES - 1) / BMM_BWD_WAVES;
+    const int s0 = c0 + wave * per < c1 ? c0 + wave * per : c1, s1 = s0 + per < c1 ? s0 + per : c1;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     // 2 x UN steps of operands in flight: the chain is load latency, not arithmetic.  Clamped addresses, values masked at use (no
@@ -246,6 +277,17 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
         f32x4 sum = red[0][lane];
 #pragma unroll
         for (int v = 1; v < BMM_BWD_WAVES; ++v) sum += red[v][lane];
+        if (C > 1) {                                                   // this chunk's partial tile + bias sums; k_bmm_dw_reduce finishes
+            float* P = a.part + ((size_t)((size_t)g * gridDim_tiles(a) + tile) * C + chunk) * BMM_PART;
+            *reinterpret_cast<f32x4*>(P + 4 * lane) = sum;
+            if (q == 0) {
+                float sb = redb[0][m];
+#pragma unroll
+                for (int v = 1; v < BMM_BWD_WAVES; ++v) sb += redb[v][m];
+                P[256 + m] = sb;
+            }
+            return;
+        }
         if (a.dw && oon) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -260,6 +302,21 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
             a.db[(size_t)g * O + o] = sb;
         }
     }
+}
+
+// Scratch of the row-chunked backward (partial dw tiles): one allocation per device, made on the first call outside a stream capture
+// (ssd_create makes it too).  ONE stream at a time may run chunked backward launches of a device (the learner's step is one stream).
+constexpr size_t BMM_SCRATCH_BYTES = 1 << 20;
+float* bmm_scratch() {
+    static float* buf[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!buf[dev]) {
+        float* p = nullptr;
+        if (hipMalloc((void**)&p, BMM_SCRATCH_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // (e.g. inside a capture: unchunked)
+        buf[dev] = p;
+    }
+    return buf[dev];
 }
 
 int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int n, int R, int I, int O, hipStream_t s) {
@@ -278,11 +335,21 @@ int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* d
     k.g = g; k.x = x; k.w = w; k.dx = dx; k.dw = dw; k.db = db; k.slope_of = slope_of; k.n = n; k.R = R; k.I = I; k.O = O;
     k.x_set = x_set ? x_set : (long)R * I; k.g_set = g_set ? g_set : (long)R * O;
     const int dxb = dx ? (((R + 15) / 16) * ((I + 15) / 16) + BMM_BWD_WAVES - 1) / BMM_BWD_WAVES : 0;
-    const int dwb = (dw || db) ? ((I + 15) / 16) * ((O + 15) / 16) : 0;
+    int dwb = (dw || db) ? ((I + 15) / 16) * ((O + 15) / 16) : 0;
     if (dxb + dwb == 0) return 0;
+    // row chunks: only for long row axes (>= 64 steps of 4 rows per wave) whose tiles would leave the chip mostly idle
+    k.row_chunks = 1;
+    const int tiles = dwb;
+    if (dwb && (R + 3) / 4 >= 64 * BMM_BWD_WAVES && dwb * n <= 128) {
+        int c = 256 / (dwb * n);
+        if (c > 8) c = 8;
+        float* part = bmm_scratch();
+        if (c > 1 && part && (size_t)n * dwb * c * BMM_PART * sizeof(float) <= BMM_SCRATCH_BYTES) { k.row_chunks = c; k.part = part; dwb *= c; }
+    }
     if ((long)R * I >= (1L << 30) || (long)R * O >= (1L << 30)) return -2;       // 32-bit byte offsets inside a weight set
     if ((O & 3) == 0) hipLaunchKernelGGL(k_bias_bmm_bwd<true>, dim3(dwb + dxb, n), dim3(BMM_BWD_WAVES * 64), 0, s, k, dwb);
     else hipLaunchKernelGGL(k_bias_bmm_bwd<false>, dim3(dwb + dxb, n), dim3(BMM_BWD_WAVES * 64), 0, s, k, dwb);
+    if (k.row_chunks > 1) hipLaunchKernelGGL(k_bmm_dw_reduce, dim3(tiles, n), dim3(64), 0, s, k);
     return 0;
 }
 
