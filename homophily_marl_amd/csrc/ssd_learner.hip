@@ -372,18 +372,24 @@ __device__ __forceinline__ uint32_t sample_draw(uint32_t s0, uint32_t s1, uint32
     return x;
 }
 __global__ __launch_bounds__(64) void k_sample_ids(uint32_t s0, uint32_t s1, uint32_t call, int population, int count, int64_t* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int i = 0; i < count; ++i) {
-        const int j = population - count + i;
-        const int t = (int)(((uint64_t)sample_draw(s0, s1, call, (uint32_t)i) * (uint32_t)(j + 1)) >> 32);
-        bool taken = false;
-        for (int k = 0; k < i; ++k) taken |= out[k] == (int64_t)t;
-        out[i] = taken ? j : t;
+    // the picks live in LDS while they are compared and swapped (through `out` every pick waited for the stores before it: 15 us for 16 ids)
+    __shared__ int32_t pick[SSD_SAMPLE_IDS_MAX];
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < count; ++i) {
+            const int j = population - count + i;
+            const int t = (int)(((uint64_t)sample_draw(s0, s1, call, (uint32_t)i) * (uint32_t)(j + 1)) >> 32);
+            bool taken = false;
+            for (int k = 0; k < i; ++k) taken |= pick[k] == t;
+            pick[i] = taken ? j : t;
+        }
+        for (int i = count - 1; i > 0; --i) {
+            const int k = (int)(((uint64_t)sample_draw(s0, s1, call, (uint32_t)(count + i)) * (uint32_t)(i + 1)) >> 32);
+            const int32_t a = pick[i]; pick[i] = pick[k]; pick[k] = a;
+        }
     }
-    for (int i = count - 1; i > 0; --i) {
-        const int k = (int)(((uint64_t)sample_draw(s0, s1, call, (uint32_t)(count + i)) * (uint32_t)(i + 1)) >> 32);
-        const int64_t a = out[i]; out[i] = out[k]; out[k] = a;
-    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < count; i += 64) out[i] = (int64_t)pick[i];
 }
 void launch_sample_ids(uint64_t seed, uint32_t call, int population, int count, int64_t* out, hipStream_t stream) {
     hipLaunchKernelGGL(k_sample_ids, dim3(1), dim3(64), 0, stream, (uint32_t)seed, (uint32_t)(seed >> 32), call, population, count, out);

@@ -566,7 +566,8 @@ def test_gru_sequence_kernels_match_the_stepwise_recurrence(T, G, B):
         assert (ops.gru_sequence(gi, wh, bh) - ref).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("n,R,I,O", [(5, 1616, 64, 192), (5, 1616, 73, 64), (5, 333, 64, 9), (3, 8080, 80, 3), (5, 50, 64, 1), (2, 17, 5, 20)])
+@pytest.mark.parametrize("n,R,I,O", [(5, 1616, 64, 192), (5, 1616, 73, 64), (5, 333, 64, 9), (3, 8080, 80, 3), (5, 50, 64, 1), (2, 17, 5, 20),
+                                     (1, 8080, 1014, 32), (5, 8081, 80, 1)])      # the last three long-row shapes take the row-chunked dw (2 launches)
 def test_bias_bmm_kernels_match_baddbmm_autograd(n, R, I, O):
     """ssd_bias_bmm_fwd / _bwd (csrc/ssd_bmm.hip: the learner's per-agent affine layers, exact-f32 MFMAs) against th.baddbmm and
     its autograd at the learner's shapes and at ragged ones (rows, inputs, outputs not multiples of 16)."""
