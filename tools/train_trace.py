@@ -6,7 +6,12 @@ import glob
 import sys
 
 f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[0]
-rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+rows = list(csv.DictReader(open(f)))
+# (--memory-copy-trace: SDMA / blit copies are not kernels; show them in the same timeline)
+for cf in glob.glob(sys.argv[1] + "/**/*memory_copy_trace.csv", recursive=True):
+    for r in csv.DictReader(open(cf)):
+        rows.append(dict(Start_Timestamp=r["Start_Timestamp"], End_Timestamp=r["End_Timestamp"], Kernel_Name="[memory copy] %s" % r.get("Direction", "")))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ends = [i for i, r in enumerate(rows) if "k_clip_adam" in r["Kernel_Name"]]
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else len(ends) - 3
 a, b = ends[skip] + 1, ends[skip + 1] + 1
