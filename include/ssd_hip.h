@@ -394,8 +394,10 @@ int ssd_gru_seq_bwd_parts(const float* dhs, const float* hs, const float* rzn, c
  * th.baddbmm(b, x, w) over the agent axis (homophily_agent.py:154-208: fc1, GRU input projections, dueling heads) and its backward,
  * f32 (exact-f32 MFMAs), contiguous tensors: x [n, rows, in], w [n, in, out], b [n, out], y / g [n, rows, out].
  *   fwd: y = b + x w
- *   bwd: dx = g w^T, dw = x^T g, db = column sums of g; each output nullable (dx needs w, dw / db need x); one launch,
- *        deterministic.  slope_of (nullable, [n, rows, in]): dx is multiplied elementwise by LeakyReLU'(.) taken from
+ *   bwd: dx = g w^T, dw = x^T g, db = column sums of g; each output nullable (dx needs w, dw / db need x); one launch --
+ *        two when a long row axis (>= 4096 rows) meets few dw tiles: the rows are then cut into chunks whose partial tiles a
+ *        second small launch adds in order through a per-device scratch (ONE stream at a time per device) --, deterministic.
+ *        Operand sets of 2^30 elements or more: SSD_ERR_UNSUPPORTED.  slope_of (nullable, [n, rows, in]): dx is multiplied elementwise by LeakyReLU'(.) taken from
  *        the sign of slope_of (the backward through a LeakyReLU whose OUTPUT is slope_of). */
 int ssd_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in, int32_t out, void* stream);
 int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int32_t n,
