@@ -553,6 +553,18 @@ int ssd_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, i
     if (launch_bias_bmm_fwd(x, w, b, y, n, rows, in, out, (hipStream_t)stream)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_fwd: a weight set of 2^31 elements or more");
     return launched();
 }
+int ssd_bias_bmm_leaky_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in, int32_t out, void* stream) {
+    if (!x || !w || !b || !y || n < 1 || rows < 1 || in < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if (launch_bias_bmm_fwd(x, w, b, y, n, rows, in, out, (hipStream_t)stream, 1)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_leaky_fwd: a weight set of 2^30 elements or more");
+    return launched();
+}
+int ssd_bias_bmm_leaky_bwd(const float* g, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of,
+                           int32_t n, int32_t rows, int32_t in, int32_t out, void* stream) {
+    if (!g || !y || n < 1 || rows < 1 || in < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    if ((dx && !w) || ((dw || db) && !x) || (slope_of && !dx)) return fail(SSD_ERR_INVALID, "dx needs w, dw / db need x, slope_of needs dx");
+    if (launch_bias_bmm_bwd(g, x, w, dx, dw, db, slope_of, n, rows, in, out, (hipStream_t)stream, 0, 0, y)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_leaky_bwd: an operand set of 2^30 elements or more");
+    return launched();
+}
 int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int32_t n,
                      int32_t rows, int32_t in, int32_t out, void* stream) {
     if (!g || n < 1 || rows < 1 || in < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");

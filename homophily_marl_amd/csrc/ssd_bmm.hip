@@ -26,6 +26,8 @@ struct BmmK {
     const float* slope_of;     // backward, nullable: dx is multiplied by LeakyReLU'(.) taken from the sign of slope_of[g][row][i]
     int n, R, I, O;
     long x_set, g_set;         // elements between two weight sets of x / g (default R * I, R * O; larger when the rows are a slice)
+    const float* act_y;        // backward of the LEAKY forward: its output y [n, R, O]; g is multiplied by LeakyReLU'(.) from y's sign where it is loaded
+    int leaky;                 // forward: y = LeakyReLU(b + x w) (nn.LeakyReLU default slope 0.01)
     float* part;               // backward with row_chunks > 1: per (set, tile, chunk) partial dw tile [64 lanes x 4] + db [16] (BMM_PART floats)
     int row_chunks;            // the rows (K of dw) are cut into this many chunks, one workgroup each; k_bmm_dw_reduce adds them in order
 };
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = row0 + 4 * q + r;
-            if (row < R) a.y[((size_t)g * R + row) * O + o] = acc[t][r];
+            const float v = acc[t][r];
+            if (row < R) a.y[((size_t)g * R + row) * O + o] = (a.leaky && !(v > 0.f)) ? 0.01f * v : v;
         }
     }
 }
@@ -162,7 +165,9 @@ __global__ __launch_bounds__(64) void k_bmm_dw_reduce(BmmK a) {
     if (a.db && it == 0 && q == 0) a.db[(size_t)g * a.O + o] = sb;
 }
 constexpr int BMM_BWD_WAVES = 16;               // the row axis (K of dw: up to T B n = 8080 rows) is split 16 ways
-template <bool OV>                              // O is a multiple of 4: 16-byte operand loads along the output axis in the dx part
+// OV: O is a multiple of 4: 16-byte operand loads along the output axis in the dx part.  ACT: the layer's forward applied LeakyReLU
+// (a.act_y = its output): every g value is multiplied by the slope at its element as it is loaded (dx, dw and db all see g slope).
+template <bool OV, bool ACT>
 __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int dw_blocks) {
     __shared__ f32x4 red[BMM_BWD_WAVES][64];
     __shared__ float redb[BMM_BWD_WAVES][16];
@@ -182,25 +187,33 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int chunks = (O + 15) >> 4;
         // reduction index = output feature; branch-free loads (clamped, masked at use), chunk c + 1 requested before chunk c is used
-        struct Pair { f32x4 g, w; };
+        struct Pair { f32x4 g, w, y; };
+        const float* yy = ACT ? a.act_y + (size_t)g * a.g_set : nullptr;
         auto fetch = [&](int c, Pair& d) {
             const int k0 = 16 * c + 4 * q;
             if constexpr (OV) {
                 const uint32_t kb = (uint32_t)(k0 < O ? k0 : O - 4);
                 d.g = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const uint8_t*>(gg) + (size_t)((grow + kb) * 4u));
                 d.w = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const uint8_t*>(ws) + (size_t)((wrow + kb) * 4u));
+                if constexpr (ACT) d.y = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const uint8_t*>(yy) + (size_t)((grow + kb) * 4u));
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const uint32_t k = (uint32_t)(k0 + r < O ? k0 + r : O - 1);
                     d.g[r] = ld32(gg, grow + k); d.w[r] = ld32(ws, wrow + k);
+                    if constexpr (ACT) d.y[r] = ld32(yy, grow + k);
                 }
             }
         };
         auto use = [&](int c, const Pair& d) {
             const int k0 = 16 * c + 4 * q;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const bool on = k0 + r < O; acc = mfma4(on ? d.g[r] : 0.f, on ? d.w[r] : 0.f, acc); }
+            for (int r = 0; r < 4; ++r) {
+                const bool on = k0 + r < O;
+                float gv = on ? d.g[r] : 0.f;
+                if constexpr (ACT) gv = d.y[r] > 0.f ? gv : 0.01f * gv;
+                acc = mfma4(gv, on ? d.w[r] : 0.f, acc);
+            }
         };
         Pair pa, pb;
         fetch(0, pa);
@@ -240,6 +253,7 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
     // branch around a load); the order of the additions is the step order, as before.
     constexpr int UN = 8;
     const uint32_t icol = ion ? i : I - 1, ocol = oon ? o : O - 1;
+    const float* yg = ACT ? a.act_y + (size_t)g * a.g_set : nullptr;
     auto fetch = [&](int s, float (&av)[UN], float (&bv)[UN]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -248,6 +262,7 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
             const uint32_t rc = row < R ? row : R - 1;
             av[u] = ld32(xg, rc * (uint32_t)I + icol);
             bv[u] = ld32(gg, rc * (uint32_t)O + ocol);
+            if constexpr (ACT) { const float yv = ld32(yg, rc * (uint32_t)O + ocol); bv[u] = yv > 0.f ? bv[u] : 0.01f * bv[u]; }
         }
     };
     auto use = [&](int s, const float (&av)[UN], const float (&bv)[UN]) {
@@ -319,9 +334,9 @@ float* bmm_scratch() {
     return buf[dev];
 }
 
-int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int n, int R, int I, int O, hipStream_t s) {
+int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int n, int R, int I, int O, hipStream_t s, int leaky) {
     BmmK k = {};
-    k.x = x; k.w = w; k.b = b; k.y = y; k.n = n; k.R = R; k.I = I; k.O = O;
+    k.x = x; k.w = w; k.b = b; k.y = y; k.n = n; k.R = R; k.I = I; k.O = O; k.leaky = leaky;
     const int otiles = (O + 15) / 16, units = ((R + 15) / 16) * ((otiles + BMM_TPW - 1) / BMM_TPW);
     if ((long)I * O >= (1L << 30) || (long)R * I >= (1L << 30)) return -2;        // 32-bit byte offsets inside a weight set
     if ((I & 3) == 0) hipLaunchKernelGGL(k_bias_bmm_fwd<true>, dim3((units + 3) / 4, n), dim3(256), 0, s, k);
@@ -330,8 +345,9 @@ int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y
 }
 
 int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int n, int R,
-                        int I, int O, hipStream_t s, long x_set, long g_set) {
+                        int I, int O, hipStream_t s, long x_set, long g_set, const float* act_y) {
     BmmK k = {};
+    k.act_y = act_y;
     k.g = g; k.x = x; k.w = w; k.dx = dx; k.dw = dw; k.db = db; k.slope_of = slope_of; k.n = n; k.R = R; k.I = I; k.O = O;
     k.x_set = x_set ? x_set : (long)R * I; k.g_set = g_set ? g_set : (long)R * O;
     const int dxb = dx ? (((R + 15) / 16) * ((I + 15) / 16) + BMM_BWD_WAVES - 1) / BMM_BWD_WAVES : 0;
@@ -347,8 +363,14 @@ int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* d
         if (c > 1 && part && (size_t)n * dwb * c * BMM_PART * sizeof(float) <= BMM_SCRATCH_BYTES) { k.row_chunks = c; k.part = part; dwb *= c; }
     }
     if ((long)R * I >= (1L << 30) || (long)R * O >= (1L << 30)) return -2;       // 32-bit byte offsets inside a weight set
-    if ((O & 3) == 0) hipLaunchKernelGGL(k_bias_bmm_bwd<true>, dim3(dwb + dxb, n), dim3(BMM_BWD_WAVES * 64), 0, s, k, dwb);
-    else hipLaunchKernelGGL(k_bias_bmm_bwd<false>, dim3(dwb + dxb, n), dim3(BMM_BWD_WAVES * 64), 0, s, k, dwb);
+    const dim3 grid(dwb + dxb, n), block(BMM_BWD_WAVES * 64);
+    if (act_y) {
+        if ((O & 3) == 0) hipLaunchKernelGGL((k_bias_bmm_bwd<true, true>), grid, block, 0, s, k, dwb);
+        else hipLaunchKernelGGL((k_bias_bmm_bwd<false, true>), grid, block, 0, s, k, dwb);
+    } else {
+        if ((O & 3) == 0) hipLaunchKernelGGL((k_bias_bmm_bwd<true, false>), grid, block, 0, s, k, dwb);
+        else hipLaunchKernelGGL((k_bias_bmm_bwd<false, false>), grid, block, 0, s, k, dwb);
+    }
     if (k.row_chunks > 1) hipLaunchKernelGGL(k_bmm_dw_reduce, dim3(tiles, n), dim3(64), 0, s, k);
     return 0;
 }

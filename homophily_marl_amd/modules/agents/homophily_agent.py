@@ -177,8 +177,8 @@ class HomophilyAgent(nn.Module):
         H = self.hidden
         tm = lambda x: x.permute(2, 1, 0, 3).reshape(n, T * B, x.shape[-1])          # time-major rows [n, T*B, f]
         x, act = tm(inputs), tm(act_onehot.to(inputs.dtype))
-        xe = F.leaky_relu(ops.bias_bmm(x, self._w("fc1_env_w"), self._b("fc1_env_b")))
-        xi = F.leaky_relu(ops.bias_bmm(th.cat([x, act], dim=-1), self._w("fc1_inc_w"), self._b("fc1_inc_b")))
+        xe = ops.bias_bmm(x, self._w("fc1_env_w"), self._b("fc1_env_b"), leaky=True)             # fc1 + LeakyReLU as one launch
+        xi = ops.bias_bmm(th.cat([x, act], dim=-1), self._w("fc1_inc_w"), self._b("fc1_inc_b"), leaky=True)
         (wie, whe, bie, bhe), (wii, whi, bii, bhi) = self._gru_weights_both()
         return [ops.bias_bmm(xe, wie, bie), ops.bias_bmm(xi, wii, bii)], th.cat([whe, whi], dim=0), th.cat([bhe, bhi], dim=0)
 

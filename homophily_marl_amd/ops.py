@@ -362,31 +362,35 @@ def _bmm_kernel_ok(x, w, b):
     return (x.is_cuda and x.dtype == th.float32 and w.dtype == th.float32 and x.dim() == 3 and w.dim() == 3)
 
 
-def _bias_bmm_fwd(x, w, b):
+def _bias_bmm_fwd(x, w, b, leaky=False):
     lib = abi.load_library()
     x, w, b = x.contiguous(), w.contiguous(), b.contiguous()
     n, R, I = x.shape
     O = w.shape[2]
     y = th.empty(n, R, O, dtype=th.float32, device=x.device)
-    abi.check(lib, lib.ssd_bias_bmm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, R, I, O, _stream(x)))
+    fn = lib.ssd_bias_bmm_leaky_fwd if leaky else lib.ssd_bias_bmm_fwd
+    abi.check(lib, fn(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, R, I, O, _stream(x)))
     return y
 
 
 class _BiasBmm(th.autograd.Function):
     """baddbmm(b [n, 1, O], x [n, R, I], w [n, I, O]) on the device: one launch forward (ssd_bias_bmm_fwd) and ONE launch for the three
     gradients (ssd_bias_bmm_bwd: dx, dw and the bias gradient as column sums -- deterministic, no ATen multi-block reduction);
-    csrc/ssd_bmm.hip."""
+    csrc/ssd_bmm.hip.  leaky: the layer is followed by nn.LeakyReLU() (fc1 of both heads): applied in the forward kernel's epilogue
+    and, backward, to the gradient as it is loaded (ssd_bias_bmm_leaky_fwd / _bwd) -- no elementwise launch in either direction."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, leaky):
         x, w = x.contiguous(), w.contiguous()
-        ctx.save_for_backward(x, w)
-        return _bias_bmm_fwd(x, w, b)
+        y = _bias_bmm_fwd(x, w, b, leaky)
+        ctx.leaky = leaky
+        ctx.save_for_backward(x, w, *((y,) if leaky else ()))
+        return y
 
     @staticmethod
     def backward(ctx, g):
         lib = abi.load_library()
-        x, w = ctx.saved_tensors
+        x, w = ctx.saved_tensors[:2]
         g = g.contiguous()
         n, R, I = x.shape
         O = w.shape[2]
@@ -395,18 +399,23 @@ class _BiasBmm(th.autograd.Function):
         dw = th.empty_like(w) if need[1] else None
         db = th.empty(n, 1, O, dtype=th.float32, device=x.device) if need[2] else None
         ptr = lambda t: None if t is None else t.data_ptr()
-        abi.check(lib, lib.ssd_bias_bmm_bwd(g.data_ptr(), x.data_ptr(), w.data_ptr(), ptr(dx), ptr(dw), ptr(db), None, n, R, I, O, _stream(x)))
-        return dx, dw, db
+        if ctx.leaky:
+            y = ctx.saved_tensors[2]
+            abi.check(lib, lib.ssd_bias_bmm_leaky_bwd(g.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), ptr(dx), ptr(dw), ptr(db), None, n, R, I, O, _stream(x)))
+        else:
+            abi.check(lib, lib.ssd_bias_bmm_bwd(g.data_ptr(), x.data_ptr(), w.data_ptr(), ptr(dx), ptr(dw), ptr(db), None, n, R, I, O, _stream(x)))
+        return dx, dw, db, None
 
 
-def bias_bmm(x, w, b):
-    """x @ w + b for per-agent weights: x [n, R, I], w [n, I, O], b [n, 1, O]."""
+def bias_bmm(x, w, b, leaky=False):
+    """x @ w + b for per-agent weights: x [n, R, I], w [n, I, O], b [n, 1, O]; leaky: followed by LeakyReLU (slope 0.01)."""
     if _bmm_kernel_ok(x, w, b):
         if th.is_grad_enabled() and (w.requires_grad or b.requires_grad or x.requires_grad):
-            return _BiasBmm.apply(x, w, b)
-        return _bias_bmm_fwd(x, w, b)
+            return _BiasBmm.apply(x, w, b, leaky)
+        return _bias_bmm_fwd(x, w, b, leaky)
     _leaving_kernels("bias_bmm", x, "dtype / rank")
-    return th.baddbmm(b, x, w)
+    y = th.baddbmm(b, x, w)
+    return th.nn.functional.leaky_relu(y) if leaky else y
 
 
 class _BiasLinear(th.autograd.Function):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSD_ABI_VERSION 4
+#define SSD_ABI_VERSION 5
 
 #define SSD_MAX_AGENTS 10   /* maps hold at most 10 spawn points; agent ids >= 10 break the reference (map_env.py:370) */
 #define SSD_MAX_CELLS 1024  /* H*W upper bound (largest reference map is 48x18 = 864) */
@@ -400,6 +400,13 @@ int ssd_gru_seq_bwd_parts(const float* dhs, const float* hs, const float* rzn, c
  *        Operand sets of 2^30 elements or more: SSD_ERR_UNSUPPORTED.  slope_of (nullable, [n, rows, in]): dx is multiplied elementwise by LeakyReLU'(.) taken from
  *        the sign of slope_of (the backward through a LeakyReLU whose OUTPUT is slope_of). */
 int ssd_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in, int32_t out, void* stream);
+/* The same layer followed by nn.LeakyReLU() (slope 0.01), as HomophilyAgent applies it to fc1 (homophily_agent.py:158,182):
+ *   leaky_fwd: y = LeakyReLU(b + x w);   leaky_bwd: g is the gradient w.r.t. y, y the forward's output -- g is multiplied by
+ *   LeakyReLU'(.) (taken from the sign of y) where it is loaded, then dx, dw, db as ssd_bias_bmm_bwd.  Two elementwise launches per
+ *   layer and direction less. */
+int ssd_bias_bmm_leaky_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in, int32_t out, void* stream);
+int ssd_bias_bmm_leaky_bwd(const float* g, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of,
+                           int32_t n, int32_t rows, int32_t in, int32_t out, void* stream);
 int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int32_t n,
                      int32_t rows, int32_t in, int32_t out, void* stream);
 

@@ -591,6 +591,32 @@ def test_bias_bmm_kernels_match_baddbmm_autograd(n, R, I, O):
         assert (ops.bias_bmm(x, w, b) - ref).abs().max() < 1e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("n,R,I,O", [(5, 1616, 73, 64), (5, 1616, 82, 64), (3, 8080, 80, 3), (2, 17, 5, 20)])
+def test_bias_bmm_with_the_leaky_relu_fused_matches_the_two_operators(n, R, I, O):
+    """ssd_bias_bmm_leaky_fwd / _bwd (fc1 + nn.LeakyReLU() of both heads, homophily_agent.py:158,182, as one launch per direction)
+    against F.leaky_relu(th.baddbmm(...)) and its autograd; zeros in the pre-activation take the negative slope, as torch does."""
+    from homophily_marl_amd import ops
+    g = th.Generator(device="cuda").manual_seed(R + I + O)
+    x = th.randn(n, R, I, generator=g, device="cuda")
+    b = th.randn(n, 1, O, generator=g, device="cuda") * 0.1
+    x[:, 0] = 0; b[:, :, 0] = 0                                           # an exact zero pre-activation in every weight set
+    x.requires_grad_(); b.requires_grad_()
+    w = (th.randn(n, I, O, generator=g, device="cuda") * 0.2).requires_grad_()
+    wout = th.randn(n, R, O, generator=g, device="cuda")
+    y = ops.bias_bmm(x, w, b, leaky=True)
+    (y * wout).sum().backward()
+    got = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    ref = th.nn.functional.leaky_relu(th.baddbmm(b, x, w))
+    (ref * wout).sum().backward()
+    assert (y - ref).abs().max() < 1e-5 * max(1.0, ref.abs().max().item())
+    for a, t, name in zip(got, (x, w, b), ("dx", "dw", "db")):
+        assert (a - t.grad).abs().max() < 2e-5 * max(1.0, t.grad.abs().max().item()), (name, (a - t.grad).abs().max().item())
+    with th.no_grad():
+        assert (ops.bias_bmm(x, w, b, leaky=True) - ref).abs().max() < 1e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_graph_runner_with_non_shipped_input_flags():
     """obs_others_last_action / obs_distance switch the controller to the torch input assembly: the graph runner then takes the
     generic (non-FastPolicy) timestep, still captured as a hipGraph, and a train step runs on its batch."""
