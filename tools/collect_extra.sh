@@ -14,4 +14,4 @@ python3 tools/bmm_prof.py > $OUT/bmm_prof.txt 2>&1 || exit 1
 python3 tools/train_prof.py > $OUT/train_prof.txt 2>&1 || exit 1
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tt -- python3 $R/tools/train_prof.py > $R/$OUT/train_prof_under_rocprof.txt 2>&1; cp /tmp/tt/*/*kernel_stats.csv $R/$OUT/train_kernel_stats.csv; python3 $R/tools/train_trace.py /tmp/tt > $R/$OUT/train_trace.txt 2>&1)
 python3 tools/soak.py --iters ${SOAK_ITERS:-2500} --every 250 > $OUT/soak_cleanup5_tspr8_seed1.txt 2>&1 || exit 1
-tail -3 $OUT/pytest_gpu.log $OUT/soak_cleanup5_tspr8_seed1.txt $OUT/train_prof.txt
+for f in pytest_gpu.log soak_cleanup5_tspr8_seed1.txt train_prof.txt; do tail -n 3 $OUT/$f; done
