@@ -181,6 +181,12 @@ def test_fused_loss_kernel_matches_the_tensor_op_loss(B, T, n, kind):
     l2 = plain.forward_backward(batch, d2)
     for k in LOG_KEYS:
         assert abs(float(l1[k]) - float(l2[k])) < 1e-5 * max(1.0, abs(float(l2[k]))), (k, float(l1[k]), float(l2[k]))
+    # what the logger reads at a log interval: all scalars through ONE device -> host copy; the quotients are formed on the host (a
+    # true f32 division there, a multiplication by the reciprocal in torch's device kernel: the last bit may differ)
+    extra = (("clean_num_mean", batch["clean_num"][:, :-1].mean()),)
+    host = dict(l1.host_items(extra))
+    assert host["clean_num_mean"] == float(extra[0][1])
+    assert all(abs(host[k] - float(l1[k])) <= 1e-6 * max(1e-3, abs(float(l1[k]))) for k in LOG_KEYS), host
     g1, g2 = fused._flat_grad, plain._flat_grad
     assert float(g2.abs().max()) > 1e-4
     assert float((g1 - g2).abs().max()) < 2e-6 * max(1.0, float(g2.abs().max())), (float((g1 - g2).abs().max()), float(g2.abs().max()))
