@@ -6,7 +6,7 @@ The native library is REQUIRED: there is no CPU fallback on the product path.  `
 import ctypes as C
 import os
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_AGENTS = 10
 MAX_CELLS = 1024
 MAX_SITES = 256
@@ -143,6 +143,14 @@ class SsdBlockCopy(C.Structure):
                 ("dst_stride", C.c_int32)]
 
 
+class SsdBlockFill(C.Structure):
+    """ssd_block_fill (include/ssd_hip.h): one 32-bit pattern fill of ssd_fill_blocks."""
+    _fields_ = [("dst", C.c_void_p), ("bytes", C.c_int64), ("value", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+FILL_BLOCKS_MAX = 16
+
+
 class SsdPolicyHead(C.Structure):
     """include/ssd_hip.h: ssd_policy_head (fused controller step, one launch per head)."""
     _fields_ = [("n_env", C.c_int32), ("n_agents", C.c_int32), ("n_actions", C.c_int32), ("input_shape", C.c_int32),
@@ -251,6 +259,8 @@ HIP_SIGNATURES["ssd_gather_rows"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p
 HIP_SIGNATURES["ssd_sample_ids"] = (C.c_int, [C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p])
 SAMPLE_IDS_MAX = 1024
 HIP_SIGNATURES["ssd_copy_blocks"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p])
+HIP_SIGNATURES["ssd_fill_blocks"] = (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p])
+HIP_SIGNATURES["ssd_runner_stats"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_fwd_parts"] = (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p])
 HIP_SIGNATURES["ssd_gru_seq_bwd_parts"] = (C.c_int, [C.c_void_p] * 6 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_fwd"] = (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p])

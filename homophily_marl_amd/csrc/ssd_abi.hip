@@ -437,6 +437,20 @@ int ssd_copy_blocks(const ssd_block_copy* blocks, int32_t count, void* stream) {
     return launched();
 }
 
+int ssd_fill_blocks(const ssd_block_fill* blocks, int32_t count, void* stream) {
+    if (!blocks || count < 1 || count > SSD_FILL_BLOCKS_MAX) return fail(SSD_ERR_INVALID, "ssd_fill_blocks: 1..SSD_FILL_BLOCKS_MAX blocks");
+    for (int i = 0; i < count; ++i)
+        if (!blocks[i].dst || blocks[i].bytes < 4 || (blocks[i].bytes & 3) || ((uintptr_t)blocks[i].dst & 3)) return fail(SSD_ERR_INVALID, "ssd_fill_blocks: a block is a 4-byte aligned multiple of 4 bytes");
+    launch_fill_blocks(blocks, count, (hipStream_t)stream);
+    return launched();
+}
+int ssd_runner_stats(const float* collective_return, const float* equality, const float* episode_return, int32_t n_env, int32_t n_returns,
+                     double* acc, void* stream) {
+    if (!collective_return || !equality || !episode_return || !acc || n_env < 1 || n_returns < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    launch_runner_stats(collective_return, equality, episode_return, n_env, n_returns, acc, (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_td_sim_loss(const ssd_td_loss_args* a, int32_t mode, void* stream) {
     if (!a || a->batch < 1 || a->t_slots < 2 || a->n_agents < 2 || a->n_agents > SSD_MAX_AGENTS || a->n_actions < 1 || a->sim_horizon < 1)
         return fail(SSD_ERR_INVALID, "bad argument");

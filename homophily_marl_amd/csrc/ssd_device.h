@@ -157,6 +157,8 @@ int launch_policy_inc_encode(const ssd_policy_head* ph, const ssd_policy_encode_
 int conv_wgrad_partial_rows(int R);
 int launch_conv_wgrad(const uint8_t* codes, const float* d_conv, float* partial, int R, int V, hipStream_t s);
 float* bmm_scratch();
+void launch_fill_blocks(const ssd_block_fill* blocks, int count, hipStream_t stream);
+void launch_runner_stats(const float* coll, const float* eq, const float* ret, int n_env, int n_ret, double* acc, hipStream_t stream);
 int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int n, int R, int I, int O, hipStream_t s, int leaky = 0);
 int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int n, int R,
                         int I, int O, hipStream_t s, long x_set = 0, long g_set = 0, const float* act_y = nullptr);

@@ -299,6 +299,54 @@ __global__ __launch_bounds__(256) void k_copy_blocks(CopyTable t) {
     }
 }
 
+// k_fill_blocks: up to SSD_FILL_BLOCKS_MAX 32-bit pattern fills in one launch (blockIdx.y = block): the runner state an episode opens
+// with (previous actions -1, previous reward / incentive actions / returns / hidden states / time index 0) was seven fill launches.
+struct FillTable { ssd_block_fill e[SSD_FILL_BLOCKS_MAX]; };
+__global__ __launch_bounds__(256) void k_fill_blocks(FillTable t) {
+    const ssd_block_fill b = t.e[blockIdx.y];
+    uint32_t* d = static_cast<uint32_t*>(b.dst);
+    const size_t words = (size_t)b.bytes >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) d[i] = b.value;
+}
+void launch_fill_blocks(const ssd_block_fill* blocks, int count, hipStream_t stream) {
+    FillTable t;
+    size_t most = 4;
+    for (int i = 0; i < SSD_FILL_BLOCKS_MAX; ++i) {
+        t.e[i] = blocks[i < count ? i : 0];
+        if (i < count && (size_t)blocks[i].bytes > most) most = (size_t)blocks[i].bytes;
+    }
+    int gx = (int)((most / 4 + 1023) / 1024);                          // 4 words per thread for the largest block
+    if (gx < 1) gx = 1;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(k_fill_blocks, dim3(gx, count), dim3(256), 0, stream, t);
+}
+
+// k_runner_stats: the device side of EpisodeRunner's episode statistics (episode_runner.py:121-152) for one rollout of all envs:
+// acc[0..3] += sum collective_return, sum equality, sum of the agents' episode returns, sum of their squares, in f64, one workgroup,
+// a fixed-order tree (deterministic) -- ten ATen launches (casts, four reductions, a product, a concatenation, an addition) before.
+__global__ __launch_bounds__(1024) void k_runner_stats(const float* __restrict__ coll, const float* __restrict__ eq, const float* __restrict__ ret,
+                                                       int n_env, int n_ret, double* __restrict__ acc) {
+    __shared__ double red[4][1024];
+    const int t = threadIdx.x;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = t; i < n_env; i += 1024) { s[0] += (double)coll[i]; s[1] += (double)eq[i]; }
+    for (int i = t; i < n_ret; i += 1024) { const double r = (double)ret[i]; s[2] += r; s[3] += r * r; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[k][t] = s[k];
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (t < w) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[k][t] += red[k][t + w];
+        }
+        __syncthreads();
+    }
+    if (t < 4) acc[t] += red[t][0];
+}
+void launch_runner_stats(const float* coll, const float* eq, const float* ret, int n_env, int n_ret, double* acc, hipStream_t stream) {
+    hipLaunchKernelGGL(k_runner_stats, dim3(1), dim3(1024), 0, stream, coll, eq, ret, n_env, n_ret, acc);
+}
+
 static int grid_for(size_t total);
 // k_dueling_q: q = v + a - mean_k a per (agent, row) of the learner's time-batched heads, output in the batch layout [B, T, n, inner, K];
 // BWD: da = dq - mean_k dq, dv = sum_k dq.  One thread per (agent, row); K <= 16.

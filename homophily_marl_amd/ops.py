@@ -177,6 +177,40 @@ def td_sim_loss(q_env, q_inc, tq_env, tq_inc, dens, batch, a):
     return _TdSimLoss.apply(q_env, q_inc, tq_env, tq_inc, dens, batch, a)
 
 
+def fill_blocks(entries):
+    """entries: (tensor, 32-bit pattern) pairs -> ONE ssd_fill_blocks launch for device tensors (contiguous, element size 4 or 8: an i64
+    -1 is the pattern 0xFFFFFFFF twice); host tensors are filled one by one."""
+    dev = [(t, v) for t, v in entries if t.is_cuda]
+    for t, v in entries:
+        if not t.is_cuda:
+            t.fill_(-1 if v == 0xFFFFFFFF else 0)
+            assert v in (0, 0xFFFFFFFF)
+    if not dev:
+        return
+    lib = abi.load_library()
+    for i in range(0, len(dev), abi.FILL_BLOCKS_MAX):
+        part = dev[i:i + abi.FILL_BLOCKS_MAX]
+        tab = (abi.SsdBlockFill * len(part))()
+        for e, (t, v) in zip(tab, part):
+            assert t.is_contiguous() and (t.numel() * t.element_size()) % 4 == 0
+            e.dst, e.bytes, e.value = t.data_ptr(), t.numel() * t.element_size(), v
+        abi.check(lib, lib.ssd_fill_blocks(tab, len(part), _stream(part[0][0])))
+
+
+def runner_stats(collective_return, equality, episode_return, acc):
+    """acc f64 [4] += [sum collective_return, sum equality, sum episode_return, sum episode_return^2] (EpisodeRunner's statistics of one
+    rollout, episode_runner.py:121-152): one launch on the device."""
+    if acc.is_cuda and all(t.is_cuda and t.dtype == th.float32 and t.is_contiguous() for t in (collective_return, equality, episode_return)):
+        lib = abi.load_library()
+        abi.check(lib, lib.ssd_runner_stats(collective_return.data_ptr(), equality.data_ptr(), episode_return.data_ptr(), collective_return.numel(),
+                                            episode_return.numel(), acc.data_ptr(), _stream(acc)))
+        return acc
+    _leaving_kernels("runner_stats", acc, "dtype / layout")
+    r = episode_return.to(th.float64)
+    acc += th.stack([collective_return.sum(dtype=th.float64), equality.sum(dtype=th.float64), r.sum(), (r * r).sum()])
+    return acc
+
+
 def column_sums(x):
     """x [R, C] -> [C] or x [G, R, C] -> [G, C]: row sums by the HIP kernel k_column_sums (one launch, deterministic, no
     cross-workgroup hand-off).  ATen's multi-block reduction kernels keep block-arrival semaphores that a memset node clears; inside a

@@ -23,7 +23,7 @@ import ctypes as C
 import torch as th
 import torch.nn.functional as F
 
-from .. import abi
+from .. import abi, ops
 
 from ..components.episode_buffer import EpisodeBatch
 from .hip_vec_runner import HipVecRunner
@@ -411,14 +411,12 @@ class HipGraphRunner(HipVecRunner):
         """the device work that opens an episode on the bound storage (everything but the epsilon scalar, which the host computes)"""
         self.env.reset_batch()
         self.env.observe_batch(self.obs_fmt, out=self.cur if getattr(self, "direct_obs", False) else None)   # fills self.cur (or obs[:, 0])
-        self.t_dev.zero_()
-        self.prev_actions.fill_(-1); self.prev_reward.zero_(); self.prev_inc.zero_()
-        self.ep_return.zero_()
-        if self.fast is None:
-            self.h_env.zero_(); self.h_inc.zero_()       # the generic timestep's hidden states (FastPolicy keeps its own)
+        # the runner state an episode opens with, as ONE launch: time index, previous actions (-1) / reward / incentive actions, the
+        # episode returns, the hidden states (the generic timestep's, or FastPolicy's own)
+        hidden = [self.h_env, self.h_inc] if self.fast is None else [h for fp in self.fasts for h in (fp.h_env, fp.h_inc)]
+        ops.fill_blocks([(self.t_dev, 0), (self.prev_actions, 0xFFFFFFFF), (self.prev_reward, 0), (self.prev_inc, 0), (self.ep_return, 0)]
+                        + [(h, 0) for h in hidden])
         if self.fast is not None:
-            for fp in self.fasts:
-                fp.reset()
             if in_capture:
                 self.fast._pack_eager()   # the learner may have stepped the weights since the last episode (packs are shared)
             else:

@@ -149,9 +149,8 @@ class HipVecRunner:
     def _stats_device(self, out, ep_return, test_mode):
         """the device side of _finish_stats: this rollout's sums added to the accumulator (a handful of launches, no synchronisation;
         the graph runner replays them as part of its episode-closing graph)"""
-        acc = self._stat_acc(test_mode)
-        r = ep_return.to(th.float64)
-        acc += th.stack([out["collective_return"].sum(dtype=th.float64), out["equality"].sum(dtype=th.float64), r.sum(), (r * r).sum()])
+        from .. import ops
+        ops.runner_stats(out["collective_return"], out["equality"], ep_return, self._stat_acc(test_mode))
 
     def _stat_acc(self, test_mode):
         """device accumulator [sum collective_return, sum equality_metric, sum of returns, sum of squared returns]"""

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSD_ABI_VERSION 5
+#define SSD_ABI_VERSION 6
 
 #define SSD_MAX_AGENTS 10   /* maps hold at most 10 spawn points; agent ids >= 10 break the reference (map_env.py:370) */
 #define SSD_MAX_CELLS 1024  /* H*W upper bound (largest reference map is 48x18 = 864) */
@@ -248,6 +248,25 @@ typedef struct ssd_block_copy {
     int32_t rows, cols, src_stride, dst_stride;
 } ssd_block_copy;
 int ssd_copy_blocks(const ssd_block_copy* blocks, int32_t count, void* stream);
+
+/* ssd_fill_blocks: `count` (1..SSD_FILL_BLOCKS_MAX) fills with a 32-bit pattern as ONE launch (dst 4-byte aligned, bytes a multiple of
+ * 4; `blocks` is a HOST array read during the call).  The vectorised runner opens an episode with it: previous actions -1 (i64: the
+ * pattern 0xFFFFFFFF), previous reward / incentive actions / episode returns / hidden states / time index 0 (episode_runner.py:48-60,
+ * homophily_controller.py:95-99 init_hidden) -- seven fill launches before. */
+#define SSD_FILL_BLOCKS_MAX 16
+typedef struct ssd_block_fill {
+    void* dst;
+    int64_t bytes;
+    uint32_t value;
+    uint32_t reserved;
+} ssd_block_fill;
+int ssd_fill_blocks(const ssd_block_fill* blocks, int32_t count, void* stream);
+
+/* ssd_runner_stats: one rollout's share of EpisodeRunner's statistics (episode_runner.py:121-152) added to a device accumulator,
+ * acc f64 [4] += { sum collective_return [n_env], sum equality [n_env], sum episode_return [n_returns], sum episode_return^2 }:
+ * one launch, f64, fixed summation order; the host reads acc at its log interval. */
+int ssd_runner_stats(const float* collective_return, const float* equality, const float* episode_return, int32_t n_env, int32_t n_returns,
+                     double* acc, void* stream);
 
 /* ssd_clip_adam_step: the optimiser tail of HomophilyLearner.cal_loss_and_step (homophily_learner.py:223-226) --
  *   clip_grad_norm_(params_inc, clip); clip_grad_norm_(params_env, clip); optimiser_inc.step(); optimiser_env.step()

@@ -623,6 +623,29 @@ def test_bias_bmm_with_the_leaky_relu_fused_matches_the_two_operators(n, R, I, O
         assert (ops.bias_bmm(x, w, b, leaky=True) - ref).abs().max() < 1e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_fill_blocks_and_runner_stats_kernels():
+    """ssd_fill_blocks (the runner state an episode opens with, one launch) and ssd_runner_stats (one rollout's statistics added to
+    the f64 accumulator, episode_runner.py:121-152) against the tensor statements they replace."""
+    from homophily_marl_amd import ops
+    g = th.Generator(device="cuda").manual_seed(3)
+    a = th.randint(0, 9, (4096, 5), generator=g, device="cuda")
+    b = th.randn(4096, 5, generator=g, device="cuda")
+    c = th.randint(0, 3, (4096, 5, 5), generator=g, device="cuda")
+    d = th.ones(1, dtype=th.long, device="cuda")
+    e = th.randn(5, 4096, 64, generator=g, device="cuda")
+    guard = [t.clone() for t in (a, b)]
+    ops.fill_blocks([(a[1:], 0xFFFFFFFF), (b[:-1], 0), (c, 0), (d, 0), (e, 0)])          # (slices: the neighbours must stay)
+    assert bool((a[1:] == -1).all()) and bool((a[0] == guard[0][0]).all()) and bool((b[:-1] == 0).all()) and bool((b[-1] == guard[1][-1]).all())
+    assert not bool(c.any()) and int(d) == 0 and not bool(e.any())
+    coll, eq = th.randn(4096, generator=g, device="cuda") * 30, th.rand(4096, generator=g, device="cuda")
+    ret = th.randn(4096, 5, generator=g, device="cuda") * 8
+    acc = th.tensor([1.0, 2.0, 3.0, 4.0], dtype=th.float64, device="cuda")
+    ops.runner_stats(coll, eq, ret, acc)
+    r = ret.double()
+    ref = th.tensor([1.0, 2.0, 3.0, 4.0], dtype=th.float64, device="cuda") + th.stack([coll.double().sum(), eq.double().sum(), r.sum(), (r * r).sum()])
+    assert float((acc - ref).abs().max()) < 1e-9 * float(ref.abs().max())
+
+
 def test_graph_runner_with_non_shipped_input_flags():
     """obs_others_last_action / obs_distance switch the controller to the torch input assembly: the graph runner then takes the
     generic (non-FastPolicy) timestep, still captured as a hipGraph, and a train step runs on its batch."""
