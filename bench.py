@@ -23,7 +23,10 @@ Workloads:
 Rank 0 prints ONE JSON line with the driver's fields plus
   `roofline`     : the kernel with the largest share of the timestep (measured live with HIP events on the launch stream),
   `kernels`      : the same object for every kernel of the rollout timestep (e2e),
-  `cpu_baseline` : the C oracle on the host cores (rank 0, N = 1 only).
+  `cpu_baseline` : the C oracle on the host cores (rank 0, N = 1 only),
+  `env_workload` : (e2e, N = 1) the SURVEY 8(d) kernel-only workload -- fused step + observe with f32 observations -- run for 300
+                   transitions in the same process AFTER the timed region: the HBM fraction of the path's byte-moving kernel,
+  `config.per_rank` : (N > 1) every rank's own ms_per_step and the time of its gradient all-reduce.
 """
 import argparse
 import json
@@ -128,6 +131,82 @@ def roofline_entry(k):
     return e
 
 
+def run_env_workload(args, c, rank, local_rank, steps, warmup, in_group=False):
+    """SURVEY.md section 8(d)'s kernel-only workload: the fused ssd_step_observe launch on pre-generated synthetic actions, format R
+    (f32 observation [n_env, n, 3, V, V]); resets at the episode boundaries are inside the wall-clock bracket, the kernel time comes
+    from HIP events around every run of back-to-back launches between two resets."""
+    import torch
+    import torch.distributed as dist
+    from homophily_marl_amd import abi
+    from homophily_marl_amd.envs.native import NativeEnv
+    n, N, T, V = c["n_agents"], c["n_env"], 100, 2 * c["view_size"] + 1
+    dev = torch.device("cuda", local_rank)
+    env = NativeEnv(c["env"], device=local_rank, map=c["map"], num_agents=n, n_env=N, view_size=c["view_size"], episode_limit=T,
+                    rng_mode=abi.RNG_COUNTER, seed=1, env_id_base=rank * N)
+    # synthetic actions: i.i.d. uniform over the available set (BASELINE.md section 3), resident in HBM
+    g = torch.Generator(device=dev).manual_seed(0x5D5D + rank)
+    avail = torch.tensor([0, 1, 2, 3, 4, 8] if c["env"] == "cleanup" else [0, 1, 2, 3, 4], dtype=torch.int32, device=dev)
+    n_act = 64
+    acts = [avail[torch.randint(0, avail.numel(), (N, n), generator=g, device=dev)].contiguous() for _ in range(n_act)]
+    bufs = env.obs_buffers(abi.OBS_F32)
+
+    def reset_env():
+        env.reset()
+        if args.warm > 0:      # pre-clean part of the waste through the state import (not a kernel of the path; outside the brackets)
+            grid = env.export_state()["grid"]
+            hit = (grid == 3) & (torch.rand(grid.shape, generator=g, device=dev) < args.warm)
+            env.import_state(grid=torch.where(hit, torch.full_like(grid, 4), grid))
+
+    for t in range(warmup):
+        if t % T == 0:
+            reset_env()
+        env.step_observe(acts[t % n_act], out=bufs)
+    # kernel time for the roofline: HIP events (torch's current stream = the launch stream) bracketing every run of
+    # back-to-back k_env<STEP_OBS> launches between two resets; average = bracket time / launches in it
+    ev, run_len = [], []
+    torch.cuda.synchronize()
+    if in_group:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    open_ev = None
+    for t in range(steps):
+        if (warmup + t) % T == 0:
+            if open_ev is not None:
+                e = torch.cuda.Event(enable_timing=True); e.record(); ev.append((open_ev, e)); open_ev = None
+            reset_env()
+        if open_ev is None:
+            open_ev = torch.cuda.Event(enable_timing=True); open_ev.record(); run_len.append(0)
+        env.step_observe(acts[t % n_act], out=bufs)
+        run_len[-1] += 1
+    e = torch.cuda.Event(enable_timing=True); e.record(); ev.append((open_ev, e))
+    torch.cuda.synchronize()
+    if in_group:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert env.poll_error() == 0
+    per_launch = sorted(1e3 * a.elapsed_time(b) / k for (a, b), k in zip(ev, run_len))
+    kern = dict(name="ssd::k_env<MODE_STEP_OBS>", bound="hbm", avg_us=sum(1e3 * a.elapsed_time(b) for a, b in ev) / sum(run_len),
+                median_us=per_launch[len(per_launch) // 2], bytes_per_launch=algorithmic_bytes_per_env_step(env.H, env.W, n, env.V) * N)
+    return dict(elapsed=elapsed, kernels=[kern], dtype="u8",
+                workload="%s_env_step_observe_fp32obs" % args.config + ("_warm%d" % round(100 * args.warm) if args.warm > 0 else ""),
+                extra=dict(obs_format="f32[n_env,n,3,%d,%d]" % (V, V)))
+
+
+def attach_traffic(kernels, config, suffix, N):
+    """PMC traffic of the committed rocprofv3 --pmc passes, per launch (same kernel, same sizes only)"""
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tj):
+        return
+    tr = json.load(open(tj))
+    for k in kernels:
+        rec = tr.get("kernels", {}).get("%s@%s%s" % (k["name"], config, suffix))
+        if rec and rec.get("n_env") == N:
+            k["traffic"] = rec.get("hbm_bytes_per_launch")
+            k["traffic_source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes of %s; not measured in this run)" % tr.get("collected", "an earlier collection")
+
+
 def self_launch(n_ranks, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks as a child `torch.distributed.run` job (one process per GPU),
     pass rank 0's JSON line through and return the job's exit code.  Called before torch is imported: this process never
@@ -205,6 +284,8 @@ def main():
                     help="env workload: fraction of the waste cells turned into clean river after every reset (SURVEY.md 8d 'warm' variant: "
                          "exercises apple spawning; 0 = start from the map's reset state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-env-workload", action="store_true", help="e2e, 1 GPU: skip the format-R env workload measured after the timed region")
+    ap.add_argument("--env-workload-steps", type=int, default=300)
     ap.add_argument("--cpu-sample-steps", type=int, default=None)
     ap.add_argument("--launch-dry-run", action="store_true", help="form the process group (gloo), count the ranks, print the launch fields; no GPU")
     args = ap.parse_args()
@@ -262,78 +343,47 @@ def main():
         result = run_e2e(args, c, rank, world, local_rank)
         units = N * n * T * args.steps * world
     else:
-        env = NativeEnv(c["env"], device=local_rank, map=c["map"], num_agents=n, n_env=N, view_size=c["view_size"], episode_limit=T,
-                        rng_mode=abi.RNG_COUNTER, seed=1, env_id_base=rank * N)
-        # synthetic actions: i.i.d. uniform over the available set, resident in HBM
-        g = torch.Generator(device=dev).manual_seed(0x5D5D + rank)
-        avail = torch.tensor([0, 1, 2, 3, 4, 8] if c["env"] == "cleanup" else [0, 1, 2, 3, 4], dtype=torch.int32, device=dev)
-        n_act = 64
-        acts = [avail[torch.randint(0, avail.numel(), (N, n), generator=g, device=dev)].contiguous() for _ in range(n_act)]
-        bufs = env.obs_buffers(abi.OBS_F32)
-
-        def reset_env():
-            env.reset()
-            if args.warm > 0:      # pre-clean part of the waste through the state import (not a kernel of the path; outside the brackets)
-                grid = env.export_state()["grid"]
-                hit = (grid == 3) & (torch.rand(grid.shape, generator=g, device=dev) < args.warm)
-                env.import_state(grid=torch.where(hit, torch.full_like(grid, 4), grid))
-
-        def one_step(t):
-            if t % T == 0:
-                reset_env()
-            env.step_observe(acts[t % n_act], out=bufs)
-
-        for t in range(args.warmup):
-            one_step(t)
-        # kernel time for the roofline: HIP events (torch's current stream = the launch stream) bracketing every run of
-        # back-to-back k_env<STEP_OBS> launches between two resets; average = bracket time / launches in it
-        ev, run_len = [], []
-        torch.cuda.synchronize()
-        if in_group:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        open_ev = None
-        for t in range(args.steps):
-            if (args.warmup + t) % T == 0:
-                if open_ev is not None:
-                    e = torch.cuda.Event(enable_timing=True); e.record(); ev.append((open_ev, e)); open_ev = None
-                reset_env()
-            if open_ev is None:
-                open_ev = torch.cuda.Event(enable_timing=True); open_ev.record(); run_len.append(0)
-            env.step_observe(acts[t % n_act], out=bufs)
-            run_len[-1] += 1
-        e = torch.cuda.Event(enable_timing=True); e.record(); ev.append((open_ev, e))
-        torch.cuda.synchronize()
-        if in_group:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        assert env.poll_error() == 0
-        per_launch = sorted(1e3 * a.elapsed_time(b) / k for (a, b), k in zip(ev, run_len))
-        kern = dict(name="ssd::k_env<MODE_STEP_OBS>", bound="hbm", avg_us=sum(1e3 * a.elapsed_time(b) for a, b in ev) / sum(run_len),
-                    median_us=per_launch[len(per_launch) // 2], bytes_per_launch=algorithmic_bytes_per_env_step(env.H, env.W, n, env.V) * N)
-        result = dict(elapsed=elapsed, kernels=[kern], dtype="u8",
-                      workload="%s_env_step_observe_fp32obs" % args.config + ("_warm%d" % round(100 * args.warm) if args.warm > 0 else ""),
-                      extra=dict(obs_format="f32[n_env,n,3,%d,%d]" % (V, V)))
+        result = run_env_workload(args, c, rank, local_rank, args.steps, args.warmup, in_group)
         units = N * n * args.steps * world
 
     elapsed = result["elapsed"]
+    per_rank = None
     if in_group:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own clock (before the closing barrier) and its gradient all-reduce times: a scaling line explains itself
+        coll = result.get("collectives") or {}
+        mine = torch.tensor([result.get("rank_elapsed", result["elapsed"]), coll.get("device_ms_avg", float("nan")),
+                             coll.get("device_ms_max", float("nan")), coll.get("host_ms_avg", float("nan")), float(coll.get("calls", 0))],
+                            dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = torch.stack(allr).cpu()
+        ms = 1e3 * rows[:, 0] / args.steps
+        per_rank = {"ms_per_step_min": float(ms.min()), "ms_per_step_max": float(ms.max()), "ms_per_step": [round(float(x), 4) for x in ms]}
+        if float(rows[0, 4]) > 0:
+            per_rank["grad_all_reduce"] = {"calls_timed": int(rows[0, 4]), "bytes": result.get("grad_bytes"),
+                                           "device_ms_avg_per_rank": [round(float(x), 4) for x in rows[:, 1]],
+                                           "device_ms_max_per_rank": [round(float(x), 4) for x in rows[:, 2]],
+                                           "host_ms_avg_per_rank": [round(float(x), 4) for x in rows[:, 3]],
+                                           "how": "HIP events on the launch stream around dist.all_reduce of the flat gradient (between the two train graphs)"}
+    env_wl = None
+    if rank == 0 and world == 1 and args.workload == "e2e" and not args.no_env_workload:
+        # the HBM claim of the path (step + observe in format R) measured in the SAME process right after the e2e
+        # timed region -- outside `elapsed`, the headline value is untouched
+        ew = run_env_workload(args, c, rank, local_rank, args.env_workload_steps, 100)
+        attach_traffic(ew["kernels"], args.config, "@env_workload", N)
+        e = roofline_entry(ew["kernels"][0])
+        env_wl = {"kernel": e["kernel"], "workload": ew["workload"], "transitions": args.env_workload_steps,
+                  "avg_us": e["kernel_avg_us"], "median_us": e["kernel_median_us"],
+                  "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"], "achieved": e["achieved"], "unit": "GB/s",
+                  "peak": e["peak"], "frac": e["frac"], "traffic": e["traffic"], "traffic_source": e["traffic_source"],
+                  "agent_steps_per_sec": N * n * args.env_workload_steps / ew["elapsed"]}
     if rank == 0:
         kernels = result["kernels"]
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):      # PMC traffic of the committed rocprofv3 --pmc passes, per launch (same kernel, same sizes only)
-            tr = json.load(open(tj))
-            suffix = "@env_workload" if args.workload == "env" else ("@f32storage" if args.obs_storage == "f32" else "")
-            for k in kernels:
-                rec = tr.get("kernels", {}).get("%s@%s%s" % (k["name"], args.config, suffix))
-                if rec and rec.get("n_env") == N:
-                    k["traffic"] = rec.get("hbm_bytes_per_launch")
-                    k["traffic_source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes of %s; not measured in this run)" % tr.get("collected", "an earlier collection")
+        attach_traffic(kernels, args.config, "@env_workload" if args.workload == "env" else ("@f32storage" if args.obs_storage == "f32" else ""), N)
         entries = [roofline_entry(k) for k in kernels]
         dominant = max(entries, key=lambda e: e["kernel_avg_us"])
         line = {
@@ -351,6 +401,10 @@ def main():
         }
         if len(entries) > 1:
             line["kernels"] = entries
+        if env_wl is not None:
+            line["env_workload"] = env_wl
+        if per_rank is not None:
+            line["config"]["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             per_step = {"cleanup5": 2000, "harvest5": 600, "cleanup10": 500}[args.config]
             line["cpu_baseline"] = cpu_baseline(c, N, args.cpu_sample_steps or per_step)

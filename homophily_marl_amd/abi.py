@@ -6,7 +6,7 @@ The native library is REQUIRED: there is no CPU fallback on the product path.  `
 import ctypes as C
 import os
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_AGENTS = 10
 MAX_CELLS = 1024
 MAX_SITES = 256
@@ -231,6 +231,15 @@ def policy_frag_piece(precision, F, term):
     return 4 * precision * c + 4 * term + ot
 
 
+def policy_head_plan(n_env, n_agents, fused_with_encoder=False):
+    """(workgroups per agent, compute waves per workgroup, tiles the busiest wave walks) of a head launch on the current device
+    (ssd_policy_head_plan); tiles > 1 = the looped kernel instantiations."""
+    lib = load_library()
+    a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    check(lib, lib.ssd_policy_head_plan(n_env, n_agents, int(bool(fused_with_encoder)), C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
 def encode_bands(V):
     return 3 if V == 31 else 1
 
@@ -267,8 +276,10 @@ HIP_SIGNATURES["ssd_bias_bmm_fwd"] = (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 
 HIP_SIGNATURES["ssd_bias_bmm_bwd"] = (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_leaky_fwd"] = (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_leaky_bwd"] = (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 4 + [C.c_void_p])
+HIP_SIGNATURES["ssd_bmm_reserve_scratch"] = (C.c_int, [C.c_void_p])
 HIP_SIGNATURES["ssd_conv_wgrad_partial_rows"] = (C.c_int, [C.c_int32])
 HIP_SIGNATURES["ssd_conv_wgrad_codes"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
+HIP_SIGNATURES["ssd_policy_head_plan"] = (C.c_int, [C.c_int32] * 3 + [C.POINTER(C.c_int32)] * 3)
 HIP_SIGNATURES["ssd_policy_encode"] = (C.c_int, [C.POINTER(SsdPolicyEncodeArgs), C.c_void_p])
 HIP_SIGNATURES["ssd_policy_head_inc_encode"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.POINTER(SsdPolicyEncodeArgs), C.c_void_p])
 HIP_SIGNATURES["ssd_policy_pack_encoder"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])

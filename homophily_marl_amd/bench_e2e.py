@@ -86,14 +86,20 @@ def run_e2e(args, c, rank, world, local_rank):
         dist.barrier()
     th.cuda.synchronize()
     state["trains"] = state["timesteps"] = 0
+    learner.profile_collectives = bool(getattr(learner, "distributed", False))
+    if learner.profile_collectives:
+        learner.collective_times()                  # (reset)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         iteration()
     th.cuda.synchronize()
+    rank_elapsed = time.perf_counter() - t0          # this rank's own clock, before it waits for the others
     if dist.is_initialized():
         dist.barrier()
     th.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    coll = learner.collective_times() if learner.profile_collectives else None
+    learner.profile_collectives = False
     timed = dict(state)
     assert runner.env.native.poll_error() == 0
     assert timed["trains"] == args.steps * tspr and timed["timesteps"] == args.steps * T
@@ -174,7 +180,7 @@ def run_e2e(args, c, rank, world, local_rank):
     tot = sum(k["avg_us"] for k in kernels)
     for k in kernels:
         k["share_of_timestep"] = round(k["avg_us"] / tot, 4)
-    return dict(elapsed=elapsed, kernels=kernels, dtype="fp32" if qnet == "fp32" else "bf16",
+    return dict(elapsed=elapsed, rank_elapsed=rank_elapsed, collectives=coll, grad_bytes=4 * sum(p.numel() for p in learner.params), kernels=kernels, dtype="fp32" if qnet == "fp32" else "bf16",
                 workload="%s_rollout_plus_homophily_train" % args.config,
                 extra=dict(obs_format=("u8 class codes [n_env,n,%d,%d] (format C)" % (V, V)) if code else "f32[n_env,n,3,%d,%d]" % (V, V),
                            qnet_dtype=("fp32 (rollout: two-term f16 split MFMA products, f32-equivalent; learner: fp32)" if qnet == "fp32"

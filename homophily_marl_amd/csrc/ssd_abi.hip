@@ -166,7 +166,7 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
     if (e == hipSuccess) e = hipMemset(E->st.epoch, 0, N * 4);
     if (e == hipSuccess) e = hipMemset(E->st.err, 0, 4);
     if (e == hipSuccess && !numeric_err_word()) e = hipErrorOutOfMemory;      // exists before anything captures a graph
-    if (e == hipSuccess && !bmm_scratch()) e = hipErrorOutOfMemory;           // (the affine layers' backward scratch: same reason)
+    if (e == hipSuccess && !bmm_scratch(nullptr)) e = hipErrorOutOfMemory;           // (the affine layers' backward scratch: same reason)
     if (e == hipSuccess) {
         // a fresh handle holds the reset image with agents on their spawn cells (the reference constructor
         // also builds agents before the first reset, map_env.py:149)
@@ -564,12 +564,12 @@ int ssd_gru_seq_bwd_parts(const float* dhs, const float* hs, const float* rzn, c
 
 int ssd_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in, int32_t out, void* stream) {
     if (!x || !w || !b || !y || n < 1 || rows < 1 || in < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
-    if (launch_bias_bmm_fwd(x, w, b, y, n, rows, in, out, (hipStream_t)stream)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_fwd: a weight set of 2^31 elements or more");
+    if (launch_bias_bmm_fwd(x, w, b, y, n, rows, in, out, (hipStream_t)stream)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_fwd: a weight / operand set of 2^30 elements or more");
     return launched();
 }
 int ssd_bias_bmm_leaky_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in, int32_t out, void* stream) {
     if (!x || !w || !b || !y || n < 1 || rows < 1 || in < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
-    if (launch_bias_bmm_fwd(x, w, b, y, n, rows, in, out, (hipStream_t)stream, 1)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_leaky_fwd: a weight set of 2^30 elements or more");
+    if (launch_bias_bmm_fwd(x, w, b, y, n, rows, in, out, (hipStream_t)stream, 1)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_leaky_fwd: a weight / operand set of 2^30 elements or more");
     return launched();
 }
 int ssd_bias_bmm_leaky_bwd(const float* g, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of,
@@ -583,10 +583,14 @@ int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, 
                      int32_t rows, int32_t in, int32_t out, void* stream) {
     if (!g || n < 1 || rows < 1 || in < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
     if ((dx && !w) || ((dw || db) && !x) || (slope_of && !dx)) return fail(SSD_ERR_INVALID, "dx needs w, dw / db need x, slope_of needs dx");
-    if (launch_bias_bmm_bwd(g, x, w, dx, dw, db, slope_of, n, rows, in, out, (hipStream_t)stream)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_bwd: an operand set of 2^31 elements or more");
+    if (launch_bias_bmm_bwd(g, x, w, dx, dw, db, slope_of, n, rows, in, out, (hipStream_t)stream)) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_bwd: an operand set of 2^30 elements or more");
     return launched();
 }
 
+int ssd_bmm_reserve_scratch(void* stream) {
+    if (!bmm_scratch((hipStream_t)stream)) return fail(SSD_ERR_DEVICE, "ssd_bmm_reserve_scratch: allocation failed (inside a stream capture?)");
+    return SSD_OK;
+}
 int ssd_conv_wgrad_partial_rows(int32_t rows) { return rows < 1 ? 0 : conv_wgrad_partial_rows(rows); }
 int ssd_conv_wgrad_codes(const uint8_t* codes, const float* d_conv, float* partial, int32_t rows, int32_t view_edge, void* stream) {
     if (!codes || !d_conv || !partial || rows < 1) return fail(SSD_ERR_INVALID, "bad argument");
@@ -699,6 +703,15 @@ int ssd_policy_head_inc_encode(const ssd_policy_head* h, const ssd_policy_encode
     if (rc == -2) return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode is instantiated for 15 x 15 / 31 x 31 windows");
     if (rc) return fail(SSD_ERR_DEVICE, "ssd_policy_head_inc_encode: launch / hipFuncSetAttribute(max dynamic LDS) failed");
     return launched();
+}
+int ssd_policy_head_plan(int32_t n_env, int32_t n_agents, int32_t fused_with_encoder, int32_t* workgroups_per_agent, int32_t* compute_waves,
+                         int32_t* tiles_per_wave) {
+    if (!workgroups_per_agent || !compute_waves || !tiles_per_wave) return fail(SSD_ERR_INVALID, "null argument");
+    if (n_env < 1 || n_agents < 1) return fail(SSD_ERR_INVALID, "ssd_policy_head_plan: n_env, n_agents >= 1");
+    int a = 0, b = 0, c = 0;
+    policy_head_plan(n_env, n_agents, fused_with_encoder, &a, &b, &c);
+    *workgroups_per_agent = a; *compute_waves = b; *tiles_per_wave = c;
+    return SSD_OK;
 }
 int ssd_policy_head_env(const ssd_policy_head* a, void* stream) { return policy_head(a, 0, stream); }
 int ssd_policy_head_inc(const ssd_policy_head* a, void* stream) { return policy_head(a, 1, stream); }

@@ -13,6 +13,7 @@
 //             output axis), dw = x^T g with the row axis as K split over the 16 waves of a workgroup and added in LDS in a fixed
 //             order, db = column sums of g taken from the operands the dw waves load anyway.  Deterministic: no atomics.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 
 namespace ssd {
@@ -319,19 +320,27 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
     }
 }
 
-// Scratch of the row-chunked backward (partial dw tiles): one allocation per device, made on the first call outside a stream capture
-// (ssd_create makes it too).  ONE stream at a time may run chunked backward launches of a device (the learner's step is one stream).
+// Scratch of the row-chunked backward (partial dw tiles): one allocation per (device, stream) -- two streams that run chunked
+// backward launches concurrently each add their partial tiles in their own buffer.  Made on the first call outside a stream capture
+// (ssd_create makes the default stream's; ssd_bmm_reserve_scratch makes a capture stream's BEFORE the capture starts -- the learner
+// captures its step on a stream of its own); inside a capture an allocation fails and the launch stays unchunked.
 constexpr size_t BMM_SCRATCH_BYTES = 1 << 20;
-float* bmm_scratch() {
-    static float* buf[64] = {};
+constexpr int BMM_SCRATCH_SLOTS = 64;                 // streams per device with a scratch of their own; later ones run unchunked
+float* bmm_scratch(hipStream_t stream) {
+    struct Slot { hipStream_t stream; float* buf; };
+    static Slot slots[64][BMM_SCRATCH_SLOTS] = {};
+    static int used[64] = {};
+    static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!buf[dev]) {
-        float* p = nullptr;
-        if (hipMalloc((void**)&p, BMM_SCRATCH_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // (e.g. inside a capture: unchunked)
-        buf[dev] = p;
-    }
-    return buf[dev];
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < used[dev]; ++i)
+        if (slots[dev][i].stream == stream) return slots[dev][i].buf;
+    if (used[dev] == BMM_SCRATCH_SLOTS) return nullptr;
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, BMM_SCRATCH_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // (e.g. inside a capture: unchunked)
+    slots[dev][used[dev]++] = Slot{stream, p};
+    return p;
 }
 
 int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int n, int R, int I, int O, hipStream_t s, int leaky) {
@@ -359,10 +368,10 @@ int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* d
     if (dwb && (R + 3) / 4 >= 64 * BMM_BWD_WAVES && dwb * n <= 128) {
         int c = 256 / (dwb * n);
         if (c > 8) c = 8;
-        float* part = bmm_scratch();
+        float* part = bmm_scratch(s);
         if (c > 1 && part && (size_t)n * dwb * c * BMM_PART * sizeof(float) <= BMM_SCRATCH_BYTES) { k.row_chunks = c; k.part = part; dwb *= c; }
     }
-    if ((long)R * I >= (1L << 30) || (long)R * O >= (1L << 30)) return -2;       // 32-bit byte offsets inside a weight set
+    if ((long)R * I >= (1L << 30) || (long)R * O >= (1L << 30) || (long)I * O >= (1L << 30)) return -2;       // 32-bit byte offsets inside a weight / operand set
     const dim3 grid(dwb + dxb, n), block(BMM_BWD_WAVES * 64);
     if (act_y) {
         if ((O & 3) == 0) hipLaunchKernelGGL((k_bias_bmm_bwd<true, true>), grid, block, 0, s, k, dwb);

@@ -153,10 +153,11 @@ void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* 
 void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* const* d_gi_parts,
                         int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s);
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s);
+void policy_head_plan(int n_env, int n_agents, int fused, int* wg_per_agent, int* waves_out, int* tiles_per_wave);
 int launch_policy_inc_encode(const ssd_policy_head* ph, const ssd_policy_encode_args* pe, hipStream_t s);
 int conv_wgrad_partial_rows(int R);
 int launch_conv_wgrad(const uint8_t* codes, const float* d_conv, float* partial, int R, int V, hipStream_t s);
-float* bmm_scratch();
+float* bmm_scratch(hipStream_t stream);
 void launch_fill_blocks(const ssd_block_fill* blocks, int count, hipStream_t stream);
 void launch_runner_stats(const float* coll, const float* eq, const float* ret, int n_env, int n_ret, double* acc, hipStream_t stream);
 int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int n, int R, int I, int O, hipStream_t s, int leaky = 0);

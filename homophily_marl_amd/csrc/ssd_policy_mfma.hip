@@ -197,6 +197,9 @@ template <int PREC, int C> __device__ __forceinline__ void chunk_ready(volatile 
             seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)*landed);
             if (seen <= (uint32_t)j) __builtin_amdgcn_s_sleep(1);
         }
+        // compiler barrier: the image's (non-volatile) ds_reads that follow must not be hoisted above the poll -- `volatile` orders the
+        // poll only against other volatile accesses.  No instruction is emitted (LDS returns in order, so the hardware needs no wait)
+        asm volatile("" ::: "memory");
     }
 }
 
@@ -442,28 +445,58 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
 // workgroup has WAVES + 1 waves, the last one is the loader.
 // LOOP: a wave walks tiles tile, tile + bpa * WAVES, ... (grids larger than the chip: Cleanup-10 x 8192 has 512 tiles per agent); with
 // LOOP = false the host guarantees at most one tile per wave and the kernel has no back edge (see run_tile).
+// The kernel arguments once more, from the kernarg segment (HeadK is the FIRST argument of k_head and of k_inc_encode): the address is
+// made opaque to the compiler, so the scalar loads are issued where the call stands and their results are not values that were live
+// since kernel entry.  The looped kernels call this at the top of every pass over a tile (see head_body).
+__device__ __forceinline__ void refetch_head_args(HeadK& out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const uint32_t k_u32;
+    uint64_t p = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    k_u32* src = (k_u32*)p;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(HeadK) / 4); ++i) dst[i] = src[i];
+#else
+    (void)out;
+#endif
+}
+static_assert(sizeof(HeadK) % 4 == 0, "HeadK is copied dword by dword");
+
 template <int INC, int PREC, int AT, int GEN, int WAVES, bool LOOP = false>
-__device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, const int block) {
+__device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw, const int block) {
     constexpr int IMAGE_BYTES = SSD_POLICY_IMAGE_BYTES(PREC);
     constexpr float XS = PREC == 2 ? HEAD_XSCALE : 1.f, INV = PREC == 2 ? 1.f / (HEAD_WSCALE * HEAD_XSCALE) : 1.f;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int agent = block / a.bpa, bia = block - agent * a.bpa;
-    const int m = lane & 15, q = lane >> 4;
-    const int N = a.N, n = a.n;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int A = AT;
-    PSTAMP(0);
-    PSTAMP_REAL(14);
-    const int tiles = (N + 15) >> 4;
-    int tile = wave < WAVES ? wave * a.bpa + bia : tiles;              // consecutive tiles go to different CUs; the loader has none
-    TileIn<INC> in;
+    uint32_t seen = 0;                                                 // last value read from the loader's progress word (kept across passes)
+    bool first = true;
     // LDS: the image (as in global memory) | per-wave scratch | the loader's progress word
     volatile lds_u32* landed = (volatile lds_u32*)(lds_raw + IMAGE_BYTES + WAVES * SCRATCH * 4);      // generic -> LDS address space
-    if (wave == WAVES) *landed = 0u;                                   // LDS holds garbage at launch: the word is valid behind this barrier
-    __builtin_amdgcn_s_barrier();                                      // (the only one: every wave is still at its first instructions)
-    if (wave == WAVES) {                                               // the loader wave: nothing but the image stream
-        stream_image<PREC>(a.weights + (size_t)agent * IMAGE_BYTES + lane * 16, (uint32_t)(uintptr_t)lds_raw, landed);
-        return;
+    {
+        const HeadK& a = a_entry;
+        const int lane = tid & 63;
+        (void)lane;
+        PSTAMP(0);
+        PSTAMP_REAL(14);
+        if (wave == WAVES) *landed = 0u;                               // LDS holds garbage at launch: the word is valid behind this barrier
+        __builtin_amdgcn_s_barrier();                                  // (the only one: every wave is still at its first instructions)
+        if (wave == WAVES) {                                           // the loader wave: nothing but the image stream
+            const int agent = block / a.bpa;
+            stream_image<PREC>(a.weights + (size_t)agent * IMAGE_BYTES + lane * 16, (uint32_t)(uintptr_t)lds_raw, landed);
+            return;
+        }
     }
+    // One PASS = one 16-row tile from its loads to its stores.  `a` and `lane` are parameters so that the looped kernels can hand every
+    // pass freshly fetched arguments and an opaque lane id: nothing of a pass is then invariant across the back edge, the compiler
+    // hoists nothing out of the loop and keeps no argument alive through the tile chain -- the pass has the register footprint of the
+    // kernel without a loop.  tile >= tiles: a wave without a tile (it only hands the counters over).
+    auto pass = [&](const HeadK& a, const int lane, const int tile) {
+    const int agent = block / a.bpa;
+    const int m = lane & 15, q = lane >> 4;
+    const int N = a.N, n = a.n;
+    const int tiles = (N + 15) >> 4;
+    TileIn<INC> in;
     if (!INC) PSTAMP_DRAINED(8);                                       // (diagnostic builds: kernel arguments fetched)
     if (!INC) PSTAMP(9);
     if (tile < tiles) load_tile<INC>(a, tile, agent, lane, in);        // queued behind the first chunks
@@ -608,12 +641,9 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
     if (tile < tiles) prepare(tile);                                   // arithmetic only
     PSTAMP(13);
     PSTAMP(1);
-    const bool had_tile = tile < tiles;
-    bool first = true;
     const uint8_t* img = lds_raw;
     const float* tail = reinterpret_cast<const float*>(img + (size_t)tail_piece<PREC>() * 1024);
     float* scratch = reinterpret_cast<float*>(lds_raw + IMAGE_BYTES) + wave * SCRATCH;
-    uint32_t seen = 0;                                                 // last value read from the loader's progress word
     // The wave's 16-row tile through the chain; the K-steps synchronise with the image still streaming in (step_sync).  A wave has
     // AT MOST ONE tile (the host sizes the grid for it: bpa = ceil(tiles per agent / 8)): with a loop over further tiles in the
     // kernel every argument and pointer of the input phase stayed live through the chain -- 118 scalar registers spilled and the
@@ -796,16 +826,39 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
 #undef SSD_LOAD_STEP
     };
     if (tile < tiles) run_tile();
-    if constexpr (LOOP) {
-        for (tile += a.bpa * WAVES; tile < tiles; tile += a.bpa * WAVES) {     // the image is resident by now (seen == every chunk)
-            load_tile<INC>(a, tile, agent, lane, in);
-            prepare(tile);
-            run_tile();
+    else hand_counters();
+    };   // pass
+    const int lane0 = tid & 63;
+    {
+        const int bia = block - (block / a_entry.bpa) * a_entry.bpa;
+        const int tile0 = wave * a_entry.bpa + bia;                    // consecutive tiles go to different CUs
+        if constexpr (!LOOP) {
+            pass(a_entry, lane0, tile0);
+        } else {
+            const int stride = a_entry.bpa * WAVES, tiles_all = (a_entry.N + 15) >> 4;
+            int tile = tile0;
+            do {                                                       // the image is resident from the second pass on (seen == every chunk)
+                HeadK al;
+                refetch_head_args(al);
+                int lane = lane0;
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(lane));
+#endif
+                pass(al, lane, tile);
+                tile += stride;
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+s"(tile));
+#endif
+            } while (tile < tiles_all);
         }
     }
-    if (!had_tile) hand_counters();
-    PSTAMP(7);
-    PSTAMP_REAL(15);
+    {
+        const HeadK& a = a_entry;
+        const int lane = lane0;
+        (void)a; (void)lane;
+        PSTAMP(7);
+        PSTAMP_REAL(15);
+    }
 }
 
 // the standalone heads: 8 tiles per workgroup + the loader wave (Cleanup-5 x 4096 envs: 256 tiles per agent -> 32 workgroups per agent, 160 in
@@ -814,7 +867,10 @@ __device__ __forceinline__ void head_body(const HeadK& a, uint8_t* lds_raw, cons
 #define SSD_HEAD_WAVES 8
 #endif
 constexpr int HEAD_WAVES = SSD_HEAD_WAVES;
-constexpr int HEAD_WAVES_LOOP = 6;             // the looped instantiations need the whole register file: 7 waves = 2 per SIMD at 256 registers
+#ifndef SSD_HEAD_WAVES_LOOP
+#define SSD_HEAD_WAVES_LOOP 8
+#endif
+constexpr int HEAD_WAVES_LOOP = SSD_HEAD_WAVES_LOOP;   // (round 3: 6, when the looped instantiations filled the register file; 160-168 registers now)
 constexpr int head_waves(bool loop) { return loop ? HEAD_WAVES_LOOP : HEAD_WAVES; }
 template <int INC, int PREC, int AT, int GEN = 0, bool LOOP = false>
 __global__ __launch_bounds__((head_waves(LOOP) + 1) * 64) void k_head(HeadK a, HeadCold cold_unused) {
@@ -868,7 +924,8 @@ static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c, int waves
     // workgroup per CU and waves that walk several tiles (the LOOP instantiations)
     const int tiles = (k.N + 15) / 16;
     k.bpa = (tiles + waves - 1) / waves;
-    if (k.n * k.bpa > chip_cus()) { k.bpa = chip_cus() / k.n; if (k.bpa < 1) k.bpa = 1; }
+    static const bool no_loop = getenv("SSD_HEAD_NO_LOOP") != nullptr;       // experiment: grids larger than the chip instead of looping waves
+    if (k.n * k.bpa > chip_cus() && !no_loop) { k.bpa = chip_cus() / k.n; if (k.bpa < 1) k.bpa = 1; }
 }
 static bool head_loops(const HeadK& k, int waves) { return k.bpa * waves < (k.N + 15) / 16; }
 // the standalone heads: 8 compute waves when one tile per wave fits the chip, else the looped kernel with 6
@@ -1353,6 +1410,24 @@ template <int PREC, int AT, int V, bool LOOP>
 static int launch_inc_encode_t(HeadK& k, HeadCold& c, EncK& e, hipStream_t s) {
     if constexpr (V == 15) { if (enc_bt(V, e.rows) == 4) return launch_inc_encode_bt<PREC, AT, V, LOOP, 4>(k, c, e, s); }
     return launch_inc_encode_bt<PREC, AT, V, LOOP, 5>(k, c, e, s);
+}
+
+// How a head launch of (n_env, n_agents) is cut: workgroups per agent, compute waves per workgroup, and the number of 16-row tiles the
+// busiest wave walks (1 = the kernel without a back edge; > 1 = the LOOP instantiation).  fused: the inc head inside k_inc_encode.
+void policy_head_plan(int n_env, int n_agents, int fused, int* wg_per_agent, int* waves_out, int* tiles_per_wave) {
+    HeadK k = {};
+    k.N = n_env; k.n = n_agents;
+    const int tiles = (n_env + 15) / 16;
+    int waves = fused ? FUSED_WAVES - 1 : HEAD_WAVES;
+    auto size = [&](int w) {
+        k.bpa = (tiles + w - 1) / w;
+        static const bool no_loop = getenv("SSD_HEAD_NO_LOOP") != nullptr;
+        if (k.n * k.bpa > chip_cus() && !no_loop) { k.bpa = chip_cus() / k.n; if (k.bpa < 1) k.bpa = 1; }
+    };
+    size(waves);
+    if (!fused && head_loops(k, waves)) { waves = HEAD_WAVES_LOOP; size(waves); }
+    *wg_per_agent = k.bpa; *waves_out = waves;
+    *tiles_per_wave = (tiles + k.bpa * waves - 1) / (k.bpa * waves);
 }
 
 // inc head (timestep t) + encoder (timestep t + 1) as one launch; -2: no instance for this window size, -3: for this action count

@@ -113,6 +113,10 @@ class HomophilyLearner:
         # SSD_FORCE_DIST=1: a process group of ONE rank still issues every collective (RCCL rehearsal on a one-GPU box)
         self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or
                                                                                os.environ.get("SSD_FORCE_DIST") == "1")
+        # profile_collectives (bench.py, N > 1): every gradient all-reduce is bracketed by a pair of events on the launch stream (the
+        # collective's own stream is joined into it) and by the host clock; collective_times() reports both
+        self.profile_collectives = False
+        self._coll_events, self._coll_wall = [], []
 
     # ---- network unroll ---------------------------------------------------------------------------------------
     @staticmethod
@@ -135,6 +139,37 @@ class HomophilyLearner:
         with th.no_grad():
             tq_env, tq_inc = tgt.agent.unroll_post(hs[G:].detach(), shared["other"])
         return q_env, q_inc, tq_env, tq_inc
+
+    def _all_reduce_grad(self):
+        """ONE flat fp32 collective (RCCL over xGMI) on the gradient buffer; timed when profile_collectives is set."""
+        if not self.profile_collectives:
+            dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+            return
+        import time
+        t0 = time.perf_counter()
+        ev = None
+        if self._flat_grad.is_cuda:
+            ev = (th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True))
+            ev[0].record()
+        dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+        if ev is not None:
+            ev[1].record()
+            self._coll_events.append(ev)
+        self._coll_wall.append(time.perf_counter() - t0)
+
+    def collective_times(self, reset=True):
+        """dict(calls, device_ms_avg / max (events on the launch stream around the all-reduce), host_ms_avg (time the host spent in the
+        call)) of the gradient all-reduces since the last reset; synchronises."""
+        out = dict(calls=len(self._coll_wall))
+        if self._coll_events:
+            th.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in self._coll_events]
+            out.update(device_ms_avg=sum(ms) / len(ms), device_ms_max=max(ms))
+        if self._coll_wall:
+            out["host_ms_avg"] = 1e3 * sum(self._coll_wall) / len(self._coll_wall)
+        if reset:
+            self._coll_events, self._coll_wall = [], []
+        return out
 
     def _global(self, x):
         """sum of a scalar tensor over the data-parallel group (loss denominators)."""
@@ -365,7 +400,7 @@ class HomophilyLearner:
         dens = self.denominators(batch)
         logs = self.forward_backward(batch, dens)
         if self.distributed:
-            dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)   # ONE flat fp32 collective (RCCL over xGMI)
+            self._all_reduce_grad()                                   # ONE flat fp32 collective (RCCL over xGMI)
         self.clip_and_step()
         return logs
 
@@ -386,11 +421,15 @@ class HomophilyLearner:
                                               device=batch.device)
             self._static_dens = th.zeros(2, device=batch.device)
             th.cuda.synchronize()
+            # the step is captured on a stream of this learner's own: per-(device, stream) kernel scratch (the row-chunked affine
+            # backward's partial tiles) baked into the graph then belongs to THIS graph and nothing else
+            self._capture_stream = th.cuda.Stream(device=batch.device)
+            ops.reserve_bmm_scratch(self._capture_stream)
             # thread_local: with an initialised process group the RCCL watchdog thread keeps polling events while we capture
             g1, g2 = th.cuda.CUDAGraph(), th.cuda.CUDAGraph()
-            with th.cuda.graph(g1, capture_error_mode="thread_local"):
+            with th.cuda.graph(g1, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._static_logs = self.forward_backward(self._static_batch, self._static_dens)
-            with th.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+            with th.cuda.graph(g2, pool=g1.pool(), stream=self._capture_stream, capture_error_mode="thread_local"):
                 self.clip_and_step()
             self._graph = (g1, g2)
         for k, v in batch.data.transition_data.items():
@@ -416,7 +455,7 @@ class HomophilyLearner:
                 raise SystemExit(3)
             self._flat_grad.copy_(got)
         if self.distributed:
-            dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+            self._all_reduce_grad()
         self._graph[1].replay()
         return self._static_logs
 
@@ -442,6 +481,22 @@ class HomophilyLearner:
                 for k, v in means + tuple(logs.items()):
                     self.logger.log_stat(k, v.item(), t_env)
             self.log_stats_t = clock
+            self.check_numeric_status(t_env)
+
+    def check_numeric_status(self, t_env=0):
+        """The sticky range flag of the f32-equivalent split products (SSD_ERRBIT_F16_RANGE: pack kernels, rollout heads, recurrence),
+        read where the host synchronises anyway (the log interval).  numeric_guard: "raise" (default) stops the run -- beyond the range
+        the products carry inf / NaN silently --, "log" records the bits as a stat, "off" skips the read."""
+        guard = str(getattr(self.args, "numeric_guard", "raise"))
+        if guard == "off" or not self.params[0].is_cuda:
+            return 0
+        bits = ops.numeric_status()
+        if self.logger is not None:
+            self.logger.log_stat("numeric_status_bits", bits, t_env)
+        if bits and guard == "raise":
+            raise FloatingPointError("numeric status bits 0x%x at t_env %d: a scaled term of the two-term f16 split products left f16's "
+                                     "range (SSD_ERRBIT_F16_RANGE = 0x20); the rollout / recurrence results are no longer f32-equivalent" % (bits, t_env))
+        return bits
 
     def _update_targets(self):
         self.target_mac.load_state(self.mac)

@@ -31,6 +31,13 @@ def numeric_status():
     return bits.value
 
 
+def reserve_bmm_scratch(stream):
+    """The per-(device, stream) scratch of the row-chunked affine backward (ssd_bias_bmm_bwd) for a stream that is about to capture
+    the train step: nothing can be allocated inside a capture."""
+    lib = abi.load_library()
+    abi.check(lib, lib.ssd_bmm_reserve_scratch(stream.cuda_stream))
+
+
 def set_strict(on=True):
     global STRICT
     STRICT = bool(on)

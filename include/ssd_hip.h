@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSD_ABI_VERSION 6
+#define SSD_ABI_VERSION 7
 
 #define SSD_MAX_AGENTS 10   /* maps hold at most 10 spawn points; agent ids >= 10 break the reference (map_env.py:370) */
 #define SSD_MAX_CELLS 1024  /* H*W upper bound (largest reference map is 48x18 = 864) */
@@ -415,8 +415,10 @@ int ssd_gru_seq_bwd_parts(const float* dhs, const float* hs, const float* rzn, c
  *   fwd: y = b + x w
  *   bwd: dx = g w^T, dw = x^T g, db = column sums of g; each output nullable (dx needs w, dw / db need x); one launch --
  *        two when a long row axis (>= 4096 rows) meets few dw tiles: the rows are then cut into chunks whose partial tiles a
- *        second small launch adds in order through a per-device scratch (ONE stream at a time per device) --, deterministic.
- *        Operand sets of 2^30 elements or more: SSD_ERR_UNSUPPORTED.  slope_of (nullable, [n, rows, in]): dx is multiplied elementwise by LeakyReLU'(.) taken from
+ *        second small launch adds in order through a 1 MiB scratch that belongs to (device, stream): launches on different streams
+ *        never share one --, deterministic.  The scratch of a stream is allocated at its first launch; a stream that is going to CAPTURE
+ *        such launches reserves its scratch before the capture starts (ssd_bmm_reserve_scratch; inside a capture nothing can be
+ *        allocated and the launch stays unchunked).  Operand sets of 2^30 elements or more: SSD_ERR_UNSUPPORTED.  slope_of (nullable, [n, rows, in]): dx is multiplied elementwise by LeakyReLU'(.) taken from
  *        the sign of slope_of (the backward through a LeakyReLU whose OUTPUT is slope_of). */
 int ssd_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in, int32_t out, void* stream);
 /* The same layer followed by nn.LeakyReLU() (slope 0.01), as HomophilyAgent applies it to fc1 (homophily_agent.py:158,182):
@@ -428,6 +430,8 @@ int ssd_bias_bmm_leaky_bwd(const float* g, const float* y, const float* x, const
                            int32_t n, int32_t rows, int32_t in, int32_t out, void* stream);
 int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int32_t n,
                      int32_t rows, int32_t in, int32_t out, void* stream);
+/* Make the row-chunk scratch of `stream` on the current device exist (SSD_ERR_DEVICE when it cannot be allocated). */
+int ssd_bmm_reserve_scratch(void* stream);
 
 /* Weight (and bias) gradient of the encoder's Conv2d(3, 6, 3) on windows given as SSD_OBS_CODE class codes u8 [rows, V, V]
  * (V = 15 / 31): d_conv = dL/d(conv output) f32 [rows, 6, V-2, V-2] -> partial f32 [ssd_conv_wgrad_partial_rows(rows), 168]: per
@@ -559,6 +563,11 @@ int ssd_build_inputs_flags(int32_t batch, int32_t n_agents, int32_t n_actions, i
                            float pos_scale, float* out, int32_t out_stride, int32_t out_offset, void* stream);
 int ssd_policy_head_env(const ssd_policy_head* args, void* stream);
 int ssd_policy_head_inc(const ssd_policy_head* args, void* stream);
+/* How a head launch of (n_env, n_agents) is cut on the current device: workgroups per agent, compute waves per workgroup (a 16-row
+ * tile each) and the number of tiles the busiest wave walks -- 1 while the grid fits the chip (the kernels without a back edge),
+ * more beyond (Cleanup-10 x 8192: the looped instantiations).  fused_with_encoder: the inc head inside ssd_policy_head_inc_encode. */
+int ssd_policy_head_plan(int32_t n_env, int32_t n_agents, int32_t fused_with_encoder, int32_t* workgroups_per_agent, int32_t* compute_waves,
+                         int32_t* tiles_per_wave);
 /* The inc head of timestep t and ssd_policy_encode of timestep t + 1 as ONE launch (declared below the encoder's arguments):
  * ssd_policy_head_inc_encode. */
 

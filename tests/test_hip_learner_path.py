@@ -398,37 +398,48 @@ def test_fast_graph_runner_stores_a_consistent_batch(groups, kind, n, view, stor
     ctx.runner.close_env()
 
 
-@pytest.mark.parametrize("kind,n,view,N", [("cleanup", 5, 7, 4096), ("harvest", 5, 15, 4096)])
-def test_the_benched_configuration_at_its_own_size(kind, n, view, N, monkeypatch):
-    """Exactly what bench.py times (BASELINE configs 2 / 3), at its own size: hip_graph runner, 4096 envs x 100 timesteps, 10 timesteps
-    per rollout hipGraph (the pipelined 3-launch timestep), class-code storage, episodes written in place into an 8 192-slot replay
-    buffer (two slabs of 4 096), train step captured as hipGraphs, device-side replay sampling and runner statistics, strict_device_ops.
-    Five iterations, so that both slabs are written by pure graph replays (slab 0: eager, captured, replayed; slab 1: captured,
-    replayed).  EVERY rollout is replayed on the CPU oracle with the stored actions (the waste permutation persists across episodes):
-    rewards / clean_num / apple_den / terminated of every step, pose and observation every 25 steps and at slot T.  Every captured
-    train step is compared, gradient by gradient, with an eager evaluation on the same sampled batch (SSD_GRAPH_CHECK)."""
+@pytest.mark.parametrize("kind,n,view,N,slabs,iters", [("cleanup", 5, 7, 4096, 2, 8), ("harvest", 5, 15, 4096, 2, 8), ("cleanup", 10, 7, 8192, 1, 4)])
+def test_the_benched_configuration_at_its_own_size(kind, n, view, N, slabs, iters, monkeypatch):
+    """Exactly what bench.py times (BASELINE configs 2 / 3 / 4), at its own size: hip_graph runner, 4096 (8192) envs x 100 timesteps, 10
+    timesteps per rollout hipGraph (the pipelined 3-launch timestep), class-code storage, episodes written in place into the replay
+    buffer (configs 2 / 3: 8 192 slots = two slabs of 4 096; config 4, Cleanup-10 x 8192 -- the looped head kernels, waves that walk
+    three tiles --: one slab, so that four iterations reach every kind of replay; its oracle replay is 4 x the work of config 2's),
+    train step captured as hipGraphs, device-side replay sampling and runner statistics, strict_device_ops.
+    A slab's episodes: 1st eager, 2nd captures the rollout graph, 3rd captures the episode-edge graphs (opening launches: reset, first
+    observation, runner-state fills, weight re-pack, encoder of slot 0; closing launches: slot-T pass + statistics), 4th is PURE
+    REPLAYS of all three -- eight iterations (four with one slab) put such an episode into every slab, with the weights stepped by
+    learner.train in between (a stale re-pack in the opening graph would change the actions the oracle replays).  EVERY rollout is
+    replayed on the CPU oracle with the stored actions (the waste permutation persists across episodes): rewards / clean_num /
+    apple_den / terminated of every step, pose and observation every 25 steps and at slot T.  Every captured train step is compared,
+    gradient by gradient, with an eager evaluation on the same sampled batch (SSD_GRAPH_CHECK)."""
     from homophily_marl_amd import ops
     from homophily_marl_amd.run import load_config, setup
     from oracle.oracle_py import OracleEnv
     T = 100
-    mp = "default10" if kind == "harvest" else "default5"
+    mp = "default10" if (kind == "harvest" or n == 10) else "default5"
     th.manual_seed(0)
     np.random.seed(0)
     monkeypatch.setenv("SSD_GRAPH_CHECK", "1")
     cfg = load_config(kind, overrides=dict(
-        runner="hip_graph", train_graph=1, steps_per_graph=10, batch_size_run=N, batch_size=16, buffer_size=2 * N, obs_storage="code",
+        runner="hip_graph", train_graph=1, steps_per_graph=10, batch_size_run=N, batch_size=16, buffer_size=slabs * N, obs_storage="code",
         buffer_cpu_only=False, store_state=False, strict_device_ops=True,
         env_args=dict(num_agents=n, map=mp, episode_limit=T, seed=1, view_size=view), use_cuda=True, save_model=False))
     ctx = setup(cfg)
     runner, buf, learner = ctx.runner, ctx.buffer, ctx.learner
+    if n == 10:      # config 4 runs the looped instantiations of both heads
+        assert abi.policy_head_plan(N, n, False)[2] > 1 and abi.policy_head_plan(N, n, True)[2] > 1
     orc = OracleEnv(kind, map=mp, num_agents=n, n_env=N, view_size=view, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=1)
     ok_actions = th.nonzero(runner.env.avail_actions_batch[0, 0]).squeeze(-1).cpu().numpy()
     ret_sums, ret_sq = [], []
+    replayed_edges = 0
     try:
-        for it in range(5):
+        for it in range(iters):
+            b_before = runner._bundles.get(buf["obs"][(it % slabs) * N:].data_ptr())
+            pure = b_before is not None and b_before.begin_graph is not None and b_before.finish_graph is not None and b_before.graph is not None
             batch = runner.run(test_mode=False)
+            replayed_edges += int(pure)
             assert runner.pipe and runner.fold_store and runner.fast.fused_enc and runner._replay is buf
-            assert batch["obs"].data_ptr() == buf["obs"][(it % 2) * N:].data_ptr()               # written in place, slab it % 2
+            assert batch["obs"].data_ptr() == buf["obs"][(it % slabs) * N:].data_ptr()           # written in place, slab it % slabs
             assert it == 0 or (runner._graph is not None and runner._graph_steps == 10)
             orc.reset()
             acts = batch["actions"].squeeze(-1).cpu().numpy()
@@ -448,23 +459,72 @@ def test_the_benched_configuration_at_its_own_size(kind, n, view, N, monkeypatch
             assert np.isin(acts, ok_actions).all() and int(batch["filled"].sum()) == N * (T + 1)
             ai = batch["actions_inc"].squeeze(-1)
             assert (ai.diagonal(dim1=2, dim2=3) == 0).all() and int(ai.max()) <= 2 and int(ai.min()) >= 0
+            # slot T holds what the closing pass filed (both heads on the last observation): available env actions, a zero diagonal
+            assert np.isin(acts[:, T], ok_actions).all()
             buf.insert_episode_batch(batch)
-            assert buf.episodes_in_buffer == min(2, it + 1) * N
+            assert buf.episodes_in_buffer == min(slabs, it + 1) * N
             sample = buf.sample(16, out=learner.sample_out())
             assert (learner.sample_out() is None) or sample is learner.sample_out()
             learner.train(sample, runner.t_env, ctx.train_steps)          # replays are checked against the eager step inside (SystemExit)
             ctx.train_steps += 1
+        assert replayed_edges >= slabs                                    # every slab saw an episode made of replays only
         assert learner._graph is not None and learner._check_n >= 2
         assert all(bool(th.isfinite(p).all()) for p in ctx.mac.parameters())
         assert runner.env.native.poll_error() == 0                        # no slot overrun, no f16 range flag
-        # device-side runner statistics (episode_runner.py:121-152): the first rollout was logged and cleared (log clock), the other
-        # four are still accumulated on the device -- against the stored batches' own sums
+        # device-side runner statistics (episode_runner.py:121-152): the first rollout was logged and cleared (log clock), the others
+        # are still accumulated on the device (by the eager launch and by the closing graph's replays) -- against the stored batches' own sums
         acc = runner._acc_train.cpu().numpy()
-        assert runner.train_stats["n_episodes"] == 4 * N and runner.train_stats["n_returns"] == 4 * N * n
+        assert runner.train_stats["n_episodes"] == (iters - 1) * N and runner.train_stats["n_returns"] == (iters - 1) * N * n
         assert abs(acc[2] - sum(ret_sums[1:])) < 1e-6 * max(1.0, abs(acc[2])) and abs(acc[3] - sum(ret_sq[1:])) < 1e-6 * max(1.0, acc[3])
     finally:
         ops.set_strict(False)
         runner.close_env()
+
+
+def test_episode_edge_graphs_equal_the_eager_episode_edges():
+    """the episode's opening and closing launches as hipGraph replays (episode_edge_graphs, on by default) against the same
+    launches issued one by one.  Two runs from the same seeds, seven episodes in ONE storage with learner.train between episodes (the
+    opening graph re-packs the weight images: a stale pack would show in the actions), edge graphs on / off: the stored batches
+    (slot T included), the runner state an episode leaves (previous actions / reward / incentive actions, returns, hidden states),
+    the packed head images and the device-side statistics must be bit-equal; with the graphs on, episodes 4 .. 7 replay both."""
+    from homophily_marl_amd.run import load_config, setup
+    N, T, n = 96, 12, 5
+
+    def run(edge):
+        cfg = load_config("cleanup", overrides=dict(
+            runner="hip_graph", train_graph=0, steps_per_graph=4, batch_size_run=N, batch_size=8, buffer_size=N, obs_storage="code",
+            buffer_cpu_only=False, store_state=False, episode_edge_graphs=edge, runner_log_interval=10 ** 12,
+            env_args=dict(num_agents=n, map="default5", episode_limit=T, seed=9), use_cuda=True, save_model=False))
+        th.manual_seed(0)
+        np.random.seed(0)
+        ctx = setup(cfg)
+        runner = ctx.runner
+        batches, replays = [], 0
+        for it in range(7):
+            b = next(iter(runner._bundles.values())) if runner._bundles else None
+            replays += int(b is not None and b.begin_graph is not None and b.finish_graph is not None)
+            batch = runner.run(test_mode=False)
+            batches.append({k: v.clone() for k, v in batch.data.transition_data.items()})
+            ctx.buffer.insert_episode_batch(batch)
+            ctx.learner.train(ctx.buffer.sample(8), runner.t_env, ctx.train_steps)
+            ctx.train_steps += 1
+        assert runner.pipe and runner.fold_store
+        state = dict(prev_actions=runner.prev_actions, prev_reward=runner.prev_reward, prev_inc=runner.prev_inc, ep_return=runner.ep_return,
+                     h_env=runner.fast.h_env, h_inc=runner.fast.h_inc, img_env=runner.fast.p["img_env"], img_inc=runner.fast.p["img_inc"],
+                     t_dev=runner.t_dev, acc=runner._acc_train)
+        state = {k: v.clone() for k, v in state.items()}
+        assert runner.env.native.poll_error() == 0
+        runner.close_env()
+        return batches, state, replays
+
+    on, s_on, r_on = run(True)
+    off, s_off, r_off = run(False)
+    assert r_on >= 3 and r_off == 0
+    for it, (x, y) in enumerate(zip(on, off)):
+        for k in x:
+            assert th.equal(x[k], y[k]), (it, k)
+    for k in s_on:
+        assert th.equal(s_on[k], s_off[k]), k
 
 
 def test_host_replay_buffer_with_a_captured_train_step():
