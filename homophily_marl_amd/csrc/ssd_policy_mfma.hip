@@ -61,8 +61,12 @@ __device__ __forceinline__ void leaky_split8(const f32x4& t0, const f32x4& t1, u
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const f32x2 x = p < 2 ? f32x2{t0[2 * p], t0[2 * p + 1]} : f32x2{t1[2 * p - 4], t1[2 * p - 3]};
-        f32x2 y;
-        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(c));
+        // The FIRST instruction that touches x is compiler-visible: t0 / t1 are MFMA results, and gfx950 does not interlock an MFMA's
+        // result write against a vector instruction that reads the register -- the compiler's hazard recogniser inserts the wait
+        // states, but it does not look into inline asm.  With `v_pk_mul_f32` as asm the 5-batch-tile 15 x 15 instantiation read the last
+        // conv accumulator of batch tile 0 two instructions behind its MFMA (round 4: every row 0..15 of every workgroup 1e-3 off at
+        // more than 32 768 rows; round 3's 16-bit-plane variant failed the same way, intermittently).  Everything below depends on y.
+        const f32x2 y = x * c;
         float m0, m1, l0, l1;
         asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(x.x), "v"(y.x));
         asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(x.y), "v"(y.y));
@@ -1331,7 +1335,11 @@ __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     encode_body<V, PREC, ACT, BT>(a, lds_raw, (int)blockIdx.x, (int)blockIdx.y);
 }
-static int enc_bt(int V, int rows) { return (V == 15 && rows <= 32768) ? 4 : 5; }
+static int enc_bt(int V, int rows) {
+    static const char* force = getenv("SSD_ENC_BT");                  // diagnostics: force the batch tiles per workgroup (4 | 5) for 15 x 15 windows
+    if (force && V == 15) return force[0] == '4' ? 4 : 5;
+    return (V == 15 && rows <= 32768) ? 4 : 5;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_inc_encode: the inc head of timestep t and the encoder of timestep t + 1 as ONE launch (pipelined rollout).  Both follow the env
