@@ -168,7 +168,8 @@ class SsdPolicyHead(C.Structure):
                 ("prev_actions_inc_out", C.c_void_p), ("prev_reward_out", C.c_void_p), ("ep_return", C.c_void_p), ("next_t_out", C.c_void_p),
                 ("precision", C.c_int32), ("env_id_base", C.c_uint32), ("feat_part", C.c_void_p), ("feat_bands", C.c_int32),
                 ("lin_b", C.c_void_p), ("input_flags", C.c_uint32),
-                ("next_step_out", C.c_void_p), ("t_copy_out", C.c_void_p), ("step_copy_out", C.c_void_p)]
+                ("next_step_out", C.c_void_p), ("t_copy_out", C.c_void_p), ("step_copy_out", C.c_void_p),
+                ("recv_inc", C.c_void_p), ("recv_inc_out", C.c_void_p), ("avail_bits", C.c_uint32)]
 
 
 class SsdPolicyHeadParams(C.Structure):

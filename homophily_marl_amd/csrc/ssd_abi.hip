@@ -663,7 +663,10 @@ static int check_head(const ssd_policy_head* a, int inc) {
     if (a->dst_reward && (!a->dst_clean_num || !a->dst_apple_den)) return fail(SSD_ERR_INVALID, "dst_reward needs dst_clean_num and dst_apple_den");
     if (a->dst_terminated && !a->terminated) return fail(SSD_ERR_INVALID, "dst_terminated needs terminated");
     if (inc ? (!a->actions || !a->pos_pre || !a->orient_pre || !a->reward || !a->clean_num || !a->apple_den)
-            : (!a->prev_actions || !a->prev_reward || !a->prev_actions_inc || !a->pos)) return fail(SSD_ERR_INVALID, "missing head input");
+            : (!a->prev_actions || !a->prev_reward || (!a->prev_actions_inc && !a->recv_inc) || !a->pos)) return fail(SSD_ERR_INVALID, "missing head input");
+    if ((a->recv_inc || a->recv_inc_out) && (a->n_agents > 16 || ((reinterpret_cast<uintptr_t>(a->recv_inc) | reinterpret_cast<uintptr_t>(a->recv_inc_out)) & 15)))
+        return fail(SSD_ERR_INVALID, "recv_inc / recv_inc_out: 16-byte records (n_agents <= 16), 16-byte aligned");
+    if (inc ? (a->recv_inc != nullptr) : (a->recv_inc_out != nullptr)) return fail(SSD_ERR_INVALID, "recv_inc is the env head's input, recv_inc_out the inc head's output");
     // layout limits of the fused kernel: 32 encoder features + tail (+ one-hot action for inc) within 64 columns, 16 fc2 rows
     {
         const uint32_t fl = a->input_flags ? (a->input_flags & ~SSD_INPUT_EXPLICIT) : (uint32_t)SSD_INPUT_FLAGS_SHIPPED;

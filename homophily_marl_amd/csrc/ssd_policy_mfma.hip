@@ -231,6 +231,8 @@ struct HeadK {
     const float *feat_part, *lin_b;
     const float* ep_ret;           // inc head: the episode return so far (read with the tile's inputs, written back in the epilogue)
     const uint8_t* term;           // inc head: the env step's terminated flags
+    const uint8_t* recv;           // env head, nullable: receiver-major incentive bytes [n, N, 16] (instead of prev_inc)
+    uint32_t avail_bits;           // env head: bit 31 set = the availability mask itself (no loads from `avail`)
     PSTAMP_DECL
 };
 struct HeadCold {
@@ -243,6 +245,7 @@ struct HeadCold {
     int32_t* numeric_err;          // the device's numeric-status word (ERR_F16_RANGE)
     int64_t* next_t;
     int64_t *next_step, *t_copy, *step_copy;   // inc head: *next_step = *step + 1; env head: *t_copy = *t_index, *step_copy = *step
+    uint8_t* recv_out;             // inc head, nullable: receiver-major copy of the incentive actions (byte `agent` of [j, N, 16])
     uint64_t tail_layout;          // env head: first tail column of each _build_inputs block as 6 signed bytes (TAIL_ABSENT = not present):
                                    // last action | agent id | sign(r) | sign(received incentives) | 1 - distances | pos
 };
@@ -355,6 +358,7 @@ struct TileIn {
     int pa, act;                   // env: last action; inc: the env action just taken
     int32_t inc[3];                // env: the incentive action giver g = q + 4 k sent this agent at the previous step (0 / 1 / 2), k = 0 .. 2:
                                    // the four lane quarters of a row share the givers between them (summed over q in prepare)
+    uint32_t rv;                   // env, receiver-major bytes given: givers 4 q .. 4 q + 3 as one dword
     float pr, p0, p1, o0, o1;      // env: last reward, pose
     int aj[3];                     // inc epilogue items (row, j) = lane + 64 k: action of j and its 7 features
     float f[3][7];
@@ -401,12 +405,18 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
         in.pr = ld32(a.prev_reward, er);
         // received incentives: prev_inc[bc, g, agent] for every giver g (values 0 / 1 / 2: the low word); givers past n re-read giver
         // n - 1 and count nothing
-        const int32_t* pi = reinterpret_cast<const int32_t*>(a.prev_inc);
+        if (a.recv) {                                                  // (wave-uniform) the row's 16 giver bytes: dword q for lane quarter q
+            in.rv = ld32(reinterpret_cast<const uint32_t*>(a.recv), arow * 4u + (uint32_t)q);
+            in.inc[0] = in.inc[1] = in.inc[2] = 0;
+        } else {
+            in.rv = 0u;
+            const int32_t* pi = reinterpret_cast<const int32_t*>(a.prev_inc);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {                                  // (counted in prepare: nothing here waits for a load)
-            const int g = q + 4 * k;
-            const uint32_t gc = (uint32_t)(g < n ? g : n - 1);
-            in.inc[k] = (k == 0 || n > 4 * k) ? ld32(pi, 2u * (((uint32_t)bc * (uint32_t)n + gc) * (uint32_t)n + (uint32_t)agent)) : 0;   // wave-uniform predicate
+            for (int k = 0; k < 3; ++k) {                              // (counted in prepare: nothing here waits for a load)
+                const int g = q + 4 * k;
+                const uint32_t gc = (uint32_t)(g < n ? g : n - 1);
+                in.inc[k] = (k == 0 || n > 4 * k) ? ld32(pi, 2u * (((uint32_t)bc * (uint32_t)n + gc) * (uint32_t)n + (uint32_t)agent)) : 0;   // wave-uniform predicate
+            }
         }
         typedef float f32x2v __attribute__((ext_vector_type(2)));
         const f32x2v pp = ld32(reinterpret_cast<const f32x2v*>(a.pos), er);      // one 8-byte load per pair
@@ -510,7 +520,7 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
     long slot_t = a.t_index ? (long)*a.t_index : 0;
     uint32_t step = 0;                                                 // (both assigned once the loads above are pinned, see below)
     bool file = false;
-    const uint32_t avail_bits = INC ? 0xFFFFFFFFu : avail_to_bits(a.avail, A);
+    const uint32_t avail_bits = INC ? 0xFFFFFFFFu : ((a.avail_bits >> 31) ? (a.avail_bits & 0x7FFFFFFFu) : avail_to_bits(a.avail, A));
     if (!INC) PSTAMP_DRAINED(11);
     u32x4 bh[2], bl[2];                                                // the fc1 operand of the current tile
     // range guard of the activations that get scaled by XS and split (PREC 2): checked where they are produced (no state carried
@@ -557,6 +567,9 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
                 const int on = (g < n && g != agent) ? 1 : 0;          // inc_mask_actions: no self incentive
                 recv += on * ((in.inc[k] == 1) - (in.inc[k] == 2));
             }
+            // receiver-major bytes: values 0 / 1 / 2, the receiver's own byte and the bytes of givers >= n are 0 (the inc head never
+            // writes them), so the count is bit 0 of every byte minus bit 1 of every byte
+            recv += __builtin_popcount(in.rv & 0x01010101u) - __builtin_popcount(in.rv & 0x02020202u);
             recv += __shfl_xor(recv, 16);                              // the row's four quarters hold different givers
             recv += __shfl_xor(recv, 32);
             const float sg_r = (float)((in.pr > 0.f) - (in.pr < 0.f)), sg_i = (float)((recv > 0) - (recv < 0));
@@ -780,6 +793,7 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
             cold_blocks(ca, &cb, nullptr);
             int64_t *out_actions = ca.out_actions, *p_inc = cb.p_inc, *d_actions_inc = cb.d_actions_inc;
             float* q_out = ca.q_out;
+            uint8_t* recv_out = COLD(uint8_t, recv_out);
             if (first) PSTAMP(9);
             const uint32_t n_magic = (65536u + (uint32_t)n - 1u) / (uint32_t)n;      // it / n for it < 192, n <= 10
 #pragma unroll
@@ -812,6 +826,7 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
                 const size_t pair = ((size_t)bb * n + agent) * n + j;
                 out_actions[pair] = act;
                 if (p_inc) p_inc[pair] = act;
+                if (recv_out) recv_out[((size_t)j * N + bb) * 16 + agent] = (uint8_t)act;      // receiver-major byte (the next env head's input)
                 if (d_actions_inc && file) d_actions_inc[(((size_t)bb * a.slots + slot_t) * n + agent) * n + j] = act;
             }
             // once per (env, agent), lanes < 16 (row = lane): this step's outcome of the agent itself, read with the tile's inputs
@@ -902,6 +917,7 @@ static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c, int waves
     k.t_index = p->t_index; k.slots = p->t_index ? p->t_slots : 1;
     k.feat_part = p->feat_part; k.feat_bands = p->feat_bands; k.lin_b = p->lin_b;
     k.ep_ret = p->ep_return; k.term = p->terminated;
+    k.recv = p->recv_inc; k.avail_bits = p->avail_bits; c.recv_out = p->recv_inc_out;
     c.out_actions = p->out_actions; c.q_out = p->q_out; c.out_actions_i32 = p->out_actions_i32; c.pos_copy = p->pos_copy; c.orient_copy = p->orient_copy;
     c.d_pos = p->dst_pos; c.d_orient = p->dst_orient; c.d_onehot = p->dst_actions_onehot; c.d_reward = p->dst_reward;
     c.d_clean = p->dst_clean_num; c.d_den = p->dst_apple_den; c.d_term = p->dst_terminated;

@@ -60,6 +60,7 @@ class FastPolicy:
         self.actions_inc = th.zeros(N, n, n, dtype=th.long, device=self.dev) if actions_inc_out is None else actions_inc_out
         assert self.actions.is_contiguous() and self.actions_inc.is_contiguous()
         self.avail = avail_mask_u8.to(device=self.dev, dtype=th.uint8).contiguous()
+        self._avail_bits = 0x80000000 | sum(1 << k for k, v in enumerate(avail_mask_u8.detach().cpu().reshape(-1).tolist()[:31]) if v)   # ssd_policy_head.avail_bits
         self.seed = seed & 0xFFFFFFFF
         self.arange_n = th.arange(n, device=self.dev).unsqueeze(1)
         if share_packs_from is not None:
@@ -268,6 +269,7 @@ class FastPolicy:
         if self.fused:
             ha = self._head_args(False, eps, step, q_out, buf)
             ha.avail = self.avail.data_ptr()
+            ha.avail_bits = self._avail_bits       # the mask itself (a constant of the env class): the kernel issues no loads for it
             ha.prev_actions, ha.prev_reward, ha.prev_actions_inc, ha.pos = (prev_actions.data_ptr(), prev_reward.data_ptr(),
                                                                           prev_inc.data_ptr(), pos.data_ptr())
             ha.out_actions = self.actions.data_ptr()

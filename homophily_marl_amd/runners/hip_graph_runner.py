@@ -64,6 +64,8 @@ class HipGraphRunner(HipVecRunner):
         self.prev_actions = th.full((N, n), -1, dtype=th.long, device=dev)
         self.prev_reward = th.zeros(N, n, device=dev)
         self.prev_inc = th.zeros(N, n, n, dtype=th.long, device=dev)
+        # the same incentive actions as receiver-major bytes [n(receiver), N, 16] (ssd_policy_head.recv_inc): what the fused env head reads
+        self.recv_inc = th.zeros(n, N, 16, dtype=th.uint8, device=dev) if n <= 16 else None
         H = a.rnn_hidden_dim
         self.h_env = th.zeros(N, n, 1, H, device=dev)
         self.h_inc = th.zeros(N, n, 1, H, device=dev)
@@ -152,11 +154,15 @@ class HipGraphRunner(HipVecRunner):
                                       dst_actions=st["actions"].data_ptr(), dst_actions_onehot=st["actions_onehot"].data_ptr(),
                                       prev_actions_out=self.prev_actions.data_ptr())
                     b.file_inc_last = dict(common, dst_actions_inc=st["actions_inc"].data_ptr())
+                    if self.recv_inc is not None and self.groups == 1:
+                        b.file_env = dict(b.file_env, recv_inc=self.recv_inc.data_ptr())
                     b.file_inc = dict(b.file_inc_last, prev_actions_inc_out=self.prev_inc.data_ptr(), dst_reward=st["reward"].data_ptr(),
                                       dst_clean_num=st["clean_num"].data_ptr(), dst_apple_den=st["apple_den"].data_ptr(),
                                       dst_terminated=st["terminated"].data_ptr(), terminated=out["terminated"].data_ptr(),
                                       prev_reward_out=self.prev_reward.data_ptr(), ep_return=self.ep_return.data_ptr(),
                                       next_t_out=self.t_dev.data_ptr())
+                    if self.recv_inc is not None and self.groups == 1:
+                        b.file_inc = dict(b.file_inc, recv_inc_out=self.recv_inc.data_ptr())
                     if self.pipe:
                         # counter hand-over without a launch writing a scalar it reads: the env head reads the masters (t_dev, rng_ctr)
                         # and writes the copies (t_store, rng_copy); the inc head reads the copies and writes the masters' next values
@@ -415,7 +421,7 @@ class HipGraphRunner(HipVecRunner):
         # episode returns, the hidden states (the generic timestep's, or FastPolicy's own)
         hidden = [self.h_env, self.h_inc] if self.fast is None else [h for fp in self.fasts for h in (fp.h_env, fp.h_inc)]
         ops.fill_blocks([(self.t_dev, 0), (self.prev_actions, 0xFFFFFFFF), (self.prev_reward, 0), (self.prev_inc, 0), (self.ep_return, 0)]
-                        + [(h, 0) for h in hidden])
+                        + ([(self.recv_inc, 0)] if self.recv_inc is not None else []) + [(h, 0) for h in hidden])
         if self.fast is not None:
             if in_capture:
                 self.fast._pack_eager()   # the learner may have stepped the weights since the last episode (packs are shared)

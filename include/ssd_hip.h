@@ -543,6 +543,17 @@ typedef struct ssd_policy_head {
      * index).  env head: *t_copy_out = *t_index, *step_copy_out = *step.  A launch never writes a scalar that it reads: the env head
      * reads the masters and writes the copies, the inc head reads the copies and writes the masters. */
     int64_t *next_step_out, *t_copy_out, *step_copy_out;
+    /* ---- ABI 7 ---- */
+    /* Compact runner state for the env head's input phase (all optional).  recv_inc: the previous step's incentive actions as
+     * RECEIVER-major bytes u8 [n(receiver), n_env, 16] (byte g = what giver g sent this receiver: 0 / 1 / 2; the receiver's own byte
+     * and bytes >= n are 0): when given, the env head reads it instead of prev_actions_inc [n_env, n(giver), n(receiver)] i64 -- one
+     * 4-byte load per lane over 256 contiguous bytes per 16-row tile instead of n 8-byte loads over n x 16 cache lines.
+     * recv_inc_out: the inc head writes byte `agent` of every receiver's record next to prev_actions_inc_out (the caller zeroes the
+     * array when an episode opens, like prev_actions_inc).  avail_bits: bit 31 set = bits 0 .. n_actions - 1 ARE the availability
+     * mask of `avail` (a constant of the env class): the env head then issues no loads for it. */
+    const uint8_t* recv_inc;
+    uint8_t* recv_inc_out;
+    uint32_t avail_bits;
 } ssd_policy_head;
 #define SSD_INPUT_LAST_ACTION 1u   /* obs_last_action: one-hot of the previous env action, n_actions columns */
 #define SSD_INPUT_AGENT_ID    2u   /* obs_agent_id: one-hot of the agent, n columns */
