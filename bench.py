@@ -275,6 +275,10 @@ def main():
     ap.add_argument("--qnet-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="e2e: arithmetic of the ROLLOUT controller kernels: fp32 (two-term f16 split MFMA products, f32-equivalent; the headline) "
                          "or bf16 (single bf16 products; a second, labelled line -- the learner stays fp32)")
+    ap.add_argument("--learner-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="e2e: arithmetic of the LEARNER's matrix products: fp32 (exact-f32 / f32-equivalent split MFMA products; the headline) or "
+                         "bf16 (single bf16 MFMA products in the affine layers, the recurrence and the encoder; f32 master weights / Adam / loss) "
+                         "-- a labelled line, never the headline")
     ap.add_argument("--train-steps-per-rollout", type=int, default=1, help="e2e: learner.train calls per rollout (reference cadence: 1)")
     ap.add_argument("--obs-storage", default="code", choices=["f32", "code"],
                     help="e2e: observation format of the episode storage / replay buffer: u8 class codes (format C, default: lossless, "

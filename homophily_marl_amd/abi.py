@@ -278,6 +278,8 @@ HIP_SIGNATURES["ssd_bias_bmm_bwd"] = (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 
 HIP_SIGNATURES["ssd_bias_bmm_leaky_fwd"] = (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_leaky_bwd"] = (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_bmm_reserve_scratch"] = (C.c_int, [C.c_void_p])
+HIP_SIGNATURES["ssd_set_learner_precision"] = (C.c_int, [C.c_int32])
+HIP_SIGNATURES["ssd_learner_precision"] = (C.c_int, [])
 HIP_SIGNATURES["ssd_conv_wgrad_partial_rows"] = (C.c_int, [C.c_int32])
 HIP_SIGNATURES["ssd_conv_wgrad_codes"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
 HIP_SIGNATURES["ssd_policy_head_plan"] = (C.c_int, [C.c_int32] * 3 + [C.POINTER(C.c_int32)] * 3)

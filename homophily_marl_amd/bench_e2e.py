@@ -53,10 +53,11 @@ def run_e2e(args, c, rank, world, local_rank):
         spg -= 1
     qnet = getattr(args, "qnet_dtype", "fp32")
     tspr = max(1, int(getattr(args, "train_steps_per_rollout", 1)))
+    ldt = str(getattr(args, "learner_dtype", "fp32"))
     cfg = load_config(c["env"], overrides=dict(
         runner=args.runner, train_graph=args.train_graph, steps_per_graph=spg, batch_size_run=N, batch_size=16, buffer_size=buffer_size,
         obs_storage=getattr(args, "obs_storage", "f32"), buffer_cpu_only=False, store_state=False, qnet_dtype=qnet,
-        train_steps_per_rollout=tspr,
+        train_steps_per_rollout=tspr, learner_dtype=ldt,
         env_args=dict(num_agents=n, map=c["map"], episode_limit=T, view_size=c["view_size"], seed=1), use_cuda=True, save_model=False,
         device_index=local_rank, env_id_base=rank * N, strict_device_ops=True))       # runner / learner statistics on, at the shipped log intervals
     th.manual_seed(0)                     # fixed-seed random-init weights, identical on every rank
@@ -180,11 +181,14 @@ def run_e2e(args, c, rank, world, local_rank):
     tot = sum(k["avg_us"] for k in kernels)
     for k in kernels:
         k["share_of_timestep"] = round(k["avg_us"] / tot, 4)
-    return dict(elapsed=elapsed, rank_elapsed=rank_elapsed, collectives=coll, grad_bytes=4 * sum(p.numel() for p in learner.params), kernels=kernels, dtype="fp32" if qnet == "fp32" else "bf16",
+    return dict(elapsed=elapsed, rank_elapsed=rank_elapsed, collectives=coll, grad_bytes=4 * sum(p.numel() for p in learner.params), kernels=kernels,
+                dtype="fp32" if (qnet == "fp32" and ldt == "fp32") else ("bf16" if (qnet != "fp32" and ldt != "fp32") else "mixed: rollout %s, learner %s" % (qnet, ldt)),
                 workload="%s_rollout_plus_homophily_train" % args.config,
                 extra=dict(obs_format=("u8 class codes [n_env,n,%d,%d] (format C)" % (V, V)) if code else "f32[n_env,n,3,%d,%d]" % (V, V),
-                           qnet_dtype=("fp32 (rollout: two-term f16 split MFMA products, f32-equivalent; learner: fp32)" if qnet == "fp32"
-                                       else "bf16 rollout inference (single bf16 MFMA products), fp32 learner"),
+                           qnet_dtype=("fp32 (rollout: two-term f16 split MFMA products, f32-equivalent)" if qnet == "fp32"
+                                       else "bf16 rollout inference (single bf16 MFMA products)"),
+                           learner_dtype=("fp32 (exact-f32 MFMAs in the affine layers, f32-equivalent split products in the recurrence and the encoder)" if ldt == "fp32"
+                                          else "bf16 (LABELLED VARIANT: single bf16 MFMA products in the affine layers, the recurrence and the encoder; f32 master weights, Adam and loss)"),
                            step="1 bench step = 1 iteration: reset + %d timesteps + slot-T pass + replay insert + sample + %d learner.train" % (T, tspr),
                            timesteps_timed=timed["timesteps"], train_steps_timed=timed["trains"], rollouts_timed=args.steps,
                            train="learner.train(batch_size 16 x T 101), double-Q + sim loss, 2x Adam; %d per rollout" % tspr,

@@ -591,6 +591,12 @@ int ssd_bmm_reserve_scratch(void* stream) {
     if (!bmm_scratch((hipStream_t)stream)) return fail(SSD_ERR_DEVICE, "ssd_bmm_reserve_scratch: allocation failed (inside a stream capture?)");
     return SSD_OK;
 }
+int ssd_set_learner_precision(int32_t precision) {
+    if (precision != 1 && precision != 2) return fail(SSD_ERR_INVALID, "ssd_set_learner_precision: 1 (bf16) or 2 (f32)");
+    set_learner_precision(precision);
+    return SSD_OK;
+}
+int ssd_learner_precision(void) { return learner_precision(); }
 int ssd_conv_wgrad_partial_rows(int32_t rows) { return rows < 1 ? 0 : conv_wgrad_partial_rows(rows); }
 int ssd_conv_wgrad_codes(const uint8_t* codes, const float* d_conv, float* partial, int32_t rows, int32_t view_edge, void* stream) {
     if (!codes || !d_conv || !partial || rows < 1) return fail(SSD_ERR_INVALID, "bad argument");

@@ -40,6 +40,20 @@ __device__ __forceinline__ float ld32(const float* base, uint32_t idx) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(base) + (size_t)(idx * 4u));
 }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// The labelled reduced-precision variant of the learner's GEMMs (learner_dtype: bf16; ssd_set_learner_precision(1)): operands rounded
+// to bf16 (round to nearest even), ONE v_mfma_f32_16x16x32_bf16 per 32 reduction indices, f32 accumulation.  A lane's eight
+// k-values are the 2 x 4 (dx / forward) or 8 x 1 (dw) values the f32 kernels feed to eight consecutive 16x16x4 steps -- the loads, the
+// masks and the order of the chunks are those of the f32 path; the parameters, the optimiser and the loss stay f32.
+using bf8 = __attribute__((ext_vector_type(8))) __bf16;
+__device__ __forceinline__ f32x4 mfma32b(const float (&a)[8], const float (&b)[8], f32x4 c) {
+    bf8 x, y;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x[j] = (__bf16)a[j]; y[j] = (__bf16)b[j]; }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+}
+static int g_learner_precision = 2;            // 2: f32 (exact-f32 MFMAs; two- / three-term splits in the recurrence), 1: single bf16 products
+int learner_precision() { return g_learner_precision; }
+void set_learner_precision(int p) { g_learner_precision = p == 1 ? 1 : 2; }
 
 // 4 consecutive floats p[k0 .. k0 + 3] of a row of `len` floats; elements at or past len read as 0
 __device__ __forceinline__ f32x4 load4(const float* p, int k0, int len) {
@@ -56,7 +70,7 @@ __device__ __forceinline__ f32x4 load4(const float* p, int k0, int len) {
 // (chunk c, r) uses k = 16 c + 4 q + r for lane quarter q.
 // XV: I is a multiple of 4, a lane's four x values of a chunk come as one 16-byte load (no chunk straddles the end of a row).
 constexpr int BMM_TPW = 3;                      // output tiles per wave
-template <bool XV>
+template <bool XV, bool BF = false>
 __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, q = lane >> 4;
@@ -112,14 +126,35 @@ __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
                 if (t0 + t < otiles) acc[t] = mfma4(xv, (kon && on[t]) ? d.w[t][r] : 0.f, acc[t]);
         }
     };
+    // bf16: chunks c and c + 1 (this lane's k = 16 c + 4 q + r and 16 (c + 1) + 4 q + r) are the 8 reduction indices of ONE K = 32 MFMA
+    auto use_pair = [&](int c, const Chunk& d0, const Chunk& d1, bool two) {
+        const int k0 = 16 * c + 4 * q;
+        float xv[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { xv[r] = k0 + r < I ? d0.x[r] : 0.f; xv[4 + r] = (two && k0 + 16 + r < I) ? d1.x[r] : 0.f; }
+#pragma unroll
+        for (int t = 0; t < BMM_TPW; ++t) {
+            if (t0 + t >= otiles) continue;
+            float wv[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { wv[r] = (k0 + r < I && on[t]) ? d0.w[t][r] : 0.f; wv[4 + r] = (two && k0 + 16 + r < I && on[t]) ? d1.w[t][r] : 0.f; }
+            acc[t] = mfma32b(xv, wv, acc[t]);
+        }
+    };
     Chunk ca, cb;
     fetch(0, ca);
     for (int c = 0; c < chunks; c += 2) {
         if (c + 1 < chunks) fetch(c + 1, cb);
-        use(c, ca);
-        if (c + 1 < chunks) {
+        if constexpr (BF) {
+            Chunk cur = ca;
             if (c + 2 < chunks) fetch(c + 2, ca);
-            use(c + 1, cb);
+            use_pair(c, cur, cb, c + 1 < chunks);
+        } else {
+            use(c, ca);
+            if (c + 1 < chunks) {
+                if (c + 2 < chunks) fetch(c + 2, ca);
+                use(c + 1, cb);
+            }
         }
     }
 #pragma unroll
@@ -168,7 +203,7 @@ __global__ __launch_bounds__(64) void k_bmm_dw_reduce(BmmK a) {
 constexpr int BMM_BWD_WAVES = 16;               // the row axis (K of dw: up to T B n = 8080 rows) is split 16 ways
 // OV: O is a multiple of 4: 16-byte operand loads along the output axis in the dx part.  ACT: the layer's forward applied LeakyReLU
 // (a.act_y = its output): every g value is multiplied by the slope at its element as it is loaded (dx, dw and db all see g slope).
-template <bool OV, bool ACT>
+template <bool OV, bool ACT, bool BF = false>
 __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int dw_blocks) {
     __shared__ f32x4 red[BMM_BWD_WAVES][64];
     __shared__ float redb[BMM_BWD_WAVES][16];
@@ -216,14 +251,32 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
                 acc = mfma4(gv, on ? d.w[r] : 0.f, acc);
             }
         };
+        auto use_pair = [&](int c, const Pair& d0, const Pair& d1, bool two) {      // bf16: two chunks = the 8 reduction indices of one K = 32 MFMA
+            const int k0 = 16 * c + 4 * q;
+            float gv[8], wv[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool on0 = k0 + r < O, on1 = two && k0 + 16 + r < O;
+                float g0 = on0 ? d0.g[r] : 0.f, g1 = on1 ? d1.g[r] : 0.f;
+                if constexpr (ACT) { g0 = d0.y[r] > 0.f ? g0 : 0.01f * g0; g1 = (on1 && !(d1.y[r] > 0.f)) ? 0.01f * g1 : g1; }
+                gv[r] = g0; gv[4 + r] = g1; wv[r] = on0 ? d0.w[r] : 0.f; wv[4 + r] = on1 ? d1.w[r] : 0.f;
+            }
+            acc = mfma32b(gv, wv, acc);
+        };
         Pair pa, pb;
         fetch(0, pa);
         for (int c = 0; c < chunks; c += 2) {
             if (c + 1 < chunks) fetch(c + 1, pb);
-            use(c, pa);
-            if (c + 1 < chunks) {
+            if constexpr (BF) {
+                const Pair cur = pa;
                 if (c + 2 < chunks) fetch(c + 2, pa);
-                use(c + 1, pb);
+                use_pair(c, cur, pb, c + 1 < chunks);
+            } else {
+                use(c, pa);
+                if (c + 1 < chunks) {
+                    if (c + 2 < chunks) fetch(c + 2, pa);
+                    use(c + 1, pb);
+                }
             }
         }
         if (i < I) {
@@ -253,6 +306,7 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
     // 2 x UN steps of operands in flight: the chain is load latency, not arithmetic.  Clamped addresses, values masked at use (no
     // branch around a load); the order of the additions is the step order, as before.
     constexpr int UN = 8;
+    static_assert(UN == 8, "the bf16 path packs UN steps into one K = 32 MFMA");
     const uint32_t icol = ion ? i : I - 1, ocol = oon ? o : O - 1;
     const float* yg = ACT ? a.act_y + (size_t)g * a.g_set : nullptr;
     auto fetch = [&](int s, float (&av)[UN], float (&bv)[UN]) {
@@ -267,12 +321,15 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
         }
     };
     auto use = [&](int s, const float (&av)[UN], const float (&bv)[UN]) {
+        float xs[UN], gs[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const bool rv = 4 * (s + u) + q < R && s + u < s1;
-            const float x = (rv && ion) ? av[u] : 0.f, gv = (rv && oon) ? bv[u] : 0.f;
-            acc = mfma4(x, gv, acc); bsum += gv;
+            xs[u] = (rv && ion) ? av[u] : 0.f; gs[u] = (rv && oon) ? bv[u] : 0.f;
+            if constexpr (!BF) acc = mfma4(xs[u], gs[u], acc);
+            bsum += gs[u];
         }
+        if constexpr (BF) acc = mfma32b(xs, gs, acc);                   // the UN = 8 steps of 4 rows are the 32 reduction indices of one MFMA
     };
     float a0[UN], b0[UN], a1[UN], b1[UN];
     if (s0 < s1) fetch(s0, a0, b0);
@@ -348,8 +405,14 @@ int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y
     k.x = x; k.w = w; k.b = b; k.y = y; k.n = n; k.R = R; k.I = I; k.O = O; k.leaky = leaky;
     const int otiles = (O + 15) / 16, units = ((R + 15) / 16) * ((otiles + BMM_TPW - 1) / BMM_TPW);
     if ((long)I * O >= (1L << 30) || (long)R * I >= (1L << 30)) return -2;        // 32-bit byte offsets inside a weight set
-    if ((I & 3) == 0) hipLaunchKernelGGL(k_bias_bmm_fwd<true>, dim3((units + 3) / 4, n), dim3(256), 0, s, k);
-    else hipLaunchKernelGGL(k_bias_bmm_fwd<false>, dim3((units + 3) / 4, n), dim3(256), 0, s, k);
+    const dim3 grid((units + 3) / 4, n);
+    if (g_learner_precision == 1) {
+        if ((I & 3) == 0) hipLaunchKernelGGL((k_bias_bmm_fwd<true, true>), grid, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((k_bias_bmm_fwd<false, true>), grid, dim3(256), 0, s, k);
+    } else {
+        if ((I & 3) == 0) hipLaunchKernelGGL((k_bias_bmm_fwd<true, false>), grid, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((k_bias_bmm_fwd<false, false>), grid, dim3(256), 0, s, k);
+    }
     return 0;
 }
 
@@ -373,13 +436,16 @@ int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* d
     }
     if ((long)R * I >= (1L << 30) || (long)R * O >= (1L << 30) || (long)I * O >= (1L << 30)) return -2;       // 32-bit byte offsets inside a weight / operand set
     const dim3 grid(dwb + dxb, n), block(BMM_BWD_WAVES * 64);
+    const bool ov = (O & 3) == 0, bf = g_learner_precision == 1;
+#define SSD_BWD(OV_, ACT_, BF_) hipLaunchKernelGGL((k_bias_bmm_bwd<OV_, ACT_, BF_>), grid, block, 0, s, k, dwb)
     if (act_y) {
-        if ((O & 3) == 0) hipLaunchKernelGGL((k_bias_bmm_bwd<true, true>), grid, block, 0, s, k, dwb);
-        else hipLaunchKernelGGL((k_bias_bmm_bwd<false, true>), grid, block, 0, s, k, dwb);
+        if (ov) { if (bf) SSD_BWD(true, true, true); else SSD_BWD(true, true, false); }
+        else { if (bf) SSD_BWD(false, true, true); else SSD_BWD(false, true, false); }
     } else {
-        if ((O & 3) == 0) hipLaunchKernelGGL((k_bias_bmm_bwd<true, false>), grid, block, 0, s, k, dwb);
-        else hipLaunchKernelGGL((k_bias_bmm_bwd<false, false>), grid, block, 0, s, k, dwb);
+        if (ov) { if (bf) SSD_BWD(true, false, true); else SSD_BWD(true, false, false); }
+        else { if (bf) SSD_BWD(false, false, true); else SSD_BWD(false, false, false); }
     }
+#undef SSD_BWD
     if (k.row_chunks > 1) hipLaunchKernelGGL(k_bmm_dw_reduce, dim3(tiles, n), dim3(64), 0, s, k);
     return 0;
 }

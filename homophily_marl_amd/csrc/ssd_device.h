@@ -158,6 +158,8 @@ int launch_policy_inc_encode(const ssd_policy_head* ph, const ssd_policy_encode_
 int conv_wgrad_partial_rows(int R);
 int launch_conv_wgrad(const uint8_t* codes, const float* d_conv, float* partial, int R, int V, hipStream_t s);
 float* bmm_scratch(hipStream_t stream);
+int learner_precision();                  // 2: f32-equivalent (default), 1: single bf16 products (ssd_set_learner_precision)
+void set_learner_precision(int p);
 void launch_fill_blocks(const ssd_block_fill* blocks, int count, hipStream_t stream);
 void launch_runner_stats(const float* coll, const float* eq, const float* ret, int n_env, int n_ret, double* acc, hipStream_t stream);
 int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int n, int R, int I, int O, hipStream_t s, int leaky = 0);

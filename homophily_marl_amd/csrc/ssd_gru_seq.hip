@@ -62,6 +62,11 @@ __device__ __forceinline__ void piece_rc(int i, int lane, int& row, int& colf) {
 __device__ __forceinline__ f32x4 mma16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
+using b8 = __attribute__((ext_vector_type(8))) __bf16;
+using b4 = __attribute__((ext_vector_type(4))) __bf16;
+__device__ __forceinline__ f32x4 mmab(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+}
 
 // gi [T, G, B, 192], wh [G, 64, 192], bh [G, 192] -> hs [G, T, B, 64]; optional (training) rzn [T, G, B, 192], ghn [T, G, B, 64]
 // One workgroup per (weight set g, 16-row tile), 4 compute waves + the writer; wave ft owns hidden features 16 ft .. 16 ft + 15 of the three gates.
@@ -86,7 +91,9 @@ __device__ __forceinline__ float* gru_part_base(const GruParts& P, int g) {
 }
 
 constexpr int FST = 324;            // staging row stride (floats): [hs 64 | r 64 | z 64 | n 64 | gh_n 64] + pad, 1296 B = 16 * 81
-template <bool TRAIN>
+// BF: the labelled reduced-precision variant (learner_dtype: bf16): W_h and the state as single bf16 terms, ONE v_mfma_f32_16x16x32_bf16
+// per product (6 per step instead of 18), no scales (bf16 has f32's exponent range), f32 accumulation and gate arithmetic.
+template <bool TRAIN, bool BF = false>
 __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_fwd(const GruParts gi, const float* __restrict__ wh, const float* __restrict__ bh,
                                                              float* __restrict__ hs, float* __restrict__ rzn, float* __restrict__ ghn, int T, int G,
                                                              int B, int tiles, int32_t* __restrict__ err) {
@@ -130,14 +137,21 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_fwd(const GruParts gi, 
     for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            h8 h, l;
+            if constexpr (BF) {
+                b8 h;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float w = wh[((size_t)g * GH + 32 * s + 8 * q + j) * G3 + gate * GH + 16 * ft + m] * GRU_WS;
-                out_of_range |= !(fabsf(w) <= F16_MAX);                // |W_h| >= 1 023.5 (or NaN): outside the split's range; |h| < 1 needs no check
-                h[j] = (_Float16)w; l[j] = (_Float16)(w - (float)h[j]);
+                for (int j = 0; j < 8; ++j) h[j] = (__bf16)wh[((size_t)g * GH + 32 * s + 8 * q + j) * G3 + gate * GH + 16 * ft + m];
+                ah[gate][s] = __builtin_bit_cast(u32x4, h); al[gate][s] = ah[gate][s];
+            } else {
+                h8 h, l;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float w = wh[((size_t)g * GH + 32 * s + 8 * q + j) * G3 + gate * GH + 16 * ft + m] * GRU_WS;
+                    out_of_range |= !(fabsf(w) <= F16_MAX);            // |W_h| >= 1 023.5 (or NaN): outside the split's range; |h| < 1 needs no check
+                    h[j] = (_Float16)w; l[j] = (_Float16)(w - (float)h[j]);
+                }
+                ah[gate][s] = __builtin_bit_cast(u32x4, h); al[gate][s] = __builtin_bit_cast(u32x4, l);
             }
-            ah[gate][s] = __builtin_bit_cast(u32x4, h); al[gate][s] = __builtin_bit_cast(u32x4, l);
         }
     if (out_of_range && err) atomicOr(err, ERR_F16_RANGE);
     f32x4 bias[3];
@@ -165,25 +179,36 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_fwd(const GruParts gi, 
         if (t > 0) {                                                   // small terms first; the three gates' chains interleave
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
+                if constexpr (BF) {
 #pragma unroll
-                for (int gate = 0; gate < 3; ++gate) acc[gate] = mma16(al[gate][s], xh[s], acc[gate]);
+                    for (int gate = 0; gate < 3; ++gate) acc[gate] = mmab(ah[gate][s], xh[s], acc[gate]);
+                } else {
 #pragma unroll
-                for (int gate = 0; gate < 3; ++gate) acc[gate] = mma16(ah[gate][s], xl[s], acc[gate]);
+                    for (int gate = 0; gate < 3; ++gate) acc[gate] = mma16(al[gate][s], xh[s], acc[gate]);
 #pragma unroll
-                for (int gate = 0; gate < 3; ++gate) acc[gate] = mma16(ah[gate][s], xh[s], acc[gate]);
+                    for (int gate = 0; gate < 3; ++gate) acc[gate] = mma16(ah[gate][s], xl[s], acc[gate]);
+#pragma unroll
+                    for (int gate = 0; gate < 3; ++gate) acc[gate] = mma16(ah[gate][s], xh[s], acc[gate]);
+                }
             }
         }
         f32x4 hn, rg, zg, ng, an;
+        constexpr float INVS = BF ? 1.f : GRU_INV;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            rg[r] = sigm_fast(gr[r] + fmaf(acc[0][r], GRU_INV, bias[0][r]));
-            zg[r] = sigm_fast(gz[r] + fmaf(acc[1][r], GRU_INV, bias[1][r]));
-            an[r] = fmaf(acc[2][r], GRU_INV, bias[2][r]);              // gh_n
+            rg[r] = sigm_fast(gr[r] + fmaf(acc[0][r], INVS, bias[0][r]));
+            zg[r] = sigm_fast(gz[r] + fmaf(acc[1][r], INVS, bias[1][r]));
+            an[r] = fmaf(acc[2][r], INVS, bias[2][r]);                 // gh_n
             ng[r] = tanh_fast_(gn[r] + rg[r] * an[r]);
             hn[r] = (1.f - zg[r]) * ng[r] + zg[r] * hown[r];
         }
         hown = hn;
-        {   // this lane's 4 new values as scaled hi / lo f16 terms -> the LDS image the other waves read their B operand from
+        if constexpr (BF) {   // this lane's 4 new values as bf16 -> the LDS image the other waves read their B operand from
+            b4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (__bf16)hn[r];
+            *reinterpret_cast<u32x2*>(&hx[t & 1][0][m][fo]) = __builtin_bit_cast(u32x2, h);
+        } else {   // ... as scaled hi / lo f16 terms
             h4 h, l;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float x = hn[r] * GRU_XS; h[r] = (_Float16)x; l[r] = (_Float16)(x - (float)h[r]); }
@@ -202,7 +227,7 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_fwd(const GruParts gi, 
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             xh[s] = *reinterpret_cast<const u32x4*>(&hx[t & 1][0][m][32 * s + 8 * q]);
-            xl[s] = *reinterpret_cast<const u32x4*>(&hx[t & 1][1][m][32 * s + 8 * q]);
+            if constexpr (!BF) xl[s] = *reinterpret_cast<const u32x4*>(&hx[t & 1][1][m][32 * s + 8 * q]);
         }
     };
     int t0 = 0;
@@ -223,11 +248,6 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_fwd(const GruParts gi, 
 // 36 MFMAs of 16 cycles per step.  dL/dW_h = sum_t h_{t-1}^T dL/dgh_t does not feed the recurrence: it is one product per weight
 // set over all (t, row) pairs, computed afterwards (launch_gru_seq_bwd) instead of inside this kernel's 100-step latency chain.
 constexpr int DSB = 200;               // LDS row stride of the bf16 dL/dgh image (halves): 400 B = 16 * odd (mod 256)
-using b8 = __attribute__((ext_vector_type(8))) __bf16;
-using b4 = __attribute__((ext_vector_type(4))) __bf16;
-__device__ __forceinline__ f32x4 mmab(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
-}
 __device__ __forceinline__ void split3(float x, __bf16& t1, __bf16& t2, __bf16& t3) {
     t1 = (__bf16)x; const float r1 = x - (float)t1;                   // both subtractions are exact
     t2 = (__bf16)r1; const float r2 = r1 - (float)t2;
@@ -236,6 +256,8 @@ __device__ __forceinline__ void split3(float x, __bf16& t1, __bf16& t2, __bf16& 
 
 constexpr int BST = 260;            // staging row stride (floats): [d_r 64 | d_z 64 | d_n 64 | d_hn 64] + pad, 1040 B = 16 * 65
 constexpr int GRU_BWD_LDS = 2 * 3 * 16 * DSB * 2 + 2 * 16 * BST * 4;   // bf16 operand image + f32 staging image: 71 680 B (dynamic)
+// BF: single bf16 terms (learner_dtype: bf16): 6 MFMAs per step instead of 36.
+template <bool BF>
 __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_bwd(const float* __restrict__ dhs, const float* __restrict__ hs, const float* __restrict__ rzn,
                                                              const float* __restrict__ ghn, const float* __restrict__ wh, const GruParts d_gi,
                                                              float* __restrict__ dgh, float* __restrict__ d_bh_part, int T, int G, int B, int tiles) {
@@ -312,7 +334,7 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_bwd(const float* __rest
             d_hn[r] = d_n[r] * rg[r];                                  // dL/dgh_n
             direct[r] = dh * zg[r];
         }
-        {   // this lane's 12 values as three bf16 terms -> the LDS image the other waves read their B operand from
+        {   // this lane's 12 values as three bf16 terms (BF: one) -> the LDS image the other waves read their B operand from
             const f32x4 v[3] = {d_r, d_z, d_hn};
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate) {
@@ -320,8 +342,10 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_bwd(const float* __rest
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { __bf16 x1, x2, x3; split3(v[gate][r], x1, x2, x3); t1[r] = x1; t2[r] = x2; t3[r] = x3; }
                 *reinterpret_cast<u32x2*>(&dgb[pb][0][m][gate * GH + fo]) = __builtin_bit_cast(u32x2, t1);
-                *reinterpret_cast<u32x2*>(&dgb[pb][1][m][gate * GH + fo]) = __builtin_bit_cast(u32x2, t2);
-                *reinterpret_cast<u32x2*>(&dgb[pb][2][m][gate * GH + fo]) = __builtin_bit_cast(u32x2, t3);
+                if constexpr (!BF) {
+                    *reinterpret_cast<u32x2*>(&dgb[pb][1][m][gate * GH + fo]) = __builtin_bit_cast(u32x2, t2);
+                    *reinterpret_cast<u32x2*>(&dgb[pb][2][m][gate * GH + fo]) = __builtin_bit_cast(u32x2, t3);
+                }
             }
         }
         {   // the step's results -> staging image (the writer wave takes them to d_gi and dgh)
@@ -338,10 +362,14 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_bwd(const float* __rest
         for (int s = 0; s < 6; ++s) {
             u32x4 bt[3];
 #pragma unroll
-            for (int term = 0; term < 3; ++term) bt[term] = *reinterpret_cast<const u32x4*>(&dgb[pb][term][m][32 * s + 8 * q]);
-            a3 = mmab(wa[s][0], bt[2], a3); a2 = mmab(wa[s][0], bt[1], a2); a1 = mmab(wa[s][0], bt[0], a1);
-            a3 = mmab(wa[s][2], bt[0], a3); a2 = mmab(wa[s][1], bt[0], a2);
-            a3 = mmab(wa[s][1], bt[1], a3);
+            for (int term = 0; term < (BF ? 1 : 3); ++term) bt[term] = *reinterpret_cast<const u32x4*>(&dgb[pb][term][m][32 * s + 8 * q]);
+            if constexpr (BF) {
+                a1 = mmab(wa[s][0], bt[0], a1);
+            } else {
+                a3 = mmab(wa[s][0], bt[2], a3); a2 = mmab(wa[s][0], bt[1], a2); a1 = mmab(wa[s][0], bt[0], a1);
+                a3 = mmab(wa[s][2], bt[0], a3); a2 = mmab(wa[s][1], bt[0], a2);
+                a3 = mmab(wa[s][1], bt[1], a3);
+            }
         }
         carry = direct + ((a3 + a2) + a1);
         // the next step writes the other LDS buffer; the one after next is ordered behind the next barrier
@@ -383,8 +411,11 @@ void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* 
     const int tiles = (B + 15) / 16;
     const GruParts P = gru_parts(const_cast<float* const*>(reinterpret_cast<const float* const*>(gi_parts)), n_parts, T, G, B);
     int32_t* err = numeric_err_word();
-    if (rzn) hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(G * tiles), dim3(GRU_THREADS), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles, err);
-    else hipLaunchKernelGGL(k_gru_seq_fwd<false>, dim3(G * tiles), dim3(GRU_THREADS), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles, err);
+    const bool bf = learner_precision() == 1;
+#define SSD_GF(TR_, BF_) hipLaunchKernelGGL((k_gru_seq_fwd<TR_, BF_>), dim3(G * tiles), dim3(GRU_THREADS), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles, err)
+    if (rzn) { if (bf) SSD_GF(true, true); else SSD_GF(true, false); }
+    else { if (bf) SSD_GF(false, true); else SSD_GF(false, false); }
+#undef SSD_GF
 }
 void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* const* d_gi_parts,
                         int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s) {
@@ -393,10 +424,12 @@ void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, con
     static bool attr_done_dev[64] = {};                                // the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done_dev[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_seq_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, GRU_BWD_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_seq_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GRU_BWD_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_seq_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GRU_BWD_LDS);
         attr_done_dev[dev] = true;                                     // a refused attribute shows as a launch error (ssd_poll_error / hipGetLastError)
     }
-    hipLaunchKernelGGL(k_gru_seq_bwd, dim3(G * tiles), dim3(GRU_THREADS), GRU_BWD_LDS, s, dhs, hs, rzn, ghn, wh, P, dgh, d_bh_part, T, G, B, tiles);
+    if (learner_precision() == 1) hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(G * tiles), dim3(GRU_THREADS), GRU_BWD_LDS, s, dhs, hs, rzn, ghn, wh, P, dgh, d_bh_part, T, G, B, tiles);
+    else hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(G * tiles), dim3(GRU_THREADS), GRU_BWD_LDS, s, dhs, hs, rzn, ghn, wh, P, dgh, d_bh_part, T, G, B, tiles);
     // dL/dW_h[g] = sum_{t >= 1, b} h_{t-1}[b]^T dL/dgh_t[b]: rows (t, b) of hs [G, T, B, 64] against rows (t + 1, b) of dgh [G, T, B, 192] --
     // the x^T g role of the per-agent-layer kernel (csrc/ssd_bmm.hip: K = (T - 1) B rows split over 16 waves per tile, exact f32)
     if (T > 1) launch_bias_bmm_bwd(dgh + (size_t)B * G3, hs, nullptr, nullptr, d_wh, nullptr, nullptr, G, (T - 1) * B, GH, G3, s, (long)T * B * GH, (long)T * B * G3);

@@ -1476,10 +1476,9 @@ int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s) {
     EncK k;
     encode_args(p, k);
     const int prec = p->precision == 1 ? 1 : 2;
-    if (p->act) {       // the learner's forward: f32-equivalent products only
-        if (prec != 2) return -2;
-        if (p->view_edge == 15) return launch_encode_t<15, 2, true>(k, s);
-        if (p->view_edge == 31) return launch_encode_t<31, 2, true>(k, s);
+    if (p->act) {       // the learner's forward (also emits LeakyReLU(conv)): f32-equivalent, or the labelled bf16 variant
+        if (p->view_edge == 15) return prec == 2 ? launch_encode_t<15, 2, true>(k, s) : launch_encode_t<15, 1, true>(k, s);
+        if (p->view_edge == 31) return prec == 2 ? launch_encode_t<31, 2, true>(k, s) : launch_encode_t<31, 1, true>(k, s);
         return -2;
     }
     if (p->view_edge == 15) return prec == 2 ? launch_encode_t<15, 2, false>(k, s) : launch_encode_t<15, 1, false>(k, s);

@@ -117,6 +117,12 @@ class HomophilyLearner:
         # collective's own stream is joined into it) and by the host clock; collective_times() reports both
         self.profile_collectives = False
         self._coll_events, self._coll_wall = [], []
+        # learner_dtype: "fp32" (default: exact-f32 / f32-equivalent split products) or "bf16" -- the labelled reduced-precision variant:
+        # single bf16 MFMA products in the affine layers, the recurrence and the encoder; master weights, Adam and the loss stay f32
+        ld = str(getattr(args, "learner_dtype", "fp32")).lower()
+        if ld not in ("fp32", "float32", "bf16", "bfloat16"):
+            raise ValueError("learner_dtype must be fp32 or bf16, got %r" % (ld,))
+        self.precision = 1 if ld in ("bf16", "bfloat16") else 2
 
     # ---- network unroll ---------------------------------------------------------------------------------------
     @staticmethod
@@ -465,6 +471,8 @@ class HomophilyLearner:
         return self._static_batch if self._graph is not None else None
 
     def train(self, batch, t_env, episode_num):
+        if batch["reward"].is_cuda:
+            ops.set_learner_precision(self.precision)      # process-wide kernel selection; a captured step keeps what it was captured with
         logs = self._graph_step(batch) if self.use_graph else self.cal_loss_and_step(batch)
         if (episode_num - self.last_target_update_episode) / self.args.target_update_interval >= 1.0:
             self._update_targets()

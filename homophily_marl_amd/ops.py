@@ -38,6 +38,21 @@ def reserve_bmm_scratch(stream):
     abi.check(lib, lib.ssd_bmm_reserve_scratch(stream.cuda_stream))
 
 
+LEARNER_PRECISION = 2
+
+
+def set_learner_precision(precision):
+    """Arithmetic of the learner's matrix products (ssd_set_learner_precision): 2 = f32 (default), 1 = the labelled bf16 variant (single
+    bf16 MFMA products in the per-agent affine layers, the recurrence and the encoder; f32 accumulation / parameters / optimiser / loss).
+    CPU tensors are unaffected (the tensor-op statements are f32)."""
+    global LEARNER_PRECISION
+    precision = int(precision)
+    if precision != LEARNER_PRECISION or precision != 2:
+        lib = abi.load_library()
+        abi.check(lib, lib.ssd_set_learner_precision(precision))
+    LEARNER_PRECISION = precision
+
+
 def set_strict(on=True):
     global STRICT
     STRICT = bool(on)
@@ -531,16 +546,17 @@ class _EncodeCodes(th.autograd.Function):
         st = _stream(codes)
         cw, lw = conv_w.detach().contiguous(), lin_w.detach().contiguous()
         cb, lb = conv_b.detach().contiguous(), lin_b.detach().contiguous()
-        cbytes, lbytes = abi.encode_frag_bytes(V, 2)
+        prec = LEARNER_PRECISION
+        cbytes, lbytes = abi.encode_frag_bytes(V, prec)
         cf, lf = th.empty(cbytes, dtype=th.uint8, device=dev), th.empty(lbytes, dtype=th.uint8, device=dev)
-        abi.check(lib, lib.ssd_policy_pack_encoder(cw.data_ptr(), cb.data_ptr(), lw.data_ptr(), V, 2, cf.data_ptr(), lf.data_ptr(), st))
+        abi.check(lib, lib.ssd_policy_pack_encoder(cw.data_ptr(), cb.data_ptr(), lw.data_ptr(), V, prec, cf.data_ptr(), lf.data_ptr(), st))
         need = any(ctx.needs_input_grad[1:])
         act = th.empty(R, 6, O, O, dtype=th.float32, device=dev) if need else None
         bands = abi.encode_bands(V)
         ea = abi.SsdPolicyEncodeArgs()
         ea.codes, ea.code_bytes = codes.data_ptr(), codes.numel()
         ea.env_stride, ea.slot_stride, ea.agent_stride, ea.slot_t = V * V, 0, V * V, None
-        ea.rows, ea.view_edge, ea.n_agents, ea.agent_major, ea.precision = R, V, 1, 0, 2
+        ea.rows, ea.view_edge, ea.n_agents, ea.agent_major, ea.precision = R, V, 1, 0, prec
         ea.alphabet = abi.CODE_CLASS
         ea.conv_frags, ea.lin_frags, ea.conv_b, ea.lin_b = cf.data_ptr(), lf.data_ptr(), cb.data_ptr(), lb.data_ptr()
         ea.act = None if act is None else act.data_ptr()

@@ -432,6 +432,15 @@ int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, 
                      int32_t rows, int32_t in, int32_t out, void* stream);
 /* Make the row-chunk scratch of `stream` on the current device exist (SSD_ERR_DEVICE when it cannot be allocated). */
 int ssd_bmm_reserve_scratch(void* stream);
+/* Arithmetic of the LEARNER's matrix products from now on (process-wide; a launch takes the value at launch -- or capture -- time):
+ *   2 (default)  f32: ssd_bias_bmm_* on exact-f32 MFMAs, ssd_gru_seq_* on two- / three-term split products (f32-equivalent);
+ *   1            the labelled reduced-precision variant (config key learner_dtype: bf16): operands rounded to bf16, ONE
+ *                v_mfma_f32_16x16x32_bf16 per 32 reduction indices in ssd_bias_bmm_fwd / _bwd (dx, dw), ssd_gru_seq_fwd / _bwd and
+ *                the weight gradient of W_h; f32 accumulation, f32 parameters / optimiser state / loss.  The learner's encoder
+ *                forward (ssd_policy_encode with `act`) takes precision 1 fragment images from ssd_policy_pack_encoder.
+ * SSD_ERR_INVALID for any other value. */
+int ssd_set_learner_precision(int32_t precision);
+int ssd_learner_precision(void);
 
 /* Weight (and bias) gradient of the encoder's Conv2d(3, 6, 3) on windows given as SSD_OBS_CODE class codes u8 [rows, V, V]
  * (V = 15 / 31): d_conv = dL/d(conv output) f32 [rows, 6, V-2, V-2] -> partial f32 [ssd_conv_wgrad_partial_rows(rows), 168]: per

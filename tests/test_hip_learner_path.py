@@ -113,6 +113,67 @@ def _learner_fixture_body(z, args, batch, mac, learner, train_graph, storage):
         assert np.abs(sqs - z["step%d_param_sq" % step]).max() / np.abs(z["step%d_param_sq" % step]).max() < 1e-5, step
 
 
+# the stated bar of the labelled bf16 learner variant: single bf16 products carry 8 significand bits (2^-9 relative per operand)
+BF16_Q_TOL = 2e-2           # |q - reference q| absolute, q of order 1 (measured: see the printed values)
+BF16_LOSS_RTOL = 5e-2       # |loss - reference loss| / |reference loss| for the two TD losses and the similarity loss
+
+
+@pytest.mark.parametrize("train_graph", [False, True])
+@pytest.mark.parametrize("name", ["learner_cleanup5.npz", "learner_harvest5.npz", "learner_cleanup5_w4.npz"])
+def test_bf16_learner_variant_is_close_to_the_reference_and_labelled(name, train_graph):
+    """learner_dtype: bf16 (the labelled reduced-precision variant of BASELINE config 2's "homophily Q-learner bf16"; never the
+    headline): the per-agent affine layers, the recurrence and the encoder evaluate single bf16 MFMA products (ssd_set_learner_precision
+    1), parameters / Adam / loss stay f32.  Against the REFERENCE's numbers of the three learner fixtures: Q-values within BF16_Q_TOL,
+    the three losses of two optimisation steps within BF16_LOSS_RTOL relative (the deviation is printed), the parameters after the
+    steps close to the reference's (Adam normalises the step size: a sign flip of a tiny gradient moves a weight by 2 lr) -- and NOT
+    equal to the fp32 path's (the variant really runs: the same checks at fp32 tolerances must fail).  The fp32 path is restored."""
+    from homophily_marl_amd import ops
+    from tests.learner_util import build, load_fixture, param_checksums
+    z, meta = load_fixture(name)
+    args, batch, mac, learner = build(z, meta, device="cuda:0", overrides=dict(train_graph=train_graph, learner_dtype="bf16"), code_obs=True)
+    assert learner.precision == 1
+    ops.set_strict(True)
+    try:
+        ops.set_learner_precision(1)
+        with th.no_grad():
+            q_env, q_inc = learner.unroll(mac, batch)
+        de, di = np.abs(q_env.cpu().numpy() - z["q_env"]).max(), np.abs(q_inc.cpu().numpy() - z["q_inc"]).max()
+        print("bf16 learner: max |q_env - ref| %.2e  |q_inc - ref| %.2e  (|q| max %.2f)" % (de, di, np.abs(z["q_env"]).max()))
+        assert 1e-5 < max(de, di) < BF16_Q_TOL                              # close, and not the f32 path
+        if train_graph:
+            sd0 = {k: v.clone() for k, v in mac.agent.state_dict().items()}
+            for _ in range(3):
+                learner.train(batch, 0, 0)
+            assert learner._graph is not None
+            mac.agent.load_state_dict(sd0); learner.target_mac.load_state(mac)
+            for opt in (learner.optimiser_env, learner.optimiser_inc):
+                for st in opt.state.values():
+                    st["step"].zero_(); st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+        worst = 0.0
+        for step in range(2):
+            if train_graph:
+                learner.train(batch, 0, 0)
+                logs = learner._static_logs
+            else:
+                ops.set_learner_precision(1)
+                logs = learner.cal_loss_and_step(batch)
+            for k in ("loss_value_env", "loss_value_inc", "loss_sim"):
+                ref = float(z["step%d_%s" % (step, k)])
+                rel = abs(float(logs[k]) - ref) / abs(ref)
+                worst = max(worst, rel)
+                assert rel < BF16_LOSS_RTOL, (step, k, float(logs[k]), ref)
+            for k in ("value_give_mean", "value_receive_mean"):          # integer counts: exact in any precision
+                assert abs(float(logs[k]) - float(z["step%d_%s" % (step, k)])) < 1e-5
+        print("bf16 learner: worst relative loss deviation over two steps %.2e" % worst)
+        _, sqs, _ = param_checksums(mac)
+        assert np.abs(sqs - z["step1_param_sq"]).max() / np.abs(z["step1_param_sq"]).max() < 2e-2
+        assert all(bool(th.isfinite(p).all()) for p in mac.parameters())
+    finally:
+        ops.set_strict(False)
+        ops.set_learner_precision(2)
+    assert abi.load_library().ssd_learner_precision() == 2
+
+
 def _random_learner_batch(B, T, n, kind, seed):
     """A synthetic sampled batch with everything the loss reads switched on: rewards of both signs, cleaning, incentives of all three
     kinds, early termination (mask), random availability."""
