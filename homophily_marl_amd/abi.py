@@ -186,7 +186,7 @@ class SsdPolicyEncodeArgs(C.Structure):
                 ("rows", C.c_int32), ("view_edge", C.c_int32), ("n_agents", C.c_int32), ("agent_major", C.c_int32), ("precision", C.c_int32),
                 ("conv_frags", C.c_void_p), ("lin_frags", C.c_void_p), ("conv_b", C.c_void_p), ("lin_b", C.c_void_p),
                 ("out", C.c_void_p), ("out_stride", C.c_int32), ("part", C.c_void_p), ("slot_t_copy", C.c_void_p), ("counter_inc", C.c_void_p),
-                ("alphabet", C.c_int32), ("act", C.c_void_p), ("slot_add", C.c_int32)]
+                ("alphabet", C.c_int32), ("act", C.c_void_p), ("slot_add", C.c_int32), ("layout", C.c_int32)]
 
 
 class SsdTdLossArgs(C.Structure):
@@ -245,8 +245,20 @@ def encode_bands(V):
     return 3 if V == 31 else 1
 
 
-def encode_frag_bytes(V, precision):
-    """(conv fragment image, Linear fragment image) sizes in bytes (include/ssd_hip.h SSD_ENCODE_*)."""
+ENCODE_LAYOUT_TOEPLITZ, ENCODE_LAYOUT_LUT = 0, 1
+ENCODE_LUT_TABLE_BYTES = 3 * 64 * 6 * 4
+
+
+def encode_lut_ksteps(V):
+    """SSD_ENCODE_LUT_KSTEPS: K-steps of the Linear image in the class-LUT layout (4 output positions each, numbered through the bands)"""
+    return 73 + 73 + 66 if V == 31 else 43
+
+
+def encode_frag_bytes(V, precision, layout=ENCODE_LAYOUT_TOEPLITZ):
+    """(conv image, Linear image) sizes in bytes (include/ssd_hip.h SSD_ENCODE_*): Toeplitz fragments, or the class-LUT table + the
+    position-major Linear image."""
+    if layout == ENCODE_LAYOUT_LUT:
+        return ENCODE_LUT_TABLE_BYTES, encode_lut_ksteps(V) * 2 * precision * 1024
     units = 29 * 2 * 3 if V == 31 else 13 * 3
     return precision * 9 * 1024, units * 2 * precision * 1024
 
@@ -285,6 +297,7 @@ HIP_SIGNATURES["ssd_conv_wgrad_codes"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_
 HIP_SIGNATURES["ssd_policy_head_plan"] = (C.c_int, [C.c_int32] * 3 + [C.POINTER(C.c_int32)] * 3)
 HIP_SIGNATURES["ssd_policy_encode"] = (C.c_int, [C.POINTER(SsdPolicyEncodeArgs), C.c_void_p])
 HIP_SIGNATURES["ssd_policy_head_inc_encode"] = (C.c_int, [C.POINTER(SsdPolicyHead), C.POINTER(SsdPolicyEncodeArgs), C.c_void_p])
+HIP_SIGNATURES["ssd_policy_pack_encoder_lut"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_policy_pack_encoder"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p])
 HIP_SIGNATURES["ssd_numeric_status"] = (C.c_int, [C.POINTER(C.c_int32)])
 ERRBIT_F16_RANGE = 32

@@ -611,7 +611,8 @@ static int check_encode(const ssd_policy_encode_args* a) {
         return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_encode is instantiated for view_size 7 and 15 (15 x 15 / 31 x 31 windows); use ssd_conv_leaky + GEMM");
     if (a->precision != 0 && a->precision != 1 && a->precision != 2) return fail(SSD_ERR_INVALID, "precision must be 1 (bf16) or 2 (f32-equivalent)");
     if (a->alphabet != SSD_CODE_CLASS && a->alphabet != SSD_CODE_CHANNEL_MASK) return fail(SSD_ERR_INVALID, "alphabet");
-    if (a->act && a->precision == 1) return fail(SSD_ERR_INVALID, "the activation output needs precision 2");
+    if (a->layout != SSD_ENCODE_LAYOUT_TOEPLITZ && a->layout != SSD_ENCODE_LAYOUT_LUT) return fail(SSD_ERR_INVALID, "layout");
+    if (a->act && a->layout != SSD_ENCODE_LAYOUT_TOEPLITZ) return fail(SSD_ERR_INVALID, "the activation output (training forward) takes the Toeplitz images");
     const int bands = SSD_ENCODE_BANDS(a->view_edge);
     if (bands == 1 ? (!a->out || a->part || a->out_stride < 32) : (!a->part || a->out)) return fail(SSD_ERR_INVALID, "one band writes `out`, several bands write `part`");
     if ((reinterpret_cast<uintptr_t>(a->conv_frags) | reinterpret_cast<uintptr_t>(a->lin_frags) | reinterpret_cast<uintptr_t>(a->part)) & 15)
@@ -630,6 +631,16 @@ int ssd_policy_encode(const ssd_policy_encode_args* a, void* stream) {
     if (const int bad = check_encode(a)) return bad;
     const int rc = launch_policy_encode(a, (hipStream_t)stream);
     if (rc) return fail(SSD_ERR_DEVICE, "hipFuncSetAttribute(max dynamic LDS) failed");
+    return launched();
+}
+
+int ssd_policy_pack_encoder_lut(const float* conv_w, const float* conv_b, const float* lin_w, int32_t view_edge, int32_t precision, void* table,
+                                void* lin_frags, void* stream) {
+    if (!conv_w || !conv_b || !lin_w || !table || !lin_frags) return fail(SSD_ERR_INVALID, "null argument");
+    if (precision != 1 && precision != 2) return fail(SSD_ERR_INVALID, "precision must be 1 or 2");
+    if ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(lin_frags)) & 15) return fail(SSD_ERR_INVALID, "images must be 16-byte aligned");
+    if (launch_pack_encoder_lut(conv_w, conv_b, lin_w, view_edge, precision, table, lin_frags, (hipStream_t)stream))
+        return fail(SSD_ERR_UNSUPPORTED, "ssd_policy_pack_encoder_lut: view_edge must be 15 or 31");
     return launched();
 }
 

@@ -146,6 +146,7 @@ void launch_gru_fwd_train(const float* gi, const float* gh, const float* h, floa
 void launch_gru_bwd(const float* dh, const float* rzn, const float* gh, const float* h, float* d_gi, float* d_gh, float* dh_prev, int R,
                     int H, hipStream_t s);
 int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s);
+int launch_pack_encoder_lut(const float* cw, const float* cb, const float* lw, int V, int prec, void* table, void* lin_frags, hipStream_t s);
 int launch_pack_encoder(const float* cw, const float* cb, const float* lw, int V, int prec, void* conv_frags, void* lin_frags, hipStream_t s);
 void launch_pack_head(const ssd_policy_head_params* p, int prec, void* image, hipStream_t s);
 void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T,

@@ -1096,6 +1096,7 @@ struct EncK {
     float* act;                        // ACT kernels: LeakyReLU(conv) f32 [rows, 6, O, O] (what the learner's backward needs)
     int64_t* slot_t_copy; int64_t* counter_inc;
     int mask_alphabet;                 // bytes are channel masks (1 R, 2 G, 4 B) instead of SSD_OBS_CODE classes
+    int layout;                        // SSD_ENCODE_LAYOUT_*: which images conv_frags / lin_frags hold (Toeplitz fragments | class-LUT table + position-major Linear)
     PSTAMP_DECL
 };
 
@@ -1346,10 +1347,242 @@ __device__ __forceinline__ void encode_body(const EncK& a, uint8_t* lds_raw, con
     PSTAMP_REAL(15);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// encode_body_lut: the same encoder with the CONVOLUTION AS A TABLE SUM (SSD_ENCODE_LAYOUT_LUT; rollout / no-gradient launches).
+// A window cell is one of four classes and lights at most one colour plane at 255/256 (cleanup.py:93-105), so for an output position
+// the three taps of input row dy contribute, for all six channels at once, a value that depends only on the three classes under them:
+//   conv[c](y, x) = sum_dy T[dy][class(y + dy, x) + 4 class(y + dy, x + 1) + 16 class(y + dy, x + 2)][c],   T[0] carries the bias
+// -- 3 x 64 entries of 6 f32 built by ssd_policy_pack_encoder_lut (exact f32 arithmetic: no split of the conv weights, no Toeplitz
+// zeros, no matrix-core work for the conv at all; round 3 executed 468 conv MFMAs per 16-row tile, 9 useful of 30 K entries each).
+// The window rows are kept in LDS as packed 2-bit classes (one dword per 15-cell row, two per 31-cell row), the table as 4.5 KiB.
+// Lane (q, m) evaluates position p = 4 s + q of batch row m for K-step s: its 6 channel values (+ 2 zeros) after LeakyReLU and the
+// split ARE its B operand of the Linear's K-step s (k = 8 q + j <-> position 4 s + q, channel j; lin image in that order), so the
+// Linear keeps its three products per term pair: 43 K-steps x 2 output tiles x 3 = 258 MFMAs per 16-row tile (15 x 15 windows)
+// instead of 702.  K-steps are dealt to the 8 waves as contiguous ranges and the partial sums added in wave order as before.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int LUT_ENTRY_F = 6, LUT_DY_F = 64 * LUT_ENTRY_F, LUT_TABLE_BYTES = SSD_ENCODE_LUT_TABLE_BYTES;      // [3][64][6] f32
+static_assert(LUT_TABLE_BYTES == 3 * LUT_DY_F * 4, "table size");
+template <int V> constexpr int lut_band_rows(int band) { return Geo<V>::O - band * Geo<V>::R < Geo<V>::R ? Geo<V>::O - band * Geo<V>::R : Geo<V>::R; }
+template <int V> constexpr int lut_band_ksteps(int band) { return (lut_band_rows<V>(band) * Geo<V>::O + 3) / 4; }
+template <int V> constexpr int lut_band_base(int band) { int b = 0; for (int k = 0; k < band; ++k) b += lut_band_ksteps<V>(k); return b; }
+static_assert(lut_band_base<15>(1) == SSD_ENCODE_LUT_KSTEPS(15) && lut_band_base<31>(3) == SSD_ENCODE_LUT_KSTEPS(31), "K-steps of the Linear image");
+template <int V> constexpr int lut_row_dwords() { return V == 15 ? 1 : 2; }
+template <int V> constexpr int lut_batch_row_dwords() { int d = (Geo<V>::R + 3) * lut_row_dwords<V>(); return d | 1; }      // odd: the 16 rows of a read hit 16 banks
+template <int V, int PREC, int BT> constexpr size_t enc_lut_lds_bytes() {
+    const size_t work = (size_t)BT * 16 * lut_batch_row_dwords<V>() * 4 + 16 + LUT_TABLE_BYTES;
+    const size_t red = (size_t)ENC_WAVES * BT * 2 * 1024;
+    return work > red ? work : red;
+}
+// 4 cells as bytes (classes 0..3) -> 8 bits
+__device__ __forceinline__ uint32_t pack4x2(uint32_t c) {
+    uint32_t t = (c | (c >> 6)) & 0x000F000Fu;
+    return (t | (t >> 12)) & 0xFFu;
+}
+
+template <int V, int PREC, int BT>
+__device__ __forceinline__ void encode_body_lut(const EncK& a, uint8_t* lds_raw, const int block_x, const int block_y) {
+    using G = Geo<V>;
+    constexpr int O = G::O, CP = G::CP, R = G::R;
+    constexpr int WPR = lut_row_dwords<V>(), PRW = lut_batch_row_dwords<V>();
+    constexpr int PACKED = (BT * 16 * PRW * 4 + 15) & ~15;
+    constexpr float INV = PREC == 2 ? 1.f / (ENC_CSCALE * ENC_LSCALE) : 1.f;
+    uint32_t* packed = reinterpret_cast<uint32_t*>(lds_raw);          // [BT * 16 rows][PRW dwords]: input rows of the band, 2 bits per cell
+    float* table = reinterpret_cast<float*>(lds_raw + PACKED);         // [3][64][6]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int row0 = block_x * (BT * 16);
+    const int band = block_y, y0 = band * R;
+    const int Rb = O - y0 < R ? O - y0 : R;                            // output rows of this band
+    const long t_off = a.slot_t ? ((long)(*a.slot_t) + a.slot_add) * a.slot_stride : 0;
+    PSTAMP(0);
+    PSTAMP_REAL(14);
+    if (block_x == 0 && block_y == 0 && tid == 0) {
+        if (a.slot_t_copy) *a.slot_t_copy = *a.slot_t;
+        if (a.counter_inc) *a.counter_inc += 1;
+    }
+    // ---- stage: the table (global -> LDS), class codes -> packed rows ------------------------------------------------------------
+    {
+        constexpr int NV = LUT_TABLE_BYTES / 16;
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.conv_frags);
+        u32x4 tv = {0u, 0u, 0u, 0u};
+        if (tid < NV) tv = src[tid];
+        constexpr int NQ = CP / 16, ITEMS = BT * 16 * (R + 2), NT = ENC_WAVES * 64, IPT = (ITEMS + NT - 1) / NT;
+        typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+        typedef __attribute__((address_space(1))) u32x4_u gl_u32x4_u;
+        typedef __attribute__((address_space(1))) uint32_t gl_u32;
+        u32x4 cw[IPT][NQ];
+        const uintptr_t cbase = reinterpret_cast<uintptr_t>(a.codes), cend = cbase + (uintptr_t)a.code_bytes;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int it = tid + k * NT;
+            const int yy = it % (R + 2), r = it / (R + 2);
+            const int row = row0 + r, y = y0 + yy;
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) cw[k][h] = u32x4{0u, 0u, 0u, 0u};
+            if (it < ITEMS && row < a.rows && y < V) {
+                const int b = row / a.n, i = row - b * a.n;
+                const uintptr_t ptr = cbase + (uintptr_t)((long)b * a.env_stride + t_off + (long)i * a.agent_stride + y * V);
+                if (ptr + 16 * NQ <= cend) {
+#pragma unroll
+                    for (int h = 0; h < NQ; ++h) cw[k][h] = *reinterpret_cast<const gl_u32x4_u*>(ptr + 16 * h);
+                } else {                                               // the last rows of the buffer: aligned dwords that hold readable bytes
+                    const uintptr_t al = ptr & ~(uintptr_t)3, lim = (cend + 3) & ~(uintptr_t)3;
+                    uint32_t prev = *reinterpret_cast<const gl_u32*>(al);
+#pragma unroll
+                    for (int h = 0; h < NQ; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uintptr_t nx = al + 4 * (4 * h + e + 1);
+                            const uint32_t next = nx + 4 <= lim ? *reinterpret_cast<const gl_u32*>(nx) : 0u;
+                            cw[k][h][e] = __builtin_amdgcn_alignbyte(next, prev, (uint32_t)(ptr & 3));
+                            prev = next;
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int it = tid + k * NT;
+            if (it >= ITEMS) continue;
+            const int yy = it % (R + 2), r = it / (R + 2);
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) {
+                u32x4 c = cw[k][h];
+                if (h == NQ - 1) c[3] &= 0x00FFFFFFu;                  // byte 16 NQ - 1 is cell V (the next row's first cell)
+                uint32_t word = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint32_t cls = c[e] & 0x03030303u;                 // SSD_OBS_CODE classes 0..3
+                    if (a.mask_alphabet) {                             // channel masks 1 R / 2 G / 4 B -> classes 2 / 1 / 3
+                        const uint32_t b0 = c[e] & 0x01010101u, b1 = (c[e] >> 1) & 0x01010101u, b2 = (c[e] >> 2) & 0x01010101u;
+                        cls = (b1 | b2) | ((b0 | b2) << 1);
+                    }
+                    word |= pack4x2(cls) << (8 * e);
+                }
+                packed[r * PRW + yy * WPR + h] = word;
+            }
+        }
+        if (tid < NV) reinterpret_cast<u32x4*>(table)[tid] = tv;
+    }
+    __syncthreads();
+    PSTAMP(1);
+    // ---- K-steps of this band, a contiguous range per wave -------------------------------------------------------------------------
+    f32x4 accl[BT][2];
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) { accl[bt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[bt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int KS = (Rb * O + 3) >> 2;
+    int ks_base = 0;                                                   // first K-step of this band in the Linear image
+#pragma unroll
+    for (int k = 0; k < G::NB; ++k) ks_base += k < band ? lut_band_ksteps<V>(k) : 0;
+    const int s_begin = (wave * KS) / ENC_WAVES, s_end = ((wave + 1) * KS) / ENC_WAVES;
+    auto load_la = [&](int sl, u32x4 (&la)[2][PREC]) {
+        const size_t gs = (size_t)(ks_base + sl);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < PREC; ++t)
+                la[mt][t] = *reinterpret_cast<const u32x4*>(a.lin_frags + (((gs * 2 + mt) * PREC + t) * 64 + lane) * 16);
+    };
+    u32x4 la[2][PREC], la_next[2][PREC];
+    if (s_begin < s_end) load_la(s_begin, la_next);
+    const uint32_t* my_rows = packed + m * PRW;
+#pragma unroll 1
+    for (int sl = s_begin; sl < s_end; ++sl) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < PREC; ++t) la[mt][t] = la_next[mt][t];
+        if (sl + 1 < s_end) load_la(sl + 1, la_next);
+        // this lane's position of the K-step: p = 4 sl + q -> (output row yl of the band, column x); positions past the band read row 0
+        // (their Linear weights are zero)
+        const int p0 = 4 * sl, yl0 = p0 / O, x0 = p0 - yl0 * O;        // (scalar)
+        int x = x0 + q, yl = yl0;
+        if (x >= O) { x -= O; yl += 1; }
+        if (yl >= Rb) { yl = 0; x = 0; }
+        const uint32_t* rp = my_rows + yl * WPR;
+        const int sh = 2 * x;
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+            const uint32_t* rb = rp + bt * 16 * PRW;
+            int idx[3];
+            if constexpr (WPR == 1) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) idx[dy] = (int)((rb[dy] >> sh) & 63u);
+            } else {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const uint64_t w = (uint64_t)rb[2 * dy] | ((uint64_t)rb[2 * dy + 1] << 32);
+                    idx[dy] = (int)((w >> sh) & 63u);
+                }
+            }
+            float v[8];
+            {
+                typedef float f32x2l __attribute__((ext_vector_type(2)));
+                const f32x2l* t0 = reinterpret_cast<const f32x2l*>(table + idx[0] * LUT_ENTRY_F);
+                const f32x2l* t1 = reinterpret_cast<const f32x2l*>(table + LUT_DY_F + idx[1] * LUT_ENTRY_F);
+                const f32x2l* t2 = reinterpret_cast<const f32x2l*>(table + 2 * LUT_DY_F + idx[2] * LUT_ENTRY_F);
+#pragma unroll
+                for (int c2 = 0; c2 < 3; ++c2) {
+                    const f32x2l s01 = t0[c2] + t1[c2], s012 = s01 + t2[c2];
+                    v[2 * c2] = leaky(s012.x); v[2 * c2 + 1] = leaky(s012.y);
+                }
+                v[6] = 0.f; v[7] = 0.f;
+            }
+            u32x4 xh, xl;
+            split8<PREC>(v, xh, xl);
+            if (PREC == 2) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) accl[bt][mt] = mma<PREC>(la[mt][PREC - 1], xh, accl[bt][mt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) accl[bt][mt] = mma<PREC>(la[mt][0], xl, accl[bt][mt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) accl[bt][mt] = mma<PREC>(la[mt][0], xh, accl[bt][mt]);
+        }
+    }
+    PSTAMP(2);
+    // ---- add the waves' partial sums in a fixed order (deterministic), finish ------------------------------------------------------
+    __syncthreads();                                                   // every wave is done with the packed rows and the table: reuse them
+    f32x4* red = reinterpret_cast<f32x4*>(lds_raw);                    // [wave][bt][mt][lane]
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) red[((wave * BT + bt) * 2 + mt) * 64 + lane] = accl[bt][mt];
+    __syncthreads();
+    for (int it = tid; it < BT * 2 * 64; it += ENC_WAVES * 64) {
+        const int l = it & 63, mt = (it >> 6) & 1, bt = it >> 7;
+        f32x4 sum = red[((0 * BT + bt) * 2 + mt) * 64 + l];
+#pragma unroll
+        for (int w = 1; w < ENC_WAVES; ++w) sum += red[((w * BT + bt) * 2 + mt) * 64 + l];
+        const int row = row0 + bt * 16 + (l & 15), f0 = 16 * mt + 4 * (l >> 4);
+        if (row < a.rows) {
+            const int b = row / a.n, i = row - b * a.n;
+            const size_t orow = a.agent_major ? (size_t)i * (a.rows / a.n) + b : (size_t)row;
+            if (a.part) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = sum[r] * INV;
+                *reinterpret_cast<f32x4*>(a.part + ((size_t)band * a.rows + orow) * 32 + f0) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.out[orow * a.out_stride + f0 + r] = leaky(fmaf(sum[r], INV, a.lin_b[f0 + r]));
+            }
+        }
+    }
+    PSTAMP(3);
+    PSTAMP_REAL(15);
+}
+
 template <int V, int PREC, bool ACT, int BT>
 __global__ __launch_bounds__(ENC_WAVES * 64) void k_encode(EncK a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     encode_body<V, PREC, ACT, BT>(a, lds_raw, (int)blockIdx.x, (int)blockIdx.y);
+}
+template <int V, int PREC, int BT>
+__global__ __launch_bounds__(ENC_WAVES * 64) void k_encode_lut(EncK a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    encode_body_lut<V, PREC, BT>(a, lds_raw, (int)blockIdx.x, (int)blockIdx.y);
 }
 static int enc_bt(int V, int rows) {
     static const char* force = getenv("SSD_ENC_BT");                  // diagnostics: force the batch tiles per workgroup (4 | 5) for 15 x 15 windows
@@ -1366,7 +1599,7 @@ static int enc_bt(int V, int rows) {
 // (x, band) index unfolded; EncK sits behind the two head arguments (the heads' cold-argument offsets are unchanged).
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int FUSED_WAVES = ENC_WAVES;          // k_inc_encode: one block size for both bodies
-template <int PREC, int AT, int V, bool LOOP, int BT>
+template <int PREC, int AT, int V, bool LOOP, int BT, bool LUT = false>
 __global__ __launch_bounds__(FUSED_WAVES * 64) void k_inc_encode(HeadK a, HeadCold cold_unused, EncK e, int heads, int enc_groups) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 #ifndef SSD_ENC_FIRST
@@ -1378,7 +1611,8 @@ __global__ __launch_bounds__(FUSED_WAVES * 64) void k_inc_encode(HeadK a, HeadCo
         head_body<1, PREC, AT, 0, FUSED_WAVES - 1, LOOP>(a, lds_raw, b);    // 7 compute waves + the loader
     } else {
         const int i = b - heads, by = i / enc_groups;
-        encode_body<V, PREC, false, BT>(e, lds_raw, i - by * enc_groups, by);
+        if constexpr (LUT) encode_body_lut<V, PREC, BT>(e, lds_raw, i - by * enc_groups, by);
+        else encode_body<V, PREC, false, BT>(e, lds_raw, i - by * enc_groups, by);
     }
 }
 
@@ -1403,24 +1637,45 @@ static int launch_encode_t(const EncK& k, hipStream_t s) {
     return launch_encode_bt<V, PREC, ACT, 5>(k, s);
 }
 
+template <int V, int PREC, int BT>
+static int launch_encode_lut_bt(const EncK& k, hipStream_t s) {
+    using G = Geo<V>;
+    constexpr size_t lds = enc_lut_lds_bytes<V, PREC, BT>();
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    if (!done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_lut<V, PREC, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        done[dev] = true;
+    }
+    const int groups = (k.rows + BT * 16 - 1) / (BT * 16);
+    hipLaunchKernelGGL((k_encode_lut<V, PREC, BT>), dim3(groups, G::NB), dim3(ENC_WAVES * 64), lds, s, k);
+    return 0;
+}
+template <int V, int PREC>
+static int launch_encode_lut_t(const EncK& k, hipStream_t s) {
+    if constexpr (V == 15) { if (enc_bt(V, k.rows) == 4) return launch_encode_lut_bt<V, PREC, 4>(k, s); }
+    return launch_encode_lut_bt<V, PREC, 5>(k, s);
+}
+
 static void encode_args(const ssd_policy_encode_args* p, EncK& k) {
     k.codes = p->codes; k.code_bytes = (long)p->code_bytes; k.env_stride = (long)p->env_stride; k.slot_stride = (long)p->slot_stride;
     k.agent_stride = (long)p->agent_stride; k.slot_t = p->slot_t; k.rows = p->rows; k.n = p->n_agents; k.agent_major = p->agent_major;
     k.conv_frags = static_cast<const uint8_t*>(p->conv_frags); k.lin_frags = static_cast<const uint8_t*>(p->lin_frags);
     k.conv_b = p->conv_b; k.lin_b = p->lin_b; k.out = p->out; k.out_stride = p->out_stride; k.part = p->part; k.act = p->act;
     k.slot_t_copy = p->slot_t_copy; k.counter_inc = p->counter_inc; k.mask_alphabet = p->alphabet == SSD_CODE_CHANNEL_MASK;
-    k.slot_add = p->slot_add;
+    k.slot_add = p->slot_add; k.layout = p->layout;
     PSTAMP_SET(k);
 }
 
-template <int PREC, int AT, int V, bool LOOP, int BT>
+template <int PREC, int AT, int V, bool LOOP, int BT, bool LUT>
 static int launch_inc_encode_bt(HeadK& k, HeadCold& c, EncK& e, hipStream_t s) {
-    const size_t lh = (size_t)head_lds_bytes(FUSED_WAVES - 1, PREC), le = enc_lds_bytes<V, PREC, BT>();
+    const size_t lh = (size_t)head_lds_bytes(FUSED_WAVES - 1, PREC), le = LUT ? enc_lut_lds_bytes<V, PREC, BT>() : enc_lds_bytes<V, PREC, BT>();
     const size_t lds = lh > le ? lh : le;
     static bool done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
-    const void* fn = reinterpret_cast<const void*>(&k_inc_encode<PREC, AT, V, LOOP, BT>);
+    const void* fn = reinterpret_cast<const void*>(&k_inc_encode<PREC, AT, V, LOOP, BT, LUT>);
     if (!done[dev]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         done[dev] = true;
@@ -1432,8 +1687,12 @@ static int launch_inc_encode_bt(HeadK& k, HeadCold& c, EncK& e, hipStream_t s) {
 }
 template <int PREC, int AT, int V, bool LOOP>
 static int launch_inc_encode_t(HeadK& k, HeadCold& c, EncK& e, hipStream_t s) {
-    if constexpr (V == 15) { if (enc_bt(V, e.rows) == 4) return launch_inc_encode_bt<PREC, AT, V, LOOP, 4>(k, c, e, s); }
-    return launch_inc_encode_bt<PREC, AT, V, LOOP, 5>(k, c, e, s);
+    if (e.layout == SSD_ENCODE_LAYOUT_LUT) {
+        if constexpr (V == 15) { if (enc_bt(V, e.rows) == 4) return launch_inc_encode_bt<PREC, AT, V, LOOP, 4, true>(k, c, e, s); }
+        return launch_inc_encode_bt<PREC, AT, V, LOOP, 5, true>(k, c, e, s);
+    }
+    if constexpr (V == 15) { if (enc_bt(V, e.rows) == 4) return launch_inc_encode_bt<PREC, AT, V, LOOP, 4, false>(k, c, e, s); }
+    return launch_inc_encode_bt<PREC, AT, V, LOOP, 5, false>(k, c, e, s);
 }
 
 // How a head launch of (n_env, n_agents) is cut: workgroups per agent, compute waves per workgroup, and the number of 16-row tiles the
@@ -1481,6 +1740,11 @@ int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s) {
         if (p->view_edge == 31) return prec == 2 ? launch_encode_t<31, 2, true>(k, s) : launch_encode_t<31, 1, true>(k, s);
         return -2;
     }
+    if (p->layout == SSD_ENCODE_LAYOUT_LUT) {
+        if (p->view_edge == 15) return prec == 2 ? launch_encode_lut_t<15, 2>(k, s) : launch_encode_lut_t<15, 1>(k, s);
+        if (p->view_edge == 31) return prec == 2 ? launch_encode_lut_t<31, 2>(k, s) : launch_encode_lut_t<31, 1>(k, s);
+        return -2;
+    }
     if (p->view_edge == 15) return prec == 2 ? launch_encode_t<15, 2, false>(k, s) : launch_encode_t<15, 1, false>(k, s);
     if (p->view_edge == 31) return prec == 2 ? launch_encode_t<31, 2, false>(k, s) : launch_encode_t<31, 1, false>(k, s);
     return -2;
@@ -1524,6 +1788,63 @@ __global__ __launch_bounds__(256) void k_pack_encoder(const float* __restrict__ 
         const float w = x < O ? lw[(size_t)(16 * mt + m) * (6 * P) + oc * P + y * O + x] * LS : 0.f;
         store_term<PREC>(lin_frags + (((size_t)(u * 2 + mt) * PREC) * 64 + lane) * 16 + 2 * j, w, (size_t)64 * 16, err);
     }
+}
+
+// ---- pack, class-LUT layout: conv_w / conv_b -> table f32 [3][64][6] (scaled by the conv activations' split scale), lin_w -> the
+// Linear image in position-major K order (see encode_body_lut) ------------------------------------------------------------------
+template <int V, int PREC>
+__global__ __launch_bounds__(256) void k_pack_encoder_lut(const float* __restrict__ cw, const float* __restrict__ cb, const float* __restrict__ lw, float* table,
+                                                          uint8_t* lin_frags, int32_t* err) {
+    using G = Geo<V>;
+    constexpr int O = G::O, R = G::R, P = O * O, KSTEPS = SSD_ENCODE_LUT_KSTEPS(V);
+    constexpr int NTAB = 3 * LUT_DY_F, NLIN = KSTEPS * 2 * 512;
+    constexpr float CS = PREC == 2 ? ENC_CSCALE : 1.f, LS = PREC == 2 ? ENC_LSCALE : 1.f;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (PREC == 2 && e < 6 && err) {      // range of the conv ACTIVATIONS at the scale CS (they are split inside the encoder): exact worst case, see k_pack_encoder
+        float bound = fabsf(cb[e]);
+        for (int tap = 0; tap < 9; ++tap) {
+            float mx = 0.f;
+            for (int ch = 0; ch < 3; ++ch) mx = fmaxf(mx, fabsf(cw[(e * 3 + ch) * 9 + tap]));
+            bound += mx * (255.f / 256.f);
+        }
+        if (!(bound * CS <= F16_MAX)) atomicOr(err, ERR_F16_RANGE);
+    }
+    if (e < NTAB) {
+        // T[dy][idx][c] = (dy == 0 ? b[c] : 0) + 255/256 * sum over dx of w[c][plane(class of cell dx)][dy][dx]; classes (SSD_OBS_CODE):
+        // 2 = waste -> R (plane 0), 1 = apple -> G (plane 1), 3 = wall / agent -> B (plane 2), 0 = nothing
+        const int dy = e / LUT_DY_F, idx = (e / LUT_ENTRY_F) % 64, c = e % LUT_ENTRY_F;
+        double v = dy == 0 ? (double)cb[c] : 0.0;
+        for (int dx = 0; dx < 3; ++dx) {
+            const int cls = (idx >> (2 * dx)) & 3;
+            const int plane = cls == 2 ? 0 : (cls == 1 ? 1 : (cls == 3 ? 2 : -1));
+            if (plane >= 0) v += (double)cw[((c * 3 + plane) * 3 + dy) * 3 + dx] * (255.0 / 256.0);
+        }
+        table[e] = (float)(v * (double)CS);
+    } else if (e < NTAB + NLIN) {
+        const int i = e - NTAB, mt = (i >> 9) & 1, gs = i >> 10, lane = (i >> 3) & 63, j = i & 7, q = lane >> 4, m = lane & 15;
+        int band = 0, base = 0;                                        // the band this K-step belongs to
+#pragma unroll
+        for (int k = 0; k < G::NB; ++k) { const int n = lut_band_ksteps<V>(k); if (gs >= base + n && k + 1 < G::NB) { base += n; band = k + 1; } }
+        const int Rb = O - band * R < R ? O - band * R : R;
+        const int p = 4 * (gs - base) + q, yl = p / O, x = p - yl * O;
+        const float w = (j < 6 && yl < Rb) ? lw[(size_t)(16 * mt + m) * (6 * P) + j * P + (band * R + yl) * O + x] * LS : 0.f;
+        store_term<PREC>(lin_frags + (((size_t)(gs * 2 + mt) * PREC) * 64 + lane) * 16 + 2 * j, w, (size_t)64 * 16, err);
+    }
+}
+
+int launch_pack_encoder_lut(const float* cw, const float* cb, const float* lw, int V, int prec, void* table, void* lin_frags, hipStream_t s) {
+    float* t = static_cast<float*>(table);
+    uint8_t* l = static_cast<uint8_t*>(lin_frags);
+    int32_t* err = numeric_err_word();
+#define SSD_PACKL(V_, P_)                                                                                                    \
+    do {                                                                                                                     \
+        const int total = 3 * LUT_DY_F + SSD_ENCODE_LUT_KSTEPS(V_) * 2 * 512;                                                 \
+        hipLaunchKernelGGL((k_pack_encoder_lut<V_, P_>), dim3((total + 255) / 256), dim3(256), 0, s, cw, cb, lw, t, l, err);  \
+    } while (0)
+    if (V == 15) { if (prec == 2) SSD_PACKL(15, 2); else SSD_PACKL(15, 1); return 0; }
+    if (V == 31) { if (prec == 2) SSD_PACKL(31, 2); else SSD_PACKL(31, 1); return 0; }
+#undef SSD_PACKL
+    return -2;
 }
 
 int launch_pack_encoder(const float* cw, const float* cb, const float* lw, int V, int prec, void* conv_frags, void* lin_frags, hipStream_t s) {

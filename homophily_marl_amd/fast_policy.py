@@ -45,9 +45,17 @@ class FastPolicy:
         # the fused encoder exists for 15 x 15 and 31 x 31 windows (view_size 7 / 15: the shipped configurations)
         self.fused_enc = self.fused and self.V in (15, 31) and tuple(a.obs_dims) == (self.V, self.V)
         self.bands = abi.encode_bands(self.V) if self.fused_enc else 1
+        # encoder images: the class-LUT layout (conv as a table sum, no conv MFMAs: include/ssd_hip.h SSD_ENCODE_LAYOUT_LUT) unless
+        # enc_layout / SSD_ENC_LAYOUT asks for round 3's Toeplitz fragments (kept as the cross-check and for the training forward)
+        import os
+        lay = getattr(a, "enc_layout", None) or os.environ.get("SSD_ENC_LAYOUT", "lut")
+        self.enc_layout = abi.ENCODE_LAYOUT_TOEPLITZ if str(lay).lower() in ("toeplitz", "0") else abi.ENCODE_LAYOUT_LUT
         # bf16 MFMA products an f32-equivalent product costs (bench.py's roofline accounting); conv: the planes are exact, 2
         self.n_products = dict(encode_conv=2, encode_lin=3, head_env=3, head_inc=3) if precision == 2 else \
             dict(encode_conv=1, encode_lin=1, head_env=1, head_inc=1)
+        if self.fused_enc and self.enc_layout == abi.ENCODE_LAYOUT_LUT:
+            self.n_products["encode_conv"] = 0      # the conv is a table sum on the vector unit: no matrix-core products
+
         # [feat | tail (| 0)], agent-major; a PAIR of buffers: the pipelined rollout (act_inc_encode) encodes timestep t + 1 into
         # the other buffer while the inc head still reads the rows of t.  Everything else uses buffer 0 (`inputs`).
         self.inputs_pair = th.zeros(2, n, N, 64 if self.fused else self.inp, **f32)
@@ -119,7 +127,7 @@ class FastPolicy:
                 for head in ("env", "inc"):
                     self.p["img_" + head] = th.zeros(self.n, abi.policy_image_bytes(self.precision), **u8)
             if self.fused_enc:
-                cbytes, lbytes = abi.encode_frag_bytes(self.V, self.precision)
+                cbytes, lbytes = abi.encode_frag_bytes(self.V, self.precision, self.enc_layout)
                 self.p["conv_frags"], self.p["lin_frags"] = th.zeros(cbytes, **u8), th.zeros(lbytes, **u8)
         else:
             for k, v in packs.items():
@@ -130,8 +138,9 @@ class FastPolicy:
                 hp = self._head_params(head)
                 abi.check(self.lib, self.lib.ssd_policy_pack_head(C.byref(hp), self.precision, self.p["img_" + head].data_ptr(), st))
         if self.fused_enc:
-            abi.check(self.lib, self.lib.ssd_policy_pack_encoder(ag.conv_to_fc[0].weight.data_ptr(), ag.conv_to_fc[0].bias.data_ptr(), lin.data_ptr(), self.V, self.precision,
-                                                                 self.p["conv_frags"].data_ptr(), self.p["lin_frags"].data_ptr(), st))
+            pack = self.lib.ssd_policy_pack_encoder_lut if self.enc_layout == abi.ENCODE_LAYOUT_LUT else self.lib.ssd_policy_pack_encoder
+            abi.check(self.lib, pack(ag.conv_to_fc[0].weight.data_ptr(), ag.conv_to_fc[0].bias.data_ptr(), lin.data_ptr(), self.V, self.precision,
+                                     self.p["conv_frags"].data_ptr(), self.p["lin_frags"].data_ptr(), st))
 
     @staticmethod
     def supports(mac, fused=True):
@@ -221,6 +230,7 @@ class FastPolicy:
         ea.alphabet = abi.CODE_CHANNEL_MASK if mask_alphabet else abi.CODE_CLASS
         ea.conv_frags, ea.lin_frags = p["conv_frags"].data_ptr(), p["lin_frags"].data_ptr()
         ea.conv_b, ea.lin_b = p["cb"].data_ptr(), p["lb"].data_ptr()
+        ea.layout = self.enc_layout
         if self.bands > 1:
             ea.part = self.feat_part.data_ptr()
         else:

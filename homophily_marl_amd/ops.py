@@ -547,16 +547,21 @@ class _EncodeCodes(th.autograd.Function):
         cw, lw = conv_w.detach().contiguous(), lin_w.detach().contiguous()
         cb, lb = conv_b.detach().contiguous(), lin_b.detach().contiguous()
         prec = LEARNER_PRECISION
-        cbytes, lbytes = abi.encode_frag_bytes(V, prec)
-        cf, lf = th.empty(cbytes, dtype=th.uint8, device=dev), th.empty(lbytes, dtype=th.uint8, device=dev)
-        abi.check(lib, lib.ssd_policy_pack_encoder(cw.data_ptr(), cb.data_ptr(), lw.data_ptr(), V, prec, cf.data_ptr(), lf.data_ptr(), st))
         need = any(ctx.needs_input_grad[1:])
+        # the training forward also emits LeakyReLU(conv) and runs on the Toeplitz images; a forward without gradients (the target net)
+        # takes the class-LUT layout: the conv as a table sum, a third of the matrix-core work
+        layout = abi.ENCODE_LAYOUT_TOEPLITZ if need else abi.ENCODE_LAYOUT_LUT
+        cbytes, lbytes = abi.encode_frag_bytes(V, prec, layout)
+        cf, lf = th.empty(cbytes, dtype=th.uint8, device=dev), th.empty(lbytes, dtype=th.uint8, device=dev)
+        pack = lib.ssd_policy_pack_encoder if need else lib.ssd_policy_pack_encoder_lut
+        abi.check(lib, pack(cw.data_ptr(), cb.data_ptr(), lw.data_ptr(), V, prec, cf.data_ptr(), lf.data_ptr(), st))
         act = th.empty(R, 6, O, O, dtype=th.float32, device=dev) if need else None
         bands = abi.encode_bands(V)
         ea = abi.SsdPolicyEncodeArgs()
         ea.codes, ea.code_bytes = codes.data_ptr(), codes.numel()
         ea.env_stride, ea.slot_stride, ea.agent_stride, ea.slot_t = V * V, 0, V * V, None
         ea.rows, ea.view_edge, ea.n_agents, ea.agent_major, ea.precision = R, V, 1, 0, prec
+        ea.layout = layout
         ea.alphabet = abi.CODE_CLASS
         ea.conv_frags, ea.lin_frags, ea.conv_b, ea.lin_b = cf.data_ptr(), lf.data_ptr(), cb.data_ptr(), lb.data_ptr()
         ea.act = None if act is None else act.data_ptr()

@@ -631,6 +631,22 @@ int ssd_policy_pack_head(const ssd_policy_head_params* params, int32_t precision
  *   lin_frags  [unit = ((y * XTP + xtp) * 3 + s)][output tile 2][term][lane][8]: element (q, m, j) = lin_w[16 Mt + m][oc * P + y * O + x],
  *              r = 4 q + (j & 3), oc = 2 s + (r >> 3), x = 8 (2 xtp + (j >> 2)) + (r & 7), 0 where x >= O   (XTP = 1 / 2 pairs of
  *              8-position tiles per output row) */
+/* SSD_ENCODE_LAYOUT_LUT (ssd_policy_encode_args.layout; launches without `act`): the CONVOLUTION AS A TABLE SUM.  A window cell is one
+ * of four classes and lights at most one plane at 255/256, so the three taps of input row dy contribute to all six channels a value
+ * that depends only on the three classes under them: conv[c](y, x) = sum_dy T[dy][cls(y+dy, x) + 4 cls(y+dy, x+1) + 16 cls(y+dy, x+2)][c]
+ * (T[0] carries the bias) -- exact f32 sums of entries built by ssd_policy_pack_encoder_lut, no matrix-core work for the conv.  Images:
+ *   conv_frags = the table f32 [3 dy][64 idx][6 channels] (SSD_ENCODE_LUT_TABLE_BYTES; precision 2: scaled by 256, the split scale of
+ *                the conv activations), classes as in SSD_OBS_CODE (2 waste -> R, 1 apple -> G, 3 wall / agent -> B);
+ *   lin_frags  = [K-step gs][output tile 2][term][lane][8] with K-steps numbered through the bands (band k: ceil(rows_k * O / 4) of
+ *                them, SSD_ENCODE_LUT_KSTEPS(V) in all): element (q, m, j) = lin_w[16 Mt + m][j * P + y * O + x] for j < 6, the position
+ *                p = 4 s + q of the band (s = gs - the band's first K-step; y = band * R + p / O, x = p mod O), 0 for j >= 6 and past the band.
+ * The kernel keeps the window rows in LDS as packed 2-bit classes; lane (q, m) evaluates position 4 s + q of batch row m and its six
+ * channel values ARE its B operand of the Linear's K-step s: 258 MFMAs per 16-row tile (15 x 15) instead of 702. */
+#define SSD_ENCODE_LAYOUT_TOEPLITZ 0
+#define SSD_ENCODE_LAYOUT_LUT 1
+#define SSD_ENCODE_LUT_TABLE_BYTES (3 * 64 * 6 * 4)
+#define SSD_ENCODE_LUT_KSTEPS(V) ((V) == 31 ? 73 + 73 + 66 : 43)
+#define SSD_ENCODE_LUT_LIN_BYTES(V, precision) (SSD_ENCODE_LUT_KSTEPS(V) * 2 * (precision) * 1024)
 #define SSD_ENCODE_BANDS(V) ((V) == 31 ? 3 : 1)
 #define SSD_ENCODE_UNITS(V) ((V) == 31 ? 29 * 2 * 3 : 13 * 1 * 3)
 #define SSD_ENCODE_CONV_FRAG_BYTES(V, precision) ((precision) * 9 * 1024)
@@ -651,6 +667,8 @@ typedef struct ssd_policy_encode_args {
                                       activations the learner's backward needs (the training forward of the encoder) */
     int32_t slot_add;              /* the time slot read is *slot_t + slot_add (the pipelined rollout encodes slot t + 1 while the
                                       device time index still says t); the caller keeps it inside the storage */
+    int32_t layout;                /* ABI 7: SSD_ENCODE_LAYOUT_TOEPLITZ (0: images of ssd_policy_pack_encoder) or SSD_ENCODE_LAYOUT_LUT (images
+                                      of ssd_policy_pack_encoder_lut; not with `act`) */
 } ssd_policy_encode_args;
 int ssd_policy_encode(const ssd_policy_encode_args* args, void* stream);
 /* ssd_policy_head_inc(inc_args) and ssd_policy_encode(enc_args) as ONE launch -- the pipelined rollout's third launch of a timestep:
@@ -659,6 +677,10 @@ int ssd_policy_encode(const ssd_policy_encode_args* args, void* stream);
  * act, no slot_t_copy / counter_inc (the heads hand the counters over, see ssd_policy_head); same precision as inc_args. */
 int ssd_policy_head_inc_encode(const ssd_policy_head* inc_args, const ssd_policy_encode_args* enc_args, void* stream);
 /* conv_b (f32 [6]): read only for the range bound of the conv activations (see SSD_ERRBIT_F16_RANGE). */
+/* conv_w f32 [6, 3, 3, 3], conv_b [6], lin_w [32, 6 (V-2)^2] -> the images of SSD_ENCODE_LAYOUT_LUT: table (SSD_ENCODE_LUT_TABLE_BYTES,
+ * 16-byte aligned) and lin_frags (SSD_ENCODE_LUT_LIN_BYTES(V, precision)). */
+int ssd_policy_pack_encoder_lut(const float* conv_w, const float* conv_b, const float* lin_w, int32_t view_edge, int32_t precision, void* table,
+                                void* lin_frags, void* stream);
 int ssd_policy_pack_encoder(const float* conv_w, const float* conv_b, const float* lin_w, int32_t view_edge, int32_t precision, void* conv_frags,
                             void* lin_frags, void* stream);
 
