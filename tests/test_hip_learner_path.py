@@ -114,8 +114,8 @@ def _learner_fixture_body(z, args, batch, mac, learner, train_graph, storage):
 
 
 # the stated bar of the labelled bf16 learner variant: single bf16 products carry 8 significand bits (2^-9 relative per operand)
-BF16_Q_TOL = 2e-2           # |q - reference q| absolute, q of order 1 (measured: see the printed values)
-BF16_LOSS_RTOL = 5e-2       # |loss - reference loss| / |reference loss| for the two TD losses and the similarity loss
+BF16_Q_TOL = 2e-2           # |q - reference q| absolute, q of order 1 (measured: 2e-4 .. 6e-3 on the three fixtures)
+BF16_LOSS_RTOL = 5e-3       # |loss - reference loss| / max(|reference loss|, 1e-2) for the two TD losses and the similarity loss (measured: < 9e-4)
 
 
 @pytest.mark.parametrize("train_graph", [False, True])
@@ -159,7 +159,7 @@ def test_bf16_learner_variant_is_close_to_the_reference_and_labelled(name, train
                 logs = learner.cal_loss_and_step(batch)
             for k in ("loss_value_env", "loss_value_inc", "loss_sim"):
                 ref = float(z["step%d_%s" % (step, k)])
-                rel = abs(float(logs[k]) - ref) / abs(ref)
+                rel = abs(float(logs[k]) - ref) / max(abs(ref), 1e-2)
                 worst = max(worst, rel)
                 assert rel < BF16_LOSS_RTOL, (step, k, float(logs[k]), ref)
             for k in ("value_give_mean", "value_receive_mean"):          # integer counts: exact in any precision
