@@ -151,7 +151,10 @@ def run_e2e(args, c, rank, world, local_rank):
                 issued = sum(fl[p] * nprod[p] for p in parts) * N * n
                 k.update(flops_per_launch=issued, peak_tf=MFMA_BF16_PEAK_TF,
                          mfma_dtype=("f16 two-term splits, f32 accumulate (f32-equivalent)" if max(nprod.values()) > 1 else "bf16, f32 accumulate"),
-                         note="algorithmic f32 FLOPs %d; 16-bit MFMA products per f32 product: %s" % (alg, {p: nprod[p] for p in parts}))
+                         note="algorithmic f32 FLOPs %d; 16-bit MFMA products per f32 product: %s%s" % (
+                             alg, {p: nprod[p] for p in parts},
+                             "; encode_conv 0 = the convolution is a class-LUT table sum on the vector unit (exact f32, no matrix-core "
+                             "products): its FLOPs are algorithmic but not part of the issued MFMA work priced here" if nprod.get("encode_conv", 1) == 0 and "encode_conv" in parts else ""))
                 if max(nprod.values()) > 1:
                     # the same launch priced the way round 1's f32 kernels were: the reference's f32 FLOPs against the f32-MFMA peak
                     k["algorithmic_f32"] = dict(flops_per_launch=alg, peak_tf=MFMA_F32_PEAK_TF)

@@ -82,6 +82,31 @@ __device__ __forceinline__ void leaky_split8(const f32x4& t0, const f32x4& t1, u
 #endif
 }
 
+// The same hand-over for SIX values that are vector-ALU results (the class-LUT encoder's channel sums; never an MFMA accumulator:
+// see the hazard note above) + two zeros: 21 vector instructions instead of ~39.
+__device__ __forceinline__ void leaky_split6(const f32x2 (&x3)[3], u32x4& hi, u32x4& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const f32x2 c = {0.01f, 0.01f};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const f32x2 x = x3[p];
+        const f32x2 y = x * c;
+        float m0, m1, l0, l1;
+        asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(x.x), "v"(y.x));
+        asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(x.y), "v"(y.y));
+        uint32_t h, l;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(m0), "v"(m1));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h), "v"(m0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h), "v"(m1));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(l0), "v"(l1));
+        hi[p] = h; lo[p] = l;
+    }
+    hi[3] = 0u; lo[3] = 0u;
+#else
+    (void)x3; hi = u32x4{0u, 0u, 0u, 0u}; lo = hi;
+#endif
+}
+
 // err: the device's numeric-status word (ssd_numeric_status); a scaled term outside f16's range (or NaN) raises ERR_F16_RANGE
 template <int PREC> __device__ __forceinline__ void store_term(uint8_t* dst, float v, size_t term_stride, int32_t* err) {
     if constexpr (PREC == 2) {
@@ -948,10 +973,12 @@ static void head_args(const ssd_policy_head* p, HeadK& k, HeadCold& c, int waves
     if (k.n * k.bpa > chip_cus() && !no_loop) { k.bpa = chip_cus() / k.n; if (k.bpa < 1) k.bpa = 1; }
 }
 static bool head_loops(const HeadK& k, int waves) { return k.bpa * waves < (k.N + 15) / 16; }
-// the standalone heads: 8 compute waves when one tile per wave fits the chip, else the looped kernel with 6
-static int head_plan(const ssd_policy_head* p, HeadK& k, HeadCold& c, bool gen) {
+// the standalone heads: one tile per wave while that grid fits the chip (the kernels without a back edge), else the looped instantiation
+// (the generic-layout kernels exist as looped instantiations only).  Returns the compute waves per workgroup; `looped` = which kernel.
+static int head_plan(const ssd_policy_head* p, HeadK& k, HeadCold& c, bool gen, bool& looped) {
     head_args(p, k, c, gen ? HEAD_WAVES_LOOP : HEAD_WAVES);
-    if (!gen && !head_loops(k, HEAD_WAVES)) return HEAD_WAVES;
+    looped = gen || head_loops(k, HEAD_WAVES);
+    if (!looped) return HEAD_WAVES;
     head_args(p, k, c, HEAD_WAVES_LOOP);
     return HEAD_WAVES_LOOP;
 }
@@ -960,7 +987,8 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     HeadK k;
     HeadCold c;
     const bool gen = !inc && p->input_flags && (p->input_flags & ~SSD_INPUT_EXPLICIT) != (uint32_t)SSD_INPUT_FLAGS_SHIPPED;
-    const int waves = head_plan(p, k, c, gen);                         // (the generic-layout kernels exist as looped instantiations only)
+    bool looped = false;
+    const int waves = head_plan(p, k, c, gen, looped);
     const int prec = p->precision == 1 ? 1 : 2;
     const int bpa = k.bpa;
     const size_t lds = (size_t)head_lds_bytes(waves, prec);
@@ -993,7 +1021,7 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
     }
     void* args[2] = {&k, &c};
     const void* fn = gen ? gen_fns[(k.A == 8 ? 2 : 0) + (prec == 1 ? 1 : 0)]
-                         : fns[(waves == HEAD_WAVES_LOOP ? 8 : 0) + (k.A == 8 ? 4 : 0) + (prec == 1 ? 2 : 0) + (inc ? 1 : 0)];
+                         : fns[(looped ? 8 : 0) + (k.A == 8 ? 4 : 0) + (prec == 1 ? 2 : 0) + (inc ? 1 : 0)];
     if (hipLaunchKernel(fn, dim3(k.n * bpa), dim3((waves + 1) * 64), args, lds, s) != hipSuccess) return -1;
     return 0;
 }
@@ -1516,21 +1544,24 @@ __device__ __forceinline__ void encode_body_lut(const EncK& a, uint8_t* lds_raw,
                     idx[dy] = (int)((w >> sh) & 63u);
                 }
             }
-            float v[8];
+            f32x2 sums[3];
             {
-                typedef float f32x2l __attribute__((ext_vector_type(2)));
-                const f32x2l* t0 = reinterpret_cast<const f32x2l*>(table + idx[0] * LUT_ENTRY_F);
-                const f32x2l* t1 = reinterpret_cast<const f32x2l*>(table + LUT_DY_F + idx[1] * LUT_ENTRY_F);
-                const f32x2l* t2 = reinterpret_cast<const f32x2l*>(table + 2 * LUT_DY_F + idx[2] * LUT_ENTRY_F);
+                const f32x2* t0 = reinterpret_cast<const f32x2*>(table + idx[0] * LUT_ENTRY_F);
+                const f32x2* t1 = reinterpret_cast<const f32x2*>(table + LUT_DY_F + idx[1] * LUT_ENTRY_F);
+                const f32x2* t2 = reinterpret_cast<const f32x2*>(table + 2 * LUT_DY_F + idx[2] * LUT_ENTRY_F);
 #pragma unroll
-                for (int c2 = 0; c2 < 3; ++c2) {
-                    const f32x2l s01 = t0[c2] + t1[c2], s012 = s01 + t2[c2];
-                    v[2 * c2] = leaky(s012.x); v[2 * c2 + 1] = leaky(s012.y);
-                }
-                v[6] = 0.f; v[7] = 0.f;
+                for (int c2 = 0; c2 < 3; ++c2) sums[c2] = (t0[c2] + t1[c2]) + t2[c2];
             }
             u32x4 xh, xl;
-            split8<PREC>(v, xh, xl);
+            if constexpr (PREC == 2) {
+                leaky_split6(sums, xh, xl);
+            } else {
+                float v[8];
+#pragma unroll
+                for (int c2 = 0; c2 < 3; ++c2) { v[2 * c2] = leaky(sums[c2].x); v[2 * c2 + 1] = leaky(sums[c2].y); }
+                v[6] = 0.f; v[7] = 0.f;
+                split8<PREC>(v, xh, xl);
+            }
             if (PREC == 2) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) accl[bt][mt] = mma<PREC>(la[mt][PREC - 1], xh, accl[bt][mt]);
