@@ -1515,7 +1515,10 @@ __device__ __forceinline__ void encode_body_lut(const EncK& a, uint8_t* lds_raw,
     u32x4 la[2][PREC], la_next[2][PREC];
     if (s_begin < s_end) load_la(s_begin, la_next);
     const uint32_t* my_rows = packed + m * PRW;
-#pragma unroll 1
+#ifndef SSD_LUT_UNROLL
+#define SSD_LUT_UNROLL 1
+#endif
+#pragma unroll SSD_LUT_UNROLL
     for (int sl = s_begin; sl < s_end; ++sl) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)

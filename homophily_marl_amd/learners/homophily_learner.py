@@ -239,18 +239,23 @@ class HomophilyLearner:
                 p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
                 off += p.numel()
 
-    def _backward(self, loss):
+    def _backward(self, loss, seeds=None):
         """optimiser_{inc,env}.zero_grad() + loss.backward() (homophily_learner.py:220-222): the gradients come back as fresh tensors
-        and ONE concatenation writes them into the flat buffer (accumulating into 44 pre-zeroed .grad views costs a launch each)."""
+        and ONE concatenation writes them into the flat buffer (accumulating into 44 pre-zeroed .grad views costs a launch each).
+        seeds: `loss` is a list of tensors and seeds their gradients (the fused loss kernel's dL/dq: no loss node in the tape)."""
         self._bind_flat_grad()
         if getattr(self.args, "grad_by_cat", True):
-            grads = th.autograd.grad(loss, self.params)
+            grads = th.autograd.grad(loss, self.params, grad_outputs=seeds)
             th.cat([g.reshape(-1) for g in grads], out=self._flat_grad)
         else:
             self._flat_grad.zero_()
-            loss.backward()
+            th.autograd.backward(loss, grad_tensors=seeds)
 
-    def forward_backward(self, batch, dens):
+    def forward_backward(self, batch, dens=None):
+        """dens None: this process's own denominators (no data parallelism: nothing to all-reduce between the stages, so the captured
+        step computes them inside the graph)."""
+        if dens is None:
+            dens = self.denominators(batch)
         if self._fused(batch):
             return self._forward_backward_fused(batch, dens)
         return self._forward_backward_ops(batch, dens)
@@ -258,8 +263,8 @@ class HomophilyLearner:
     def _forward_backward_fused(self, batch, dens):
         a, n = self.args, self.n_agents
         q_env, q_inc, tq_env, tq_inc = self.unroll_pair(batch)
-        loss, sums = ops.td_sim_loss(q_env, q_inc, tq_env, tq_inc, dens, batch, a)
-        self._backward(loss)
+        dq_env, dq_inc, sums = ops.td_sim_loss_grads(q_env, q_inc, tq_env, tq_inc, dens, batch, a)
+        self._backward([q_env, q_inc], seeds=[dq_env, dq_inc])
         return _FusedLogs(sums, dens, float(batch.batch_size * (batch.max_seq_length - 1) * n), n)
 
     def _forward_backward_ops(self, batch, dens):
@@ -434,7 +439,8 @@ class HomophilyLearner:
             # thread_local: with an initialised process group the RCCL watchdog thread keeps polling events while we capture
             g1, g2 = th.cuda.CUDAGraph(), th.cuda.CUDAGraph()
             with th.cuda.graph(g1, stream=self._capture_stream, capture_error_mode="thread_local"):
-                self._static_logs = self.forward_backward(self._static_batch, self._static_dens)
+                # data parallel: the denominators are all-reduced OUTSIDE the graph and handed in; else they are part of the graph
+                self._static_logs = self.forward_backward(self._static_batch, self._static_dens if self.distributed else None)
             with th.cuda.graph(g2, pool=g1.pool(), stream=self._capture_stream, capture_error_mode="thread_local"):
                 self.clip_and_step()
             self._graph = (g1, g2)
@@ -442,11 +448,12 @@ class HomophilyLearner:
             dst = self._static_data[k]
             if v.data_ptr() != dst.data_ptr() or v.shape != dst.shape:      # not sampled straight into the static batch (sample_out)
                 dst.copy_(v)
-        self._static_dens.copy_(self.denominators(self._static_batch))
+        if self.distributed:
+            self._static_dens.copy_(self.denominators(self._static_batch))
         self._graph[0].replay()
         if os.environ.get("SSD_GRAPH_CHECK"):      # diagnostic: the replayed gradient against an eager evaluation of the same step
             got = self._flat_grad.clone()
-            self.forward_backward(self._static_batch, self._static_dens)
+            self.forward_backward(self._static_batch, self._static_dens if self.distributed else None)
             ref = self._flat_grad.clone()
             err = float((got - ref).abs().max())
             self._check_n = getattr(self, "_check_n", 0) + 1

@@ -161,7 +161,7 @@ def loss_denominators(batch, a, n_actions):
     (mode 0) instead of ~30 tensor ops; device tensors only."""
     lib = abi.load_library()
     B, T, n = batch.batch_size, batch.max_seq_length - 1, batch["reward"].shape[-1]
-    partials = th.zeros(B * T * n, abi.TD_LOSS_PARTIALS, dtype=th.float32, device=batch["reward"].device)
+    partials = th.empty(B * T * n, abi.TD_LOSS_PARTIALS, dtype=th.float32, device=batch["reward"].device)   # mode 0 writes columns 0, 1 of every row
     t, keep = _td_loss_args(batch, a, n_actions, partials)
     abi.check(lib, lib.ssd_td_sim_loss(C.byref(t), 0, _stream(partials)))
     return column_sums(partials)[:2]
@@ -197,6 +197,24 @@ class _TdSimLoss(th.autograd.Function):
 
 def td_sim_loss(q_env, q_inc, tq_env, tq_inc, dens, batch, a):
     return _TdSimLoss.apply(q_env, q_inc, tq_env, tq_inc, dens, batch, a)
+
+
+def td_sim_loss_grads(q_env, q_inc, tq_env, tq_inc, dens, batch, a):
+    """(dL/dq_env, dL/dq_inc, column sums of the per-row partials) of the same loss from the same launch, WITHOUT an autograd node:
+    the learner seeds the backward pass of the two Q tensors with the gradients directly (th.autograd.grad(..., grad_outputs=...)) --
+    the loss scalar is a logged quantity only (_FusedLogs forms it when it is read), so the six scalar launches that assembled it and
+    the two multiplications by d loss / d loss = 1 of the autograd form are gone.  Columns 13..15 of the partials are never written or read."""
+    lib = abi.load_library()
+    B, T, n = batch.batch_size, batch.max_seq_length - 1, q_env.shape[2]
+    q_env, q_inc, tq_env, tq_inc = q_env.detach().contiguous(), q_inc.detach().contiguous(), tq_env.contiguous(), tq_inc.contiguous()
+    partials = th.empty(B * T * n, abi.TD_LOSS_PARTIALS, dtype=th.float32, device=q_env.device)
+    dq_env, dq_inc = th.empty_like(q_env), th.empty_like(q_inc)
+    t, keep = _td_loss_args(batch, a, q_env.shape[-1], partials)
+    t.q_env, t.q_inc, t.tq_env, t.tq_inc = q_env.data_ptr(), q_inc.data_ptr(), tq_env.data_ptr(), tq_inc.data_ptr()
+    dens = dens.contiguous().float()
+    t.dens, t.dq_env, t.dq_inc = dens.data_ptr(), dq_env.data_ptr(), dq_inc.data_ptr()
+    abi.check(lib, lib.ssd_td_sim_loss(C.byref(t), 1, _stream(q_env)))
+    return dq_env, dq_inc, column_sums(partials)
 
 
 def fill_blocks(entries):
