@@ -191,10 +191,17 @@ class HomophilyMAC(nn.Module):
         hist = None if (kernel_tail and on_dev) else (
             prev(acts, -1).reshape(B * T, n), prev(batch["reward"], 0).reshape(B * T, n),
             prev(batch["actions_inc"].squeeze(-1), 0).reshape(B * T, n, n), batch["agent_pos"].reshape(B * T, n, 2))
-        onehot = F.one_hot(acts, num_classes=a.n_actions)
-        sh = dict(obs=None if codes is not None else (obs.float() if a.rgb_input else obs), codes=codes, hist=hist, onehot=onehot, tail=None,
-                  other=self.agent.unroll_other(onehot, batch["agent_pos"] / self.pos_scale, batch["agent_orientation"], batch["reward"],
-                                                batch["clean_num"], batch["apple_den"], th.float32))
+        sh = dict(obs=None if codes is not None else (obs.float() if a.rgb_input else obs), codes=codes, hist=hist, tail=None)
+        if on_dev and acts.dtype == th.long:
+            # one launch: the incentive head's per-receiver features and the one-hot actions in the agent-major layout fc1_inc reads
+            sh["onehot"] = None
+            sh["other"], sh["act_tm"] = ops.unroll_other(acts, batch["agent_pos"], batch["agent_orientation"], batch["reward"], batch["clean_num"],
+                                                         batch["apple_den"], self.pos_scale, a.n_actions)
+        else:
+            onehot = F.one_hot(acts, num_classes=a.n_actions)
+            sh.update(onehot=onehot, act_tm=None,
+                      other=self.agent.unroll_other(onehot, batch["agent_pos"] / self.pos_scale, batch["agent_orientation"], batch["reward"],
+                                                    batch["clean_num"], batch["apple_den"], th.float32))
         if kernel_tail:
             # the non-visual input columns do not depend on the weights either
             tail = th.empty(B * T * n, self.input_shape - a.obs_dim_net, dtype=th.float32, device=batch["obs"].device)
@@ -223,7 +230,7 @@ class HomophilyMAC(nn.Module):
             inputs = th.cat([feat, shared["tail"]], dim=1).reshape(B, T, n, -1)
         else:
             inputs = self.assemble_inputs(feat, *shared["hist"], False).reshape(B, T, n, -1)
-        return self.agent.unroll_pre(inputs, shared["onehot"])
+        return self.agent.unroll_pre(inputs, shared["onehot"], act_tm=shared.get("act_tm"))
 
     def _build_inputs(self, batch, t):
         if self.args.rgb_input:

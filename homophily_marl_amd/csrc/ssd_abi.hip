@@ -354,6 +354,14 @@ int ssd_build_inputs(int32_t batch, int32_t n_agents, int32_t n_actions, int32_t
     return launched();
 }
 
+int ssd_unroll_other(const int64_t* actions, const float* pos, const float* orient, const float* reward, const float* clean_num, const float* apple_den,
+                     float pos_scale, int32_t batch, int32_t T, int32_t n_agents, int32_t n_actions, float* other, float* act_tm, void* stream) {
+    if (!actions || !pos || !orient || !reward || !clean_num || !apple_den || !other || !act_tm || batch < 1 || T < 1 || n_agents < 1 || n_actions < 1 ||
+        !(pos_scale > 0.f)) return fail(SSD_ERR_INVALID, "bad argument");
+    launch_unroll_other(actions, pos, orient, reward, clean_num, apple_den, pos_scale, batch, T, n_agents, n_actions, other, act_tm, (hipStream_t)stream);
+    return launched();
+}
+
 int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int64_t* actions_inc, const float* rewards,
                            float effect_ratio, float cost_ratio, float incentive, float seq_len, float* give,
                            float* recv_pos, float* recv_neg, float* recv_zero, float* rewards_for_env,
@@ -528,18 +536,21 @@ int ssd_gru_seq_fwd(const float* gi, const float* wh, const float* bh, float* hs
     if (!gi || !wh || !bh || !hs || T < 1 || G < 1 || B < 1 || (!rzn) != (!ghn)) return fail(SSD_ERR_INVALID, "bad argument");
     if (B % 16) return fail(SSD_ERR_INVALID, "B must be a multiple of 16 (pad the sequences)");
     if (!al16(gi) || !al16(wh) || !al16(bh) || !al16(hs) || !al16(rzn) || !al16(ghn)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
-    launch_gru_seq_fwd(&gi, 0, wh, bh, hs, rzn, ghn, T, G, B, (hipStream_t)stream);
+    launch_gru_seq_fwd(&gi, 0, &wh, &bh, 1, hs, rzn, ghn, T, G, B, (hipStream_t)stream);
     return launched();
 }
-int ssd_gru_seq_fwd_parts(const float* const* gi_parts, int32_t n_parts, const float* wh, const float* bh, float* hs, float* rzn, float* ghn,
-                          int32_t T, int32_t G, int32_t B, void* stream) {
-    if (!gi_parts || n_parts < 1 || n_parts > 4 || !wh || !bh || !hs || T < 1 || G < 1 || G % n_parts || B < 1 || (!rzn) != (!ghn))
+int ssd_gru_seq_fwd_parts(const float* const* gi_parts, int32_t n_parts, const float* const* wh_parts, const float* const* bh_parts, int32_t n_wparts,
+                          float* hs, float* rzn, float* ghn, int32_t T, int32_t G, int32_t B, void* stream) {
+    if (!gi_parts || n_parts < 1 || n_parts > 4 || !wh_parts || !bh_parts || n_wparts < 1 || n_wparts > 4 || !hs || T < 1 || G < 1 || G % n_parts ||
+        G % n_wparts || B < 1 || (!rzn) != (!ghn))
         return fail(SSD_ERR_INVALID, "bad argument");
+    for (int k = 0; k < n_wparts; ++k)
+        if (!wh_parts[k] || !bh_parts[k] || !al16(wh_parts[k]) || !al16(bh_parts[k])) return fail(SSD_ERR_INVALID, "weight parts must be non-null and 16-byte aligned");
     if (B % 16) return fail(SSD_ERR_INVALID, "B must be a multiple of 16 (pad the sequences)");
     for (int k = 0; k < n_parts; ++k)
         if (!gi_parts[k] || !al16(gi_parts[k])) return fail(SSD_ERR_INVALID, "gi parts must be non-null and 16-byte aligned");
-    if (!al16(wh) || !al16(bh) || !al16(hs) || !al16(rzn) || !al16(ghn)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
-    launch_gru_seq_fwd(gi_parts, n_parts, wh, bh, hs, rzn, ghn, T, G, B, (hipStream_t)stream);
+    if (!al16(hs) || !al16(rzn) || !al16(ghn)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
+    launch_gru_seq_fwd(gi_parts, n_parts, wh_parts, bh_parts, n_wparts, hs, rzn, ghn, T, G, B, (hipStream_t)stream);
     return launched();
 }
 int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* d_gi, float* dgh,
@@ -547,18 +558,20 @@ int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const f
     if (!dhs || !hs || !rzn || !ghn || !wh || !d_gi || !dgh || !d_wh || !d_bh_part || T < 1 || G < 1 || B < 1) return fail(SSD_ERR_INVALID, "bad argument");
     if (B % 16) return fail(SSD_ERR_INVALID, "B must be a multiple of 16 (pad the sequences)");
     if (!al16(dhs) || !al16(hs) || !al16(rzn) || !al16(ghn) || !al16(wh) || !al16(d_gi) || !al16(dgh)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
-    launch_gru_seq_bwd(dhs, hs, rzn, ghn, wh, &d_gi, 0, dgh, d_wh, d_bh_part, T, G, B, (hipStream_t)stream);
+    launch_gru_seq_bwd(dhs, hs, rzn, ghn, &wh, 1, &d_gi, 0, dgh, d_wh, d_bh_part, T, G, B, (hipStream_t)stream);
     return launched();
 }
-int ssd_gru_seq_bwd_parts(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* const* d_gi_parts,
-                          int32_t n_parts, float* dgh, float* d_wh, float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream) {
-    if (!dhs || !hs || !rzn || !ghn || !wh || !d_gi_parts || n_parts < 1 || n_parts > 4 || !dgh || !d_wh || !d_bh_part || T < 1 || G < 1 ||
-        G % n_parts || B < 1) return fail(SSD_ERR_INVALID, "bad argument");
+int ssd_gru_seq_bwd_parts(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* const* wh_parts, int32_t n_wparts,
+                          float* const* d_gi_parts, int32_t n_parts, float* dgh, float* d_wh, float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream) {
+    if (!dhs || !hs || !rzn || !ghn || !wh_parts || n_wparts < 1 || n_wparts > 4 || !d_gi_parts || n_parts < 1 || n_parts > 4 || !dgh || !d_wh ||
+        !d_bh_part || T < 1 || G < 1 || G % n_parts || G % n_wparts || B < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    for (int k = 0; k < n_wparts; ++k)
+        if (!wh_parts[k] || !al16(wh_parts[k])) return fail(SSD_ERR_INVALID, "weight parts must be non-null and 16-byte aligned");
     if (B % 16) return fail(SSD_ERR_INVALID, "B must be a multiple of 16 (pad the sequences)");
     for (int k = 0; k < n_parts; ++k)
         if (!d_gi_parts[k] || !al16(d_gi_parts[k])) return fail(SSD_ERR_INVALID, "d_gi parts must be non-null and 16-byte aligned");
-    if (!al16(dhs) || !al16(hs) || !al16(rzn) || !al16(ghn) || !al16(wh) || !al16(dgh)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
-    launch_gru_seq_bwd(dhs, hs, rzn, ghn, wh, d_gi_parts, n_parts, dgh, d_wh, d_bh_part, T, G, B, (hipStream_t)stream);
+    if (!al16(dhs) || !al16(hs) || !al16(rzn) || !al16(ghn) || !al16(dgh)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
+    launch_gru_seq_bwd(dhs, hs, rzn, ghn, wh_parts, n_wparts, d_gi_parts, n_parts, dgh, d_wh, d_bh_part, T, G, B, (hipStream_t)stream);
     return launched();
 }
 

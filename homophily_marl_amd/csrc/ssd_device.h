@@ -149,15 +149,17 @@ int launch_policy_encode(const ssd_policy_encode_args* p, hipStream_t s);
 int launch_pack_encoder_lut(const float* cw, const float* cb, const float* lw, int V, int prec, void* table, void* lin_frags, hipStream_t s);
 int launch_pack_encoder(const float* cw, const float* cb, const float* lw, int V, int prec, void* conv_frags, void* lin_frags, hipStream_t s);
 void launch_pack_head(const ssd_policy_head_params* p, int prec, void* image, hipStream_t s);
-void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T,
-                        int G, int B, hipStream_t s);
-void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* const* d_gi_parts,
-                        int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s);
+void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* const* wh_parts, const float* const* bh_parts, int n_wparts, float* hs,
+                        float* rzn, float* ghn, int T, int G, int B, hipStream_t s);
+void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* const* wh_parts, int n_wparts,
+                        float* const* d_gi_parts, int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s);
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s);
 void policy_head_plan(int n_env, int n_agents, int fused, int* wg_per_agent, int* waves_out, int* tiles_per_wave);
 int launch_policy_inc_encode(const ssd_policy_head* ph, const ssd_policy_encode_args* pe, hipStream_t s);
 int conv_wgrad_partial_rows(int R);
 int launch_conv_wgrad(const uint8_t* codes, const float* d_conv, float* partial, int R, int V, hipStream_t s);
+void launch_unroll_other(const int64_t* actions, const float* pos, const float* orient, const float* reward, const float* clean, const float* den,
+                         float pos_scale, int B, int T, int n, int A, float* other, float* act_tm, hipStream_t stream);
 float* bmm_scratch(hipStream_t stream);
 int learner_precision();                  // 2: f32-equivalent (default), 1: single bf16 products (ssd_set_learner_precision)
 void set_learner_precision(int p);

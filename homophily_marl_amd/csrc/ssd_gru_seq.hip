@@ -90,11 +90,29 @@ __device__ __forceinline__ float* gru_part_base(const GruParts& P, int g) {
     return b + (size_t)(g - part * P.spp) * P.set_stride;
 }
 
+// The recurrence weights as up to 4 separately allocated parts of G / n_parts weight sets each (wh [sets, 64, 192], bh [sets, 192]): the
+// learner hands over the live net's and the target net's images as they are (no concatenation per step).
+struct GruW {
+    const float* wh[4];
+    const float* bh[4];
+    int spp;                       // weight sets per part
+};
+__device__ __forceinline__ const float* gru_wh(const GruW& W, int g) {
+    const int part = g / W.spp;
+    const float* b = part == 0 ? W.wh[0] : (part == 1 ? W.wh[1] : (part == 2 ? W.wh[2] : W.wh[3]));
+    return b + (size_t)(g - part * W.spp) * GH * G3;
+}
+__device__ __forceinline__ const float* gru_bh(const GruW& W, int g) {
+    const int part = g / W.spp;
+    const float* b = part == 0 ? W.bh[0] : (part == 1 ? W.bh[1] : (part == 2 ? W.bh[2] : W.bh[3]));
+    return b + (size_t)(g - part * W.spp) * G3;
+}
+
 constexpr int FST = 324;            // staging row stride (floats): [hs 64 | r 64 | z 64 | n 64 | gh_n 64] + pad, 1296 B = 16 * 81
 // BF: the labelled reduced-precision variant (learner_dtype: bf16): W_h and the state as single bf16 terms, ONE v_mfma_f32_16x16x32_bf16
 // per product (6 per step instead of 18), no scales (bf16 has f32's exponent range), f32 accumulation and gate arithmetic.
 template <bool TRAIN, bool BF = false>
-__global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_fwd(const GruParts gi, const float* __restrict__ wh, const float* __restrict__ bh,
+__global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_fwd(const GruParts gi, const GruW W,
                                                              float* __restrict__ hs, float* __restrict__ rzn, float* __restrict__ ghn, int T, int G,
                                                              int B, int tiles, int32_t* __restrict__ err) {
     __shared__ __attribute__((aligned(16))) _Float16 hx[2][2][16][HSH];   // [buffer][term][row][feature]
@@ -130,6 +148,8 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_fwd(const GruParts gi, 
     }
     const int m = lane & 15, q = lane >> 4;
     const int row = tile * 16 + m, rc = row;
+    const float* __restrict__ wh = gru_wh(W, g);                       // this weight set's [64, 192] / [192]
+    const float* __restrict__ bh = gru_bh(W, g);
     // resident A fragments: lane (q, m) = output feature gate * 64 + 16 ft + m, reduction indices k = 32 s + 8 q + j
     u32x4 ah[3][2], al[3][2];
     bool out_of_range = false;                                        // ONE test after the 48 loads: a branch per value made each load wait for the one before (14 us)
@@ -140,13 +160,13 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_fwd(const GruParts gi, 
             if constexpr (BF) {
                 b8 h;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) h[j] = (__bf16)wh[((size_t)g * GH + 32 * s + 8 * q + j) * G3 + gate * GH + 16 * ft + m];
+                for (int j = 0; j < 8; ++j) h[j] = (__bf16)wh[(size_t)(32 * s + 8 * q + j) * G3 + gate * GH + 16 * ft + m];
                 ah[gate][s] = __builtin_bit_cast(u32x4, h); al[gate][s] = ah[gate][s];
             } else {
                 h8 h, l;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float w = wh[((size_t)g * GH + 32 * s + 8 * q + j) * G3 + gate * GH + 16 * ft + m] * GRU_WS;
+                    const float w = wh[(size_t)(32 * s + 8 * q + j) * G3 + gate * GH + 16 * ft + m] * GRU_WS;
                     out_of_range |= !(fabsf(w) <= F16_MAX);            // |W_h| >= 1 023.5 (or NaN): outside the split's range; |h| < 1 needs no check
                     h[j] = (_Float16)w; l[j] = (_Float16)(w - (float)h[j]);
                 }
@@ -156,7 +176,7 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_fwd(const GruParts gi, 
     if (out_of_range && err) atomicOr(err, ERR_F16_RANGE);
     f32x4 bias[3];
 #pragma unroll
-    for (int gate = 0; gate < 3; ++gate) bias[gate] = *reinterpret_cast<const f32x4*>(bh + (size_t)g * G3 + gate * GH + 16 * ft + 4 * q);
+    for (int gate = 0; gate < 3; ++gate) bias[gate] = *reinterpret_cast<const f32x4*>(bh + gate * GH + 16 * ft + 4 * q);
     const int fo = 16 * ft + 4 * q;                                   // this lane's 4 features
     f32x4 hown = {0.f, 0.f, 0.f, 0.f};                                // h_{t-1}[row m][fo .. fo + 3]
     u32x4 xh[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, xl[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};   // B operand: h_0 = 0
@@ -259,7 +279,7 @@ constexpr int GRU_BWD_LDS = 2 * 3 * 16 * DSB * 2 + 2 * 16 * BST * 4;   // bf16 o
 // BF: single bf16 terms (learner_dtype: bf16): 6 MFMAs per step instead of 36.
 template <bool BF>
 __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_bwd(const float* __restrict__ dhs, const float* __restrict__ hs, const float* __restrict__ rzn,
-                                                             const float* __restrict__ ghn, const float* __restrict__ wh, const GruParts d_gi,
+                                                             const float* __restrict__ ghn, const GruW W, const GruParts d_gi,
                                                              float* __restrict__ dgh, float* __restrict__ d_bh_part, int T, int G, int B, int tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gru_lds[];
     __bf16 (*dgb)[3][16][DSB] = reinterpret_cast<__bf16 (*)[3][16][DSB]>(gru_lds);                    // dL/dgh of the step: [buffer][term][row][192]
@@ -289,6 +309,7 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_bwd(const float* __rest
     const int m = lane & 15, q = lane >> 4;
     const int row = tile * 16 + m, rc = row;                          // B is a multiple of 16 (the host pads): see k_gru_seq_fwd
     const int fo = 16 * ft + 4 * q;
+    const float* __restrict__ wh = gru_wh(W, g);
     // resident A fragments of W_h: lane (q, m) = hidden feature 16 ft + m, reduction indices (gate outputs) k = 32 s + 8 q + j
     u32x4 wa[6][3];
 #pragma unroll
@@ -297,7 +318,7 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_bwd(const float* __rest
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             __bf16 x1, x2, x3;
-            split3(wh[((size_t)g * GH + 16 * ft + m) * G3 + 32 * s + 8 * q + j], x1, x2, x3);
+            split3(wh[(size_t)(16 * ft + m) * G3 + 32 * s + 8 * q + j], x1, x2, x3);
             t1[j] = x1; t2[j] = x2; t3[j] = x3;
         }
         wa[s][0] = __builtin_bit_cast(u32x4, t1); wa[s][1] = __builtin_bit_cast(u32x4, t2); wa[s][2] = __builtin_bit_cast(u32x4, t3);
@@ -406,20 +427,29 @@ static GruParts gru_parts(float* const* parts, int n_parts, int T, int G, int B)
 }
 
 // n_parts 0: gi_parts[0] is one time-major tensor; else set-major parts (see GruParts)
-void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* wh, const float* bh, float* hs, float* rzn, float* ghn, int T,
-                        int G, int B, hipStream_t s) {
+static GruW gru_w(const float* const* wh_parts, const float* const* bh_parts, int n_wparts, int G) {
+    GruW W;
+    const int np = n_wparts < 1 ? 1 : n_wparts;
+    for (int k = 0; k < 4; ++k) { W.wh[k] = wh_parts[k < np ? k : 0]; W.bh[k] = bh_parts ? bh_parts[k < np ? k : 0] : nullptr; }
+    W.spp = G / np;
+    return W;
+}
+void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* const* wh_parts, const float* const* bh_parts, int n_wparts, float* hs,
+                        float* rzn, float* ghn, int T, int G, int B, hipStream_t s) {
     const int tiles = (B + 15) / 16;
+    const GruW W = gru_w(wh_parts, bh_parts, n_wparts, G);
     const GruParts P = gru_parts(const_cast<float* const*>(reinterpret_cast<const float* const*>(gi_parts)), n_parts, T, G, B);
     int32_t* err = numeric_err_word();
     const bool bf = learner_precision() == 1;
-#define SSD_GF(TR_, BF_) hipLaunchKernelGGL((k_gru_seq_fwd<TR_, BF_>), dim3(G * tiles), dim3(GRU_THREADS), 0, s, P, wh, bh, hs, rzn, ghn, T, G, B, tiles, err)
+#define SSD_GF(TR_, BF_) hipLaunchKernelGGL((k_gru_seq_fwd<TR_, BF_>), dim3(G * tiles), dim3(GRU_THREADS), 0, s, P, W, hs, rzn, ghn, T, G, B, tiles, err)
     if (rzn) { if (bf) SSD_GF(true, true); else SSD_GF(true, false); }
     else { if (bf) SSD_GF(false, true); else SSD_GF(false, false); }
 #undef SSD_GF
 }
-void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* const* d_gi_parts,
-                        int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s) {
+void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* const* wh_parts, int n_wparts,
+                        float* const* d_gi_parts, int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s) {
     const int tiles = (B + 15) / 16;
+    const GruW W = gru_w(wh_parts, nullptr, n_wparts, G);
     const GruParts P = gru_parts(d_gi_parts, n_parts, T, G, B);
     static bool attr_done_dev[64] = {};                                // the attribute is per device
     int dev = 0;
@@ -428,8 +458,8 @@ void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, con
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_seq_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GRU_BWD_LDS);
         attr_done_dev[dev] = true;                                     // a refused attribute shows as a launch error (ssd_poll_error / hipGetLastError)
     }
-    if (learner_precision() == 1) hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(G * tiles), dim3(GRU_THREADS), GRU_BWD_LDS, s, dhs, hs, rzn, ghn, wh, P, dgh, d_bh_part, T, G, B, tiles);
-    else hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(G * tiles), dim3(GRU_THREADS), GRU_BWD_LDS, s, dhs, hs, rzn, ghn, wh, P, dgh, d_bh_part, T, G, B, tiles);
+    if (learner_precision() == 1) hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(G * tiles), dim3(GRU_THREADS), GRU_BWD_LDS, s, dhs, hs, rzn, ghn, W, P, dgh, d_bh_part, T, G, B, tiles);
+    else hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(G * tiles), dim3(GRU_THREADS), GRU_BWD_LDS, s, dhs, hs, rzn, ghn, W, P, dgh, d_bh_part, T, G, B, tiles);
     // dL/dW_h[g] = sum_{t >= 1, b} h_{t-1}[b]^T dL/dgh_t[b]: rows (t, b) of hs [G, T, B, 64] against rows (t + 1, b) of dgh [G, T, B, 192] --
     // the x^T g role of the per-agent-layer kernel (csrc/ssd_bmm.hip: K = (T - 1) B rows split over 16 waves per tile, exact f32)
     if (T > 1) launch_bias_bmm_bwd(dgh + (size_t)B * G3, hs, nullptr, nullptr, d_wh, nullptr, nullptr, G, (T - 1) * B, GH, G3, s, (long)T * B * GH, (long)T * B * G3);

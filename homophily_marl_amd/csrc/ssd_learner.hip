@@ -606,6 +606,31 @@ void launch_build_inputs_flags(int32_t batch, int32_t n, int32_t A, int32_t t0, 
                        last_reward, last_actions_inc, pos, pos_scale, out, out_stride, out_offset);
 }
 
+// other_j = [one-hot(a_j), pos_j / scale, orient_j, r_j, clean_j, apple_den_j] (homophily_agent.py:194-201) of every (episode b, step t,
+// agent j) as other [T * B, n, A + 7] (rows t * B + b: the layout the time-batched incentive head consumes), and the one-hot alone a
+// second time as act_tm [n, T * B, A] (agent-major: the extra input columns of fc1_inc).  One thread per (b, t, j): the reference
+// builds this from F.one_hot, a division, a concatenation and two permuted copies -- six launches here, plus two per network for act_tm.
+__global__ __launch_bounds__(256) void k_unroll_other(const int64_t* __restrict__ actions, const float* __restrict__ pos, const float* __restrict__ orient,
+                                                      const float* __restrict__ reward, const float* __restrict__ clean, const float* __restrict__ den,
+                                                      float pos_scale, int B, int T, int n, int A, float* __restrict__ other, float* __restrict__ act_tm) {
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= B * T * n) return;
+    const int j = it % n, bt = it / n, t = bt % T, b = bt / T;
+    const int a = (int)actions[it];
+    const int E = A + 7;
+    float* o = other + ((size_t)(t * B + b) * n + j) * E;
+    float* at = act_tm + ((size_t)j * T * B + (size_t)t * B + b) * A;
+    for (int k = 0; k < A; ++k) { const float v = k == a ? 1.f : 0.f; o[k] = v; at[k] = v; }
+    o[A] = pos[(size_t)it * 2] / pos_scale; o[A + 1] = pos[(size_t)it * 2 + 1] / pos_scale;
+    o[A + 2] = orient[(size_t)it * 2]; o[A + 3] = orient[(size_t)it * 2 + 1];
+    o[A + 4] = reward[it]; o[A + 5] = clean[it]; o[A + 6] = den[it];
+}
+void launch_unroll_other(const int64_t* actions, const float* pos, const float* orient, const float* reward, const float* clean, const float* den,
+                         float pos_scale, int B, int T, int n, int A, float* other, float* act_tm, hipStream_t stream) {
+    const int total = B * T * n;
+    hipLaunchKernelGGL(k_unroll_other, dim3((total + 255) / 256), dim3(256), 0, stream, actions, pos, orient, reward, clean, den, pos_scale, B, T, n, A, other, act_tm);
+}
+
 void launch_incentive_transfer(int32_t B, int32_t T, int32_t n, const int64_t* a_inc, const float* rewards,
                                float effect_ratio, float cost_ratio, float incentive, float seq_len, float* give,
                                float* recv_pos, float* recv_neg, float* recv_zero, float* r_env, float* r_inc,

@@ -169,18 +169,19 @@ class HomophilyAgent(nn.Module):
         hs = ops.gru_sequence_parts(parts, inputs.shape[1], inputs.shape[0], wh, bh)   # [2n, T, B, H]: one launch for the T steps
         return self.unroll_post(hs, self.unroll_other(act_onehot, agent_pos, agent_orientation, reward, clean_num, apple_den, inputs.dtype))
 
-    def unroll_pre(self, inputs, act_onehot):
+    def unroll_pre(self, inputs, act_onehot, act_tm=None):
         """fc1 + the input-side GRU projections of both heads over all T: [gi_env, gi_inc], each [n, T * B, 3H] (set-major, rows
-        t * B + b: ops.gru_sequence_parts takes them as they are), and the recurrence weights wh [2n, H, 3H], bh [2n, 1, 3H] (env sets
-        first)."""
+        t * B + b: ops.gru_sequence_parts takes them as they are), and the recurrence weights as parts [wh_env, wh_inc] (each [n, H, 3H]),
+        [bh_env, bh_inc] (each [n, 1, 3H])."""
         B, T, n = inputs.shape[0], inputs.shape[1], self.n_agents
         H = self.hidden
         tm = lambda x: x.permute(2, 1, 0, 3).reshape(n, T * B, x.shape[-1])          # time-major rows [n, T*B, f]
-        x, act = tm(inputs), tm(act_onehot.to(inputs.dtype))
+        x = tm(inputs)
+        act = act_tm if act_tm is not None else tm(act_onehot.to(inputs.dtype))   # act_tm: the one-hot actions already agent-major (ops.unroll_other)
         xe = ops.bias_bmm(x, self._w("fc1_env_w"), self._b("fc1_env_b"), leaky=True)             # fc1 + LeakyReLU as one launch
         xi = ops.bias_bmm(th.cat([x, act], dim=-1), self._w("fc1_inc_w"), self._b("fc1_inc_b"), leaky=True)
         (wie, whe, bie, bhe), (wii, whi, bii, bhi) = self._gru_weights_both()
-        return [ops.bias_bmm(xe, wie, bie), ops.bias_bmm(xi, wii, bii)], th.cat([whe, whi], dim=0), th.cat([bhe, bhi], dim=0)
+        return [ops.bias_bmm(xe, wie, bie), ops.bias_bmm(xi, wii, bii)], [whe, whi], [bhe, bhi]      # (weight parts: no concatenation)
 
     @staticmethod
     def unroll_other(act_onehot, agent_pos, agent_orientation, reward, clean_num, apple_den, dtype):

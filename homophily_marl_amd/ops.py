@@ -38,6 +38,21 @@ def reserve_bmm_scratch(stream):
     abi.check(lib, lib.ssd_bmm_reserve_scratch(stream.cuda_stream))
 
 
+def unroll_other(actions, pos, orient, reward, clean_num, apple_den, pos_scale, n_actions):
+    """(other [T * B, n, A + 7], act_tm [n, T * B, A]) of a sampled batch on the device in ONE launch (ssd_unroll_other): the
+    incentive head's per-receiver features [one-hot(a_j), pos_j / scale, orient_j, r_j, clean_j, apple_den_j] (homophily_agent.py:194-201)
+    and the one-hot actions agent-major.  actions i64 [B, T, n], pos / orient [B, T, n, 2], reward / clean_num / apple_den [B, T, n]."""
+    lib = abi.load_library()
+    B, T, n = actions.shape[:3]
+    c = lambda x: x.contiguous()
+    actions, pos, orient, reward, clean_num, apple_den = c(actions), c(pos.float()), c(orient.float()), c(reward.float()), c(clean_num.float()), c(apple_den.float())
+    other = th.empty(T * B, n, n_actions + 7, dtype=th.float32, device=actions.device)
+    act_tm = th.empty(n, T * B, n_actions, dtype=th.float32, device=actions.device)
+    abi.check(lib, lib.ssd_unroll_other(actions.data_ptr(), pos.data_ptr(), orient.data_ptr(), reward.data_ptr(), clean_num.data_ptr(), apple_den.data_ptr(),
+                                        float(pos_scale), B, T, n, n_actions, other.data_ptr(), act_tm.data_ptr(), _stream(other)))
+    return other, act_tm
+
+
 LEARNER_PRECISION = 2
 
 
@@ -698,13 +713,14 @@ class _GruSeq(th.autograd.Function):
 class _GruSeqParts(th.autograd.Function):
     """_GruSeq with the input-side projections given as separately allocated set-major parts [sets, T * B, 3H] (the per-agent affine
     layers' outputs as they are: ssd_gru_seq_fwd_parts / _bwd_parts) -- no concatenation / transpose copies, and the gradients come back
-    per part, contiguous.  B is a multiple of 16 here (gru_sequence_parts falls back otherwise)."""
+    per part, contiguous.  The recurrence weights come as n_w separately allocated parts too (wh [sets, H, 3H], bh [sets, 1, 3H]: the
+    live net's and the target net's images as they are).  B is a multiple of 16 here (gru_sequence_parts falls back otherwise)."""
 
     @staticmethod
-    def forward(ctx, T, B, wh, bh, *parts):
+    def forward(ctx, T, B, n_w, *tensors):
         lib = abi.load_library()
-        parts = [p.contiguous() for p in parts]
-        wh, bh = wh.contiguous(), bh.contiguous()
+        whs, bhs = [t.contiguous() for t in tensors[:n_w]], [t.contiguous() for t in tensors[n_w:2 * n_w]]
+        parts = [p.contiguous() for p in tensors[2 * n_w:]]
         G, H3 = sum(p.shape[0] for p in parts), parts[0].shape[-1]
         H = H3 // 3
         dev = parts[0].device
@@ -713,17 +729,22 @@ class _GruSeqParts(th.autograd.Function):
         rzn = th.empty(T, G, B, H3, dtype=th.float32, device=dev) if need else None
         ghn = th.empty(T, G, B, H, dtype=th.float32, device=dev) if need else None
         ptrs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
-        abi.check(lib, lib.ssd_gru_seq_fwd_parts(ptrs, len(parts), wh.data_ptr(), bh.data_ptr(), hs.data_ptr(), None if rzn is None else rzn.data_ptr(),
+        wptrs = (C.c_void_p * n_w)(*[w.data_ptr() for w in whs])
+        bptrs = (C.c_void_p * n_w)(*[b.data_ptr() for b in bhs])
+        abi.check(lib, lib.ssd_gru_seq_fwd_parts(ptrs, len(parts), wptrs, bptrs, n_w, hs.data_ptr(), None if rzn is None else rzn.data_ptr(),
                                                  None if ghn is None else ghn.data_ptr(), T, G, B, _stream(hs)))
         if need:
-            ctx.save_for_backward(hs, rzn, ghn, wh)
+            ctx.save_for_backward(hs, rzn, ghn, *whs)
             ctx.shapes = [p.shape for p in parts]
+            ctx.n_w = n_w
         return hs
 
     @staticmethod
     def backward(ctx, dhs):
         lib = abi.load_library()
-        hs, rzn, ghn, wh = ctx.saved_tensors
+        hs, rzn, ghn = ctx.saved_tensors[:3]
+        whs = ctx.saved_tensors[3:]
+        n_w = ctx.n_w
         T, G, B, H3 = rzn.shape
         dhs = dhs.contiguous()
         d_parts = [th.empty(sh, dtype=th.float32, device=rzn.device) for sh in ctx.shapes]      # parts without a gradient: scratch
@@ -732,18 +753,28 @@ class _GruSeqParts(th.autograd.Function):
         tiles = B // 16
         d_bh = th.empty(G, tiles, H3, dtype=th.float32, device=rzn.device)
         ptrs = (C.c_void_p * len(d_parts))(*[p.data_ptr() for p in d_parts])
-        abi.check(lib, lib.ssd_gru_seq_bwd_parts(dhs.data_ptr(), hs.data_ptr(), rzn.data_ptr(), ghn.data_ptr(), wh.data_ptr(), ptrs, len(d_parts),
+        wptrs = (C.c_void_p * n_w)(*[w.data_ptr() for w in whs])
+        abi.check(lib, lib.ssd_gru_seq_bwd_parts(dhs.data_ptr(), hs.data_ptr(), rzn.data_ptr(), ghn.data_ptr(), wptrs, n_w, ptrs, len(d_parts),
                                                  dgh.data_ptr(), d_wh.data_ptr(), d_bh.data_ptr(), T, G, B, _stream(rzn)))
         need = ctx.needs_input_grad
-        return (None, None, d_wh, (column_sums(d_bh) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)) + tuple(d if need[4 + k] else None for k, d in enumerate(d_parts))
+        d_bh_all = (column_sums(d_bh) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)                    # [G, 1, 3H]
+        spw = G // n_w
+        g_wh = tuple(d_wh[k * spw:(k + 1) * spw] if need[3 + k] else None for k in range(n_w))       # views of the one output: no copies
+        g_bh = tuple(d_bh_all[k * spw:(k + 1) * spw] if need[3 + n_w + k] else None for k in range(n_w))
+        return (None, None, None) + g_wh + g_bh + tuple(d if need[3 + 2 * n_w + k] else None for k, d in enumerate(d_parts))
 
 
 def gru_sequence_parts(parts, T, B, wh, bh):
     """gru_sequence for projections held as equally sized set-major parts [sets, T * B, 3H] (rows t * B + b); wh [G, H, 3H], bh [G, 1, 3H]
-    over all sets in part order.  hs [G, T, B, H]."""
+    over all sets in part order -- each either ONE tensor or a list of 1..4 equally sized parts over the sets (no concatenation).
+    hs [G, T, B, H]."""
     H3 = parts[0].shape[-1]
-    if (parts[0].is_cuda and H3 == 192 and B % 16 == 0 and 1 <= len(parts) <= 4 and all(p.shape == parts[0].shape and p.dtype == th.float32 for p in parts)):
-        return _GruSeqParts.apply(T, B, wh, bh, *parts)
+    whs, bhs = (list(wh) if isinstance(wh, (list, tuple)) else [wh]), (list(bh) if isinstance(bh, (list, tuple)) else [bh])
+    G = sum(p.shape[0] for p in parts)
+    if (parts[0].is_cuda and H3 == 192 and B % 16 == 0 and 1 <= len(parts) <= 4 and all(p.shape == parts[0].shape and p.dtype == th.float32 for p in parts)
+            and len(whs) == len(bhs) and 1 <= len(whs) <= 4 and all(w.shape == whs[0].shape for w in whs) and whs[0].shape[0] * len(whs) == G):
+        return _GruSeqParts.apply(T, B, len(whs), *whs, *bhs, *parts)
+    wh, bh = (whs[0] if len(whs) == 1 else th.cat(whs, dim=0)), (bhs[0] if len(bhs) == 1 else th.cat(bhs, dim=0))
     if H3 != 192 or parts[0].dtype != th.float32:
         _leaving_kernels("gru_sequence_parts", parts[0], "hidden size %d / dtype" % (H3 // 3))
     # ragged batches (B % 16) and other part counts: the time-major launch (it pads the batch itself); still the HIP recurrence

@@ -199,6 +199,12 @@ int ssd_build_inputs(int32_t batch, int32_t n_agents, int32_t n_actions, int32_t
 /* Incentive reward transfer (learners/homophily_learner.py:94-115).  actions_inc int64[B,T,n,n] (giver dim 2,
  * receiver dim 3), rewards f32[B,T-1,n].  Outputs f32: give[B,T-1,n], recv_pos/neg/zero[B,T,n],
  * rewards_for_env/inc[B,T-1,n] = (r +/- ...) / seq_len with seq_len = batch.max_seq_length (true division). */
+/* The time-batched incentive head's per-receiver features (homophily_agent.py:194-201) of a sampled batch, one launch:
+ * actions i64 [B, T, n], pos / orient f32 [B, T, n, 2], reward / clean_num / apple_den f32 [B, T, n] (contiguous) ->
+ * other f32 [T * B, n, n_actions + 7] = [one-hot(a_j), pos_j / pos_scale, orient_j, r_j, clean_j, apple_den_j] at row t * B + b, and
+ * act_tm f32 [n, T * B, n_actions] = the one-hot alone, agent-major (the extra input columns of fc1_inc). */
+int ssd_unroll_other(const int64_t* actions, const float* pos, const float* orient, const float* reward, const float* clean_num, const float* apple_den,
+                     float pos_scale, int32_t batch, int32_t T, int32_t n_agents, int32_t n_actions, float* other, float* act_tm, void* stream);
 int ssd_incentive_transfer(int32_t batch, int32_t T, int32_t n_agents, const int64_t* actions_inc,
                            const float* rewards, float effect_ratio, float cost_ratio, float incentive,
                            float seq_len, float* give, float* recv_pos, float* recv_neg, float* recv_zero,
@@ -404,10 +410,14 @@ int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const f
  * gi_parts[k] f32 [G / n_parts, T, B, 192] (what ssd_bias_bmm_fwd leaves for a group of weight sets; the learner passes live / target net
  * x env / inc head as they are -- no concatenation, no transpose to time-major), and their gradients written into d_gi_parts[k] of the
  * same shape (every part must be valid memory; a part that needs no gradient is scratch).  hs, rzn, ghn, dgh, d_wh, d_bh_part as above. */
-int ssd_gru_seq_fwd_parts(const float* const* gi_parts, int32_t n_parts, const float* wh, const float* bh, float* hs, float* rzn, float* ghn,
-                          int32_t T, int32_t G, int32_t B, void* stream);
-int ssd_gru_seq_bwd_parts(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* wh, float* const* d_gi_parts,
-                          int32_t n_parts, float* dgh, float* d_wh, float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream);
+int ssd_gru_seq_fwd_parts(const float* const* gi_parts, int32_t n_parts, const float* const* wh_parts, const float* const* bh_parts, int32_t n_wparts,
+                          float* hs, float* rzn, float* ghn, int32_t T, int32_t G, int32_t B, void* stream);
+int ssd_gru_seq_bwd_parts(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* const* wh_parts, int32_t n_wparts,
+                          float* const* d_gi_parts, int32_t n_parts, float* dgh, float* d_wh, float* d_bh_part, int32_t T, int32_t G, int32_t B,
+                          void* stream);
+/* ABI 7: the recurrence weights of the _parts launches come as n_wparts (1..4) separately allocated tensors wh_parts[k] f32 [G / n_wparts, 64, 192]
+ * and bh_parts[k] f32 [G / n_wparts, 192] over the sets in order (the learner: live net [2n], target net [2n] -- no concatenation per step);
+ * d_wh [G, 64, 192] and d_bh_part stay single outputs over all sets. */
 
 /* ---- the learner's per-agent affine layers (csrc/ssd_bmm.hip) ---------------------------------------------------------------
  * th.baddbmm(b, x, w) over the agent axis (homophily_agent.py:154-208: fc1, GRU input projections, dueling heads) and its backward,

@@ -5,6 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 import torch as th
+import torch.nn.functional as F
 
 from homophily_marl_amd import abi
 
@@ -742,6 +743,25 @@ def test_bias_bmm_with_the_leaky_relu_fused_matches_the_two_operators(n, R, I, O
         assert (a - t.grad).abs().max() < 2e-5 * max(1.0, t.grad.abs().max().item()), (name, (a - t.grad).abs().max().item())
     with th.no_grad():
         assert (ops.bias_bmm(x, w, b, leaky=True) - ref).abs().max() < 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,T,n,A", [(16, 101, 5, 9), (3, 7, 10, 9), (5, 4, 5, 8)])
+def test_unroll_other_kernel_matches_the_tensor_expression(B, T, n, A):
+    """ssd_unroll_other (one launch) against the tensor-op assembly it replaces (F.one_hot + division + concatenation + two permuted
+    copies): the incentive head's per-receiver features [T * B, n, A + 7] and the one-hot actions agent-major [n, T * B, A], bit for bit."""
+    from homophily_marl_amd import ops
+    from homophily_marl_amd.modules.agents.homophily_agent import HomophilyAgent
+    g = th.Generator(device="cuda").manual_seed(B + T)
+    acts = th.randint(0, A, (B, T, n), generator=g, device="cuda")
+    pos = th.randint(0, 25, (B, T, n, 2), generator=g, device="cuda").float()
+    orient = th.randint(-1, 2, (B, T, n, 2), generator=g, device="cuda").float()
+    rew, cln, den = (th.rand(B, T, n, generator=g, device="cuda") for _ in range(3))
+    scale = 30.805843601498726
+    other, act_tm = ops.unroll_other(acts, pos, orient, rew, cln, den, scale, A)
+    onehot = F.one_hot(acts, num_classes=A)
+    ref = HomophilyAgent.unroll_other(onehot, pos / scale, orient, rew, cln, den, th.float32)
+    assert th.equal(other, ref)
+    assert th.equal(act_tm, onehot.float().permute(2, 1, 0, 3).reshape(n, T * B, A))
 
 
 def test_fill_blocks_and_runner_stats_kernels():
