@@ -166,7 +166,8 @@ class HomophilyMAC(nn.Module):
         the input assembly and all non-recurrent layers evaluated once over all T."""
         shared = self.unroll_shared(batch)
         parts, wh, bh = self.unroll_pre(batch, shared)
-        return self.agent.unroll_post(ops.gru_sequence_parts(parts, batch.max_seq_length, batch.batch_size, wh, bh), shared["other"])
+        he, hi = ops.gru_sequence_parts(parts, batch.max_seq_length, batch.batch_size, wh, bh)
+        return self.agent.unroll_post(he, hi, shared["other"])
 
     def unroll_shared(self, batch):
         """Everything of an unroll that does not depend on the weights (the learner evaluates the live and the target net on the

@@ -558,20 +558,24 @@ int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const f
     if (!dhs || !hs || !rzn || !ghn || !wh || !d_gi || !dgh || !d_wh || !d_bh_part || T < 1 || G < 1 || B < 1) return fail(SSD_ERR_INVALID, "bad argument");
     if (B % 16) return fail(SSD_ERR_INVALID, "B must be a multiple of 16 (pad the sequences)");
     if (!al16(dhs) || !al16(hs) || !al16(rzn) || !al16(ghn) || !al16(wh) || !al16(d_gi) || !al16(dgh)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
-    launch_gru_seq_bwd(dhs, hs, rzn, ghn, &wh, 1, &d_gi, 0, dgh, d_wh, d_bh_part, T, G, B, (hipStream_t)stream);
+    launch_gru_seq_bwd(&dhs, hs, rzn, ghn, &wh, 1, &d_gi, 0, dgh, d_wh, d_bh_part, T, G, G, B, (hipStream_t)stream);
     return launched();
 }
-int ssd_gru_seq_bwd_parts(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* const* wh_parts, int32_t n_wparts,
-                          float* const* d_gi_parts, int32_t n_parts, float* dgh, float* d_wh, float* d_bh_part, int32_t T, int32_t G, int32_t B, void* stream) {
-    if (!dhs || !hs || !rzn || !ghn || !wh_parts || n_wparts < 1 || n_wparts > 4 || !d_gi_parts || n_parts < 1 || n_parts > 4 || !dgh || !d_wh ||
-        !d_bh_part || T < 1 || G < 1 || G % n_parts || G % n_wparts || B < 1) return fail(SSD_ERR_INVALID, "bad argument");
+int ssd_gru_seq_bwd_parts(const float* const* dhs_parts, const float* hs, const float* rzn, const float* ghn, const float* const* wh_parts, int32_t n_wparts,
+                          float* const* d_gi_parts, int32_t n_parts, float* dgh, float* d_wh, float* d_bh_part, int32_t T, int32_t G, int32_t G_grad, int32_t B,
+                          void* stream) {
+    if (!dhs_parts || !hs || !rzn || !ghn || !wh_parts || n_wparts < 1 || n_wparts > 4 || !d_gi_parts || n_parts < 1 || n_parts > 4 || !dgh || !d_wh ||
+        !d_bh_part || T < 1 || G < 1 || G % n_parts || G % n_wparts || B < 1 || G_grad < 1 || G_grad > G || G_grad % (G / n_parts))
+        return fail(SSD_ERR_INVALID, "bad argument");
+    for (int k = 0; k * (G / n_parts) < G_grad; ++k)
+        if (!dhs_parts[k] || !al16(dhs_parts[k])) return fail(SSD_ERR_INVALID, "dhs parts of the sets with a gradient must be non-null and 16-byte aligned");
     for (int k = 0; k < n_wparts; ++k)
         if (!wh_parts[k] || !al16(wh_parts[k])) return fail(SSD_ERR_INVALID, "weight parts must be non-null and 16-byte aligned");
     if (B % 16) return fail(SSD_ERR_INVALID, "B must be a multiple of 16 (pad the sequences)");
-    for (int k = 0; k < n_parts; ++k)
-        if (!d_gi_parts[k] || !al16(d_gi_parts[k])) return fail(SSD_ERR_INVALID, "d_gi parts must be non-null and 16-byte aligned");
-    if (!al16(dhs) || !al16(hs) || !al16(rzn) || !al16(ghn) || !al16(dgh)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
-    launch_gru_seq_bwd(dhs, hs, rzn, ghn, wh_parts, n_wparts, d_gi_parts, n_parts, dgh, d_wh, d_bh_part, T, G, B, (hipStream_t)stream);
+    for (int k = 0; k * (G / n_parts) < G_grad; ++k)
+        if (!d_gi_parts[k] || !al16(d_gi_parts[k])) return fail(SSD_ERR_INVALID, "d_gi parts of the sets with a gradient must be non-null and 16-byte aligned");
+    if (!al16(hs) || !al16(rzn) || !al16(ghn) || !al16(dgh)) return fail(SSD_ERR_INVALID, "tensors must be 16-byte aligned");
+    launch_gru_seq_bwd(dhs_parts, hs, rzn, ghn, wh_parts, n_wparts, d_gi_parts, n_parts, dgh, d_wh, d_bh_part, T, G, G_grad, B, (hipStream_t)stream);
     return launched();
 }
 

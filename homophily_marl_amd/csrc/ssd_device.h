@@ -151,8 +151,8 @@ int launch_pack_encoder(const float* cw, const float* cb, const float* lw, int V
 void launch_pack_head(const ssd_policy_head_params* p, int prec, void* image, hipStream_t s);
 void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* const* wh_parts, const float* const* bh_parts, int n_wparts, float* hs,
                         float* rzn, float* ghn, int T, int G, int B, hipStream_t s);
-void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* const* wh_parts, int n_wparts,
-                        float* const* d_gi_parts, int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s);
+void launch_gru_seq_bwd(const float* const* dhs_parts, const float* hs, const float* rzn, const float* ghn, const float* const* wh_parts, int n_wparts,
+                        float* const* d_gi_parts, int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int Gn, int B, hipStream_t s);
 int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s);
 void policy_head_plan(int n_env, int n_agents, int fused, int* wg_per_agent, int* waves_out, int* tiles_per_wave);
 int launch_policy_inc_encode(const ssd_policy_head* ph, const ssd_policy_encode_args* pe, hipStream_t s);

@@ -278,7 +278,7 @@ constexpr int BST = 260;            // staging row stride (floats): [d_r 64 | d_
 constexpr int GRU_BWD_LDS = 2 * 3 * 16 * DSB * 2 + 2 * 16 * BST * 4;   // bf16 operand image + f32 staging image: 71 680 B (dynamic)
 // BF: single bf16 terms (learner_dtype: bf16): 6 MFMAs per step instead of 36.
 template <bool BF>
-__global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_bwd(const float* __restrict__ dhs, const float* __restrict__ hs, const float* __restrict__ rzn,
+__global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_bwd(const GruParts dhs, const float* __restrict__ hs, const float* __restrict__ rzn,
                                                              const float* __restrict__ ghn, const GruW W, const GruParts d_gi,
                                                              float* __restrict__ dgh, float* __restrict__ d_bh_part, int T, int G, int B, int tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gru_lds[];
@@ -328,9 +328,10 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_seq_bwd(const float* __rest
     // everything a step reads from global memory is requested PF steps ahead; the compute waves issue no stores (see k_gru_seq_fwd)
     constexpr int PF = 2;                                              // 2 steps ~ 2 us ahead; 4 would need 48 more registers than the 256 a wave has when 5 waves share 4 SIMDs
     struct StepIn { f32x4 dout, rg, zg, ng, gn, hprev; };
+    const float* dbase = gru_part_base(dhs, g) + (size_t)rc * GH + fo;      // dL/dhs of this set: parts [sets, T, B, 64], + t * t_stride
     auto load_step = [&](int t, StepIn& in) {
         const size_t tr = ((size_t)t * G + g) * B + rc;
-        in.dout = *reinterpret_cast<const f32x4*>(dhs + (((size_t)g * T + t) * B + rc) * GH + fo);
+        in.dout = *reinterpret_cast<const f32x4*>(dbase + (size_t)t * dhs.t_stride);
         const float* s = rzn + tr * G3 + fo;
         in.rg = *reinterpret_cast<const f32x4*>(s); in.zg = *reinterpret_cast<const f32x4*>(s + GH); in.ng = *reinterpret_cast<const f32x4*>(s + 2 * GH);
         in.gn = *reinterpret_cast<const f32x4*>(ghn + tr * GH + fo);
@@ -446,10 +447,19 @@ void launch_gru_seq_fwd(const float* const* gi_parts, int n_parts, const float* 
     else { if (bf) SSD_GF(false, true); else SSD_GF(false, false); }
 #undef SSD_GF
 }
-void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* const* wh_parts, int n_wparts,
-                        float* const* d_gi_parts, int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int B, hipStream_t s) {
+// Gn <= G: only the first Gn weight sets are walked (the sets whose outputs carry a gradient: the live net's; the target net's follow);
+// rzn / ghn keep their [T, G, B, .] strides, dgh / d_wh / d_bh_part are [Gn, ...].  dhs_parts: n_parts (or one, n_parts 0) tensors
+// [sets, T, B, 64]; parts past Gn are not read.
+void launch_gru_seq_bwd(const float* const* dhs_parts, const float* hs, const float* rzn, const float* ghn, const float* const* wh_parts, int n_wparts,
+                        float* const* d_gi_parts, int n_parts, float* dgh, float* d_wh, float* d_bh_part, int T, int G, int Gn, int B, hipStream_t s) {
     const int tiles = (B + 15) / 16;
     const GruW W = gru_w(wh_parts, nullptr, n_wparts, G);
+    GruParts D;
+    {
+        const int np = n_parts < 1 ? 1 : n_parts;
+        for (int k = 0; k < 4; ++k) D.p[k] = const_cast<float*>(dhs_parts[(k < np && k * (G / np) < Gn) ? k : 0]);
+        D.spp = G / np; D.set_stride = (long)T * B * GH; D.t_stride = (long)B * GH;
+    }
     const GruParts P = gru_parts(d_gi_parts, n_parts, T, G, B);
     static bool attr_done_dev[64] = {};                                // the attribute is per device
     int dev = 0;
@@ -458,12 +468,12 @@ void launch_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, con
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_seq_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GRU_BWD_LDS);
         attr_done_dev[dev] = true;                                     // a refused attribute shows as a launch error (ssd_poll_error / hipGetLastError)
     }
-    if (learner_precision() == 1) hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(G * tiles), dim3(GRU_THREADS), GRU_BWD_LDS, s, dhs, hs, rzn, ghn, W, P, dgh, d_bh_part, T, G, B, tiles);
-    else hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(G * tiles), dim3(GRU_THREADS), GRU_BWD_LDS, s, dhs, hs, rzn, ghn, W, P, dgh, d_bh_part, T, G, B, tiles);
+    if (learner_precision() == 1) hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(Gn * tiles), dim3(GRU_THREADS), GRU_BWD_LDS, s, D, hs, rzn, ghn, W, P, dgh, d_bh_part, T, G, B, tiles);
+    else hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(Gn * tiles), dim3(GRU_THREADS), GRU_BWD_LDS, s, D, hs, rzn, ghn, W, P, dgh, d_bh_part, T, G, B, tiles);
     // dL/dW_h[g] = sum_{t >= 1, b} h_{t-1}[b]^T dL/dgh_t[b]: rows (t, b) of hs [G, T, B, 64] against rows (t + 1, b) of dgh [G, T, B, 192] --
     // the x^T g role of the per-agent-layer kernel (csrc/ssd_bmm.hip: K = (T - 1) B rows split over 16 waves per tile, exact f32)
-    if (T > 1) launch_bias_bmm_bwd(dgh + (size_t)B * G3, hs, nullptr, nullptr, d_wh, nullptr, nullptr, G, (T - 1) * B, GH, G3, s, (long)T * B * GH, (long)T * B * G3);
-    else (void)hipMemsetAsync(d_wh, 0, (size_t)G * GH * G3 * sizeof(float), s);
+    if (T > 1) launch_bias_bmm_bwd(dgh + (size_t)B * G3, hs, nullptr, nullptr, d_wh, nullptr, nullptr, Gn, (T - 1) * B, GH, G3, s, (long)T * B * GH, (long)T * B * G3);
+    else (void)hipMemsetAsync(d_wh, 0, (size_t)Gn * GH * G3 * sizeof(float), s);
 }
 
 }  // namespace ssd

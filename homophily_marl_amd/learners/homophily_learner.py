@@ -138,13 +138,12 @@ class HomophilyLearner:
         gi, wh, bh = mac.unroll_pre(batch, shared)
         with th.no_grad():
             gi_t, wh_t, bh_t = tgt.unroll_pre(batch, shared)
-        G = sum(w.shape[0] for w in wh)
         # live env / inc, target env / inc: the four projection outputs AND the four recurrence weight images go to the sequence kernel
-        # as they are (no concatenation)
-        hs = ops.gru_sequence_parts(list(gi) + list(gi_t), batch.max_seq_length, batch.batch_size, list(wh) + list(wh_t), list(bh) + list(bh_t))
-        q_env, q_inc = mac.agent.unroll_post(hs[:G], shared["other"])
+        # as they are (no concatenation), and the states come back as four tensors (no slicing: a slice's backward is a zero-fill + copy)
+        he, hi, he_t, hi_t = ops.gru_sequence_parts(list(gi) + list(gi_t), batch.max_seq_length, batch.batch_size, list(wh) + list(wh_t), list(bh) + list(bh_t))
+        q_env, q_inc = mac.agent.unroll_post(he, hi, shared["other"])
         with th.no_grad():
-            tq_env, tq_inc = tgt.agent.unroll_post(hs[G:].detach(), shared["other"])
+            tq_env, tq_inc = tgt.agent.unroll_post(he_t.detach(), hi_t.detach(), shared["other"])
         return q_env, q_inc, tq_env, tq_inc
 
     def _all_reduce_grad(self):

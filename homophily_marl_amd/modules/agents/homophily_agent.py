@@ -166,8 +166,8 @@ class HomophilyAgent(nn.Module):
         arithmetic, env and inc head together as 2n weight sets) is one sequence kernel per direction on the GPU.
         = unroll_pre -> ops.gru_sequence -> unroll_post (the learner runs the live and the target net through ONE sequence launch)."""
         parts, wh, bh = self.unroll_pre(inputs, act_onehot)
-        hs = ops.gru_sequence_parts(parts, inputs.shape[1], inputs.shape[0], wh, bh)   # [2n, T, B, H]: one launch for the T steps
-        return self.unroll_post(hs, self.unroll_other(act_onehot, agent_pos, agent_orientation, reward, clean_num, apple_den, inputs.dtype))
+        he, hi = ops.gru_sequence_parts(parts, inputs.shape[1], inputs.shape[0], wh, bh)   # 2 x [n, T, B, H]: one launch for the T steps
+        return self.unroll_post(he, hi, self.unroll_other(act_onehot, agent_pos, agent_orientation, reward, clean_num, apple_den, inputs.dtype))
 
     def unroll_pre(self, inputs, act_onehot, act_tm=None):
         """fc1 + the input-side GRU projections of both heads over all T: [gi_env, gi_inc], each [n, T * B, 3H] (set-major, rows
@@ -191,12 +191,12 @@ class HomophilyAgent(nn.Module):
         return th.cat([act_onehot.to(dtype), agent_pos, agent_orientation, reward.unsqueeze(-1), clean_num.unsqueeze(-1),
                        apple_den.unsqueeze(-1)], dim=-1).permute(1, 0, 2, 3).reshape(T * B, n, -1)
 
-    def unroll_post(self, hs, other):
-        """Both dueling heads on the recurrence states hs [2n, T, B, H] (env sets first) and other [T*B, n(j), E]:
+    def unroll_post(self, he, hi, other):
+        """Both dueling heads on the recurrence states of the env and the inc head (each [n, T, B, H]) and other [T*B, n(j), E]:
         q_env [B, T, n, A], q_inc [B, T, n, n, 3]."""
         n, H, A = self.n_agents, self.hidden, self.n_actions
-        T, B = hs.shape[1], hs.shape[2]
-        he, hi = hs[:n].reshape(n, T * B, H), hs[n:].reshape(n, T * B, H)
+        T, B = he.shape[1], he.shape[2]
+        he, hi = he.reshape(n, T * B, H), hi.reshape(n, T * B, H)
         a = ops.bias_bmm(he, self._w("fc2_env_w"), self._b("fc2_env_b"))
         v = ops.bias_bmm(he, self._w("fc2_env_v_w"), self._b("fc2_env_v_b"))
         q_env = ops.dueling_q(a, v, B, T, 1)                                           # v + a - mean(a) as [B, T, n, A]

@@ -618,7 +618,7 @@ class _EncodeCodes(th.autograd.Function):
         R = codes.shape[0]
         K = act[0].numel()
         st = _stream(codes)
-        g2 = d_feat * th.where(feat > 0, 1.0, 0.01)                 # dL/d(Linear output): LeakyReLU'(x) from the sign of LeakyReLU(x)
+        g2 = th.ops.aten.leaky_relu_backward(d_feat.contiguous(), feat, 0.01, True)   # dL/d(Linear output): LeakyReLU'(x) from the sign of LeakyReLU(x), one launch
         d_lin_b = column_sums(g2)
         # the two products of the Linear's backward on the per-agent-layer kernels (csrc/ssd_bmm.hip, one weight set):
         #   d_lin_w [32, K] = g2^T act   (its "dw" role: rows = K of the product, split over 16 waves per tile)
@@ -737,49 +737,67 @@ class _GruSeqParts(th.autograd.Function):
             ctx.save_for_backward(hs, rzn, ghn, *whs)
             ctx.shapes = [p.shape for p in parts]
             ctx.n_w = n_w
-        return hs
+        ctx.set_materialize_grads(False)       # states without a gradient (the target net's) arrive as None, not as zero tensors
+        spp = parts[0].shape[0]
+        # one output per projection part: views of the one state buffer (slicing a single output would cost a zero-fill + copy + add per
+        # slice in the backward pass)
+        return tuple(hs[k * spp:(k + 1) * spp] for k in range(len(parts)))
 
     @staticmethod
-    def backward(ctx, dhs):
+    def backward(ctx, *dhs_parts):
         lib = abi.load_library()
         hs, rzn, ghn = ctx.saved_tensors[:3]
         whs = ctx.saved_tensors[3:]
         n_w = ctx.n_w
         T, G, B, H3 = rzn.shape
-        dhs = dhs.contiguous()
-        d_parts = [th.empty(sh, dtype=th.float32, device=rzn.device) for sh in ctx.shapes]      # parts without a gradient: scratch
-        dgh = th.empty(G, T, B, H3, dtype=th.float32, device=rzn.device)
-        d_wh = th.empty(G, H3 // 3, H3, dtype=th.float32, device=rzn.device)
-        tiles = B // 16
-        d_bh = th.empty(G, tiles, H3, dtype=th.float32, device=rzn.device)
-        ptrs = (C.c_void_p * len(d_parts))(*[p.data_ptr() for p in d_parts])
-        wptrs = (C.c_void_p * n_w)(*[w.data_ptr() for w in whs])
-        abi.check(lib, lib.ssd_gru_seq_bwd_parts(dhs.data_ptr(), hs.data_ptr(), rzn.data_ptr(), ghn.data_ptr(), wptrs, n_w, ptrs, len(d_parts),
-                                                 dgh.data_ptr(), d_wh.data_ptr(), d_bh.data_ptr(), T, G, B, _stream(rzn)))
+        n_parts = len(ctx.shapes)
+        spp = G // n_parts
         need = ctx.needs_input_grad
-        d_bh_all = (column_sums(d_bh) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)                    # [G, 1, 3H]
+        # the sets whose states carry a gradient form a prefix (the live net's parts come first); the kernel walks only those
+        last = max([k for k, d in enumerate(dhs_parts) if d is not None], default=-1)
+        if last < 0:
+            return (None,) * len(need)
+        Gn = (last + 1) * spp
+        dhs = [(d.contiguous() if d is not None else th.zeros(spp, T, B, H3 // 3, dtype=th.float32, device=rzn.device)) for d in dhs_parts[:last + 1]]
+        d_parts = [th.empty(sh, dtype=th.float32, device=rzn.device) for sh in ctx.shapes[:last + 1]]
+        dgh = th.empty(Gn, T, B, H3, dtype=th.float32, device=rzn.device)
+        d_wh = th.empty(Gn, H3 // 3, H3, dtype=th.float32, device=rzn.device)
+        tiles = B // 16
+        d_bh = th.empty(Gn, tiles, H3, dtype=th.float32, device=rzn.device)
+        pad = lambda xs: [x.data_ptr() for x in xs] + [xs[0].data_ptr()] * (n_parts - len(xs))       # parts past Gn: never touched
+        ptrs = (C.c_void_p * n_parts)(*pad(d_parts))
+        dptrs = (C.c_void_p * n_parts)(*pad(dhs))
+        wptrs = (C.c_void_p * n_w)(*[w.data_ptr() for w in whs])
+        abi.check(lib, lib.ssd_gru_seq_bwd_parts(dptrs, hs.data_ptr(), rzn.data_ptr(), ghn.data_ptr(), wptrs, n_w, ptrs, n_parts,
+                                                 dgh.data_ptr(), d_wh.data_ptr(), d_bh.data_ptr(), T, G, Gn, B, _stream(rzn)))
+        d_bh_all = (column_sums(d_bh) if tiles > 1 else d_bh[:, 0]).unsqueeze(1)                    # [Gn, 1, 3H]
         spw = G // n_w
-        g_wh = tuple(d_wh[k * spw:(k + 1) * spw] if need[3 + k] else None for k in range(n_w))       # views of the one output: no copies
-        g_bh = tuple(d_bh_all[k * spw:(k + 1) * spw] if need[3 + n_w + k] else None for k in range(n_w))
-        return (None, None, None) + g_wh + g_bh + tuple(d if need[3 + 2 * n_w + k] else None for k, d in enumerate(d_parts))
+        have = lambda k: (k + 1) * spw <= Gn                                                         # weight part k lies inside the walked sets
+        g_wh = tuple(d_wh[k * spw:(k + 1) * spw] if (need[3 + k] and have(k)) else None for k in range(n_w))       # views of the one output: no copies
+        g_bh = tuple(d_bh_all[k * spw:(k + 1) * spw] if (need[3 + n_w + k] and have(k)) else None for k in range(n_w))
+        g_parts = tuple(d_parts[k] if (k <= last and need[3 + 2 * n_w + k]) else None for k in range(n_parts))
+        return (None, None, None) + g_wh + g_bh + g_parts
 
 
 def gru_sequence_parts(parts, T, B, wh, bh):
     """gru_sequence for projections held as equally sized set-major parts [sets, T * B, 3H] (rows t * B + b); wh [G, H, 3H], bh [G, 1, 3H]
     over all sets in part order -- each either ONE tensor or a list of 1..4 equally sized parts over the sets (no concatenation).
-    hs [G, T, B, H]."""
+    Returns the states as a LIST with one tensor [sets, T, B, H] per projection part.  A weight part whose sets' states carry no
+    gradient gets none (the learner puts the target net's parts last).  """
     H3 = parts[0].shape[-1]
     whs, bhs = (list(wh) if isinstance(wh, (list, tuple)) else [wh]), (list(bh) if isinstance(bh, (list, tuple)) else [bh])
     G = sum(p.shape[0] for p in parts)
     if (parts[0].is_cuda and H3 == 192 and B % 16 == 0 and 1 <= len(parts) <= 4 and all(p.shape == parts[0].shape and p.dtype == th.float32 for p in parts)
             and len(whs) == len(bhs) and 1 <= len(whs) <= 4 and all(w.shape == whs[0].shape for w in whs) and whs[0].shape[0] * len(whs) == G):
-        return _GruSeqParts.apply(T, B, len(whs), *whs, *bhs, *parts)
+        return list(_GruSeqParts.apply(T, B, len(whs), *whs, *bhs, *parts))
     wh, bh = (whs[0] if len(whs) == 1 else th.cat(whs, dim=0)), (bhs[0] if len(bhs) == 1 else th.cat(bhs, dim=0))
     if H3 != 192 or parts[0].dtype != th.float32:
         _leaving_kernels("gru_sequence_parts", parts[0], "hidden size %d / dtype" % (H3 // 3))
     # ragged batches (B % 16) and other part counts: the time-major launch (it pads the batch itself); still the HIP recurrence
     gi = th.cat([p.reshape(p.shape[0], T, B, H3) for p in parts], dim=0).transpose(0, 1).contiguous()      # [T, G, B, 3H]
-    return gru_sequence(gi, wh, bh)
+    hs = gru_sequence(gi, wh, bh)
+    spp = parts[0].shape[0]
+    return [hs[k * spp:(k + 1) * spp] for k in range(len(parts))]
 
 
 def gru_sequence(gi, wh, bh):

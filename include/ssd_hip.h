@@ -412,12 +412,15 @@ int ssd_gru_seq_bwd(const float* dhs, const float* hs, const float* rzn, const f
  * same shape (every part must be valid memory; a part that needs no gradient is scratch).  hs, rzn, ghn, dgh, d_wh, d_bh_part as above. */
 int ssd_gru_seq_fwd_parts(const float* const* gi_parts, int32_t n_parts, const float* const* wh_parts, const float* const* bh_parts, int32_t n_wparts,
                           float* hs, float* rzn, float* ghn, int32_t T, int32_t G, int32_t B, void* stream);
-int ssd_gru_seq_bwd_parts(const float* dhs, const float* hs, const float* rzn, const float* ghn, const float* const* wh_parts, int32_t n_wparts,
-                          float* const* d_gi_parts, int32_t n_parts, float* dgh, float* d_wh, float* d_bh_part, int32_t T, int32_t G, int32_t B,
-                          void* stream);
+int ssd_gru_seq_bwd_parts(const float* const* dhs_parts, const float* hs, const float* rzn, const float* ghn, const float* const* wh_parts,
+                          int32_t n_wparts, float* const* d_gi_parts, int32_t n_parts, float* dgh, float* d_wh, float* d_bh_part, int32_t T, int32_t G,
+                          int32_t G_grad, int32_t B, void* stream);
 /* ABI 7: the recurrence weights of the _parts launches come as n_wparts (1..4) separately allocated tensors wh_parts[k] f32 [G / n_wparts, 64, 192]
  * and bh_parts[k] f32 [G / n_wparts, 192] over the sets in order (the learner: live net [2n], target net [2n] -- no concatenation per step);
- * d_wh [G, 64, 192] and d_bh_part stay single outputs over all sets. */
+ * d_wh and d_bh_part stay single outputs.  The backward walks only the first G_grad sets (a whole number of gi parts: the sets whose
+ * states carry a gradient -- the live net's, the target net's follow): dhs_parts[k] f32 [G / n_parts, T, B, 64] are the gradients of the
+ * states per gi part (parts past G_grad are not read), d_gi_parts past G_grad are not written, dgh [G_grad, T, B, 192],
+ * d_wh [G_grad, 64, 192], d_bh_part [G_grad, tiles, 192]; hs / rzn / ghn keep the forward's shapes over all G sets. */
 
 /* ---- the learner's per-agent affine layers (csrc/ssd_bmm.hip) ---------------------------------------------------------------
  * th.baddbmm(b, x, w) over the agent axis (homophily_agent.py:154-208: fc1, GRU input projections, dueling heads) and its backward,

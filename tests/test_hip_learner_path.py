@@ -759,7 +759,8 @@ def test_unroll_other_kernel_matches_the_tensor_expression(B, T, n, A):
     scale = 30.805843601498726
     other, act_tm = ops.unroll_other(acts, pos, orient, rew, cln, den, scale, A)
     onehot = F.one_hot(acts, num_classes=A)
-    ref = HomophilyAgent.unroll_other(onehot, pos / scale, orient, rew, cln, den, th.float32)
+    # pos / scale as the reference forms it: a true f32 division (CPU torch; torch's device kernel multiplies by 1 / scale instead)
+    ref = HomophilyAgent.unroll_other(onehot, (pos.cpu() / scale).cuda(), orient, rew, cln, den, th.float32)
     assert th.equal(other, ref)
     assert th.equal(act_tm, onehot.float().permute(2, 1, 0, 3).reshape(n, T * B, A))
 
@@ -967,15 +968,36 @@ def test_gru_sequence_parts_equals_the_time_major_launch(T, n, B, k):
     wh = (th.randn(k * n, H, 3 * H, generator=g, device="cuda") * 0.1).requires_grad_()
     bh = (th.randn(k * n, 1, 3 * H, generator=g, device="cuda") * 0.1).requires_grad_()
     w = th.randn(k * n, T, B, H, generator=g, device="cuda")
-    hs = ops.gru_sequence_parts(parts, T, B, wh, bh)
+    hs_parts = ops.gru_sequence_parts(parts, T, B, wh, bh)                 # one tensor [n, T, B, H] per projection part
+    assert len(hs_parts) == k and all(h.shape == (n, T, B, H) for h in hs_parts)
+    hs = th.cat(list(hs_parts), dim=0)
     gi = th.cat([p.reshape(n, T, B, 3 * H) for p in parts], dim=0).transpose(0, 1).contiguous()
     ref = ops.gru_sequence(gi, wh, bh)
     assert th.equal(hs, ref)
     live = [p for p in parts if p.requires_grad]
-    got = th.autograd.grad((hs * w).sum(), live + [wh, bh])
+    got = th.autograd.grad(sum((h * w[i * n:(i + 1) * n]).sum() for i, h in enumerate(hs_parts)), live + [wh, bh])
     exp = th.autograd.grad((ref * w).sum(), live + [wh, bh])
     for a, b in zip(got, exp):
         assert a.is_contiguous() and th.equal(a, b)
+    # the learner's form: the recurrence weights as k separately allocated parts too, and only the FIRST parts' states (the live net's)
+    # enter the loss -- the backward walks that prefix of the sets only; the other parts' weights get no gradient at all
+    kl = max(1, k // 2)
+    whs = [wh.detach()[i * n:(i + 1) * n].clone().requires_grad_() for i in range(k)]
+    bhs = [bh.detach()[i * n:(i + 1) * n].clone().requires_grad_() for i in range(k)]
+    hs2 = ops.gru_sequence_parts(parts, T, B, whs, bhs)
+    assert all(th.equal(a, b) for a, b in zip(hs2, hs_parts))
+    got2 = th.autograd.grad(sum((h * w[i * n:(i + 1) * n]).sum() for i, h in enumerate(hs2[:kl])), live + whs + bhs, allow_unused=True)
+    wm = w.clone(); wm[kl * n:] = 0
+    exp2 = th.autograd.grad((ops.gru_sequence(gi, wh, bh) * wm).sum(), live + [wh, bh])
+    nl = len(live)
+    for i in range(nl):
+        assert th.equal(got2[i], exp2[i])
+    for i in range(k):
+        gw, gb = got2[nl + i], got2[nl + k + i]
+        if B % 16 == 0:
+            assert (gw is None) == (i >= kl) and (gb is None) == (i >= kl)
+        if gw is not None:
+            assert th.equal(gw, exp2[nl][i * n:(i + 1) * n]) and th.equal(gb, exp2[nl + 1][i * n:(i + 1) * n])
 
 
 def test_replay_sample_into_a_batch_is_one_gather_launch_with_the_same_episodes():
