@@ -13,6 +13,10 @@ python3 bench.py --no-cpu-baseline --qnet-dtype bf16 > $OUT/bench_e2e_cleanup5_b
 python3 bench.py --no-cpu-baseline --obs-storage f32 > $OUT/bench_e2e_cleanup5_f32storage.json 2> $OUT/f32.err || exit 1
 python3 bench.py --workload env > $OUT/bench_env_cleanup5.json 2> $OUT/env.err || exit 1
 python3 bench.py --no-cpu-baseline --train-steps-per-rollout 8 > $OUT/bench_e2e_cleanup5_tspr8.json 2> $OUT/tspr8.err || exit 1
+# labelled variants: the bf16 learner (single bf16 MFMA products in the learner's GEMMs), alone and with the bf16 rollout; round 3's Toeplitz encoder
+python3 bench.py --no-cpu-baseline --learner-dtype bf16 --train-steps-per-rollout 8 > $OUT/bench_e2e_cleanup5_learner_bf16_tspr8.json 2> $OUT/lbf16.err || exit 1
+python3 bench.py --no-cpu-baseline --learner-dtype bf16 --qnet-dtype bf16 > $OUT/bench_e2e_cleanup5_all_bf16.json 2> $OUT/allbf16.err || exit 1
+SSD_ENC_LAYOUT=toeplitz python3 bench.py --no-cpu-baseline > $OUT/bench_e2e_cleanup5_toeplitz_encoder.json 2> $OUT/toeplitz.err || exit 1
 # the multi-rank front door (python bench.py --gpus N starts its own ranks): a 1-rank RCCL group and a 2-rank gloo group on this one GPU
 SSD_FORCE_DIST=1 python3 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_e2e_1rank_rccl_rehearsal.json 2> $OUT/rccl1.err || exit 1
 SSD_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 3 --warmup 1 --n-env 1024 --no-cpu-baseline > $OUT/bench_e2e_2rank_gloo_rehearsal.json 2> $OUT/gloo.err || exit 1
