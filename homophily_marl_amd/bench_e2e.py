@@ -80,6 +80,8 @@ def run_e2e(args, c, rank, world, local_rank):
     # warm-up iterations; this is the analogue of compiling the step and is excluded from the warm-up and the timed region.
     for _ in range(max(4, 2 * (buffer_size // N) + 1)):
         iteration()
+    from .run import settle_gc
+    settle_gc()                           # the shipped loop does the same once its graphs exist (run.run_sequential)
     for _ in range(args.warmup):
         iteration()
     th.cuda.synchronize()
@@ -90,10 +92,33 @@ def run_e2e(args, c, rank, world, local_rank):
     learner.profile_collectives = bool(getattr(learner, "distributed", False))
     if learner.profile_collectives:
         learner.collective_times()                  # (reset)
+    prof = None
+    if __import__("os").environ.get("SSD_BENCH_TRACE") == "profile":      # (diagnostic: host-side profile of the timed loop)
+        import cProfile
+        prof = cProfile.Profile(); prof.enable()
     t0 = time.perf_counter()
+    trace = [] if __import__("os").environ.get("SSD_BENCH_TRACE") else None
+    if trace is not None:
+        ctx._trace_marks = []
     for _ in range(args.steps):
+        if trace is not None:
+            e0 = th.cuda.Event(enable_timing=True); e0.record()
         iteration()
+        if trace is not None:
+            e1 = th.cuda.Event(enable_timing=True); e1.record()
+            trace.append((1e3 * (time.perf_counter() - t0), e0, e1))      # (diagnostic: HOST time at which the iteration was issued + device events)
     th.cuda.synchronize()
+    if prof is not None:
+        import pstats
+        prof.disable(); pstats.Stats(prof, stream=__import__("sys").stderr).sort_stats("tottime").print_stats(14)
+    if trace is not None:
+        print("[bench trace] host issue times (ms): " + " ".join("%.1f" % x[0] for x in trace) + " | drained at %.1f" % (1e3 * (time.perf_counter() - t0)), file=__import__("sys").stderr, flush=True)
+        print("[bench trace] device ms per iteration: " + " ".join("%.1f" % x[1].elapsed_time(x[2]) for x in trace), file=__import__("sys").stderr, flush=True)
+        mk = ctx._trace_marks
+        gaps = [(mk[i][0], mk[i - 1][1].elapsed_time(mk[i][1])) for i in range(1, len(mk))]
+        slow = [(i, t, round(d, 2)) for i, (t, d) in enumerate(gaps) if (t == "train" and d > 2.0) or (t == "rollout" and d > 8.0) or (t == "start" and d > 1.0)]
+        print("[bench trace] phases slower than usual (index, phase ending, device ms): %s" % slow, file=__import__("sys").stderr, flush=True)
+        ctx._trace_marks = None
     rank_elapsed = time.perf_counter() - t0          # this rank's own clock, before it waits for the others
     if dist.is_initialized():
         dist.barrier()

@@ -97,12 +97,31 @@ def setup(config, logger=None):
     return SimpleNamespace(args=args, logger=logger, runner=runner, buffer=buffer, mac=mac, learner=learner, train_steps=0)
 
 
+def settle_gc():
+    """Call once the loop's long-lived objects exist (networks, buffers, captured graphs): collect what setup left behind and move
+    every surviving object into the permanent generation (gc.freeze).  A full collection of CPython's cyclic GC walks every tracked
+    object -- with the tensors, modules and ctypes tables of this loop that is a 40-70 ms host pause, and at 8 train steps per
+    rollout one of them lands every few dozen iterations; the host runs only ~5 iterations ahead of the GPU, so the device ran dry
+    (bench trace, round 4: one train step of 55 ms on the device timeline).  Frozen objects are not walked again; the loop's own
+    short-lived garbage stays cheap to collect."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def train_iteration(ctx, episode):
     """One pass of the while-loop body of run.py:181-210: rollout, insert, sample, train (train_steps_per_rollout times; the
     reference's cadence is one).  The learner's episode counter (target sync every target_update_interval, homophily_learner.py:255-257)
     is the env-episode count under schedule_unit "env_steps" and the number of learner.train calls under "rollouts"."""
     a = ctx.args
+    marks = getattr(ctx, "_trace_marks", None)          # diagnostic (bench SSD_BENCH_TRACE): device events between the phases
+
+    def mark(tag):
+        if marks is not None:
+            e = th.cuda.Event(enable_timing=True); e.record(); marks.append((tag, e))
+    mark("start")
     batch = ctx.runner.run(test_mode=False)
+    mark("rollout")
     ctx.buffer.insert_episode_batch(batch)
     if ctx.buffer.can_sample(a.batch_size):
         for _ in range(a.train_steps_per_rollout):
@@ -115,6 +134,7 @@ def train_iteration(ctx, episode):
                 sample.to(a.device)
             ctx.learner.train(sample, ctx.runner.t_env, ctx.train_steps if a.schedule_unit == "rollouts" else episode)
             ctx.train_steps += 1
+            mark("train")
     return episode + a.batch_size_run
 
 
@@ -132,8 +152,12 @@ def run_sequential(config, logger=None):
             runner.close_env()
             return ctx
     episode, last_test_T, last_log_T, saved_at = 0, -a.test_interval - 1, 0, 0
+    settled = 0
     while runner.t_env <= a.t_max:
         episode = train_iteration(ctx, episode)
+        if settled < 2 and ctx.train_steps >= (4, 64)[settled]:      # after the graphs are captured, and once more when everything is warm
+            settle_gc()
+            settled += 1
         if (runner.t_env - last_test_T) / a.test_interval >= 1.0:
             last_test_T = runner.t_env
             for _ in range(max(1, a.test_nepisode // runner.batch_size)):
