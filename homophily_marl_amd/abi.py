@@ -289,6 +289,11 @@ HIP_SIGNATURES["ssd_bias_bmm_fwd"] = (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 
 HIP_SIGNATURES["ssd_bias_bmm_bwd"] = (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_leaky_fwd"] = (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p])
 HIP_SIGNATURES["ssd_bias_bmm_leaky_bwd"] = (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 4 + [C.c_void_p])
+HIP_SIGNATURES["ssd_bias_bmm2_fwd"] = (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p])
+HIP_SIGNATURES["ssd_bias_bmm2_bwd_w"] = (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p])
+HIP_SIGNATURES["ssd_bias_bmm_bwd_x"] = (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_int64, C.c_void_p])
+HIP_SIGNATURES["ssd_dueling_head_fwd"] = (C.c_int, [C.c_void_p] * 2 + [C.c_int32] * 5 + [C.c_void_p])
+HIP_SIGNATURES["ssd_dueling_head_bwd"] = (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_void_p])
 HIP_SIGNATURES["ssd_unroll_other"] = (C.c_int, [C.c_void_p] * 6 + [C.c_float] + [C.c_int32] * 4 + [C.c_void_p] * 3)
 HIP_SIGNATURES["ssd_bmm_reserve_scratch"] = (C.c_int, [C.c_void_p])
 HIP_SIGNATURES["ssd_set_learner_precision"] = (C.c_int, [C.c_int32])

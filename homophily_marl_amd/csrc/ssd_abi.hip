@@ -604,6 +604,39 @@ int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, 
     return launched();
 }
 
+int ssd_dueling_head_fwd(const float* y, float* q, int32_t n, int32_t T, int32_t B, int32_t inner, int32_t K, void* stream) {
+    if (!y || !q || n < 1 || T < 1 || B < 1 || inner < 1 || K < 1 || K > 15) return fail(SSD_ERR_INVALID, "bad argument");
+    launch_dueling_q(y, y + K, q, nullptr, nullptr, nullptr, n, T, B, inner, K, (hipStream_t)stream, K + 1, 1, nullptr);
+    return launched();
+}
+int ssd_dueling_head_bwd(const float* dq, float* dy, float* gs, int32_t n, int32_t T, int32_t B, int32_t inner, int32_t K, void* stream) {
+    if (!dq || !dy || n < 1 || T < 1 || B < 1 || inner < 1 || K < 1 || K > 15) return fail(SSD_ERR_INVALID, "bad argument");
+    launch_dueling_q(nullptr, nullptr, nullptr, dq, dy, dy + K, n, T, B, inner, K, (hipStream_t)stream, K + 1, 1, gs);
+    return launched();
+}
+int ssd_bias_bmm2_fwd(const float* x1, const float* x2, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in1, int32_t in2,
+                      int32_t out, int32_t x1_div, int32_t x2_shared, void* stream) {
+    if (!x1 || !x2 || !w || !b || !y || n < 1 || rows < 1 || in1 < 1 || in2 < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    const int rc = launch_bias_bmm2_fwd(x1, x2, w, b, y, n, rows, in1, in2, out, x1_div, x2_shared, (hipStream_t)stream);
+    if (rc == -3) return fail(SSD_ERR_INVALID, "ssd_bias_bmm2_fwd: in1 a multiple of 16, in2 a multiple of 4, rows a multiple of x1_div >= 1");
+    if (rc) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm2_fwd: a weight / operand set of 2^30 elements or more");
+    return launched();
+}
+int ssd_bias_bmm2_bwd_w(const float* g, const float* x1, const float* x2, float* dw, float* db, int32_t n, int32_t rows, int32_t in1, int32_t in2,
+                        int32_t out, int32_t x1_div, int32_t x2_shared, void* stream) {
+    if (!g || !x1 || !x2 || (!dw && !db) || n < 1 || rows < 1 || in1 < 1 || in2 < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
+    const int rc = launch_bias_bmm_bwd(g, x1, nullptr, nullptr, dw, db, nullptr, n, rows, in1 + in2, out, (hipStream_t)stream, 0, 0, nullptr, x2, in1, x1_div,
+                                       x2_shared, 0);
+    if (rc == -3) return fail(SSD_ERR_INVALID, "ssd_bias_bmm2_bwd_w: in1 a multiple of 16, in2 a multiple of 4, rows a multiple of x1_div >= 1");
+    if (rc) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm2_bwd_w: an operand set of 2^30 elements or more");
+    return launched();
+}
+int ssd_bias_bmm_bwd_x(const float* g, const float* w, float* dx, int32_t n, int32_t rows, int32_t in, int32_t out, int64_t w_set, void* stream) {
+    if (!g || !w || !dx || n < 1 || rows < 1 || in < 1 || out < 1 || w_set < (int64_t)in * out) return fail(SSD_ERR_INVALID, "bad argument");
+    if (launch_bias_bmm_bwd(g, nullptr, w, dx, nullptr, nullptr, nullptr, n, rows, in, out, (hipStream_t)stream, 0, 0, nullptr, nullptr, 0, 1, 0, (long)w_set))
+        return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm_bwd_x: an operand set of 2^30 elements or more");
+    return launched();
+}
 int ssd_bmm_reserve_scratch(void* stream) {
     if (!bmm_scratch((hipStream_t)stream)) return fail(SSD_ERR_DEVICE, "ssd_bmm_reserve_scratch: allocation failed (inside a stream capture?)");
     return SSD_OK;

@@ -29,6 +29,11 @@ struct BmmK {
     long x_set, g_set;         // elements between two weight sets of x / g (default R * I, R * O; larger when the rows are a slice)
     const float* act_y;        // backward of the LEAKY forward: its output y [n, R, O]; g is multiplied by LeakyReLU'(.) from y's sign where it is loaded
     int leaky;                 // forward: y = LeakyReLU(b + x w) (nn.LeakyReLU default slope 0.01)
+    // two-source rows (the incentive head's [h_i | other_j] rows without materialising them): columns [0, I1) of row r come from
+    // x [n, R / x1_div, I1] at row r / x1_div, columns [I1, I) from x2 at row r (x2_set elements between weight sets: 0 = shared)
+    const float* x2; int I1, x1_div; long x2_set;
+    uint32_t x1_magic;         // ceil(2^32 / x1_div) (0 when x1_div == 1): r / x1_div == __umulhi(r, x1_magic) for r < 2^28
+    long w_set;                // elements between two weight sets of w (default I * O; larger when w is the leading rows of a wider layer)
     float* part;               // backward with row_chunks > 1: per (set, tile, chunk) partial dw tile [64 lanes x 4] + db [16] (BMM_PART floats)
     int row_chunks;            // the rows (K of dw) are cut into this many chunks, one workgroup each; k_bmm_dw_reduce adds them in order
 };
@@ -80,9 +85,13 @@ __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
     if (unit >= rtiles * groups) return;
     const int g = blockIdx.y, row0 = (unit / groups) * 16, t0 = (unit % groups) * BMM_TPW;
     const int rowc = row0 + m < R ? row0 + m : R - 1;
-    const float* xs = a.x + (size_t)g * R * I;                        // the weight set's rows (uniform); this lane's row starts at xrow
-    const uint32_t xrow = (uint32_t)rowc * (uint32_t)I;
-    const float* wg = a.w + (size_t)g * I * O;
+    const bool two = a.x2 != nullptr;                                  // (uniform) two-source rows, see BmmK
+    const int I1 = two ? a.I1 : I;
+    const float* xs = a.x + (two ? (size_t)g * (size_t)(R / a.x1_div) * I1 : (size_t)g * R * I);      // the weight set's rows (uniform)
+    const uint32_t xrow = two ? (uint32_t)(rowc / a.x1_div) * (uint32_t)I1 : (uint32_t)rowc * (uint32_t)I;   // this lane's row starts at xrow
+    const float* x2s = two ? a.x2 + (size_t)g * a.x2_set : a.x;
+    const uint32_t x2row = (uint32_t)rowc * (uint32_t)(I - I1);
+    const float* wg = a.w + (size_t)g * (a.w_set ? a.w_set : (long)I * O);
     f32x4 acc[BMM_TPW];
 #pragma unroll
     for (int t = 0; t < BMM_TPW; ++t) {
@@ -103,7 +112,11 @@ __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
     auto fetch = [&](int c, Chunk& d) {
         const int k0 = 16 * c + 4 * q;
         if constexpr (XV) {
-            const f32x4 v = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const uint8_t*>(xs) + (size_t)((xrow + (uint32_t)(k0 < I ? k0 : I - 4)) * 4u));
+            const int kc = k0 < I ? k0 : I - 4;
+            const bool second = 16 * c >= I1;                          // (uniform: I1 is a multiple of 16) this chunk lies in the second source
+            const float* base = second ? x2s : xs;
+            const uint32_t off = second ? x2row + (uint32_t)(kc - I1) : xrow + (uint32_t)kc;
+            const f32x4 v = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const uint8_t*>(base) + (size_t)(off * 4u));
 #pragma unroll
             for (int r = 0; r < 4; ++r) d.x[r] = v[r];
         }
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
         if (unit >= rtiles * itiles) return;
         const int row0 = (unit / itiles) * 16, i = 16 * (unit % itiles) + m;
         const int rowc = row0 + m < R ? row0 + m : R - 1;
-        const float* ws = a.w + (size_t)g * I * O;
+        const float* ws = a.w + (size_t)g * (a.w_set ? a.w_set : (long)I * O);
         const uint32_t grow = (uint32_t)rowc * (uint32_t)O, wrow = (uint32_t)(i < I ? i : I - 1) * (uint32_t)O;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int chunks = (O + 15) >> 4;
@@ -309,13 +322,19 @@ __global__ __launch_bounds__(BMM_BWD_WAVES * 64) void k_bias_bmm_bwd(BmmK a, int
     static_assert(UN == 8, "the bf16 path packs UN steps into one K = 32 MFMA");
     const uint32_t icol = ion ? i : I - 1, ocol = oon ? o : O - 1;
     const float* yg = ACT ? a.act_y + (size_t)g * a.g_set : nullptr;
+    // two-source rows: this tile's 16 input columns lie in x (row r / x1_div, I1 columns) or in x2 (row r, I - I1 columns) -- uniform
+    const bool two = a.x2 != nullptr, second = two && 16 * it >= a.I1;
+    const uint32_t xmagic = (two && !second) ? a.x1_magic : 0u;        // 0: the row itself
+    const uint32_t xld = two ? (second ? (uint32_t)(I - a.I1) : (uint32_t)a.I1) : (uint32_t)I;
+    const float* xsrc = two ? (second ? a.x2 + (size_t)g * a.x2_set : a.x + (size_t)g * (size_t)(R / a.x1_div) * a.I1) : xg;
+    const uint32_t xcol = second ? icol - (uint32_t)a.I1 : icol;
     auto fetch = [&](int s, float (&av)[UN], float (&bv)[UN]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int su = s + u < s1 ? s + u : s1 - 1;                 // past the wave's part: its last step again (the same cache lines)
             const int row = 4 * su + q;
             const uint32_t rc = row < R ? row : R - 1;
-            av[u] = ld32(xg, rc * (uint32_t)I + icol);
+            av[u] = ld32(xsrc, (xmagic ? __umulhi(rc, xmagic) : rc) * xld + xcol);
             bv[u] = ld32(gg, rc * (uint32_t)O + ocol);
             if constexpr (ACT) { const float yv = ld32(yg, rc * (uint32_t)O + ocol); bv[u] = yv > 0.f ? bv[u] : 0.01f * bv[u]; }
         }
@@ -416,10 +435,34 @@ int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y
     return 0;
 }
 
+// y = b + [x1 (row r / x1_div) | x2 (row r)] w: the two-source forward (see BmmK); in1 a multiple of 16, in2 a multiple of 4
+int launch_bias_bmm2_fwd(const float* x1, const float* x2, const float* w, const float* b, float* y, int n, int R, int I1, int I2, int O, int x1_div,
+                         int x2_shared, hipStream_t s) {
+    BmmK k = {};
+    const int I = I1 + I2;
+    k.x = x1; k.x2 = x2; k.I1 = I1; k.x1_div = x1_div; k.x2_set = x2_shared ? 0 : (long)R * I2;
+    k.w = w; k.b = b; k.y = y; k.n = n; k.R = R; k.I = I; k.O = O;
+    if ((I1 & 15) || (I2 & 3) || x1_div < 1 || R % x1_div) return -3;
+    if ((long)I * O >= (1L << 30) || (long)R * I >= (1L << 30)) return -2;
+    const int otiles = (O + 15) / 16, units = ((R + 15) / 16) * ((otiles + BMM_TPW - 1) / BMM_TPW);
+    const dim3 grid((units + 3) / 4, n);
+    if (g_learner_precision == 1) hipLaunchKernelGGL((k_bias_bmm_fwd<true, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((k_bias_bmm_fwd<true, false>), grid, dim3(256), 0, s, k);
+    return 0;
+}
+
 int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int n, int R,
-                        int I, int O, hipStream_t s, long x_set, long g_set, const float* act_y) {
+                        int I, int O, hipStream_t s, long x_set, long g_set, const float* act_y, const float* x2, int I1, int x1_div, int x2_shared,
+                        long w_set) {
     BmmK k = {};
     k.act_y = act_y;
+    if (x2) {                      // two-source rows: dw / db only (dx of the first source is a row-group sum: the caller forms it from the summed g)
+        if (dx || (I1 & 15) || ((I - I1) & 3) || x1_div < 1 || R % x1_div) return -3;
+        k.x2 = x2; k.I1 = I1; k.x1_div = x1_div; k.x2_set = x2_shared ? 0 : (long)R * (I - I1);
+        k.x1_magic = x1_div == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)x1_div - 1) / (uint64_t)x1_div);
+        if (R >= (1 << 28)) return -2;
+    }
+    k.w_set = w_set;
     k.g = g; k.x = x; k.w = w; k.dx = dx; k.dw = dw; k.db = db; k.slope_of = slope_of; k.n = n; k.R = R; k.I = I; k.O = O;
     k.x_set = x_set ? x_set : (long)R * I; k.g_set = g_set ? g_set : (long)R * O;
     const int dxb = dx ? (((R + 15) / 16) * ((I + 15) / 16) + BMM_BWD_WAVES - 1) / BMM_BWD_WAVES : 0;

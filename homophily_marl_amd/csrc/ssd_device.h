@@ -131,7 +131,8 @@ void launch_incentive_transfer(int32_t B, int32_t T, int32_t n, const int64_t* a
 void launch_column_sums(const float* x, float* out, int G, int R, int C, float* workspace, hipStream_t stream);
 void launch_copy_blocks(const ssd_block_copy* blocks, int count, hipStream_t stream);
 void launch_clip_adam(const ssd_clip_adam_args* a, hipStream_t stream);
-void launch_dueling_q(const float* a, const float* v, float* q, const float* dq, float* da, float* dv, int n, int T, int B, int inner, int K, hipStream_t stream);
+void launch_dueling_q(const float* a, const float* v, float* q, const float* dq, float* da, float* dv, int n, int T, int B, int inner, int K, hipStream_t stream,
+                      int ld = 0, int merged = 0, float* gs = nullptr);
 void launch_sample_ids(uint64_t seed, uint32_t call, int population, int count, int64_t* out, hipStream_t stream);
 void launch_gather_rows(const ssd_row_gather* fields, int count, const int64_t* ids, int n_ids, hipStream_t stream);
 void launch_td_sim_loss(const ssd_td_loss_args* a, int mode, hipStream_t stream);
@@ -167,7 +168,10 @@ void launch_fill_blocks(const ssd_block_fill* blocks, int count, hipStream_t str
 void launch_runner_stats(const float* coll, const float* eq, const float* ret, int n_env, int n_ret, double* acc, hipStream_t stream);
 int launch_bias_bmm_fwd(const float* x, const float* w, const float* b, float* y, int n, int R, int I, int O, hipStream_t s, int leaky = 0);
 int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int n, int R,
-                        int I, int O, hipStream_t s, long x_set = 0, long g_set = 0, const float* act_y = nullptr);
+                        int I, int O, hipStream_t s, long x_set = 0, long g_set = 0, const float* act_y = nullptr, const float* x2 = nullptr, int I1 = 0,
+                        int x1_div = 1, int x2_shared = 0, long w_set = 0);
+int launch_bias_bmm2_fwd(const float* x1, const float* x2, const float* w, const float* b, float* y, int n, int R, int I1, int I2, int O, int x1_div,
+                         int x2_shared, hipStream_t s);
 #ifdef SSD_STAMPS
 void set_policy_stamps(unsigned long long* buf);
 #endif

@@ -349,36 +349,55 @@ void launch_runner_stats(const float* coll, const float* eq, const float* ret, i
 
 static int grid_for(size_t total);
 // k_dueling_q: q = v + a - mean_k a per (agent, row) of the learner's time-batched heads, output in the batch layout [B, T, n, inner, K];
-// BWD: da = dq - mean_k dq, dv = sum_k dq.  One thread per (agent, row); K <= 16.
+// BWD: da = dq - mean_k dq, dv = sum_k dq.  One thread per (agent, row); K <= 16.  ld: floats per row of a (and da); v / dv rows have the
+// same stride when `merged` (advantages and value are columns 0..K-1 and K of ONE layer output [n, rows, K + 1]), else 1.
+// gs (BWD, merged, nullable): the row-group sums of the gradient, gs[i, tb, 0..K] = sum over the `inner` rows of (i, tb) -- what the part
+// of the layer input that is shared by the group (the incentive head's h_i under all receivers j) receives.
 template <bool BWD>
 __global__ __launch_bounds__(256) void k_dueling_q(const float* __restrict__ a, const float* __restrict__ v, float* __restrict__ q,
                                                    const float* __restrict__ dq, float* __restrict__ da, float* __restrict__ dv, int n, int T, int B,
-                                                   int inner, int K) {
+                                                   int inner, int K, int ld, int merged, float* __restrict__ gs) {
     const long rows = (long)T * B * inner, total = rows * n;
+    const int vld = merged ? ld : 1;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int i = (int)(idx / rows);
         const long r = idx - (long)i * rows;
         const long tb = r / inner;
         const int j = (int)(r - tb * inner), t = (int)(tb / B), b = (int)(tb - (long)t * B);
-        const size_t qo = ((((size_t)b * T + t) * n + i) * inner + j) * K, ao = ((size_t)i * rows + r) * K;
+        const size_t qo = ((((size_t)b * T + t) * n + i) * inner + j) * K, ao = ((size_t)i * rows + r) * ld;
         float x[16], sum = 0.f;
         for (int k = 0; k < K; ++k) { x[k] = BWD ? dq[qo + k] : a[ao + k]; sum += x[k]; }
         if (BWD) {
             const float mean = sum / (float)K;
             for (int k = 0; k < K; ++k) da[ao + k] = x[k] - mean;
-            dv[(size_t)i * rows + r] = sum;
+            dv[((size_t)i * rows + r) * vld] = sum;
+            if (gs && j == 0) {                                        // this thread also adds the group's rows in order (deterministic)
+                float g[17];
+                for (int k = 0; k <= K; ++k) g[k] = 0.f;
+                for (int jj = 0; jj < inner; ++jj) {
+                    const size_t qj = qo + (size_t)jj * K;
+                    float y[16], s2 = 0.f;
+                    for (int k = 0; k < K; ++k) { y[k] = dq[qj + k]; s2 += y[k]; }
+                    const float m2 = s2 / (float)K;
+                    for (int k = 0; k < K; ++k) g[k] += y[k] - m2;
+                    g[K] += s2;
+                }
+                float* go = gs + ((size_t)i * (rows / inner) + tb) * (K + 1);
+                for (int k = 0; k <= K; ++k) go[k] = g[k];
+            }
         } else {
-            const float vv = v[(size_t)i * rows + r], mean = sum / (float)K;
+            const float vv = v[((size_t)i * rows + r) * vld], mean = sum / (float)K;
             for (int k = 0; k < K; ++k) q[qo + k] = (vv + x[k]) - mean;               // v + a - mean(a), in the reference's order
         }
     }
 }
 
 void launch_dueling_q(const float* a, const float* v, float* q, const float* dq, float* da, float* dv, int n, int T, int B, int inner, int K,
-                      hipStream_t stream) {
+                      hipStream_t stream, int ld, int merged, float* gs) {
     const size_t total = (size_t)n * T * B * inner;
-    if (dq) hipLaunchKernelGGL(k_dueling_q<true>, dim3(grid_for(total)), dim3(256), 0, stream, a, v, q, dq, da, dv, n, T, B, inner, K);
-    else hipLaunchKernelGGL(k_dueling_q<false>, dim3(grid_for(total)), dim3(256), 0, stream, a, v, q, dq, da, dv, n, T, B, inner, K);
+    if (ld <= 0) ld = K;
+    if (dq) hipLaunchKernelGGL(k_dueling_q<true>, dim3(grid_for(total)), dim3(256), 0, stream, a, v, q, dq, da, dv, n, T, B, inner, K, ld, merged, gs);
+    else hipLaunchKernelGGL(k_dueling_q<false>, dim3(grid_for(total)), dim3(256), 0, stream, a, v, q, dq, da, dv, n, T, B, inner, K, ld, merged, gs);
 }
 
 // k_gather_rows: rows ids[e] of up to SSD_COPY_BLOCKS_MAX fields into consecutive rows of their destinations (blockIdx.y = field,

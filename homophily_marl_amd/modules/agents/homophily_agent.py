@@ -24,6 +24,7 @@ class HomophilyAgent(nn.Module):
         self.hidden = H = args.rnn_hidden_dim
         self.extra_input_shape = args.n_actions + 2 + 2 + 3   # action one-hot, pos, orientation, reward/clean_num/apple_den
         self._gru_cache = None
+        self._fc2_cache = None
         if args.rgb_input:
             k = args.conv_kernel
             flat = args.conv_out * (args.obs_dims[0] - k + 1) * (args.obs_dims[1] - k + 1)
@@ -151,10 +152,17 @@ class HomophilyAgent(nn.Module):
                 for h, bufs in self._gru_cache.items():
                     for dst, src in zip(bufs, self._gru_weights_cat(h)):
                         dst.copy_(src)
+        if self._fc2_cache is not None:
+            with th.no_grad():
+                bufs, self._fc2_cache = self._fc2_cache, None
+                for dst, src in zip(bufs, self._fc2_merged()):
+                    dst.copy_(src)
+                self._fc2_cache = bufs
         return out
 
     def _apply(self, fn, *args, **kwargs):
-        self._gru_cache = None                   # .cuda() / .to(): the cache is rebuilt on the new device at the next use
+        self._gru_cache = None                   # .cuda() / .to(): the caches are rebuilt on the new device at the next use
+        self._fc2_cache = None
         return super()._apply(fn, *args, **kwargs)
 
     def unroll(self, inputs, act_onehot, agent_pos, agent_orientation, reward, clean_num, apple_den):
@@ -191,22 +199,30 @@ class HomophilyAgent(nn.Module):
         return th.cat([act_onehot.to(dtype), agent_pos, agent_orientation, reward.unsqueeze(-1), clean_num.unsqueeze(-1),
                        apple_den.unsqueeze(-1)], dim=-1).permute(1, 0, 2, 3).reshape(T * B, n, -1)
 
+    def _fc2_merged(self):
+        """(w_env [n, H, A + 1], b_env [n, 1, A + 1], w_inc [n, H + E, 4], b_inc [n, 1, 4]): the advantage and the value layer of each
+        dueling head side by side (one layer, one launch per head and direction); ONE launch for the four concatenations (a frozen
+        copy of the net -- the learner's target network -- keeps them in buffers that load_state_dict refreshes)."""
+        frozen = not self.fc2_env_w.requires_grad
+        if frozen and self._fc2_cache is not None:
+            return self._fc2_cache
+        groups = [[self._w("fc2_env_w"), self._w("fc2_env_v_w")], [self._b("fc2_env_b"), self._b("fc2_env_v_b")],
+                  [self._w("fc2_inc_w"), self._w("fc2_inc_v_w")], [self._b("fc2_inc_b"), self._b("fc2_inc_v_b")]]
+        out = tuple(ops.cat_groups(groups))
+        if frozen and not th.is_grad_enabled():
+            self._fc2_cache = out
+        return out
+
     def unroll_post(self, he, hi, other):
         """Both dueling heads on the recurrence states of the env and the inc head (each [n, T, B, H]) and other [T*B, n(j), E]:
-        q_env [B, T, n, A], q_inc [B, T, n, n, 3]."""
-        n, H, A = self.n_agents, self.hidden, self.n_actions
+        q_env [B, T, n, A], q_inc [B, T, n, n, 3].  Per head ONE layer ([advantage | value] columns) and one dueling launch; the
+        incentive head's rows [h_i | other_j] (homophily_agent.py:194-201) are read from the two tensors, never materialised."""
+        n, H = self.n_agents, self.hidden
         T, B = he.shape[1], he.shape[2]
         he, hi = he.reshape(n, T * B, H), hi.reshape(n, T * B, H)
-        a = ops.bias_bmm(he, self._w("fc2_env_w"), self._b("fc2_env_b"))
-        v = ops.bias_bmm(he, self._w("fc2_env_v_w"), self._b("fc2_env_v_b"))
-        q_env = ops.dueling_q(a, v, B, T, 1)                                           # v + a - mean(a) as [B, T, n, A]
-        # inc head: per ordered pair (i -> j) [h_i | other_j]
-        E = other.shape[-1]
-        cat = th.cat([hi.unsqueeze(2).expand(n, T * B, n, H), other.unsqueeze(0).expand(n, T * B, n, E)], dim=-1)
-        cat = cat.reshape(n, T * B * n, H + E)
-        a = ops.bias_bmm(cat, self._w("fc2_inc_w"), self._b("fc2_inc_b"))
-        v = ops.bias_bmm(cat, self._w("fc2_inc_v_w"), self._b("fc2_inc_v_b"))
-        q_inc = ops.dueling_q(a, v, B, T, n)                                           # [B, T, n(i), n(j), 3]
+        w_env, b_env, w_inc, b_inc = self._fc2_merged()
+        q_env = ops.dueling_head(he, None, w_env, b_env, B, T, 1)                      # v + a - mean(a) as [B, T, n, A]
+        q_inc = ops.dueling_head(hi, other, w_inc, b_inc, B, T, n)                     # [B, T, n(i), n(j), 3]
         return q_env, q_inc
 
     # ---- heads --------------------------------------------------------------------------------------------------

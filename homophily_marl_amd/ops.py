@@ -330,6 +330,84 @@ def dueling_q(a, v, B, T, inner):
     return q.reshape(B, T, n, K) if inner == 1 else q
 
 
+class _DuelingHead(th.autograd.Function):
+    """One dueling head of the learner's time-batched evaluation as TWO launches forward (the layer, the dueling combination) and three
+    backward: w [n, in, K + 1] holds the advantage layer (columns 0..K-1) and the value layer (column K) side by side, b [n, 1, K + 1].
+    other None (env head): rows = h [n, T * B, in].  other [T * B, inner, E] (incentive head): the layer input of row (tb, j) is
+    [h[i, tb] | other[tb, j]] -- read from the two tensors where they are (ssd_bias_bmm2_fwd), never concatenated; backward, the
+    gradient of h comes from the row-group sums the dueling backward emits (ssd_dueling_head_bwd gs -> ssd_bias_bmm_bwd_x)."""
+
+    @staticmethod
+    def forward(ctx, h, other, w, b, B, T, inner):
+        lib = abi.load_library()
+        h, w, b = h.contiguous(), w.contiguous(), b.contiguous()
+        n, TB, H = h.shape
+        K = w.shape[2] - 1
+        st = _stream(h)
+        y = th.empty(n, TB * inner, K + 1, dtype=th.float32, device=h.device)
+        if other is None:
+            assert inner == 1 and w.shape[1] == H
+            abi.check(lib, lib.ssd_bias_bmm_fwd(h.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, TB, H, K + 1, st))
+        else:
+            other = other.contiguous()
+            E = other.shape[-1]
+            assert other.shape[0] == TB and other.shape[1] == inner and w.shape[1] == H + E
+            abi.check(lib, lib.ssd_bias_bmm2_fwd(h.data_ptr(), other.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, TB * inner, H, E, K + 1,
+                                                 inner, 1, st))
+        q = th.empty((B, T, n, inner, K), dtype=th.float32, device=h.device)
+        abi.check(lib, lib.ssd_dueling_head_fwd(y.data_ptr(), q.data_ptr(), n, T, B, inner, K, st))
+        ctx.save_for_backward(h, w, *(() if other is None else (other,)))
+        ctx.dims = (B, T, inner, K)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        lib = abi.load_library()
+        h, w = ctx.saved_tensors[:2]
+        other = ctx.saved_tensors[2] if len(ctx.saved_tensors) > 2 else None
+        B, T, inner, K = ctx.dims
+        n, TB, H = h.shape
+        st = _stream(h)
+        dq = dq.contiguous()
+        need = ctx.needs_input_grad
+        dy = th.empty(n, TB * inner, K + 1, dtype=th.float32, device=h.device)
+        two = other is not None
+        gs = th.empty(n, TB, K + 1, dtype=th.float32, device=h.device) if (two and need[0]) else None
+        abi.check(lib, lib.ssd_dueling_head_bwd(dq.data_ptr(), dy.data_ptr(), None if gs is None else gs.data_ptr(), n, T, B, inner, K, st))
+        dw = th.empty_like(w) if need[2] else None
+        db = th.empty(n, 1, K + 1, dtype=th.float32, device=h.device) if need[3] else None
+        ptr = lambda t: None if t is None else t.data_ptr()
+        dh = None
+        if not two:
+            dh = th.empty_like(h) if need[0] else None
+            abi.check(lib, lib.ssd_bias_bmm_bwd(dy.data_ptr(), h.data_ptr(), w.data_ptr(), ptr(dh), ptr(dw), ptr(db), None, n, TB, H, K + 1, st))
+        else:
+            E = other.shape[-1]
+            if dw is not None or db is not None:
+                abi.check(lib, lib.ssd_bias_bmm2_bwd_w(dy.data_ptr(), h.data_ptr(), other.data_ptr(), ptr(dw), ptr(db), n, TB * inner, H, E, K + 1, inner, 1, st))
+            if need[0]:
+                dh = th.empty_like(h)
+                abi.check(lib, lib.ssd_bias_bmm_bwd_x(gs.data_ptr(), w.data_ptr(), dh.data_ptr(), n, TB, H, K + 1, (H + E) * (K + 1), st))
+        return dh, None, dw, db, None, None, None
+
+
+def dueling_head(h, other, w, b, B, T, inner):
+    """q [B, T, n, K] (inner = 1, other None) or [B, T, n, inner, K] of one dueling head: h [n, T * B, H] the recurrence states (rows
+    t * B + b), other [T * B, inner, E] or None, w [n, H (+ E), K + 1] = [advantage layer | value layer], b [n, 1, K + 1]."""
+    n, K = h.shape[0], w.shape[2] - 1
+    if h.is_cuda and h.dtype == th.float32 and K <= 15 and h.shape[-1] % 16 == 0 and (other is None or other.shape[-1] % 4 == 0):
+        q = _DuelingHead.apply(h, other, w, b, B, T, inner)
+    else:
+        _leaving_kernels("dueling_head", h, "layout")
+        TB = h.shape[1]
+        x = h if other is None else th.cat([h.unsqueeze(2).expand(n, TB, inner, h.shape[-1]), other.unsqueeze(0).expand(n, TB, inner, other.shape[-1])],
+                                          dim=-1).reshape(n, TB * inner, -1)
+        y = th.baddbmm(b, x, w)
+        a, v = y[..., :K], y[..., K:]
+        q = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, T, B, inner, K).permute(2, 1, 0, 3, 4)
+    return q.reshape(B, T, n, K) if inner == 1 else q
+
+
 def _mix32p(x):
     x &= 0xFFFFFFFF
     x ^= x >> 17; x = (x * 0xed5ad4bb) & 0xFFFFFFFF; x ^= x >> 11; x = (x * 0xac4c1b51) & 0xFFFFFFFF

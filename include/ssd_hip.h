@@ -443,6 +443,26 @@ int ssd_bias_bmm_leaky_bwd(const float* g, const float* y, const float* x, const
                            int32_t n, int32_t rows, int32_t in, int32_t out, void* stream);
 int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, const float* slope_of, int32_t n,
                      int32_t rows, int32_t in, int32_t out, void* stream);
+/* ---- ABI 7: the dueling heads of the learner as ONE layer per head + one dueling launch ---------------------------------------------
+ * The reference evaluates the advantage and the value layer of a head separately (homophily_agent.py:166-170,202-207) and, for the
+ * incentive head, on materialised rows [h_i | other_j] of every ordered pair (:194-201).  Here the two layers are the columns 0..K-1 and K
+ * of one weight [n, in, K + 1] (the caller concatenates the parameters once per step), and the pair rows are never built:
+ *   ssd_bias_bmm2_fwd    y[g][r] = b[g] + [x1[g][r / x1_div] | x2[(g)][r]] w[g]: TWO-SOURCE rows -- columns [0, in1) from x1 f32
+ *                        [n, rows / x1_div, in1] (h_i, the same for the x1_div receivers j), columns [in1, in1 + in2) from x2 f32
+ *                        [rows, in2] shared by all weight sets (x2_shared) or [n, rows, in2]; in1 a multiple of 16, in2 of 4.
+ *   ssd_bias_bmm2_bwd_w  dw [n, in1 + in2, out] = rows^T g and db = column sums of g for the same two-source rows (either nullable).
+ *   ssd_bias_bmm_bwd_x   dx [n, rows, in] = g w^T where w[g] are the LEADING `in` rows of a wider layer (w_set floats between two weight sets):
+ *                        the gradient of x1 from the row-group sums of g (ssd_dueling_head_bwd's gs).
+ *   ssd_dueling_head_fwd q [B, T, n, inner, K] = v + a - mean_k a from y f32 [n, T * B * inner, K + 1] (a = columns 0..K-1, v = column K).
+ *   ssd_dueling_head_bwd dq -> dy (same shape as y: da = dq - mean_k dq, dv = sum_k dq) and, when gs is given, gs f32 [n, T * B, K + 1] =
+ *                        the sum of dy over the `inner` rows of every (agent, t, b) in row order (deterministic). */
+int ssd_bias_bmm2_fwd(const float* x1, const float* x2, const float* w, const float* b, float* y, int32_t n, int32_t rows, int32_t in1, int32_t in2,
+                      int32_t out, int32_t x1_div, int32_t x2_shared, void* stream);
+int ssd_bias_bmm2_bwd_w(const float* g, const float* x1, const float* x2, float* dw, float* db, int32_t n, int32_t rows, int32_t in1, int32_t in2,
+                        int32_t out, int32_t x1_div, int32_t x2_shared, void* stream);
+int ssd_bias_bmm_bwd_x(const float* g, const float* w, float* dx, int32_t n, int32_t rows, int32_t in, int32_t out, int64_t w_set, void* stream);
+int ssd_dueling_head_fwd(const float* y, float* q, int32_t n, int32_t T, int32_t B, int32_t inner, int32_t K, void* stream);
+int ssd_dueling_head_bwd(const float* dq, float* dy, float* gs, int32_t n, int32_t T, int32_t B, int32_t inner, int32_t K, void* stream);
 /* Make the row-chunk scratch of `stream` on the current device exist (SSD_ERR_DEVICE when it cannot be allocated). */
 int ssd_bmm_reserve_scratch(void* stream);
 /* Arithmetic of the LEARNER's matrix products from now on (process-wide; a launch takes the value at launch -- or capture -- time):

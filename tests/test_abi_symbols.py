@@ -11,7 +11,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 def _declared():
     src = open(os.path.join(ROOT, "include", "ssd_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(ssd_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(ssd_[a-z_0-9]+)\s*\(", src)))
 
 
 def test_header_and_ctypes_table_agree():

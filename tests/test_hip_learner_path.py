@@ -765,6 +765,33 @@ def test_unroll_other_kernel_matches_the_tensor_expression(B, T, n, A):
     assert th.equal(act_tm, onehot.float().permute(2, 1, 0, 3).reshape(n, T * B, A))
 
 
+@pytest.mark.parametrize("n,T,B,inner,K,E", [(5, 101, 16, 1, 9, 0), (5, 101, 16, 5, 3, 16), (3, 7, 5, 3, 3, 16), (10, 4, 9, 10, 3, 16), (5, 6, 4, 1, 8, 0)])
+def test_dueling_head_matches_the_two_layers_and_the_concatenated_rows(n, T, B, inner, K, E):
+    """ops.dueling_head (ssd_bias_bmm[2]_fwd + ssd_dueling_head_fwd; backward ssd_dueling_head_bwd + ssd_bias_bmm2_bwd_w + ssd_bias_bmm_bwd_x)
+    against the reference's formulation in tensor ops: separate advantage / value layers (homophily_agent.py:166-170,202-207) on rows
+    that are, for the incentive head, the materialised concatenations [h_i | other_j] of every ordered pair (:194-201).  Values and
+    all gradients (h, both layers' weights and biases) within f32 round-off of the different summation order."""
+    from homophily_marl_amd import ops
+    g = th.Generator(device="cuda").manual_seed(n * 100 + T)
+    H, TB = 64, T * B
+    h = (th.randn(n, TB, H, generator=g, device="cuda") * 0.5).requires_grad_()
+    other = th.randn(TB, inner, E, generator=g, device="cuda") if E else None
+    wa = (th.randn(n, H + E, K, generator=g, device="cuda") * 0.2).requires_grad_()
+    wv = (th.randn(n, H + E, 1, generator=g, device="cuda") * 0.2).requires_grad_()
+    ba = (th.randn(n, 1, K, generator=g, device="cuda") * 0.2).requires_grad_()
+    bv = (th.randn(n, 1, 1, generator=g, device="cuda") * 0.2).requires_grad_()
+    wgt = th.randn(B, T, n, inner, K, generator=g, device="cuda")
+    q = ops.dueling_head(h, other, th.cat([wa, wv], dim=2), th.cat([ba, bv], dim=2), B, T, inner)
+    x = h if other is None else th.cat([h.unsqueeze(2).expand(n, TB, inner, H), other.unsqueeze(0).expand(n, TB, inner, E)], dim=-1).reshape(n, TB * inner, H + E)
+    a, v = th.baddbmm(ba, x, wa), th.baddbmm(bv, x, wv)
+    ref = (v + a - a.mean(dim=-1, keepdim=True)).reshape(n, T, B, inner, K).permute(2, 1, 0, 3, 4)
+    assert (q.reshape(ref.shape) - ref).abs().max() < 2e-6
+    got = th.autograd.grad((q.reshape(ref.shape) * wgt).sum(), [h, wa, wv, ba, bv])
+    exp = th.autograd.grad((ref * wgt).sum(), [h, wa, wv, ba, bv])
+    for x_, y_ in zip(got, exp):
+        assert (x_ - y_).abs().max() <= 2e-5 * max(1.0, float(y_.abs().max())), float((x_ - y_).abs().max())
+
+
 def test_fill_blocks_and_runner_stats_kernels():
     """ssd_fill_blocks (the runner state an episode opens with, one launch) and ssd_runner_stats (one rollout's statistics added to
     the f64 accumulator, episode_runner.py:121-152) against the tensor statements they replace."""
