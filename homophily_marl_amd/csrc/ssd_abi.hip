@@ -618,7 +618,7 @@ int ssd_bias_bmm2_fwd(const float* x1, const float* x2, const float* w, const fl
                       int32_t out, int32_t x1_div, int32_t x2_shared, void* stream) {
     if (!x1 || !x2 || !w || !b || !y || n < 1 || rows < 1 || in1 < 1 || in2 < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
     const int rc = launch_bias_bmm2_fwd(x1, x2, w, b, y, n, rows, in1, in2, out, x1_div, x2_shared, (hipStream_t)stream);
-    if (rc == -3) return fail(SSD_ERR_INVALID, "ssd_bias_bmm2_fwd: in1 a multiple of 16, in2 a multiple of 4, rows a multiple of x1_div >= 1");
+    if (rc == -3) return fail(SSD_ERR_INVALID, "ssd_bias_bmm2_fwd: in1 a multiple of 16, rows a multiple of x1_div >= 1");
     if (rc) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm2_fwd: a weight / operand set of 2^30 elements or more");
     return launched();
 }
@@ -627,7 +627,7 @@ int ssd_bias_bmm2_bwd_w(const float* g, const float* x1, const float* x2, float*
     if (!g || !x1 || !x2 || (!dw && !db) || n < 1 || rows < 1 || in1 < 1 || in2 < 1 || out < 1) return fail(SSD_ERR_INVALID, "bad argument");
     const int rc = launch_bias_bmm_bwd(g, x1, nullptr, nullptr, dw, db, nullptr, n, rows, in1 + in2, out, (hipStream_t)stream, 0, 0, nullptr, x2, in1, x1_div,
                                        x2_shared, 0);
-    if (rc == -3) return fail(SSD_ERR_INVALID, "ssd_bias_bmm2_bwd_w: in1 a multiple of 16, in2 a multiple of 4, rows a multiple of x1_div >= 1");
+    if (rc == -3) return fail(SSD_ERR_INVALID, "ssd_bias_bmm2_bwd_w: in1 a multiple of 16, rows a multiple of x1_div >= 1");
     if (rc) return fail(SSD_ERR_UNSUPPORTED, "ssd_bias_bmm2_bwd_w: an operand set of 2^30 elements or more");
     return launched();
 }

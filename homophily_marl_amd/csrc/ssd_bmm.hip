@@ -123,7 +123,10 @@ __global__ __launch_bounds__(256) void k_bias_bmm_fwd(BmmK a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = k0 + r < I ? k0 + r : I - 1;
-            if constexpr (!XV) d.x[r] = ld32(xs, xrow + (uint32_t)k);
+            if constexpr (!XV) {
+                const bool sec = k >= I1;                              // (per lane: any width of the second source)
+                d.x[r] = ld32(sec ? x2s : xs, sec ? x2row + (uint32_t)(k - I1) : xrow + (uint32_t)k);
+            }
 #pragma unroll
             for (int t = 0; t < BMM_TPW; ++t) d.w[t][r] = ld32(wg, (uint32_t)k * (uint32_t)O + (uint32_t)oc[t]);
         }
@@ -442,12 +445,18 @@ int launch_bias_bmm2_fwd(const float* x1, const float* x2, const float* w, const
     const int I = I1 + I2;
     k.x = x1; k.x2 = x2; k.I1 = I1; k.x1_div = x1_div; k.x2_set = x2_shared ? 0 : (long)R * I2;
     k.w = w; k.b = b; k.y = y; k.n = n; k.R = R; k.I = I; k.O = O;
-    if ((I1 & 15) || (I2 & 3) || x1_div < 1 || R % x1_div) return -3;
+    if ((I1 & 15) || x1_div < 1 || R % x1_div) return -3;
     if ((long)I * O >= (1L << 30) || (long)R * I >= (1L << 30)) return -2;
     const int otiles = (O + 15) / 16, units = ((R + 15) / 16) * ((otiles + BMM_TPW - 1) / BMM_TPW);
     const dim3 grid((units + 3) / 4, n);
-    if (g_learner_precision == 1) hipLaunchKernelGGL((k_bias_bmm_fwd<true, true>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((k_bias_bmm_fwd<true, false>), grid, dim3(256), 0, s, k);
+    const bool xv = (I2 & 3) == 0;      // 16-byte row loads need rows of whole quads in both sources (Harvest: 15 extra features -> scalar loads)
+    if (g_learner_precision == 1) {
+        if (xv) hipLaunchKernelGGL((k_bias_bmm_fwd<true, true>), grid, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((k_bias_bmm_fwd<false, true>), grid, dim3(256), 0, s, k);
+    } else {
+        if (xv) hipLaunchKernelGGL((k_bias_bmm_fwd<true, false>), grid, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((k_bias_bmm_fwd<false, false>), grid, dim3(256), 0, s, k);
+    }
     return 0;
 }
 
@@ -457,7 +466,7 @@ int launch_bias_bmm_bwd(const float* g, const float* x, const float* w, float* d
     BmmK k = {};
     k.act_y = act_y;
     if (x2) {                      // two-source rows: dw / db only (dx of the first source is a row-group sum: the caller forms it from the summed g)
-        if (dx || (I1 & 15) || ((I - I1) & 3) || x1_div < 1 || R % x1_div) return -3;
+        if (dx || (I1 & 15) || x1_div < 1 || R % x1_div) return -3;
         k.x2 = x2; k.I1 = I1; k.x1_div = x1_div; k.x2_set = x2_shared ? 0 : (long)R * (I - I1);
         k.x1_magic = x1_div == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)x1_div - 1) / (uint64_t)x1_div);
         if (R >= (1 << 28)) return -2;

@@ -395,7 +395,7 @@ def dueling_head(h, other, w, b, B, T, inner):
     """q [B, T, n, K] (inner = 1, other None) or [B, T, n, inner, K] of one dueling head: h [n, T * B, H] the recurrence states (rows
     t * B + b), other [T * B, inner, E] or None, w [n, H (+ E), K + 1] = [advantage layer | value layer], b [n, 1, K + 1]."""
     n, K = h.shape[0], w.shape[2] - 1
-    if h.is_cuda and h.dtype == th.float32 and K <= 15 and h.shape[-1] % 16 == 0 and (other is None or other.shape[-1] % 4 == 0):
+    if h.is_cuda and h.dtype == th.float32 and K <= 15 and h.shape[-1] % 16 == 0:
         q = _DuelingHead.apply(h, other, w, b, B, T, inner)
     else:
         _leaving_kernels("dueling_head", h, "layout")

@@ -449,7 +449,7 @@ int ssd_bias_bmm_bwd(const float* g, const float* x, const float* w, float* dx, 
  * of one weight [n, in, K + 1] (the caller concatenates the parameters once per step), and the pair rows are never built:
  *   ssd_bias_bmm2_fwd    y[g][r] = b[g] + [x1[g][r / x1_div] | x2[(g)][r]] w[g]: TWO-SOURCE rows -- columns [0, in1) from x1 f32
  *                        [n, rows / x1_div, in1] (h_i, the same for the x1_div receivers j), columns [in1, in1 + in2) from x2 f32
- *                        [rows, in2] shared by all weight sets (x2_shared) or [n, rows, in2]; in1 a multiple of 16, in2 of 4.
+ *                        [rows, in2] shared by all weight sets (x2_shared) or [n, rows, in2]; in1 a multiple of 16.
  *   ssd_bias_bmm2_bwd_w  dw [n, in1 + in2, out] = rows^T g and db = column sums of g for the same two-source rows (either nullable).
  *   ssd_bias_bmm_bwd_x   dx [n, rows, in] = g w^T where w[g] are the LEADING `in` rows of a wider layer (w_set floats between two weight sets):
  *                        the gradient of x1 from the row-group sums of g (ssd_dueling_head_bwd's gs).
