@@ -26,7 +26,9 @@ def _check_roofline(r):
 
 @pytest.mark.parametrize("name", ["r02_bench_e2e_cleanup5.json", "r02_bench_e2e_harvest5.json", "r02_bench_e2e_cleanup10.json",
                                   "r02_bench_env_cleanup5.json", "r03_bench_e2e_cleanup5.json", "r03_bench_e2e_harvest5.json",
-                                  "r03_bench_e2e_cleanup10.json", "r03_bench_env_cleanup5.json", "r03_bench_e2e_cleanup5_tspr8.json"])
+                                  "r03_bench_e2e_cleanup10.json", "r03_bench_env_cleanup5.json", "r03_bench_e2e_cleanup5_tspr8.json",
+                                  "r04_bench_e2e_cleanup5.json", "r04_bench_e2e_harvest5.json", "r04_bench_e2e_cleanup10.json", "r04_bench_env_cleanup5.json",
+                                  "r04_bench_e2e_cleanup5_tspr8.json", "r04_bench_e2e_cleanup5_learner_bf16_tspr8.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     d = json.load(open(os.path.join(ROOT, "profiles", name)))
     for k in REQUIRED:
@@ -44,6 +46,10 @@ def test_committed_bench_line_has_the_contract_fields(name):
         units *= cfg["episode_limit"]
         assert cfg["timesteps_timed"] == d["steps"] * cfg["episode_limit"] and cfg["train_steps_timed"] >= d["steps"]
     assert abs(d["value"] - units / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-3 * d["value"]
+    ew = d.get("env_workload")      # round 4: the format-R env workload measured after the timed region of the e2e line (1 GPU)
+    if name.startswith("r04_bench_e2e") and d["n_gpus"] == 1:
+        assert ew is not None and ew["unit"] == "GB/s" and ew["peak"] == 8000.0 and abs(ew["frac"] - ew["achieved"] / ew["peak"]) < 1e-9
+        assert abs(ew["achieved"] - ew["algorithmic_bytes_per_launch"] / (ew["avg_us"] * 1e-6) / 1e9) < 1e-6 * ew["achieved"] and ew["transitions"] >= 100
     c = d.get("cpu_baseline")
     assert c is None or c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "agent-steps/s" and c["sample"]
 
