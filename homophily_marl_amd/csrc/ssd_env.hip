@@ -122,7 +122,20 @@ struct Env {
     int P;          // my agent's cell (r * W + c); unique negative for non-agent lanes
     int O;          // orientation
     int ap[4], ws[4];  // my lanes' apple / waste site cells (site index = chunk * 64 + lane), preloaded
+    // Table windows requested with the state loads, so that the step's two table look-ups are lane reads instead of dependent
+    // trips to L2 in the middle of the wave's chain: lane l holds tab_p_apple / tab_p_waste [w0 - l] (beams only remove waste)
+    // and tab_den[a0 - 8 + l] (at most n apples eaten; more than 55 grown in one step falls back to the load).  w0 / a0 < 0: none.
+    int w0, a0;
+    double pf_pa, pf_pw;
+    float pf_den;
+    bool pm_zeroed;     // the padded class map was cleared with the state loads and nothing wrote to it since
 };
+__device__ __forceinline__ double rl_f64(double v, int idx) {
+    const int i = __builtin_amdgcn_readfirstlane(idx);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)__double_as_longlong(v), i);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)__double_as_longlong(v) >> 32), i);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 __device__ __forceinline__ int agent_char(int a) { int v = (a % 10) + 1; return v >= 10 ? 1 : v; }  // '<U1' truncation, map_env.py:370,377
 
@@ -324,7 +337,9 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
     const int lane = E.lane;
     // compute_probabilities (cleanup.py:189-204): looked up by the waste count in the host-built fp64 tables
     const int current = h->n_waste > 0 ? n_waste_cells : 0;    // kept incrementally in the env state
-    const double p_apple = S->tab_p_apple[current], p_waste = S->tab_p_waste[current];
+    const int back = E.w0 - current;                           // (wave-uniform)
+    const bool pf = E.w0 >= 0 && (unsigned)back < (unsigned)kWave;
+    const double p_apple = pf ? rl_f64(E.pf_pa, back) : S->tab_p_apple[current], p_waste = pf ? rl_f64(E.pf_pw, back) : S->tab_p_waste[current];
     const uint32_t t_apple = Rng::threshold(p_apple), t_waste = Rng::threshold(p_waste);
     int k = 0;
     // apples: one draw per site that holds neither an agent nor an apple, in site order (cleanup.py:168-174).
@@ -350,6 +365,7 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
         const int nw = h->n_waste;
         uint16_t* scratch = (uint16_t*)E.pm;                  // tape mode: rank of each site in the shuffled list
         if (R.tape) {
+            E.pm_zeroed = false;
             for (int base = 0; base < nw; base += kWave) {
                 const int p = base + lane;
                 if (p < nw) {
@@ -405,13 +421,12 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
     return k;
 }
 
-__device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R, int& n_apple_cells) {
-    const DevSpec* S = E.S;
+__device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R, int& n_apple_cells, const double (&harvest_p)[4]) {
     const DevHead* h = E.h;
     const int lane = E.lane, W = E.W, H = h->H;
     uint32_t t_harvest[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t_harvest[i] = Rng::threshold(S->harvest_p[i]);
+    for (int i = 0; i < 4; ++i) t_harvest[i] = Rng::threshold(harvest_p[i]);
     int k = 0;
     uint32_t spawn_bits = 0;  // decisions are applied after ALL sites were examined (synchronous update, harvest.py:86-90)
 #pragma unroll
@@ -432,7 +447,7 @@ __device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R, int& n_apple_
                         if ((unsigned)x < (unsigned)H && (unsigned)y < (unsigned)W) num += E.g[x * W + y] == C_APPLE;
                     }
                 const int pi = num < 3 ? num : 3;
-                if (R.below(k + (int)lanes_below(bal), S->harvest_p[pi], t_harvest[pi])) spawn_bits |= 1u << ch;
+                if (R.below(k + (int)lanes_below(bal), pi == 0 ? harvest_p[0] : pi == 1 ? harvest_p[1] : pi == 2 ? harvest_p[2] : harvest_p[3], t_harvest[pi])) spawn_bits |= 1u << ch;
             }
             n_apple_cells += popc64(ballot((spawn_bits >> ch) & 1));
             k += popc64(bal);
@@ -588,18 +603,39 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
         else { ci0 = 1; cj0 = -Wp; c00 = (V - 1) * Wp; }
         const int base0 = pr0 * Wp + pc0 + c00;
         const int dumpc = delta + L;                                  // one byte behind the last window (inside the planes' slack)
-        for (int a = 0; a < n; ++a) {
-            const int sb = rl(base0, a), sci = rl(ci0, a), scj = rl(cj0, a);
-            const int sstep = rpi * sci, dstep = rpi * V;
-            int sidx = sb + il * sci + j * scj;
-            int d = delta + a * VV + il * V + j;
-            for (int i = il; i < V; i += 4 * rpi, sidx += 4 * sstep, d += 4 * dstep) {
-                int cls[4];
+        // Agents in groups of AG: every class read of the group is in flight before the first code is written (one LDS round
+        // trip per group and trip, not one per agent -- the reads and writes are byte accesses to buffers the compiler must
+        // assume to alias, so it keeps the source order).
+        constexpr int AG = 5;
+        const int dstep = rpi * V;
+        for (int a0 = 0; a0 < n; a0 += AG) {
+            int sidx[AG], sstep[AG];
+#pragma unroll
+            for (int g = 0; g < AG; ++g) {
+                const int a = a0 + g < n ? a0 + g : n - 1;
+                const int sb = rl(base0, a), sci = rl(ci0, a), scj = rl(cj0, a);
+                sstep[g] = rpi * sci;
+                sidx[g] = sb + il * sci + j * scj;
+            }
+            int d = delta + a0 * VV + il * V + j;
+            for (int i = il; i < V; i += 4 * rpi, d += 4 * dstep) {
+                uint8_t cls[AG][4];
                 bool ok[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { ok[u] = jv && i + u * rpi < V; cls[u] = E.pm[ok[u] ? sidx + u * sstep : 0]; }
+                for (int u = 0; u < 4; ++u) ok[u] = jv && i + u * rpi < V;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) E.pl[ok[u] ? d + u * dstep : dumpc] = PMC ? (uint8_t)cls[u] : (uint8_t)((0x30120u >> (4 * cls[u])) & 0xFu);   // class bit 1 / 2 / 4 -> code 2 / 1 / 3
+                for (int g = 0; g < AG; ++g) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cls[g][u] = E.pm[ok[u] ? sidx[g] + u * sstep[g] : 0];
+                    sidx[g] += 4 * sstep[g];
+                }
+#pragma unroll
+                for (int g = 0; g < AG; ++g) {
+                    const bool live = a0 + g < n;                     // (wave-uniform)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)   // class bit 1 / 2 / 4 -> code 2 / 1 / 3
+                        E.pl[(ok[u] && live) ? d + g * VV + u * dstep : dumpc] = PMC ? cls[g][u] : (uint8_t)((0x30120u >> (4 * cls[g][u])) & 0xFu);
+                }
             }
         }
         wsync();
@@ -681,7 +717,8 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
     if (FULL) { if (lane < 48) lut[lane] = S->lut[lane]; }
     // pass 0: zero-padded class map, pm[(r + v) * Wp + (c + v)] = class of map cell (r, c); the padding IS
     // return_view's zero padding (utility_funcs.py:93-116), so the window gather needs no bounds test
-    for (int i = lane * 16; i < h->PMS; i += kWave * 16) *(uint4*)(E.pm + i) = make_uint4(0, 0, 0, 0);
+    if (!E.pm_zeroed)
+        for (int i = lane * 16; i < h->PMS; i += kWave * 16) *(uint4*)(E.pm + i) = make_uint4(0, 0, 0, 0);
     wsync();
     const bool codes_in_map = !FULL && oo.obs && oo.fmt == SSD_OBS_CODE && !oo.state;     // (wave-uniform)
     if (!FULL) {
@@ -840,6 +877,31 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     const int ep_step0 = MODE == MODE_RESET ? 0 : st.ep_step[env];
     const uint32_t counts0 = (MODE == MODE_STEP || MODE == MODE_STEP_OBS) ? st.counts[env] : 0u;
     E.obs_slot = MODE == MODE_STEP_OBS ? ep_step0 + 1 : ep_step0;
+    // the observation's padded class map is cleared here, under the state loads (tape-mode spawns use it as scratch and say so)
+    E.pm_zeroed = false;
+    if (MODE == MODE_STEP_OBS || MODE == MODE_OBS) {
+        for (int i = lane * 16; i < h->PMS; i += kWave * 16) *(uint4*)(E.pm + i) = make_uint4(0, 0, 0, 0);
+        E.pm_zeroed = true;
+    }
+    // table windows around the counts the env state carries (Env::w0): requested now, read by lane index after the beams / the spawn
+    E.w0 = E.a0 = -1; E.pf_pa = E.pf_pw = 0.0; E.pf_den = 0.f;
+    double harvest_p[4] = {0.0, 0.0, 0.0, 0.0};
+    if (MODE == MODE_STEP || MODE == MODE_STEP_OBS) {
+        if (h->kind != SSD_ENV_CLEANUP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) harvest_p[i] = S->harvest_p[i];
+        }
+        if (counts0 != 0xFFFFFFFFu) {
+            if (h->kind == SSD_ENV_CLEANUP) {
+                E.w0 = h->n_waste > 0 ? (int)(counts0 >> 16) : 0;
+                const int wi = E.w0 - lane;
+                if (wi >= 0 && wi <= SSD_MAX_SITES) { E.pf_pa = S->tab_p_apple[wi]; E.pf_pw = S->tab_p_waste[wi]; }
+            }
+            E.a0 = (int)(counts0 & 0xFFFFu);
+            const int ai = E.a0 - 8 + lane;
+            if (ai >= 0 && ai <= h->HW) E.pf_den = S->tab_den[ai];
+        }
+    }
 
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
@@ -927,8 +989,12 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
         wsync();
         int n_waste_cells = h->kind == SSD_ENV_CLEANUP ? h->n_waste : 0;       // custom_reset: all waste present / all apples grown
         int n_apple_cells = h->kind == SSD_ENV_CLEANUP ? 0 : h->n_apple;
+        if (h->kind != SSD_ENV_CLEANUP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) harvest_p[i] = S->harvest_p[i];
+        }
         n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste, n_waste_cells, n_apple_cells)
-                                             : spawn_harvest(E, R, n_apple_cells);                        // map_env.py:313
+                                             : spawn_harvest(E, R, n_apple_cells, harvest_p);             // map_env.py:313
         ep_r = 0;
         if (lane == 0) {
             st.counts[env] = ((uint32_t)n_waste_cells << 16) | (uint32_t)n_apple_cells;
@@ -974,12 +1040,14 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
         }
         STAMP(4);
         n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste, n_waste_cells, n_apple_cells)
-                                             : spawn_harvest(E, R, n_apple_cells);                        // map_env.py:263
+                                             : spawn_harvest(E, R, n_apple_cells, harvest_p);             // map_env.py:263
         STAMP(5);
         // scalars (map_env.py:291-292, 883-914).  After the consume loop no agent stands on an apple and nothing spawns
         // under an agent, so the apples visible in map_with_agents are all apples of the grid.
         const int apples = n_apple_cells;
-        const float den = S->tab_den[apples];                     // host-tabulated fp64 quotient for every count 0..H*W (imported grids too)
+        // host-tabulated fp64 quotient for every count 0..H*W (imported grids too): from the window requested with the state loads
+        const int dslot = apples - E.a0 + 8;                      // (wave-uniform)
+        const float den = (E.a0 >= 0 && (unsigned)dslot < (unsigned)kWave) ? __int_as_float(rl(__float_as_int(E.pf_den), dslot)) : S->tab_den[apples];
         ep_r += reward;
         const int step = ep_step0 + 1;
         const bool term = step >= h->episode_limit;
