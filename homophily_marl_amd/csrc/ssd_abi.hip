@@ -107,9 +107,14 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
                 pa = one_minus * S.p_apple;
             }
         }
-        S.tab_p_apple[current] = pa; S.tab_p_waste[current] = pw;
+        S.tab_p[current][0] = pa; S.tab_p[current][1] = pw;
     }
     for (int a = 0; a <= SSD_MAX_CELLS; ++a) S.tab_den[a] = (float)((double)a / (double)S.HW);
+    for (int l = 0; l < 64; ++l)
+        for (int ch = 0; ch < 4; ++ch) {
+            S.site_t[l][ch] = ch * 64 + l < S.n_apple ? S.apple[ch * 64 + l] : (uint16_t)0;
+            S.site_t[l][4 + ch] = ch * 64 + l < S.n_waste ? S.waste[ch * 64 + l] : (uint16_t)0;
+        }
     E->n_spawn = (int)spawn.size();
     S.random_spawn = cfg->random_spawn_point ? 1 : 0; S.n_spawn = (int)spawn.size();
     S.spawn_len = (S.kind == SSD_ENV_CLEANUP ? 2 : 1) * S.n_spawn;   // Cleanup's constructor appends every point again (cleanup.py:79-80)
@@ -149,21 +154,18 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
     const size_t N = (size_t)S.N, n = (size_t)S.n;
     if (e == hipSuccess) e = hipMalloc((void**)&E->dspec, sizeof(DevSpec));
     if (e == hipSuccess) e = hipMalloc((void**)&E->st.grid, N * S.GS);
-    if (e == hipSuccess) e = hipMalloc((void**)&E->st.arec, N * n * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&E->st.ep_reward, N * n * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&E->st.ep_step, N * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&E->st.epoch, N * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&E->st.agents, N * n * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&E->st.hdr, N * sizeof(ssd::EnvHdr));
     if (e == hipSuccess) e = hipMalloc((void**)&E->st.err, 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&E->st.rng_base, N * 16);
-    if (e == hipSuccess) e = hipMemset(E->st.rng_base, 0, N * 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&E->st.counts, N * 4);
-    if (e == hipSuccess) e = hipMemset(E->st.counts, 0xFF, N * 4);
     if (e == hipSuccess) e = hipMemcpy(E->dspec, &S, sizeof(DevSpec), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(E->st.grid, 0, N * S.GS);
-    if (e == hipSuccess) e = hipMemset(E->st.arec, 0, N * n * 4);
-    if (e == hipSuccess) e = hipMemset(E->st.ep_reward, 0, N * n * 4);
-    if (e == hipSuccess) e = hipMemset(E->st.ep_step, 0, N * 4);
-    if (e == hipSuccess) e = hipMemset(E->st.epoch, 0, N * 4);
+    if (e == hipSuccess) e = hipMemset(E->st.agents, 0, N * n * 8);
+    if (e == hipSuccess) {      // counts unknown (recount at the first step), everything else 0
+        std::vector<ssd::EnvHdr> hz(N);
+        memset(hz.data(), 0, N * sizeof(ssd::EnvHdr));
+        for (size_t i = 0; i < N; ++i) hz[i].counts = 0xFFFFFFFFu;
+        e = hipMemcpy(E->st.hdr, hz.data(), N * sizeof(ssd::EnvHdr), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemset(E->st.err, 0, 4);
     if (e == hipSuccess && !numeric_err_word()) e = hipErrorOutOfMemory;      // exists before anything captures a graph
     if (e == hipSuccess && !bmm_scratch(nullptr)) e = hipErrorOutOfMemory;           // (the affine layers' backward scratch: same reason)
@@ -178,10 +180,13 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
             rec[a] = r | (c << 8) | ((uint32_t)(S.spawn_rotation < 0 ? 0 : S.spawn_rotation) << 16);
         }
         std::vector<uint8_t> gall(N * S.GS);
-        std::vector<uint32_t> rall(N * n);
-        for (size_t i = 0; i < N; ++i) { std::memcpy(&gall[i * S.GS], g.data(), (size_t)S.GS); std::memcpy(&rall[i * n], rec.data(), n * 4); }
+        std::vector<uint32_t> rall(N * n * 2, 0u);      // {arec, episode reward = 0}
+        for (size_t i = 0; i < N; ++i) {
+            std::memcpy(&gall[i * S.GS], g.data(), (size_t)S.GS);
+            for (size_t a = 0; a < n; ++a) rall[(i * n + a) * 2] = rec[a];
+        }
         e = hipMemcpy(E->st.grid, gall.data(), gall.size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(E->st.arec, rall.data(), rall.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(E->st.agents, rall.data(), rall.size() * 4, hipMemcpyHostToDevice);
     }
     (void)hipSetDevice(prev);
     if (e != hipSuccess) {
@@ -195,8 +200,7 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
 
 int ssd_destroy(ssd_env* E) {
     if (!E) return SSD_OK;
-    (void)hipFree(E->dspec); (void)hipFree(E->st.grid); (void)hipFree(E->st.arec); (void)hipFree(E->st.ep_reward);
-    (void)hipFree(E->st.ep_step); (void)hipFree(E->st.epoch); (void)hipFree(E->st.err); (void)hipFree(E->st.counts); (void)hipFree(E->st.rng_base);
+    (void)hipFree(E->dspec); (void)hipFree(E->st.grid); (void)hipFree(E->st.agents); (void)hipFree(E->st.hdr); (void)hipFree(E->st.err);
     delete E;
     return SSD_OK;
 }
@@ -305,7 +309,7 @@ int ssd_step_observe(ssd_env* E, const int32_t* actions, const ssd_tape* tape, s
 }
 
 #ifdef SSD_STAMPS
-// diagnostic build only: device buffer [n_env, 16] of u64 receiving the phase stamps
+// diagnostic build only: device buffer [n_env, 32] of u64 receiving the phase stamps
 int ssd_debug_set_stamps(ssd_env* E, unsigned long long* buf) { E->st.stamps = buf; return SSD_OK; }
 int ssd_debug_set_policy_stamps(unsigned long long* buf) { ssd::set_policy_stamps(buf); return SSD_OK; }
 #endif

@@ -39,11 +39,13 @@ struct DevSpec : DevHead {
     double harvest_p[4];
     // compute_probabilities (cleanup.py:189-204) tabulated on the host by the number of waste cells on the map: the
     // same fp64 expression evaluated once per possible count (-ffp-contract=off), so the kernel needs no fp64 division
-    double tab_p_apple[SSD_MAX_SITES + 1];
-    double tab_p_waste[SSD_MAX_SITES + 1];
+    alignas(16) double tab_p[SSD_MAX_SITES + 1][2];   // {p_apple, p_waste}: one 16-byte read
     float tab_den[SSD_MAX_CELLS + 1];    // apple_den = (float)(apples / (H * W)) in fp64 (map_env.py:291-292) by the apple count (0..H*W)
     uint16_t apple[SSD_MAX_SITES];       // cell index of each apple site, row-major scan order
     uint16_t waste[SSD_MAX_SITES];
+    // the same lists as the step kernel's lanes hold them: record l = {apple[l], apple[64 + l], .., waste[l], waste[64 + l], ..}
+    // (0 past the end of a list), so that a wave fetches its eight site cells per lane with ONE 16-byte request instead of eight
+    alignas(16) uint16_t site_t[64][8];
     uint16_t spawn_cell[SSD_MAX_AGENTS]; // spawn cell of agent a under random_spawn_point = False
     uint16_t spawn_all[SSD_MAX_SPAWN];   // every spawn cell in row-major order (random_spawn_point = True)
     alignas(16) uint8_t reset_grid[SSD_MAX_CELLS];   // world after reset_map + custom_reset
@@ -51,16 +53,20 @@ struct DevSpec : DevHead {
 };
 
 // Mutable per-env state (device pointers).  arec packs one agent into 32 bits: row | col << 8 | orient << 16.
+// One env's counters, 32 bytes: a wave reads them with ONE request (lanes 0 and 1, 16 bytes each) instead of four.
+struct EnvHdr {
+    uint32_t rng_base[4];  // Philox base words of the current episode (COUNTER mode), written by reset / import
+    uint32_t epoch;        // resets so far
+    int32_t ep_step;       // steps since the last reset
+    uint32_t counts;       // waste cells << 16 | apple cells of the grid, 0xFFFFFFFF = unknown (recount)
+    uint32_t pad;
+};
 struct DevState {
     uint8_t* grid;       // [N, GS]
-    uint32_t* arec;      // [N, n]
-    int32_t* ep_reward;  // [N, n]
-    int32_t* ep_step;    // [N]
-    uint32_t* epoch;     // [N]
-    uint4* rng_base;     // [N] Philox base words of the current episode (COUNTER mode), written by reset / import
-    uint32_t* counts;    // [N] waste cells << 16 | apple cells of the grid, 0xFFFFFFFF = unknown (recount)
+    uint2* agents;       // [N, n] {arec, episode reward}
+    EnvHdr* hdr;         // [N]
     int32_t* err;        // [1] sticky error bits
-    unsigned long long* stamps;  // diagnostic builds only (-DSSD_STAMPS): [N, 16] s_memtime per phase; else null
+    unsigned long long* stamps;  // diagnostic builds only (-DSSD_STAMPS): [N, 32] s_memtime per phase; else null
 };
 
 struct DevTape {

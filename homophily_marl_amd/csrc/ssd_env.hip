@@ -22,22 +22,24 @@ namespace ssd {
 // Diagnostic build (tools/stamps.py, -DSSD_STAMPS): lane 0 records s_memtime at phase boundaries after draining
 // the wave's outstanding memory operations.  In the product build the macros are empty and no stamp executes.
 #ifdef SSD_STAMPS
+// -DSSD_STAMPS=2: wait for the LDS / scalar-memory queue only (vmcnt stays as it is), so that stores in flight are not charged
+// to the phase that issued them -- the timeline of the product build, at the price of phases that no longer add up exactly
 #define STAMP_TO(buf, i)                                                                               \
     do {                                                                                               \
-        __builtin_amdgcn_s_waitcnt(0);                                                                 \
+        __builtin_amdgcn_s_waitcnt(SSD_STAMPS == 2 ? 0xC07F : 0);                                      \
         unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
-        if ((buf) && lane == 0) (buf)[(size_t)env * 16 + (i)] = t_;                                    \
+        if ((buf) && lane == 0) (buf)[(size_t)env * 32 + (i)] = t_;                                    \
     } while (0)
 // slot i <- the chip-wide 100 MHz clock (s_memrealtime: comparable across XCDs, s_memtime is not), slot j <- XCC_ID | HW_ID << 8
 #define STAMP_REAL(buf, i)                                                                             \
     do {                                                                                               \
         unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                      \
-        if ((buf) && lane == 0) (buf)[(size_t)env * 16 + (i)] = t_;                                    \
+        if ((buf) && lane == 0) (buf)[(size_t)env * 32 + (i)] = t_;                                    \
     } while (0)
 #define STAMP_HWID(buf, j)                                                                             \
     do {                                                                                               \
         unsigned x_ = __builtin_amdgcn_s_getreg((3 << 11) | 20), h_ = __builtin_amdgcn_s_getreg((31 << 11) | 4); \
-        if ((buf) && lane == 0) (buf)[(size_t)env * 16 + (j)] = (unsigned long long)x_ | ((unsigned long long)h_ << 8); \
+        if ((buf) && lane == 0) (buf)[(size_t)env * 32 + (j)] = (unsigned long long)x_ | ((unsigned long long)h_ << 8); \
     } while (0)
 #else
 #define STAMP_TO(buf, i) do {} while (0)
@@ -128,6 +130,7 @@ struct Env {
     int w0, a0;
     double pf_pa, pf_pw;
     float pf_den;
+    unsigned long long* stamps; int env;   // diagnostic builds
     bool pm_zeroed;     // the padded class map was cleared with the state loads and nothing wrote to it since
 };
 __device__ __forceinline__ double rl_f64(double v, int idx) {
@@ -339,9 +342,22 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
     const int current = h->n_waste > 0 ? n_waste_cells : 0;    // kept incrementally in the env state
     const int back = E.w0 - current;                           // (wave-uniform)
     const bool pf = E.w0 >= 0 && (unsigned)back < (unsigned)kWave;
-    const double p_apple = pf ? rl_f64(E.pf_pa, back) : S->tab_p_apple[current], p_waste = pf ? rl_f64(E.pf_pw, back) : S->tab_p_waste[current];
+    const double p_apple = pf ? rl_f64(E.pf_pa, back) : S->tab_p[current][0], p_waste = pf ? rl_f64(E.pf_pw, back) : S->tab_p[current][1];
     const uint32_t t_apple = Rng::threshold(p_apple), t_waste = Rng::threshold(p_waste);
     int k = 0;
+    // Every LDS read of the phase first -- the apple sites' overlay and grid bytes and the waste sites' grid bytes, <= 12 reads in ONE
+    // round trip: written per chunk (`occ == 0 && g != 'A'`, then the store of the grown apple) each chunk costs two dependent
+    // trips, and the waste sites' reads cannot move above the apple stores by themselves (byte buffers alias for the compiler).
+    // Apple sites and waste sites are disjoint cells, every site is its own cell and the beams are done, so nothing written below
+    // changes what another read of this phase would have seen.
+    const int nw = h->n_waste;
+    int a_oc[4], a_gc[4], w_gc[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        a_oc[ch] = 1; a_gc[ch] = C_APPLE; w_gc[ch] = C_WASTE;
+        if (ch * kWave < h->n_apple) { a_oc[ch] = E.occ[E.ap[ch]]; a_gc[ch] = E.g[E.ap[ch]]; }
+        if (ch * kWave < nw) w_gc[ch] = E.g[E.ws[ch]];
+    }
     // apples: one draw per site that holds neither an agent nor an apple, in site order (cleanup.py:168-174).
     // Apple sites and waste sites are disjoint, so writing 'A' at once is equivalent to the deferred update_map.
 #pragma unroll
@@ -349,7 +365,7 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
         if (ch * kWave < h->n_apple) {
             const bool in = ch * kWave + lane < h->n_apple;
             const int cell = E.ap[ch];
-            const bool elig = in && E.occ[cell] == 0 && E.g[cell] != C_APPLE;
+            const bool elig = in & (a_oc[ch] == 0) & (a_gc[ch] != C_APPLE);
             const uint64_t bal = ballot(elig);
             bool grow = false;
             if (elig && p_apple > 0) {
@@ -360,9 +376,9 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
             k += popc64(bal);
         }
     }
+    { const int env = E.env; STAMP_TO(E.stamps, 14); }
     // waste: at most one spawn, first free site in shuffled order whose draw succeeds (cleanup.py:177-186)
     if (!(fabs(p_waste) <= 1e-8)) {                           // np.isclose(p, 0)
-        const int nw = h->n_waste;
         uint16_t* scratch = (uint16_t*)E.pm;                  // tape mode: rank of each site in the shuffled list
         if (R.tape) {
             E.pm_zeroed = false;
@@ -384,7 +400,7 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
             best[ch] = ~0u;
             const int s = ch * kWave + lane;
             if (ch * kWave < nw) {
-                const bool fr = s < nw && E.g[E.ws[ch]] != C_WASTE;
+                const bool fr = s < nw && w_gc[ch] != C_WASTE;
                 nfree += popc64(ballot(fr));
                 if (fr) {
                     const uint32_t key = R.tape ? (uint32_t)scratch[s] : (R.u32(SSD_STREAM_WASTE, (uint32_t)s) >> 8);
@@ -401,6 +417,7 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
             if (b) J = base + first_lane(b);
         }
         k += J >= 0 ? J + 1 : nfree;
+        { const int env = E.env; STAMP_TO(E.stamps, 15); }
         if (J >= 0) {
             // the (J+1)-th smallest (key, site) among the free sites
             uint32_t sel = ~0u;
@@ -412,8 +429,8 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
 #pragma unroll
                 for (int ch = 0; ch < 4; ++ch) if (best[ch] == sel) best[ch] = ~0u;
             }
-            const int s = (int)(sel & 0xFFu);
-            if (lane == 0) E.g[S->waste[s]] = C_WASTE;
+            const int s = (int)(sel & 0xFFu), sc = s >> 6;           // site s = chunk sc, lane s & 63: that lane holds its cell
+            if (lane == (s & 63)) E.g[sc == 0 ? E.ws[0] : sc == 1 ? E.ws[1] : sc == 2 ? E.ws[2] : E.ws[3]] = C_WASTE;
             n_waste_cells += 1;
         }
     }
@@ -713,7 +730,7 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
     const DevSpec* S = E.S;
     const DevHead* h = E.h;
     const int lane = E.lane, n = E.n, W = E.W, v = h->v, Wp = h->Wp;
-    uint8_t* lut = E.pl + lds_planes_bytes(*S);  // 48 bytes behind the planes
+    uint8_t* lut = E.pl + lds_planes_bytes(*h);  // 48 bytes behind the planes
     if (FULL) { if (lane < 48) lut[lane] = S->lut[lane]; }
     // pass 0: zero-padded class map, pm[(r + v) * Wp + (c + v)] = class of map cell (r, c); the padding IS
     // return_view's zero padding (utility_funcs.py:93-116), so the window gather needs no bounds test
@@ -816,10 +833,15 @@ struct EnvArgs {
 template <typename T>
 __device__ __forceinline__ T cold_kernarg(int offset) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // A typed read of the constant address space through a pointer the optimizer cannot see through: scalar-memory loads (s_load),
+    // placed here, and pointer members stay pointers (the compiler then knows they are global, not flat).  Read through a CHAR
+    // pointer the copy is an under-aligned access, compiled to VECTOR-memory loads followed by s_waitcnt vmcnt(0): a trip to memory
+    // that also waits for every store the wave has in flight.
     auto p = __builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));                                     // loads through p cannot be hoisted above this point
+    typedef const T __attribute__((address_space(4))) kt;
     T out;
-    __builtin_memcpy(&out, (const char __attribute__((address_space(4)))*)p + offset, sizeof(T));
+    __builtin_memcpy(&out, (kt*)((const char __attribute__((address_space(4)))*)p + offset), sizeof(T));
     return out;
 #else
     return T{};                                                     // host pass of the single-source compile: never called
@@ -838,6 +860,11 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     extern __shared__ uint4 smem[];
     const int lane = threadIdx.x & 63;
     const DevHead* h = &hd;
+    // Every kernel argument the load phase reads, requested in ONE batch with the first one (the compiler fetches by-value arguments
+    // from the kernarg segment where they are first used: seven dependent scalar-memory trips, ~ 1 K cycles each while the
+    // segment is cold, between the wave's start and its last state load otherwise).
+    asm volatile("" :: "s"(h->N), "s"(st.grid), "s"(st.agents), "s"(st.hdr), "s"(actions), "s"(S), "s"(h->GS), "s"(h->PMS), "s"(h->rng_mode),
+                       "s"(h->kind), "s"(h->HW), "s"(h->W), "s"(h->n), "s"(h->n_actions), "s"(h->n_waste), "s"(lds_stride));
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: per-env addresses live in SGPRs
     const int env = blockIdx.x * kWavesPerBlock + wave;
     if (env >= h->N) return;
@@ -862,54 +889,76 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     E.cbuf = E.g + lds_stride - lds_code_bytes(*h);
     E.ag = lane < E.n;
     E.err = st.err;
+    E.stamps = st.stamps; E.env = env;
     const int n = E.n, GS = E.GS;
     STAMP(0);
     STAMP_REAL(st.stamps, 12);
     STAMP_HWID(st.stamps, 11);
 
+    STAMP(16);
     uint8_t* ggrid = st.grid + (size_t)env * GS;
-    // ---- issue every global load up front: grid (or reset image), agents, actions, counters, site lists ----
-    for (int i = lane * 16; i < GS; i += kWave * 16) {
-        *(uint4*)(E.g + i) = MODE == MODE_RESET ? *(const uint4*)(S->reset_grid + i) : *(const uint4*)(ggrid + i);
-        *(uint4*)(E.occ + i) = make_uint4(0, 0, 0, 0);
+    // ---- issue every global load up front: counters + generator base, agents, actions, grid (or reset image), site lists ----
+    // The loads land in registers and are consumed only after the last one was requested: written as `LDS[i] = global[i]` (or
+    // with the counters decoded where they are loaded) the compiler waits for each group before it requests the next one --
+    // four dependent trips to memory at the head of every wave's chain instead of one.  And FEW requests: the sixteen waves of a
+    // CU arrive here together, and the CU's address unit takes >= 4 cycles per wave and request (16 for 16-byte ones): the env's
+    // counters are one 32-byte record (lanes 0 / 1), an agent's two words one 8-byte record, a lane's eight site cells one
+    // 16-byte record (DevSpec::site_t) -- 7 requests per wave where the separate arrays took 20.
+    const bool tape_mode = h->rng_mode == SSD_RNG_TAPE;
+    uint4 hv = make_uint4(0, 0, 0, 0);
+    if (lane < 2) hv = ((const uint4*)(st.hdr + env))[lane];
+    uint2 ar = make_uint2(0u, 0u);
+    int act = 4;
+    if (E.ag && MODE != MODE_RESET) ar = st.agents[(size_t)env * n + lane];
+    if (E.ag && (MODE == MODE_STEP || MODE == MODE_STEP_OBS)) act = actions[(size_t)env * n + lane];
+    uint4 gv = make_uint4(0, 0, 0, 0);                           // GS <= SSD_MAX_CELLS = 64 lanes x 16 bytes: one vector per lane
+    if (lane * 16 < GS) gv = MODE == MODE_RESET ? *(const uint4*)(S->reset_grid + lane * 16) : *(const uint4*)(ggrid + lane * 16);
+    if (MODE != MODE_OBS) {
+        const uint4 sv = *(const uint4*)S->site_t[lane];
+        E.ap[0] = (int)(sv.x & 0xFFFFu); E.ap[1] = (int)(sv.x >> 16); E.ap[2] = (int)(sv.y & 0xFFFFu); E.ap[3] = (int)(sv.y >> 16);
+        E.ws[0] = (int)(sv.z & 0xFFFFu); E.ws[1] = (int)(sv.z >> 16); E.ws[2] = (int)(sv.w & 0xFFFFu); E.ws[3] = (int)(sv.w >> 16);
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) E.ap[ch] = E.ws[ch] = 0;
     }
-    const uint32_t epoch = st.epoch[env];
-    const int ep_step0 = MODE == MODE_RESET ? 0 : st.ep_step[env];
-    const uint32_t counts0 = (MODE == MODE_STEP || MODE == MODE_STEP_OBS) ? st.counts[env] : 0u;
-    E.obs_slot = MODE == MODE_STEP_OBS ? ep_step0 + 1 : ep_step0;
-    // the observation's padded class map is cleared here, under the state loads (tape-mode spawns use it as scratch and say so)
+    double harvest_p[4] = {0.0, 0.0, 0.0, 0.0};
+    if (MODE != MODE_OBS && h->kind != SSD_ENV_CLEANUP) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) harvest_p[i] = S->harvest_p[i];
+    }
+    // LDS clears under the loads: the agent overlay, and the observation's padded class map (tape-mode spawns use that one as
+    // scratch and say so)
+    for (int i = lane * 16; i < GS; i += kWave * 16) *(uint4*)(E.occ + i) = make_uint4(0, 0, 0, 0);
     E.pm_zeroed = false;
     if (MODE == MODE_STEP_OBS || MODE == MODE_OBS) {
         for (int i = lane * 16; i < h->PMS; i += kWave * 16) *(uint4*)(E.pm + i) = make_uint4(0, 0, 0, 0);
         E.pm_zeroed = true;
     }
-    // table windows around the counts the env state carries (Env::w0): requested now, read by lane index after the beams / the spawn
+    STAMP(17);
+    // ---- second level: table windows around the counts the env state carries (Env::w0), read by lane index after the beams / spawn ----
+    const uint32_t epoch = (uint32_t)__builtin_amdgcn_readlane((int)hv.x, 1);
+    const int ep_step0 = MODE == MODE_RESET ? 0 : __builtin_amdgcn_readlane((int)hv.y, 1);
+    const uint32_t counts0 = (MODE == MODE_STEP || MODE == MODE_STEP_OBS) ? (uint32_t)__builtin_amdgcn_readlane((int)hv.z, 1) : 0u;
+    int ep_r = (int)ar.y;
+    const uint32_t rec_v = ar.x;
+    E.obs_slot = MODE == MODE_STEP_OBS ? ep_step0 + 1 : ep_step0;
     E.w0 = E.a0 = -1; E.pf_pa = E.pf_pw = 0.0; E.pf_den = 0.f;
-    double harvest_p[4] = {0.0, 0.0, 0.0, 0.0};
-    if (MODE == MODE_STEP || MODE == MODE_STEP_OBS) {
-        if (h->kind != SSD_ENV_CLEANUP) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) harvest_p[i] = S->harvest_p[i];
+    if ((MODE == MODE_STEP || MODE == MODE_STEP_OBS) && counts0 != 0xFFFFFFFFu) {
+        if (h->kind == SSD_ENV_CLEANUP) {
+            E.w0 = h->n_waste > 0 ? (int)(counts0 >> 16) : 0;
+            const int wi = E.w0 - lane;
+            if (wi >= 0 && wi <= SSD_MAX_SITES) { const double2 pp = *(const double2*)S->tab_p[wi]; E.pf_pa = pp.x; E.pf_pw = pp.y; }
         }
-        if (counts0 != 0xFFFFFFFFu) {
-            if (h->kind == SSD_ENV_CLEANUP) {
-                E.w0 = h->n_waste > 0 ? (int)(counts0 >> 16) : 0;
-                const int wi = E.w0 - lane;
-                if (wi >= 0 && wi <= SSD_MAX_SITES) { E.pf_pa = S->tab_p_apple[wi]; E.pf_pw = S->tab_p_waste[wi]; }
-            }
-            E.a0 = (int)(counts0 & 0xFFFFu);
-            const int ai = E.a0 - 8 + lane;
-            if (ai >= 0 && ai <= h->HW) E.pf_den = S->tab_den[ai];
-        }
+        E.a0 = (int)(counts0 & 0xFFFFu);
+        const int ai = E.a0 - 8 + lane;
+        if (ai >= 0 && ai <= h->HW) E.pf_den = S->tab_den[ai];
     }
+    // ---- consume ----
+    if (lane * 16 < GS) *(uint4*)(E.g + lane * 16) = gv;
+    STAMP(18);
 
-#pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-        E.ap[ch] = (MODE != MODE_OBS && ch * kWave + lane < h->n_apple) ? S->apple[ch * kWave + lane] : 0;
-        E.ws[ch] = (MODE != MODE_OBS && ch * kWave + lane < h->n_waste) ? S->waste[ch * kWave + lane] : 0;
-    }
     Rng R;
-    R.tape = h->rng_mode == SSD_RNG_TAPE;
+    R.tape = tape_mode;
     R.ustride = tape.ustride;
     R.tape_u = R.tape ? tape.uniforms + (size_t)env * tape.ustride : nullptr;
     R.err = st.err;
@@ -917,17 +966,15 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     if (MODE == MODE_RESET && !R.tape) {
         // a new episode: derive its Philox base (once per episode, scalar unit) and keep it in the env state
         philox4(0u, 0u, h->env_id_base + (uint32_t)env, epoch + 1u, h->seed_lo, h->seed_hi, R.b);
-        if (lane == 0) st.rng_base[env] = make_uint4(R.b[0], R.b[1], R.b[2], R.b[3]);
+        if (lane == 0) *(uint4*)st.hdr[env].rng_base = make_uint4(R.b[0], R.b[1], R.b[2], R.b[3]);
     } else if ((MODE == MODE_STEP || MODE == MODE_STEP_OBS) && !R.tape) {
-        const uint4 bw = st.rng_base[env];
         const uint32_t call = ((uint32_t)(ep_step0 + 1)) << 16;      // call index inside the episode (reset = 0)
-        R.b[0] = __builtin_amdgcn_readfirstlane(bw.x) ^ call; R.b[1] = __builtin_amdgcn_readfirstlane(bw.y) ^ call;
-        R.b[2] = __builtin_amdgcn_readfirstlane(bw.z) ^ call; R.b[3] = __builtin_amdgcn_readfirstlane(bw.w) ^ call;
+        R.b[0] = __builtin_amdgcn_readfirstlane(hv.x) ^ call; R.b[1] = __builtin_amdgcn_readfirstlane(hv.y) ^ call;
+        R.b[2] = __builtin_amdgcn_readfirstlane(hv.z) ^ call; R.b[3] = __builtin_amdgcn_readfirstlane(hv.w) ^ call;
     }
     const uint8_t* tape_order = tape.move_order ? tape.move_order + (size_t)env * n : nullptr;
     const uint8_t* tape_waste = tape.waste_order ? tape.waste_order + (size_t)env * h->n_waste : nullptr;
 
-    int act = 4, ep_r = 0;
     int spawn_p = 0;
     if (MODE == MODE_RESET && h->random_spawn) {
         // random_spawn_point: every agent's spawn_point() first shuffles the spawn list (map_env.py:776-777), then takes the LAST
@@ -968,13 +1015,10 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
             else if (R.tape) E.O = tape.spawn_rot[(size_t)env * n + lane] & 3;
             else E.O = (int)(R.u32(SSD_STREAM_SPAWN_ROT, (uint32_t)lane) >> 30);
         } else {
-            const uint32_t rec = st.arec[(size_t)env * n + lane];
-            E.P = (int)(rec & 0xFF) * E.W + (int)((rec >> 8) & 0xFF);
-            E.O = (int)((rec >> 16) & 3);
-            ep_r = st.ep_reward[(size_t)env * n + lane];
+            E.P = (int)(rec_v & 0xFF) * E.W + (int)((rec_v >> 8) & 0xFF);
+            E.O = (int)((rec_v >> 16) & 3);
         }
         if (MODE == MODE_STEP || MODE == MODE_STEP_OBS) {
-            act = actions[(size_t)env * n + lane];
             if ((unsigned)act >= (unsigned)h->n_actions) { atomicOr(st.err, ERR_BAD_ACTION); act = 4; }  // KeyError in action_map
         }
     } else {
@@ -989,16 +1033,11 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
         wsync();
         int n_waste_cells = h->kind == SSD_ENV_CLEANUP ? h->n_waste : 0;       // custom_reset: all waste present / all apples grown
         int n_apple_cells = h->kind == SSD_ENV_CLEANUP ? 0 : h->n_apple;
-        if (h->kind != SSD_ENV_CLEANUP) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) harvest_p[i] = S->harvest_p[i];
-        }
         n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste, n_waste_cells, n_apple_cells)
                                              : spawn_harvest(E, R, n_apple_cells, harvest_p);             // map_env.py:313
         ep_r = 0;
         if (lane == 0) {
-            st.counts[env] = ((uint32_t)n_waste_cells << 16) | (uint32_t)n_apple_cells;
-            st.ep_step[env] = 0; st.epoch[env] = epoch + 1;
+            *(uint4*)&st.hdr[env].epoch = make_uint4(epoch + 1, 0u, ((uint32_t)n_waste_cells << 16) | (uint32_t)n_apple_cells, 0u);
             int32_t* nd = cold_kernarg<int32_t*>((int)(offsetof(EnvArgs, so) + offsetof(DevStepOut, n_draws)));
             if (nd) nd[env] = n_draws;
             if (R.tape && n_draws > R.ustride) atomicOr(st.err, ERR_TAPE_OVERRUN);
@@ -1047,11 +1086,16 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
         const int apples = n_apple_cells;
         // host-tabulated fp64 quotient for every count 0..H*W (imported grids too): from the window requested with the state loads
         const int dslot = apples - E.a0 + 8;                      // (wave-uniform)
-        const float den = (E.a0 >= 0 && (unsigned)dslot < (unsigned)kWave) ? __int_as_float(rl(__float_as_int(E.pf_den), dslot)) : S->tab_den[apples];
+        // (outside the window: the same correctly rounded fp64 quotient computed here -- NOT a load: a load that may be pending makes
+        // every later use of its register wait for vmcnt(0), i.e. for all the stores of this phase)
+        const float den = (E.a0 >= 0 && (unsigned)dslot < (unsigned)kWave) ? __int_as_float(rl(__float_as_int(E.pf_den), dslot))
+                                                                          : (float)((double)apples / (double)E.HW);
         ep_r += reward;
         const int step = ep_step0 + 1;
         const bool term = step >= h->episode_limit;
+        STAMP(19);
         const DevStepOut so = cold_kernarg<DevStepOut>((int)offsetof(EnvArgs, so));
+        STAMP(20);
         if (E.ag) {
             const size_t o = (size_t)env * n + lane;
             if (so.reward) so.reward[o] = (float)reward;
@@ -1069,8 +1113,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
             if (lane == 0) { if (so.collective) so.collective[env] = (float)sum; if (so.equality) so.equality[env] = (float)eq; }
         }
         if (lane == 0) {
-            st.counts[env] = ((uint32_t)n_waste_cells << 16) | (uint32_t)n_apple_cells;
-            st.ep_step[env] = step;
+            *(uint4*)&st.hdr[env].epoch = make_uint4(epoch, (uint32_t)step, ((uint32_t)n_waste_cells << 16) | (uint32_t)n_apple_cells, 0u);
             if (so.terminated) so.terminated[env] = term ? 1 : 0;
             if (so.n_draws) so.n_draws[env] = n_draws;
             if (R.tape && n_draws > R.ustride) atomicOr(st.err, ERR_TAPE_OVERRUN);
@@ -1089,8 +1132,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
         for (int i = lane * 16; i < GS; i += kWave * 16) *(uint4*)(ggrid + i) = *(const uint4*)(E.g + i);
         if (E.ag) {
             const int pr = (int)udiv((uint32_t)E.P, h->magic_W), pc = E.P - pr * E.W;
-            st.arec[(size_t)env * n + lane] = (uint32_t)pr | ((uint32_t)pc << 8) | ((uint32_t)E.O << 16);
-            st.ep_reward[(size_t)env * n + lane] = ep_r;
+            st.agents[(size_t)env * n + lane] = make_uint2((uint32_t)pr | ((uint32_t)pc << 8) | ((uint32_t)E.O << 16), (uint32_t)ep_r);
         }
     }
     STAMP(7);
@@ -1142,14 +1184,15 @@ __global__ void k_export(DevSpec const* S, DevState st, ssd_state d) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
     if (d.grid) for (size_t i = tid; i < (size_t)N * HW; i += nt) { size_t e = i / HW; d.grid[i] = st.grid[e * GS + (i - e * HW)]; }
     for (size_t i = tid; i < (size_t)N * n; i += nt) {
-        const uint32_t rec = st.arec[i];
+        const uint2 ar = st.agents[i];
+        const uint32_t rec = ar.x;
         if (d.pos) { d.pos[2 * i] = (int16_t)(rec & 0xFF); d.pos[2 * i + 1] = (int16_t)((rec >> 8) & 0xFF); }
         if (d.orient) d.orient[i] = (uint8_t)((rec >> 16) & 3);
-        if (d.ep_reward) d.ep_reward[i] = st.ep_reward[i];
+        if (d.ep_reward) d.ep_reward[i] = (int32_t)ar.y;
     }
     for (size_t i = tid; i < (size_t)N; i += nt) {
-        if (d.ep_step) d.ep_step[i] = st.ep_step[i];
-        if (d.epoch) d.epoch[i] = st.epoch[i];
+        if (d.ep_step) d.ep_step[i] = st.hdr[i].ep_step;
+        if (d.epoch) d.epoch[i] = st.hdr[i].epoch;
     }
 }
 
@@ -1163,25 +1206,25 @@ __global__ void k_import(DevSpec const* S, DevState st, ssd_state s) {
         st.grid[e * GS + (i - e * HW)] = c <= C_STREAM ? c : (uint8_t)C_EMPTY;
     }
     for (size_t i = tid; i < (size_t)N * n; i += nt) {
-        uint32_t rec = st.arec[i];
+        uint2 ar = st.agents[i];
+        uint32_t rec = ar.x;
         if (s.pos) {
             int r = s.pos[2 * i], c = s.pos[2 * i + 1];
             r = r < 0 ? 0 : r >= h->H ? h->H - 1 : r; c = c < 0 ? 0 : c >= h->W ? h->W - 1 : c;
             rec = (rec & ~0xFFFFu) | (uint32_t)r | ((uint32_t)c << 8);
         }
         if (s.orient) rec = (rec & ~0x30000u) | ((uint32_t)(s.orient[i] & 3) << 16);
-        st.arec[i] = rec;
-        if (s.ep_reward) st.ep_reward[i] = s.ep_reward[i];
+        ar.x = rec;
+        if (s.ep_reward) ar.y = (uint32_t)s.ep_reward[i];
+        st.agents[i] = ar;
     }
     for (size_t i = tid; i < (size_t)N; i += nt) {
-        if (s.ep_step) st.ep_step[i] = s.ep_step[i];
+        if (s.ep_step) st.hdr[i].ep_step = s.ep_step[i];
         if (s.epoch) {
-            st.epoch[i] = s.epoch[i];
-            uint32_t b[4];
-            philox4(0u, 0u, h->env_id_base + (uint32_t)i, s.epoch[i], h->seed_lo, h->seed_hi, b);
-            st.rng_base[i] = make_uint4(b[0], b[1], b[2], b[3]);
+            st.hdr[i].epoch = s.epoch[i];
+            philox4(0u, 0u, h->env_id_base + (uint32_t)i, s.epoch[i], h->seed_lo, h->seed_hi, st.hdr[i].rng_base);
         }
-        if (s.grid || s.pos) st.counts[i] = 0xFFFFFFFFu;   // imported grid / agents: recount at the next step
+        if (s.grid || s.pos) st.hdr[i].counts = 0xFFFFFFFFu;   // imported grid / agents: recount at the next step
     }
 }
 

@@ -16,11 +16,13 @@ ap.add_argument("--n-env", type=int, default=4096)
 ap.add_argument("--mode", default="step_observe")
 ap.add_argument("--dest", default="dense", choices=["dense", "storage"])
 ap.add_argument("--fmt", default="f32", choices=["f32", "code"], help="observation format: f32 planes (format R) or u8 class codes (format C, the rollout's)")
+ap.add_argument("--env-kind", default="cleanup")
+ap.add_argument("--light", action="store_true", help="stamps wait for the LDS / scalar queue only, not for loads and stores in flight (-DSSD_STAMPS=2)")
 a = ap.parse_args()
 out = os.path.join(ROOT, "gpurun_out", "libssd_hip_stamps.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 srcs = [os.path.join(G.CSRC, s) for s in G.HIP_SOURCES]
-subprocess.check_call(["/opt/rocm/bin/hipcc"] + G.HIPCC_FLAGS + ["-DSSD_STAMPS", "-o", out] + srcs)
+subprocess.check_call(["/opt/rocm/bin/hipcc"] + G.HIPCC_FLAGS + ["-DSSD_STAMPS=%d" % (2 if a.light else 1), "-o", out] + srcs)
 os.environ["SSD_HIP_LIB_PATH"] = out
 import torch  # noqa: E402
 from homophily_marl_amd import abi  # noqa: E402
@@ -28,7 +30,7 @@ from homophily_marl_amd.envs.native import NativeEnv  # noqa: E402
 
 N, n = a.n_env, 5
 env = NativeEnv("cleanup", device=0, map="default5", num_agents=n, n_env=N, view_size=7, episode_limit=100, rng_mode=abi.RNG_COUNTER, seed=1)
-stamps = torch.zeros(N, 16, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(N, 32, dtype=torch.int64, device="cuda")
 env.lib.ssd_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
 env.lib.ssd_debug_set_stamps(env.h, stamps.data_ptr())
 avail = torch.tensor([0, 1, 2, 3, 4, 8], dtype=torch.int32, device="cuda")
@@ -57,6 +59,14 @@ for i, nm in enumerate(names):
     x = d[..., i].flatten()
     print("  %-14s %8.0f %8.0f" % (nm, x.median().item(), x.quantile(0.9).item()))
 print("  %-14s %8.0f %8.0f" % ("total", tot.flatten().median().item(), tot.flatten().quantile(0.9).item()))
+for nm, x in (("load: kernel arguments", s[..., 16] - s[..., 0]), ("load: requests issued", s[..., 17] - s[..., 16]), ("load: counters landed, windows requested, grid in LDS", s[..., 18] - s[..., 17]),
+              ("load: rest", s[..., 1] - s[..., 18]), ("scalars: table look-up", s[..., 19] - s[..., 5]), ("scalars: output pointers", s[..., 20] - s[..., 19]), ("scalars: stores", s[..., 6] - s[..., 20])):
+    x = x.flatten()
+    print("  %-54s %8.0f %8.0f" % (nm, x.median().item(), x.quantile(0.9).item()))
+if a.env_kind == "cleanup":
+    for nm, x in (("spawn: apples", s[..., 14] - s[..., 4]), ("spawn: waste keys + J", s[..., 15] - s[..., 14]), ("spawn: selection", s[..., 5] - s[..., 15])):
+        x = x.flatten()
+        print("  %-22s %8.0f %8.0f" % (nm, x.median().item(), x.quantile(0.9).item()))
 
 # timeline of ONE launch on the chip-wide 100 MHz clock (10 ns ticks): when do waves start (dispatch ramp) and end (tail)?
 one = acc[-1].cpu()
