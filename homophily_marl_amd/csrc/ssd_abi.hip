@@ -37,6 +37,9 @@ extern "C" {
 int ssd_abi_version(void) { return SSD_ABI_VERSION; }
 const char* ssd_last_error(void) { return g_err; }
 
+// `u < p` for the COUNTER-mode draw u = m * 2^-24 (24-bit integer m): p * 2^24 is an exact fp64 scaling, so u < p  <=>  m < ceil(p * 2^24)
+static uint32_t draw_threshold(double p) { return p >= 1.0 ? (1u << 24) : !(p > 0.0) ? 0u : (uint32_t)std::ceil(p * 16777216.0); }
+
 int ssd_create(const ssd_config* cfg, ssd_env** out) {
     if (!cfg || !out || !cfg->ascii_map) return fail(SSD_ERR_INVALID, "null argument");
     if (cfg->n_agents < 1 || cfg->n_agents > SSD_MAX_AGENTS) return fail(SSD_ERR_INVALID, "n_agents out of range (1..10)");
@@ -68,7 +71,7 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
     S.magic_W = magic(S.W); S.magic_V = magic(S.V); S.magic_VV = magic(S.VV); S.magic_3VV = magic(3 * S.VV); S.magic_HW = magic(S.HW);
     S.thr_dep = cfg->threshold_depletion; S.thr_res = cfg->threshold_restoration;
     S.p_waste = cfg->waste_spawn_prob; S.p_apple = cfg->apple_respawn_prob;
-    for (int i = 0; i < 4; ++i) S.harvest_p[i] = cfg->harvest_spawn_prob[i];
+    for (int i = 0; i < 4; ++i) { S.harvest_p[i] = cfg->harvest_spawn_prob[i]; S.harvest_thr[i] = draw_threshold(S.harvest_p[i]); }
     if ((long)S.n * 3 * S.VV >= 65536) { delete E; return fail(SSD_ERR_INVALID, "n_agents * 3 * V * V must stay below 65536"); }
 
     // Row-major scan of the layout (map_env.py:143-148, cleanup.py:77-90, harvest.py:31-35).
@@ -108,6 +111,10 @@ int ssd_create(const ssd_config* cfg, ssd_env** out) {
             }
         }
         S.tab_p[current][0] = pa; S.tab_p[current][1] = pw;
+        const double pa_ = pa, pw_ = pw;
+        S.tab_thr[current][0] = draw_threshold(pa_); S.tab_thr[current][1] = draw_threshold(pw_);
+        S.tab_thr[current][2] = (pa_ > 0 ? 1u : 0u) | (!(std::fabs(pw_) <= 1e-8) ? 2u : 0u);
+        S.tab_thr[current][3] = 0;
     }
     for (int a = 0; a <= SSD_MAX_CELLS; ++a) S.tab_den[a] = (float)((double)a / (double)S.HW);
     for (int l = 0; l < 64; ++l)

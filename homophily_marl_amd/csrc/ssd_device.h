@@ -39,7 +39,11 @@ struct DevSpec : DevHead {
     double harvest_p[4];
     // compute_probabilities (cleanup.py:189-204) tabulated on the host by the number of waste cells on the map: the
     // same fp64 expression evaluated once per possible count (-ffp-contract=off), so the kernel needs no fp64 division
-    alignas(16) double tab_p[SSD_MAX_SITES + 1][2];   // {p_apple, p_waste}: one 16-byte read
+    alignas(16) double tab_p[SSD_MAX_SITES + 1][2];   // {p_apple, p_waste}: one 16-byte read (TAPE mode compares recorded doubles)
+    // COUNTER mode compares 24-bit integers (Rng::threshold): {threshold(p_apple), threshold(p_waste), flags, 0} with
+    // flags bit 0 = p_apple > 0, bit 1 = not np.isclose(p_waste, 0) -- the kernel then needs no fp64 instruction at all
+    alignas(16) uint32_t tab_thr[SSD_MAX_SITES + 1][4];
+    uint32_t harvest_thr[4];
     float tab_den[SSD_MAX_CELLS + 1];    // apple_den = (float)(apples / (H * W)) in fp64 (map_env.py:291-292) by the apple count (0..H*W)
     uint16_t apple[SSD_MAX_SITES];       // cell index of each apple site, row-major scan order
     uint16_t waste[SSD_MAX_SITES];
@@ -109,10 +113,15 @@ __host__ __device__ inline int lds_planes_bytes(const DevHead& s) { return ((s.n
 // (+ one agent's class-code window, V * V rounded up to 16, + 16 for the dump byte of idle lanes: the obs_code side output)
 __host__ __device__ inline bool lds_code_all(const DevHead& s) { return s.n * SSD_CODE_AGENT_STRIDE(s.V) <= 2560; }   // all agents' windows fit
 __host__ __device__ inline int lds_code_bytes(const DevHead& s) { return (lds_code_all(s) ? s.n : 1) * SSD_CODE_AGENT_STRIDE(s.V) + 16; }
+#if defined(SSD_STAMPS) && SSD_STAMPS == 2
+constexpr int kStampLds = 256;     // diagnostic build: the wave's stamps, at the end of its slice
+#else
+constexpr int kStampLds = 0;
+#endif
 __host__ __device__ inline int lds_per_wave(const DevHead& s) {
     int obs = s.PMS + lds_planes_bytes(s);
     if (obs < 512) obs = 512;
-    return (2 * s.GS + obs + 64 + lds_code_bytes(s) + 255) & ~255;   // a multiple of the 256-byte LDS bank row
+    return ((2 * s.GS + obs + 64 + lds_code_bytes(s) + 255) & ~255) + kStampLds;   // a multiple of the 256-byte LDS bank row
 }
 
 void launch_env(int mode, const DevSpec* spec, const DevSpec& host_spec, DevState st, const int32_t* actions,

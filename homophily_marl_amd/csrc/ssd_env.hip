@@ -21,12 +21,33 @@ namespace ssd {
 
 // Diagnostic build (tools/stamps.py, -DSSD_STAMPS): lane 0 records s_memtime at phase boundaries after draining
 // the wave's outstanding memory operations.  In the product build the macros are empty and no stamp executes.
-#ifdef SSD_STAMPS
-// -DSSD_STAMPS=2: wait for the LDS / scalar-memory queue only (vmcnt stays as it is), so that stores in flight are not charged
-// to the phase that issued them -- the timeline of the product build, at the price of phases that no longer add up exactly
+#if defined(SSD_STAMPS) && SSD_STAMPS == 2
+// -DSSD_STAMPS=2: stamps go to 256 bytes of LDS per wave and leave in one store at the end of the kernel: no wait for anything in
+// flight, no store in flight that a later `s_waitcnt vmcnt(0)` of the kernel would have to wait for -- the product's timeline
 #define STAMP_TO(buf, i)                                                                               \
     do {                                                                                               \
-        __builtin_amdgcn_s_waitcnt(SSD_STAMPS == 2 ? 0xC07F : 0);                                      \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
+        if (lane == 0) E.stamp_lds[i] = t_;                                                            \
+    } while (0)
+#define STAMP_REAL(buf, i)                                                                             \
+    do {                                                                                               \
+        unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                      \
+        if (lane == 0) E.stamp_lds[i] = t_;                                                            \
+    } while (0)
+#define STAMP_HWID(buf, j)                                                                             \
+    do {                                                                                               \
+        unsigned x_ = __builtin_amdgcn_s_getreg((3 << 11) | 20), h_ = __builtin_amdgcn_s_getreg((31 << 11) | 4); \
+        if (lane == 0) E.stamp_lds[j] = (unsigned long long)x_ | ((unsigned long long)h_ << 8);        \
+    } while (0)
+#define STAMP_FLUSH(buf)                                                                               \
+    do {                                                                                               \
+        wsync();                                                                                       \
+        if ((buf) && lane < 32) (buf)[(size_t)env * 32 + lane] = E.stamp_lds[lane];                     \
+    } while (0)
+#elif defined(SSD_STAMPS)
+#define STAMP_TO(buf, i)                                                                               \
+    do {                                                                                               \
+        __builtin_amdgcn_s_waitcnt(0);                                                                 \
         unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
         if ((buf) && lane == 0) (buf)[(size_t)env * 32 + (i)] = t_;                                    \
     } while (0)
@@ -41,10 +62,12 @@ namespace ssd {
         unsigned x_ = __builtin_amdgcn_s_getreg((3 << 11) | 20), h_ = __builtin_amdgcn_s_getreg((31 << 11) | 4); \
         if ((buf) && lane == 0) (buf)[(size_t)env * 32 + (j)] = (unsigned long long)x_ | ((unsigned long long)h_ << 8); \
     } while (0)
+#define STAMP_FLUSH(buf) do {} while (0)
 #else
 #define STAMP_TO(buf, i) do {} while (0)
 #define STAMP_REAL(buf, i) do {} while (0)
 #define STAMP_HWID(buf, j) do {} while (0)
+#define STAMP_FLUSH(buf) do {} while (0)
 #endif
 #define STAMP(i) STAMP_TO(st.stamps, i)
 #define STAMP_OBS(i) STAMP_TO(oo.stamps, i)
@@ -125,20 +148,14 @@ struct Env {
     int O;          // orientation
     int ap[4], ws[4];  // my lanes' apple / waste site cells (site index = chunk * 64 + lane), preloaded
     // Table windows requested with the state loads, so that the step's two table look-ups are lane reads instead of dependent
-    // trips to L2 in the middle of the wave's chain: lane l holds tab_p_apple / tab_p_waste [w0 - l] (beams only remove waste)
-    // and tab_den[a0 - 8 + l] (at most n apples eaten; more than 55 grown in one step falls back to the load).  w0 / a0 < 0: none.
+    // trips to L2 in the middle of the wave's chain: lane l holds tab_thr[w0 - l] (COUNTER mode; beams only remove waste) and
+    // tab_den[a0 - 8 + l] (at most n apples eaten; more than 55 grown in one step: computed).  w0 / a0 < 0: none.
     int w0, a0;
-    double pf_pa, pf_pw;
+    uint32_t pf_ta, pf_tw, pf_fl;
     float pf_den;
-    unsigned long long* stamps; int env;   // diagnostic builds
+    unsigned long long* stamps; unsigned long long* stamp_lds; int env;   // diagnostic builds
     bool pm_zeroed;     // the padded class map was cleared with the state loads and nothing wrote to it since
 };
-__device__ __forceinline__ double rl_f64(double v, int idx) {
-    const int i = __builtin_amdgcn_readfirstlane(idx);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)__double_as_longlong(v), i);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)__double_as_longlong(v) >> 32), i);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
 
 __device__ __forceinline__ int agent_char(int a) { int v = (a % 10) + 1; return v >= 10 ? 1 : v; }  // '<U1' truncation, map_env.py:370,377
 
@@ -334,16 +351,32 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+template <bool TAPE>
 __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t* tape_waste, int& n_waste_cells, int& n_apple_cells) {
     const DevSpec* S = E.S;
     const DevHead* h = E.h;
     const int lane = E.lane;
-    // compute_probabilities (cleanup.py:189-204): looked up by the waste count in the host-built fp64 tables
+    // compute_probabilities (cleanup.py:189-204): looked up by the waste count in the host-built tables -- the fp64 probabilities
+    // where recorded doubles are compared (TAPE), the 24-bit thresholds of Rng::threshold and two flags where the counter
+    // generator's integers are (no fp64 instruction in that instantiation)
     const int current = h->n_waste > 0 ? n_waste_cells : 0;    // kept incrementally in the env state
-    const int back = E.w0 - current;                           // (wave-uniform)
-    const bool pf = E.w0 >= 0 && (unsigned)back < (unsigned)kWave;
-    const double p_apple = pf ? rl_f64(E.pf_pa, back) : S->tab_p[current][0], p_waste = pf ? rl_f64(E.pf_pw, back) : S->tab_p[current][1];
-    const uint32_t t_apple = Rng::threshold(p_apple), t_waste = Rng::threshold(p_waste);
+    double p_apple = 0.0, p_waste = 0.0;
+    uint32_t t_apple = 0, t_waste = 0;
+    bool apple_on, waste_on;
+    if (TAPE) {
+        p_apple = S->tab_p[current][0]; p_waste = S->tab_p[current][1];
+        apple_on = p_apple > 0; waste_on = !(fabs(p_waste) <= 1e-8);                 // np.isclose(p, 0)
+    } else {
+        const int back = E.w0 - current;                       // (wave-uniform)
+        uint32_t fl;
+        if (E.w0 >= 0 && (unsigned)back < (unsigned)kWave) {
+            t_apple = (uint32_t)rl((int)E.pf_ta, back); t_waste = (uint32_t)rl((int)E.pf_tw, back); fl = (uint32_t)rl((int)E.pf_fl, back);
+        } else {
+            const uint4 tv = *(const uint4*)S->tab_thr[current];
+            t_apple = tv.x; t_waste = tv.y; fl = tv.z;
+        }
+        apple_on = fl & 1u; waste_on = fl & 2u;
+    }
     int k = 0;
     // Every LDS read of the phase first -- the apple sites' overlay and grid bytes and the waste sites' grid bytes, <= 12 reads in ONE
     // round trip: written per chunk (`occ == 0 && g != 'A'`, then the store of the grown apple) each chunk costs two dependent
@@ -368,17 +401,17 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
             const bool elig = in & (a_oc[ch] == 0) & (a_gc[ch] != C_APPLE);
             const uint64_t bal = ballot(elig);
             bool grow = false;
-            if (elig && p_apple > 0) {
+            if (elig && apple_on) {
                 grow = R.below(k + (int)lanes_below(bal), p_apple, t_apple);
                 if (grow) E.g[cell] = C_APPLE;
             }
-            if (p_apple > 0) n_apple_cells += popc64(ballot(grow));
+            if (apple_on) n_apple_cells += popc64(ballot(grow));
             k += popc64(bal);
         }
     }
     { const int env = E.env; STAMP_TO(E.stamps, 14); }
     // waste: at most one spawn, first free site in shuffled order whose draw succeeds (cleanup.py:177-186)
-    if (!(fabs(p_waste) <= 1e-8)) {                           // np.isclose(p, 0)
+    if (waste_on) {
         uint16_t* scratch = (uint16_t*)E.pm;                  // tape mode: rank of each site in the shuffled list
         if (R.tape) {
             E.pm_zeroed = false;
@@ -438,12 +471,9 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
     return k;
 }
 
-__device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R, int& n_apple_cells, const double (&harvest_p)[4]) {
+__device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R, int& n_apple_cells, const double (&harvest_p)[4], const uint32_t (&t_harvest)[4]) {
     const DevHead* h = E.h;
     const int lane = E.lane, W = E.W, H = h->H;
-    uint32_t t_harvest[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t_harvest[i] = Rng::threshold(harvest_p[i]);
     int k = 0;
     uint32_t spawn_bits = 0;  // decisions are applied after ALL sites were examined (synchronous update, harvest.py:86-90)
 #pragma unroll
@@ -464,7 +494,7 @@ __device__ __forceinline__ int spawn_harvest(Env& E, const Rng& R, int& n_apple_
                         if ((unsigned)x < (unsigned)H && (unsigned)y < (unsigned)W) num += E.g[x * W + y] == C_APPLE;
                     }
                 const int pi = num < 3 ? num : 3;
-                if (R.below(k + (int)lanes_below(bal), pi == 0 ? harvest_p[0] : pi == 1 ? harvest_p[1] : pi == 2 ? harvest_p[2] : harvest_p[3], t_harvest[pi])) spawn_bits |= 1u << ch;
+                if (R.below(k + (int)lanes_below(bal), pi == 0 ? harvest_p[0] : pi == 1 ? harvest_p[1] : pi == 2 ? harvest_p[2] : harvest_p[3], pi == 0 ? t_harvest[0] : pi == 1 ? t_harvest[1] : pi == 2 ? t_harvest[2] : t_harvest[3])) spawn_bits |= 1u << ch;
             }
             n_apple_cells += popc64(ballot((spawn_bits >> ch) & 1));
             k += popc64(bal);
@@ -581,7 +611,7 @@ __device__ __forceinline__ void expand_range(const uint8_t* src, T* out, int q0,
 // WC: also emit the window as one channel-mask byte per cell (bit 0 R, 1 G, 2 B; simplified palette) into the dense side buffer
 // oo.code -- what the rollout-time encoder reads: one extra LDS byte per cell in the gather, one 16-byte store per lane and agent.
 // PMC: the class map already holds SSD_OBS_CODE values (observe_phase wrote them: nothing else reads the map in this call)
-template <bool FULL, int FMT, bool WC, bool PMC = false>
+template <bool FULL, int FMT, bool WC, bool PMC = false, int NT = 0>
 __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut& oo, const uint8_t* lut) {
     typedef typename std::conditional<FMT == SSD_OBS_F32, float, typename std::conditional<FMT == SSD_OBS_BF16, uint16_t, uint8_t>::type>::type T;
     constexpr bool CODE = FMT == SSD_OBS_CODE;
@@ -622,8 +652,12 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
         const int dumpc = delta + L;                                  // one byte behind the last window (inside the planes' slack)
         // Agents in groups of AG: every class read of the group is in flight before the first code is written (one LDS round
         // trip per group and trip, not one per agent -- the reads and writes are byte accesses to buffers the compiler must
-        // assume to alias, so it keeps the source order).
-        constexpr int AG = 5;
+        // assume to alias, so it keeps the source order).  The kernel is bound by the NUMBER of vector instructions (4 waves per
+        // SIMD keep the vector pipe ~ 3/4 busy), so nothing here is predicated per agent: lanes outside the window (column V of
+        // the 2^vshift dealt, rows past V) read whatever byte their affine index lands on -- within a row and a column of the
+        // window, inside this wave's LDS -- and write it to a dump zone behind the last window: the destination offsets are
+        // computed once per trip, an agent adds its a * VV.
+        constexpr int AG = (NT > 0 && NT < 5) ? NT : 5;
         const int dstep = rpi * V;
         for (int a0 = 0; a0 < n; a0 += AG) {
             int sidx[AG], sstep[AG];
@@ -637,21 +671,21 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
             int d = delta + a0 * VV + il * V + j;
             for (int i = il; i < V; i += 4 * rpi, d += 4 * dstep) {
                 uint8_t cls[AG][4];
-                bool ok[4];
+                int wr[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) ok[u] = jv && i + u * rpi < V;
+                for (int u = 0; u < 4; ++u) wr[u] = (jv && i + u * rpi < V) ? d + u * dstep : dumpc;
 #pragma unroll
                 for (int g = 0; g < AG; ++g) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) cls[g][u] = E.pm[ok[u] ? sidx[g] + u * sstep[g] : 0];
+                    for (int u = 0; u < 4; ++u) cls[g][u] = E.pm[sidx[g] + u * sstep[g]];
                     sidx[g] += 4 * sstep[g];
                 }
 #pragma unroll
                 for (int g = 0; g < AG; ++g) {
-                    const bool live = a0 + g < n;                     // (wave-uniform)
+                    const bool live = (NT > 0 && NT % AG == 0) || a0 + g < n;         // (wave-uniform; a constant for the shipped team sizes)
 #pragma unroll
                     for (int u = 0; u < 4; ++u)   // class bit 1 / 2 / 4 -> code 2 / 1 / 3
-                        E.pl[(ok[u] && live) ? d + g * VV + u * dstep : dumpc] = PMC ? cls[g][u] : (uint8_t)((0x30120u >> (4 * cls[g][u])) & 0xFu);
+                        E.pl[(live ? wr[u] : dumpc) + g * VV] = PMC ? cls[g][u] : (uint8_t)((0x30120u >> (4 * cls[g][u])) & 0xFu);
                 }
             }
         }
@@ -725,7 +759,7 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
     if (t0 + lane < L) dst[t0 + lane] = Cvt<T>::f(E.pl[t0 + lane + delta] * (ONE ? 255u : 1u));
 }
 
-template <bool FULL>
+template <bool FULL, int NT>
 __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& oo) {
     const DevSpec* S = E.S;
     const DevHead* h = E.h;
@@ -788,13 +822,13 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
             if (oo.fmt == SSD_OBS_F32) observe_windows<FULL, SSD_OBS_F32, true>(E, env, oo, lut);
             else if (oo.fmt == SSD_OBS_BF16) observe_windows<FULL, SSD_OBS_BF16, true>(E, env, oo, lut);
             else if (oo.fmt == SSD_OBS_U8) observe_windows<FULL, SSD_OBS_U8, true>(E, env, oo, lut);
-            else if (codes_in_map) observe_windows<false, SSD_OBS_CODE, false, true>(E, env, oo, lut);
-            else observe_windows<false, SSD_OBS_CODE, false>(E, env, oo, lut);
+            else if (codes_in_map) observe_windows<false, SSD_OBS_CODE, false, true, NT>(E, env, oo, lut);
+            else observe_windows<false, SSD_OBS_CODE, false, false, NT>(E, env, oo, lut);
         } else if (oo.fmt == SSD_OBS_F32) observe_windows<FULL, SSD_OBS_F32, false>(E, env, oo, lut);
         else if (oo.fmt == SSD_OBS_BF16) observe_windows<FULL, SSD_OBS_BF16, false>(E, env, oo, lut);
         else if (oo.fmt == SSD_OBS_U8) observe_windows<FULL, SSD_OBS_U8, false>(E, env, oo, lut);
-        else if (codes_in_map) observe_windows<false, SSD_OBS_CODE, false, true>(E, env, oo, lut);
-        else observe_windows<false, SSD_OBS_CODE, false>(E, env, oo, lut);
+        else if (codes_in_map) observe_windows<false, SSD_OBS_CODE, false, true, NT>(E, env, oo, lut);
+        else observe_windows<false, SSD_OBS_CODE, false, false, NT>(E, env, oo, lut);
     }
     STAMP_OBS(9);
     if (oo.state) {  // get_state (map_env.py:950-957): [3, H, W] / 256
@@ -848,7 +882,8 @@ __device__ __forceinline__ T cold_kernarg(int offset) {
 #endif
 }
 
-template <int MODE, int NT>
+// TAPE: recorded random draws (the reference-parity path; instantiated for NT = 0 only) or the counter generator
+template <int MODE, int NT, bool TAPE>
 __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     const DevHead& hd = A.hd;
     const DevSpec* __restrict__ S = A.S;
@@ -886,7 +921,8 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     E.occ = E.g + E.GS;
     E.pm = E.occ + E.GS;
     E.pl = E.pm + h->PMS;
-    E.cbuf = E.g + lds_stride - lds_code_bytes(*h);
+    E.cbuf = E.g + lds_stride - kStampLds - lds_code_bytes(*h);
+    E.stamp_lds = (unsigned long long*)(E.g + lds_stride - 256);
     E.ag = lane < E.n;
     E.err = st.err;
     E.stamps = st.stamps; E.env = env;
@@ -904,7 +940,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     // CU arrive here together, and the CU's address unit takes >= 4 cycles per wave and request (16 for 16-byte ones): the env's
     // counters are one 32-byte record (lanes 0 / 1), an agent's two words one 8-byte record, a lane's eight site cells one
     // 16-byte record (DevSpec::site_t) -- 7 requests per wave where the separate arrays took 20.
-    const bool tape_mode = h->rng_mode == SSD_RNG_TAPE;
+    constexpr bool tape_mode = TAPE;
     uint4 hv = make_uint4(0, 0, 0, 0);
     if (lane < 2) hv = ((const uint4*)(st.hdr + env))[lane];
     uint2 ar = make_uint2(0u, 0u);
@@ -922,9 +958,10 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
         for (int ch = 0; ch < 4; ++ch) E.ap[ch] = E.ws[ch] = 0;
     }
     double harvest_p[4] = {0.0, 0.0, 0.0, 0.0};
+    uint32_t harvest_t[4] = {0u, 0u, 0u, 0u};
     if (MODE != MODE_OBS && h->kind != SSD_ENV_CLEANUP) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) harvest_p[i] = S->harvest_p[i];
+        for (int i = 0; i < 4; ++i) { if (TAPE) harvest_p[i] = S->harvest_p[i]; else harvest_t[i] = S->harvest_thr[i]; }
     }
     // LDS clears under the loads: the agent overlay, and the observation's padded class map (tape-mode spawns use that one as
     // scratch and say so)
@@ -942,12 +979,12 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     int ep_r = (int)ar.y;
     const uint32_t rec_v = ar.x;
     E.obs_slot = MODE == MODE_STEP_OBS ? ep_step0 + 1 : ep_step0;
-    E.w0 = E.a0 = -1; E.pf_pa = E.pf_pw = 0.0; E.pf_den = 0.f;
+    E.w0 = E.a0 = -1; E.pf_ta = E.pf_tw = E.pf_fl = 0u; E.pf_den = 0.f;
     if ((MODE == MODE_STEP || MODE == MODE_STEP_OBS) && counts0 != 0xFFFFFFFFu) {
-        if (h->kind == SSD_ENV_CLEANUP) {
+        if (!TAPE && h->kind == SSD_ENV_CLEANUP) {
             E.w0 = h->n_waste > 0 ? (int)(counts0 >> 16) : 0;
             const int wi = E.w0 - lane;
-            if (wi >= 0 && wi <= SSD_MAX_SITES) { const double2 pp = *(const double2*)S->tab_p[wi]; E.pf_pa = pp.x; E.pf_pw = pp.y; }
+            if (wi >= 0 && wi <= SSD_MAX_SITES) { const uint4 tv = *(const uint4*)S->tab_thr[wi]; E.pf_ta = tv.x; E.pf_tw = tv.y; E.pf_fl = tv.z; }
         }
         E.a0 = (int)(counts0 & 0xFFFFu);
         const int ai = E.a0 - 8 + lane;
@@ -1033,8 +1070,8 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
         wsync();
         int n_waste_cells = h->kind == SSD_ENV_CLEANUP ? h->n_waste : 0;       // custom_reset: all waste present / all apples grown
         int n_apple_cells = h->kind == SSD_ENV_CLEANUP ? 0 : h->n_apple;
-        n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste, n_waste_cells, n_apple_cells)
-                                             : spawn_harvest(E, R, n_apple_cells, harvest_p);             // map_env.py:313
+        n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup<TAPE>(E, R, tape_waste, n_waste_cells, n_apple_cells)
+                                             : spawn_harvest(E, R, n_apple_cells, harvest_p, harvest_t);             // map_env.py:313
         ep_r = 0;
         if (lane == 0) {
             *(uint4*)&st.hdr[env].epoch = make_uint4(epoch + 1, 0u, ((uint32_t)n_waste_cells << 16) | (uint32_t)n_apple_cells, 0u);
@@ -1078,8 +1115,8 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
             }
         }
         STAMP(4);
-        n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup(E, R, tape_waste, n_waste_cells, n_apple_cells)
-                                             : spawn_harvest(E, R, n_apple_cells, harvest_p);             // map_env.py:263
+        n_draws = h->kind == SSD_ENV_CLEANUP ? spawn_cleanup<TAPE>(E, R, tape_waste, n_waste_cells, n_apple_cells)
+                                             : spawn_harvest(E, R, n_apple_cells, harvest_p, harvest_t);             // map_env.py:263
         STAMP(5);
         // scalars (map_env.py:291-292, 883-914).  After the consume loop no agent stands on an apple and nothing spawns
         // under an agent, so the apples visible in map_with_agents are all apples of the grid.
@@ -1144,11 +1181,12 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
             E.obs_slot = oo.t_slots - 1;
             if (lane == 0) atomicOr(st.err, ERR_SLOT_OVERRUN);
         }
-        if (h->obs_color == SSD_COLOR_FULL) observe_phase<true>(E, env, oo);
-        else observe_phase<false>(E, env, oo);
+        if (h->obs_color == SSD_COLOR_FULL) observe_phase<true, NT>(E, env, oo);
+        else observe_phase<false, NT>(E, env, oo);
     }
     STAMP(10);
     STAMP_REAL(st.stamps, 13);
+    STAMP_FLUSH(st.stamps);
 }
 
 void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, const int32_t* actions,
@@ -1159,17 +1197,22 @@ void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, c
     EnvArgs A;
     A.hd = (const DevHead&)hs; A.S = spec; A.st = st; A.actions = actions; A.env_mask = env_mask; A.tape = tape; A.lds_stride = stride;
     A.so = so; A.oo = oo;
-#define SSD_LAUNCH(M, NT_) hipLaunchKernelGGL((k_env<M, NT_>), dim3(blocks), dim3(kBlock), lds, stream, A)
+#define SSD_LAUNCH(M, NT_, TP_) hipLaunchKernelGGL((k_env<M, NT_, TP_>), dim3(blocks), dim3(kBlock), lds, stream, A)
 #define SSD_LAUNCH_N(M)                                                                                   \
     do {                                                                                                  \
-        if (hs.n == 5) SSD_LAUNCH(M, 5); else if (hs.n == 10) SSD_LAUNCH(M, 10);                          \
-        else if (hs.n == 3) SSD_LAUNCH(M, 3); else SSD_LAUNCH(M, 0);                                      \
+        if (tape_mode) SSD_LAUNCH(M, 0, true);                                                            \
+        else if (hs.n == 5) SSD_LAUNCH(M, 5, false); else if (hs.n == 10) SSD_LAUNCH(M, 10, false);       \
+        else if (hs.n == 3) SSD_LAUNCH(M, 3, false); else SSD_LAUNCH(M, 0, false);                        \
     } while (0)
+    const bool tape_mode = hs.rng_mode == SSD_RNG_TAPE;
     switch (mode) {
-        case MODE_RESET: SSD_LAUNCH(MODE_RESET, 0); break;
+        case MODE_RESET: if (tape_mode) SSD_LAUNCH(MODE_RESET, 0, true); else SSD_LAUNCH(MODE_RESET, 0, false); break;
         case MODE_STEP: SSD_LAUNCH_N(MODE_STEP); break;
         case MODE_STEP_OBS: SSD_LAUNCH_N(MODE_STEP_OBS); break;
-        default: SSD_LAUNCH_N(MODE_OBS); break;
+        default:                                                      // observations draw nothing
+            if (hs.n == 5) SSD_LAUNCH(MODE_OBS, 5, false); else if (hs.n == 10) SSD_LAUNCH(MODE_OBS, 10, false);
+            else if (hs.n == 3) SSD_LAUNCH(MODE_OBS, 3, false); else SSD_LAUNCH(MODE_OBS, 0, false);
+            break;
     }
 #undef SSD_LAUNCH_N
 #undef SSD_LAUNCH
