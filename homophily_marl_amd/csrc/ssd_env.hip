@@ -759,7 +759,13 @@ __device__ __forceinline__ void observe_windows(Env& E, int env, const DevObsOut
     if (t0 + lane < L) dst[t0 + lane] = Cvt<T>::f(E.pl[t0 + lane + delta] * (ONE ? 255u : 1u));
 }
 
-template <bool FULL, int NT>
+// OV: the observation variant this instantiation serves.  OV_ANY dispatches on the request at run time (every format, both
+// palettes, the side outputs); the other two are what the rollout (class-code windows into the episode storage) and the
+// format-R workload (f32 planes, nothing else) ask for, compiled without the dispatch: the step kernel is bound by the number of
+// instructions a wave executes and by its footprint in the instruction cache (the all-formats kernel is ~ 12 K instructions,
+// a wave executes ~ 1.5 K of them scattered over the whole image).
+enum { OV_ANY = 0, OV_CODE = 1, OV_F32 = 2 };
+template <bool FULL, int NT, int OV>
 __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& oo) {
     const DevSpec* S = E.S;
     const DevHead* h = E.h;
@@ -771,7 +777,7 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
     if (!E.pm_zeroed)
         for (int i = lane * 16; i < h->PMS; i += kWave * 16) *(uint4*)(E.pm + i) = make_uint4(0, 0, 0, 0);
     wsync();
-    const bool codes_in_map = !FULL && oo.obs && oo.fmt == SSD_OBS_CODE && !oo.state;     // (wave-uniform)
+    const bool codes_in_map = OV == OV_CODE || (OV == OV_ANY && !FULL && oo.obs && oo.fmt == SSD_OBS_CODE && !oo.state);     // (wave-uniform)
     if (!FULL) {
         // simplified palette: 4 cells per lane and trip, classes by byte-SWAR on the packed cell codes (all codes < 0x80):
         // wall or agent -> 4, apple -> 2, waste (Cleanup) -> 1, else 0
@@ -816,7 +822,9 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
     wsync();
     STAMP_OBS(8);
     // an env stepped past its episode storage writes no observation (it would land in the next env's block)
-    if (oo.obs) {
+    if (OV == OV_CODE) observe_windows<false, SSD_OBS_CODE, false, true, NT>(E, env, oo, lut);
+    else if (OV == OV_F32) observe_windows<false, SSD_OBS_F32, false>(E, env, oo, lut);
+    else if (oo.obs) {
         // gather windows into LDS in output order, expand to the output dtype (value / 256, CHW; map_env.py:945)
         if (oo.code && !FULL) {
             if (oo.fmt == SSD_OBS_F32) observe_windows<FULL, SSD_OBS_F32, true>(E, env, oo, lut);
@@ -831,7 +839,7 @@ __device__ __forceinline__ void observe_phase(Env& E, int env, const DevObsOut& 
         else observe_windows<false, SSD_OBS_CODE, false, false, NT>(E, env, oo, lut);
     }
     STAMP_OBS(9);
-    if (oo.state) {  // get_state (map_env.py:950-957): [3, H, W] / 256
+    if (OV == OV_ANY && oo.state) {  // get_state (map_env.py:950-957): [3, H, W] / 256
         const int L = 3 * E.HW;
         const size_t off = (size_t)env * L;
         emit<float>(oo.state + off, off, L, lane, [&](int f) -> uint32_t {
@@ -883,7 +891,7 @@ __device__ __forceinline__ T cold_kernarg(int offset) {
 }
 
 // TAPE: recorded random draws (the reference-parity path; instantiated for NT = 0 only) or the counter generator
-template <int MODE, int NT, bool TAPE>
+template <int MODE, int NT, bool TAPE, int OV = OV_ANY>
 __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     const DevHead& hd = A.hd;
     const DevSpec* __restrict__ S = A.S;
@@ -1181,8 +1189,9 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
             E.obs_slot = oo.t_slots - 1;
             if (lane == 0) atomicOr(st.err, ERR_SLOT_OVERRUN);
         }
-        if (h->obs_color == SSD_COLOR_FULL) observe_phase<true, NT>(E, env, oo);
-        else observe_phase<false, NT>(E, env, oo);
+        if (OV != OV_ANY) observe_phase<false, NT, OV>(E, env, oo);
+        else if (h->obs_color == SSD_COLOR_FULL) observe_phase<true, NT, OV_ANY>(E, env, oo);
+        else observe_phase<false, NT, OV_ANY>(E, env, oo);
     }
     STAMP(10);
     STAMP_REAL(st.stamps, 13);
@@ -1208,7 +1217,17 @@ void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, c
     switch (mode) {
         case MODE_RESET: if (tape_mode) SSD_LAUNCH(MODE_RESET, 0, true); else SSD_LAUNCH(MODE_RESET, 0, false); break;
         case MODE_STEP: SSD_LAUNCH_N(MODE_STEP); break;
-        case MODE_STEP_OBS: SSD_LAUNCH_N(MODE_STEP_OBS); break;
+        case MODE_STEP_OBS: {
+            // the two requests with an instantiation of their own (observe_phase): simplified palette, windows only
+            const bool plain = !tape_mode && hs.obs_color != SSD_COLOR_FULL && oo.obs && !oo.state && (hs.n == 5 || hs.n == 10);
+            const int ov = !plain ? OV_ANY : oo.fmt == SSD_OBS_CODE ? OV_CODE : (oo.fmt == SSD_OBS_F32 && !oo.code) ? OV_F32 : OV_ANY;
+            if (ov == OV_CODE) { if (hs.n == 5) hipLaunchKernelGGL((k_env<MODE_STEP_OBS, 5, false, OV_CODE>), dim3(blocks), dim3(kBlock), lds, stream, A);
+                                 else hipLaunchKernelGGL((k_env<MODE_STEP_OBS, 10, false, OV_CODE>), dim3(blocks), dim3(kBlock), lds, stream, A); }
+            else if (ov == OV_F32) { if (hs.n == 5) hipLaunchKernelGGL((k_env<MODE_STEP_OBS, 5, false, OV_F32>), dim3(blocks), dim3(kBlock), lds, stream, A);
+                                     else hipLaunchKernelGGL((k_env<MODE_STEP_OBS, 10, false, OV_F32>), dim3(blocks), dim3(kBlock), lds, stream, A); }
+            else SSD_LAUNCH_N(MODE_STEP_OBS);
+            break;
+        }
         default:                                                      // observations draw nothing
             if (hs.n == 5) SSD_LAUNCH(MODE_OBS, 5, false); else if (hs.n == 10) SSD_LAUNCH(MODE_OBS, 10, false);
             else if (hs.n == 3) SSD_LAUNCH(MODE_OBS, 3, false); else SSD_LAUNCH(MODE_OBS, 0, false);
