@@ -446,10 +446,9 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
         typedef float f32x2v __attribute__((ext_vector_type(2)));
         const f32x2v pp = ld32(reinterpret_cast<const f32x2v*>(a.pos), er);      // one 8-byte load per pair
         in.p0 = pp.x; in.p1 = pp.y;
-        const float* orient = a.orient ? a.orient : a.pos;             // no orientation given: read something valid, use zeros
-        const float ok = a.orient ? 1.f : 0.f;
+        const float* orient = a.orient ? a.orient : a.pos;             // no orientation given: read something valid; file_inputs writes zeros
         const f32x2v oo = ld32(reinterpret_cast<const f32x2v*>(orient), er);
-        in.o0 = oo.x * ok; in.o1 = oo.y * ok;
+        in.o0 = oo.x; in.o1 = oo.y;                                    // (raw: an arithmetic use here would be a wait for every load of the tile)
     } else {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) in.x[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)((ro + 16u * ct) * 4u));
@@ -518,6 +517,17 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
         (void)lane;
         PSTAMP(0);
         PSTAMP_REAL(14);
+        // Every kernel argument the input phase reads, requested in ONE batch with the first one (by-value arguments are fetched from
+        // the kernarg segment where they are first used: three dependent scalar-memory trips, ~ 1 K cycles each while the segment
+        // is cold, stand between the wave's start and its first tile load otherwise).
+        if (!LOOP) {
+            if (!INC) asm volatile("" :: "s"(a.N), "s"(a.n), "s"(a.bpa), "s"(a.h), "s"(a.inputs), "s"(a.weights), "s"(a.eps), "s"(a.step), "s"(a.t_index),
+                                         "s"(a.prev_actions), "s"(a.prev_reward), "s"(a.recv), "s"(a.prev_inc), "s"(a.pos), "s"(a.orient), "s"(a.feat_part),
+                                         "s"(a.lin_b), "s"(a.feat_bands), "s"(a.avail_bits), "s"(a.pos_scale));
+            else asm volatile("" :: "s"(a.N), "s"(a.n), "s"(a.bpa), "s"(a.h), "s"(a.inputs), "s"(a.weights), "s"(a.eps), "s"(a.step), "s"(a.t_index),
+                                    "s"(a.actions), "s"(a.pos_pre), "s"(a.orient_pre), "s"(a.reward), "s"(a.clean), "s"(a.den), "s"(a.ep_ret), "s"(a.term),
+                                    "s"(a.inp), "s"(a.pos_scale));
+        }
         if (wave == WAVES) *landed = 0u;                               // LDS holds garbage at launch: the word is valid behind this barrier
         __builtin_amdgcn_s_barrier();                                  // (the only one: every wave is still at its first instructions)
         if (wave == WAVES) {                                           // the loader wave: nothing but the image stream
@@ -538,11 +548,12 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
     TileIn<INC> in;
     if (!INC) PSTAMP_DRAINED(8);                                       // (diagnostic builds: kernel arguments fetched)
     if (!INC) PSTAMP(9);
-    if (tile < tiles) load_tile<INC>(a, tile, agent, lane, in);        // queued behind the first chunks
-    if (!INC) PSTAMP(10);
+    // the device-side counters first: scalar loads through pointers, in flight under the tile's loads instead of behind them
     float eps = *a.eps;
     int64_t step64 = *a.step;
     long slot_t = a.t_index ? (long)*a.t_index : 0;
+    if (tile < tiles) load_tile<INC>(a, tile, agent, lane, in);        // queued behind the first chunks
+    if (!INC) PSTAMP(10);
     uint32_t step = 0;                                                 // (both assigned once the loads above are pinned, see below)
     bool file = false;
     const uint32_t avail_bits = INC ? 0xFFFFFFFFu : ((a.avail_bits >> 31) ? (a.avail_bits & 0x7FFFFFFFu) : avail_to_bits(a.avail, A));
@@ -652,12 +663,13 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
             const size_t er = (size_t)b * n + agent;                   // env-major row
             ColdA ca; ColdC cc;
             cold_blocks(ca, nullptr, &cc);
+            const float o0 = a.orient ? in.o0 : 0.f, o1 = a.orient ? in.o1 : 0.f;     // no orientation given: zeros
             if (ca.pos_copy) {
-                ca.pos_copy[er * 2] = in.p0; ca.pos_copy[er * 2 + 1] = in.p1; ca.orient_copy[er * 2] = in.o0; ca.orient_copy[er * 2 + 1] = in.o1;
+                ca.pos_copy[er * 2] = in.p0; ca.pos_copy[er * 2 + 1] = in.p1; ca.orient_copy[er * 2] = o0; ca.orient_copy[er * 2 + 1] = o1;
             }
             if (cc.d_pos && file) {
                 const size_t sr = (((size_t)b * a.slots + slot_t) * n + agent) * 2;
-                cc.d_pos[sr] = in.p0; cc.d_pos[sr + 1] = in.p1; cc.d_orient[sr] = in.o0; cc.d_orient[sr + 1] = in.o1;
+                cc.d_pos[sr] = in.p0; cc.d_pos[sr + 1] = in.p1; cc.d_orient[sr] = o0; cc.d_orient[sr + 1] = o1;
             }
         }
     };
