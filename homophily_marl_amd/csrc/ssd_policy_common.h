@@ -26,9 +26,10 @@ __device__ __forceinline__ uint32_t mix32p(uint32_t x) {
 // action_selectors.py:44-68).  The exploration draws are keyed by (seed, step, r).  Returns the action; q (nullable) gets Q.
 // avail_bits: bit k set = action k available (all ones: no mask).  AT > 0: compile-time action count (the loops unroll and `a`
 // stays in registers); AT = 0: runtime A.
-template <int AT = 0>
+// QP: the type of the q pointer (a plain float*, or a pointer that carries its address space)
+template <int AT = 0, typename QP = float*>
 __device__ __forceinline__ int dueling_pick_bits(const float* a, float v, int A_rt, uint32_t avail_bits, float eps, uint32_t step,
-                                                 uint32_t seed, uint32_t r, float* q_out) {
+                                                 uint32_t seed, uint32_t r, QP q_out) {
     const int A = AT ? AT : A_rt;
     float mean = 0.f;
 #pragma unroll

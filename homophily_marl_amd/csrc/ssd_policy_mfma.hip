@@ -277,20 +277,25 @@ struct HeadCold {
 static_assert(offsetof(HeadCold, p_inc) == 64 && offsetof(HeadCold, d_pos) == 128, "cold argument blocks");
 constexpr int TAIL_ABSENT = -64;
 constexpr int HEAD_COLD_OFFSET = (int)((sizeof(HeadK) + alignof(HeadCold) - 1) / alignof(HeadCold) * alignof(HeadCold));   // second kernel argument
+// The cold pointers are GLOBAL pointers by type: assembled from scalar loads the compiler knows nothing about their address space
+// and a plain `T*` becomes a FLAT access -- which counts in lgkmcnt as well as in vmcnt, so that the next wait for an LDS read or
+// a scalar load (every K-step has one) would also wait for every by-product store in flight.
+#define SSD_GLOBAL __attribute__((address_space(1)))
 template <typename T>
-__device__ __forceinline__ T* cold_ptr(int field_offset) {
+__device__ __forceinline__ T SSD_GLOBAL* cold_ptr(int field_offset) {
     auto ka = __builtin_amdgcn_kernarg_segment_ptr();
     uint64_t v;
     asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "s"(HEAD_COLD_OFFSET + field_offset) : "memory");
-    return reinterpret_cast<T*>(v);
+    return (T SSD_GLOBAL*)v;
 }
 // Several cold pointers at once: ONE scalar-load burst and ONE wait instead of a load + wait per pointer (~150 cycles each on a wave
 // that is alone on its SIMD).  cold_blocks: block A [+ block B] [+ block C] of HeadCold.
 typedef uint32_t u32x16s __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-struct ColdA { int64_t* out_actions; float* q_out; int32_t* out_actions_i32; int64_t* p_act; int64_t* d_actions; float* d_onehot; float *pos_copy, *orient_copy; };
-struct ColdB { int64_t *p_inc, *d_actions_inc; float *d_reward, *p_rew, *ep_ret, *d_clean, *d_den; uint8_t* d_term; };
-struct ColdC { float *d_pos, *d_orient; };
+struct ColdA { int64_t SSD_GLOBAL* out_actions; float SSD_GLOBAL* q_out; int32_t SSD_GLOBAL* out_actions_i32; int64_t SSD_GLOBAL* p_act; int64_t SSD_GLOBAL* d_actions;
+               float SSD_GLOBAL* d_onehot; float SSD_GLOBAL *pos_copy, *orient_copy; };
+struct ColdB { int64_t SSD_GLOBAL *p_inc, *d_actions_inc; float SSD_GLOBAL *d_reward, *p_rew, *ep_ret, *d_clean, *d_den; uint8_t SSD_GLOBAL* d_term; };
+struct ColdC { float SSD_GLOBAL *d_pos, *d_orient; };
 __device__ __forceinline__ void cold_blocks(ColdA& A, ColdB* B, ColdC* C) {
 #if defined(__HIP_DEVICE_COMPILE__)
     auto ka = __builtin_amdgcn_kernarg_segment_ptr();
@@ -308,7 +313,7 @@ __device__ __forceinline__ void cold_blocks(ColdA& A, ColdB* B, ColdC* C) {
 #endif
 }
 #define COLD(T, field) cold_ptr<T>((int)offsetof(HeadCold, field))
-#define COLD_U64(field) reinterpret_cast<uint64_t>(cold_ptr<void>((int)offsetof(HeadCold, field)))
+#define COLD_U64(field) ((uint64_t)cold_ptr<void>((int)offsetof(HeadCold, field)))
 
 // One K-step (c) of a 4-output-tile product as two halves, so that a SEQUENCE of products can request the next step's A fragments
 // from LDS before the current step's MFMAs issue (a wave that is alone on its SIMD has nothing else to hide the ds_read latency):
@@ -563,8 +568,8 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
     // through the tile chain -- the env head has no register to spare); the branch is never taken on a healthy network
     auto range_check = [&](float amax) {
         if (!(amax * XS <= F16_MAX)) {
-            int32_t* nerr = COLD(int32_t, numeric_err);
-            if (nerr) atomicOr(nerr, ERR_F16_RANGE);
+            auto nerr = COLD(int32_t, numeric_err);
+            if (nerr) atomicOr((int32_t*)nerr, ERR_F16_RANGE);
         }
     };
     // Everything of a tile that only needs its inputs -- the input tail (controller :137-184) and the split of the fc1 operand -- is
@@ -679,11 +684,11 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
     auto hand_counters = [&]() {
       if (block == 0 && tid == 0) {
         if (INC) {
-            int64_t *next_t = COLD(int64_t, next_t), *next_step = COLD(int64_t, next_step);
+            auto next_t = COLD(int64_t, next_t); auto next_step = COLD(int64_t, next_step);
             if (next_t) *next_t = slot_t + 1;
             if (next_step) *next_step = step64 + 1;
         } else {
-            int64_t *t_copy = COLD(int64_t, t_copy), *step_copy = COLD(int64_t, step_copy);
+            auto t_copy = COLD(int64_t, t_copy); auto step_copy = COLD(int64_t, step_copy);
             if (t_copy) *t_copy = slot_t;
             if (step_copy) *step_copy = step64;
         }
@@ -799,9 +804,9 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
             const int bb = tile * 16 + lane;
             ColdA ca;
             cold_blocks(ca, nullptr, nullptr);
-            int64_t *out_actions = ca.out_actions, *p_act = ca.p_act, *d_actions = ca.d_actions;
-            int32_t* out_i32 = ca.out_actions_i32;
-            float *q_out = ca.q_out, *d_onehot = ca.d_onehot;
+            auto out_actions = ca.out_actions; auto p_act = ca.p_act; auto d_actions = ca.d_actions;
+            auto out_i32 = ca.out_actions_i32;
+            auto q_out = ca.q_out; auto d_onehot = ca.d_onehot;
             if (lane < 16 && bb < N) {
                 float av[16];
 #pragma unroll
@@ -812,7 +817,7 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
                 const float val = av[A];
                 const uint32_t rq = (uint32_t)(agent * N + bb);                                  // q_out row (agent-major)
                 const uint32_t rk = (a.env_id_base + (uint32_t)bb) * (uint32_t)n + (uint32_t)agent;   // exploration key: global env id
-                const int act = dueling_pick_bits<AT>(av, val, A, avail_bits, eps, step, a.seed, rk, q_out ? q_out + (size_t)rq * A : nullptr);
+                const int act = dueling_pick_bits<AT>(av, val, A, avail_bits, eps, step, a.seed, rk, q_out ? q_out + (size_t)rq * A : (decltype(q_out))nullptr);
                 out_actions[(size_t)bb * n + agent] = act;
                 if (out_i32) out_i32[(size_t)bb * n + agent] = act;
                 if (p_act) p_act[(size_t)bb * n + agent] = act;
@@ -828,9 +833,9 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
             const float* w2o = tail + HT_W2O;                          // [E][4]: 3 advantages + value per extra feature
             ColdA ca; ColdB cb;
             cold_blocks(ca, &cb, nullptr);
-            int64_t *out_actions = ca.out_actions, *p_inc = cb.p_inc, *d_actions_inc = cb.d_actions_inc;
-            float* q_out = ca.q_out;
-            uint8_t* recv_out = COLD(uint8_t, recv_out);
+            auto out_actions = ca.out_actions; auto p_inc = cb.p_inc; auto d_actions_inc = cb.d_actions_inc;
+            auto q_out = ca.q_out;
+            auto recv_out = COLD(uint8_t, recv_out);
             if (first) PSTAMP(9);
             const uint32_t n_magic = (65536u + (uint32_t)n - 1u) / (uint32_t)n;      // it / n for it < 192, n <= 10
 #pragma unroll
@@ -858,7 +863,7 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
                 }
                 const uint32_t rq = (uint32_t)((agent * N + bb) * n + j);
                 const uint32_t rk = ((a.env_id_base + (uint32_t)bb) * (uint32_t)n + (uint32_t)agent) * (uint32_t)n + (uint32_t)j;
-                int act = dueling_pick_bits<3>(av, av[3], 3, 0xFFFFFFFFu, eps, step, a.seed, rk, q_out ? q_out + (size_t)rq * 3 : nullptr);
+                int act = dueling_pick_bits<3>(av, av[3], 3, 0xFFFFFFFFu, eps, step, a.seed, rk, q_out ? q_out + (size_t)rq * 3 : (decltype(q_out))nullptr);
                 if (j == agent) act = 0;                               // no self incentive (homophily_controller.py:44-46)
                 const size_t pair = ((size_t)bb * n + agent) * n + j;
                 out_actions[pair] = act;
