@@ -1439,11 +1439,21 @@ __device__ __forceinline__ void encode_body_lut(const EncK& a, uint8_t* lds_raw,
     const int row0 = block_x * (BT * 16);
     const int band = block_y, y0 = band * R;
     const int Rb = O - y0 < R ? O - y0 : R;                            // output rows of this band
-    const long t_off = a.slot_t ? ((long)(*a.slot_t) + a.slot_add) * a.slot_stride : 0;
+    // Every argument the staging reads, requested in ONE batch (by-value arguments are fetched where they are first used: six
+    // dependent scalar-memory trips before the first code byte is requested otherwise), then the time slot -- read ONCE.
+    asm volatile("" :: "s"(a.codes), "s"(a.code_bytes), "s"(a.env_stride), "s"(a.slot_stride), "s"(a.agent_stride), "s"(a.slot_t), "s"(a.slot_add),
+                       "s"(a.rows), "s"(a.n), "s"(a.conv_frags), "s"(a.lin_frags), "s"(a.mask_alphabet), "s"(a.slot_t_copy), "s"(a.counter_inc));
+    int64_t slot_now = 0;                                              // (a scalar load: the pointer is a kernel argument)
+    if (a.slot_t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(slot_now) : "s"(a.slot_t) : "memory");
+#endif
+    }
+    const long t_off = a.slot_t ? ((long)slot_now + a.slot_add) * a.slot_stride : 0;
     PSTAMP(0);
     PSTAMP_REAL(14);
     if (block_x == 0 && block_y == 0 && tid == 0) {
-        if (a.slot_t_copy) *a.slot_t_copy = *a.slot_t;
+        if (a.slot_t_copy) *a.slot_t_copy = slot_now;
         if (a.counter_inc) *a.counter_inc += 1;
     }
     // ---- stage: the table (global -> LDS), class codes -> packed rows ------------------------------------------------------------
@@ -1458,6 +1468,11 @@ __device__ __forceinline__ void encode_body_lut(const EncK& a, uint8_t* lds_raw,
         typedef __attribute__((address_space(1))) uint32_t gl_u32;
         u32x4 cw[IPT][NQ];
         const uintptr_t cbase = reinterpret_cast<uintptr_t>(a.codes), cend = cbase + (uintptr_t)a.code_bytes;
+        // every item's 16-byte reads first (predicated, no use): written as `if (inside) load; else tail path` per item, each item's
+        // loads are waited for at the join before the next item's are requested.  The tail path (the buffer's last rows, where a
+        // 16-byte read would cross the end) runs afterwards, for the workgroup that holds them.
+        uintptr_t ptrs[IPT];
+        bool tail[IPT];
 #pragma unroll
         for (int k = 0; k < IPT; ++k) {
             const int it = tid + k * NT;
@@ -1465,25 +1480,32 @@ __device__ __forceinline__ void encode_body_lut(const EncK& a, uint8_t* lds_raw,
             const int row = row0 + r, y = y0 + yy;
 #pragma unroll
             for (int h = 0; h < NQ; ++h) cw[k][h] = u32x4{0u, 0u, 0u, 0u};
+            ptrs[k] = 0; tail[k] = false;
             if (it < ITEMS && row < a.rows && y < V) {
                 const int b = row / a.n, i = row - b * a.n;
                 const uintptr_t ptr = cbase + (uintptr_t)((long)b * a.env_stride + t_off + (long)i * a.agent_stride + y * V);
+                ptrs[k] = ptr;
                 if (ptr + 16 * NQ <= cend) {
 #pragma unroll
                     for (int h = 0; h < NQ; ++h) cw[k][h] = *reinterpret_cast<const gl_u32x4_u*>(ptr + 16 * h);
-                } else {                                               // the last rows of the buffer: aligned dwords that hold readable bytes
-                    const uintptr_t al = ptr & ~(uintptr_t)3, lim = (cend + 3) & ~(uintptr_t)3;
-                    uint32_t prev = *reinterpret_cast<const gl_u32*>(al);
+                } else tail[k] = true;
+            }
+        }
 #pragma unroll
-                    for (int h = 0; h < NQ; ++h)
+        for (int k = 0; k < IPT; ++k) {
+            if (tail[k]) {                                             // the last rows of the buffer: aligned dwords that hold readable bytes
+                const uintptr_t ptr = ptrs[k];
+                const uintptr_t al = ptr & ~(uintptr_t)3, lim = (cend + 3) & ~(uintptr_t)3;
+                uint32_t prev = *reinterpret_cast<const gl_u32*>(al);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const uintptr_t nx = al + 4 * (4 * h + e + 1);
-                            const uint32_t next = nx + 4 <= lim ? *reinterpret_cast<const gl_u32*>(nx) : 0u;
-                            cw[k][h][e] = __builtin_amdgcn_alignbyte(next, prev, (uint32_t)(ptr & 3));
-                            prev = next;
-                        }
-                }
+                for (int h = 0; h < NQ; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uintptr_t nx = al + 4 * (4 * h + e + 1);
+                        const uint32_t next = nx + 4 <= lim ? *reinterpret_cast<const gl_u32*>(nx) : 0u;
+                        cw[k][h][e] = __builtin_amdgcn_alignbyte(next, prev, (uint32_t)(ptr & 3));
+                        prev = next;
+                    }
             }
         }
 #pragma unroll
