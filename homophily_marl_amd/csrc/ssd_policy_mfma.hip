@@ -1671,7 +1671,11 @@ static int enc_bt(int V, int rows) {
 // starts on each CU the moment its head workgroup retires.  Workgroups [0, heads) run head_body, the rest encode_body with the
 // (x, band) index unfolded; EncK sits behind the two head arguments (the heads' cold-argument offsets are unchanged).
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int FUSED_WAVES = ENC_WAVES;          // k_inc_encode: one block size for both bodies
+#ifndef SSD_FUSED_WAVES
+#define SSD_FUSED_WAVES SSD_ENC_WAVES
+#endif
+constexpr int FUSED_WAVES = SSD_FUSED_WAVES;    // k_inc_encode: one block size for both bodies (waves past ENC_WAVES leave an encoder workgroup at once)
+static_assert(FUSED_WAVES >= ENC_WAVES, "the encoder body needs its waves");
 template <int PREC, int AT, int V, bool LOOP, int BT, bool LUT = false>
 __global__ __launch_bounds__(FUSED_WAVES * 64) void k_inc_encode(HeadK a, HeadCold cold_unused, EncK e, int heads, int enc_groups) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -1684,6 +1688,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64) void k_inc_encode(HeadK a, HeadCo
         head_body<1, PREC, AT, 0, FUSED_WAVES - 1, LOOP>(a, lds_raw, b);    // 7 compute waves + the loader
     } else {
         const int i = b - heads, by = i / enc_groups;
+        if (FUSED_WAVES > ENC_WAVES && (int)threadIdx.x >= ENC_WAVES * 64) return;
         if constexpr (LUT) encode_body_lut<V, PREC, BT>(e, lds_raw, i - by * enc_groups, by);
         else encode_body<V, PREC, false, BT>(e, lds_raw, i - by * enc_groups, by);
     }
