@@ -872,6 +872,8 @@ struct EnvArgs {
     DevHead hd; const DevSpec* S; DevState st; const int32_t* actions; const uint8_t* env_mask; DevTape tape; int lds_stride;
     DevStepOut so; DevObsOut oo;
 };
+// k_env's kernarg segment: five pointers and four ints (the preloadable head, see k_env), then the EnvArgs struct
+constexpr int kEnvArgsOffset = (5 * 8 + 4 * 4 + (int)alignof(EnvArgs) - 1) / (int)alignof(EnvArgs) * (int)alignof(EnvArgs);
 template <typename T>
 __device__ __forceinline__ T cold_kernarg(int offset) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -891,26 +893,27 @@ __device__ __forceinline__ T cold_kernarg(int offset) {
 }
 
 // TAPE: recorded random draws (the reference-parity path; instantiated for NT = 0 only) or the counter generator
+// The first nine arguments repeat what the wave needs for its first requests (the env's records, the actions, the spec, three sizes)
+// as SCALAR kernel arguments in front of the struct: built with -mllvm -amdgpu-kernarg-preload-count=14 they arrive in SGPRs with
+// the wave (gfx950 kernarg preload; struct arguments are not preloaded), so the state loads are requested before the first
+// scalar-memory trip to the kernarg segment has returned.  Without the flag they are ordinary arguments.
 template <int MODE, int NT, bool TAPE, int OV = OV_ANY>
-__global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
+__global__ __launch_bounds__(kBlock) void k_env(EnvHdr* p_hdr, uint2* p_agents, uint8_t* p_grid, const int32_t* p_actions, const DevSpec* p_spec,
+                                                int p_N, int p_GS, int p_PMS, int p_lds_stride, const EnvArgs A) {
     const DevHead& hd = A.hd;
-    const DevSpec* __restrict__ S = A.S;
-    const DevState st = A.st;
-    const int32_t* __restrict__ actions = A.actions;
+    const DevSpec* __restrict__ S = p_spec;
+    DevState st;
+    st.grid = p_grid; st.agents = p_agents; st.hdr = p_hdr; st.err = A.st.err; st.stamps = A.st.stamps;
+    const int32_t* __restrict__ actions = p_actions;
     const uint8_t* __restrict__ env_mask = A.env_mask;
     const DevTape tape = A.tape;
-    const int lds_stride = A.lds_stride;
+    const int lds_stride = p_lds_stride;
     extern __shared__ uint4 smem[];
     const int lane = threadIdx.x & 63;
     const DevHead* h = &hd;
-    // Every kernel argument the load phase reads, requested in ONE batch with the first one (the compiler fetches by-value arguments
-    // from the kernarg segment where they are first used: seven dependent scalar-memory trips, ~ 1 K cycles each while the
-    // segment is cold, between the wave's start and its last state load otherwise).
-    asm volatile("" :: "s"(h->N), "s"(st.grid), "s"(st.agents), "s"(st.hdr), "s"(actions), "s"(S), "s"(h->GS), "s"(h->PMS), "s"(h->rng_mode),
-                       "s"(h->kind), "s"(h->HW), "s"(h->W), "s"(h->n), "s"(h->n_actions), "s"(h->n_waste), "s"(lds_stride));
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: per-env addresses live in SGPRs
     const int env = blockIdx.x * kWavesPerBlock + wave;
-    if (env >= h->N) return;
+    if (env >= p_N) return;
     if (MODE == MODE_RESET && env_mask && !env_mask[env]) return;
 
     // Speed only (never correctness): the 4 waves that share a SIMD get distinct static priorities from their hardware
@@ -924,11 +927,11 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     }
 
     Env E;
-    E.S = S; E.h = h; E.lane = lane; E.n = NT ? NT : h->n; E.W = h->W; E.HW = h->HW; E.GS = h->GS;
+    E.S = S; E.h = h; E.lane = lane; E.n = NT ? NT : h->n; E.W = h->W; E.HW = h->HW; E.GS = p_GS;
     E.g = (uint8_t*)smem + (size_t)wave * lds_stride;
     E.occ = E.g + E.GS;
     E.pm = E.occ + E.GS;
-    E.pl = E.pm + h->PMS;
+    E.pl = E.pm + p_PMS;
     E.cbuf = E.g + lds_stride - kStampLds - lds_code_bytes(*h);
     E.stamp_lds = (unsigned long long*)(E.g + lds_stride - 256);
     E.ag = lane < E.n;
@@ -965,6 +968,10 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) E.ap[ch] = E.ws[ch] = 0;
     }
+    // Every other kernel argument the load phase reads, requested in ONE batch (the compiler fetches by-value arguments from the
+    // kernarg segment where they are first used: seven dependent scalar-memory trips, ~ 0.4-1 K cycles each while the segment is
+    // cold, between the wave's start and its last state load otherwise).
+    asm volatile("" :: "s"(h->rng_mode), "s"(h->kind), "s"(h->HW), "s"(h->W), "s"(h->n), "s"(h->n_actions), "s"(h->n_waste), "s"(h->n_apple), "s"(st.err));
     double harvest_p[4] = {0.0, 0.0, 0.0, 0.0};
     uint32_t harvest_t[4] = {0u, 0u, 0u, 0u};
     if (MODE != MODE_OBS && h->kind != SSD_ENV_CLEANUP) {
@@ -976,7 +983,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     for (int i = lane * 16; i < GS; i += kWave * 16) *(uint4*)(E.occ + i) = make_uint4(0, 0, 0, 0);
     E.pm_zeroed = false;
     if (MODE == MODE_STEP_OBS || MODE == MODE_OBS) {
-        for (int i = lane * 16; i < h->PMS; i += kWave * 16) *(uint4*)(E.pm + i) = make_uint4(0, 0, 0, 0);
+        for (int i = lane * 16; i < p_PMS; i += kWave * 16) *(uint4*)(E.pm + i) = make_uint4(0, 0, 0, 0);
         E.pm_zeroed = true;
     }
     STAMP(17);
@@ -1083,7 +1090,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
         ep_r = 0;
         if (lane == 0) {
             *(uint4*)&st.hdr[env].epoch = make_uint4(epoch + 1, 0u, ((uint32_t)n_waste_cells << 16) | (uint32_t)n_apple_cells, 0u);
-            int32_t* nd = cold_kernarg<int32_t*>((int)(offsetof(EnvArgs, so) + offsetof(DevStepOut, n_draws)));
+            int32_t* nd = cold_kernarg<int32_t*>((int)(kEnvArgsOffset + offsetof(EnvArgs, so) + offsetof(DevStepOut, n_draws)));
             if (nd) nd[env] = n_draws;
             if (R.tape && n_draws > R.ustride) atomicOr(st.err, ERR_TAPE_OVERRUN);
         }
@@ -1139,7 +1146,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
         const int step = ep_step0 + 1;
         const bool term = step >= h->episode_limit;
         STAMP(19);
-        const DevStepOut so = cold_kernarg<DevStepOut>((int)offsetof(EnvArgs, so));
+        const DevStepOut so = cold_kernarg<DevStepOut>((int)(kEnvArgsOffset + offsetof(EnvArgs, so)));
         STAMP(20);
         if (E.ag) {
             const size_t o = (size_t)env * n + lane;
@@ -1182,7 +1189,7 @@ __global__ __launch_bounds__(kBlock) void k_env(const EnvArgs A) {
     }
     STAMP(7);
     if (MODE == MODE_STEP_OBS || MODE == MODE_OBS) {
-        const DevObsOut oo = cold_kernarg<DevObsOut>((int)offsetof(EnvArgs, oo));
+        const DevObsOut oo = cold_kernarg<DevObsOut>((int)(kEnvArgsOffset + offsetof(EnvArgs, oo)));
         if (oo.t_slots > 0 && E.obs_slot >= oo.t_slots) {
             // stepped past the episode storage: never write into the next env's block -- the observation lands in this env's LAST
             // slot and the sticky error bit tells the caller (ssd_poll_error)
@@ -1206,7 +1213,8 @@ void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, c
     EnvArgs A;
     A.hd = (const DevHead&)hs; A.S = spec; A.st = st; A.actions = actions; A.env_mask = env_mask; A.tape = tape; A.lds_stride = stride;
     A.so = so; A.oo = oo;
-#define SSD_LAUNCH(M, NT_, TP_) hipLaunchKernelGGL((k_env<M, NT_, TP_>), dim3(blocks), dim3(kBlock), lds, stream, A)
+#define SSD_ENV_ARGS st.hdr, st.agents, st.grid, actions, spec, (int)hs.N, (int)hs.GS, (int)hs.PMS, stride, A
+#define SSD_LAUNCH(M, NT_, TP_) hipLaunchKernelGGL((k_env<M, NT_, TP_>), dim3(blocks), dim3(kBlock), lds, stream, SSD_ENV_ARGS)
 #define SSD_LAUNCH_N(M)                                                                                   \
     do {                                                                                                  \
         if (tape_mode) SSD_LAUNCH(M, 0, true);                                                            \
@@ -1221,10 +1229,10 @@ void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, c
             // the two requests with an instantiation of their own (observe_phase): simplified palette, windows only
             const bool plain = !tape_mode && hs.obs_color != SSD_COLOR_FULL && oo.obs && !oo.state && (hs.n == 5 || hs.n == 10);
             const int ov = !plain ? OV_ANY : oo.fmt == SSD_OBS_CODE ? OV_CODE : (oo.fmt == SSD_OBS_F32 && !oo.code) ? OV_F32 : OV_ANY;
-            if (ov == OV_CODE) { if (hs.n == 5) hipLaunchKernelGGL((k_env<MODE_STEP_OBS, 5, false, OV_CODE>), dim3(blocks), dim3(kBlock), lds, stream, A);
-                                 else hipLaunchKernelGGL((k_env<MODE_STEP_OBS, 10, false, OV_CODE>), dim3(blocks), dim3(kBlock), lds, stream, A); }
-            else if (ov == OV_F32) { if (hs.n == 5) hipLaunchKernelGGL((k_env<MODE_STEP_OBS, 5, false, OV_F32>), dim3(blocks), dim3(kBlock), lds, stream, A);
-                                     else hipLaunchKernelGGL((k_env<MODE_STEP_OBS, 10, false, OV_F32>), dim3(blocks), dim3(kBlock), lds, stream, A); }
+            if (ov == OV_CODE) { if (hs.n == 5) hipLaunchKernelGGL((k_env<MODE_STEP_OBS, 5, false, OV_CODE>), dim3(blocks), dim3(kBlock), lds, stream, SSD_ENV_ARGS);
+                                 else hipLaunchKernelGGL((k_env<MODE_STEP_OBS, 10, false, OV_CODE>), dim3(blocks), dim3(kBlock), lds, stream, SSD_ENV_ARGS); }
+            else if (ov == OV_F32) { if (hs.n == 5) hipLaunchKernelGGL((k_env<MODE_STEP_OBS, 5, false, OV_F32>), dim3(blocks), dim3(kBlock), lds, stream, SSD_ENV_ARGS);
+                                     else hipLaunchKernelGGL((k_env<MODE_STEP_OBS, 10, false, OV_F32>), dim3(blocks), dim3(kBlock), lds, stream, SSD_ENV_ARGS); }
             else SSD_LAUNCH_N(MODE_STEP_OBS);
             break;
         }
@@ -1235,6 +1243,7 @@ void launch_env(int mode, const DevSpec* spec, const DevSpec& hs, DevState st, c
     }
 #undef SSD_LAUNCH_N
 #undef SSD_LAUNCH
+#undef SSD_ENV_ARGS
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ if [ "$mode" = build ]; then
   mkdir -p $R/build/variants
   while [ $# -gt 1 ]; do
     name=$1; flags=$2; shift 2
-    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math $flags -o $R/build/variants/libssd_$name.so $R/homophily_marl_amd/csrc/*.hip 2>/dev/null && echo built $name ) &
+    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=14 $flags -o $R/build/variants/libssd_$name.so $R/homophily_marl_amd/csrc/*.hip 2>/dev/null && echo built $name ) &
   done
   wait
 else
