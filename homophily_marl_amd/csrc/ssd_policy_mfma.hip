@@ -281,11 +281,12 @@ constexpr int HEAD_COLD_OFFSET = (int)((sizeof(HeadK) + alignof(HeadCold) - 1) /
 // and a plain `T*` becomes a FLAT access -- which counts in lgkmcnt as well as in vmcnt, so that the next wait for an LDS read or
 // a scalar load (every K-step has one) would also wait for every by-product store in flight.
 #define SSD_GLOBAL __attribute__((address_space(1)))
+// (cold_base: the offset of the launch's HeadCold argument in its kernarg segment = the kernel's leading scalars + HEAD_COLD_OFFSET)
 template <typename T>
-__device__ __forceinline__ T SSD_GLOBAL* cold_ptr(int field_offset) {
+__device__ __forceinline__ T SSD_GLOBAL* cold_ptr(int cold_base, int field_offset) {
     auto ka = __builtin_amdgcn_kernarg_segment_ptr();
     uint64_t v;
-    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "s"(HEAD_COLD_OFFSET + field_offset) : "memory");
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "s"(cold_base + field_offset) : "memory");
     return (T SSD_GLOBAL*)v;
 }
 // Several cold pointers at once: ONE scalar-load burst and ONE wait instead of a load + wait per pointer (~150 cycles each on a wave
@@ -296,15 +297,15 @@ struct ColdA { int64_t SSD_GLOBAL* out_actions; float SSD_GLOBAL* q_out; int32_t
                float SSD_GLOBAL* d_onehot; float SSD_GLOBAL *pos_copy, *orient_copy; };
 struct ColdB { int64_t SSD_GLOBAL *p_inc, *d_actions_inc; float SSD_GLOBAL *d_reward, *p_rew, *ep_ret, *d_clean, *d_den; uint8_t SSD_GLOBAL* d_term; };
 struct ColdC { float SSD_GLOBAL *d_pos, *d_orient; };
-__device__ __forceinline__ void cold_blocks(ColdA& A, ColdB* B, ColdC* C) {
+__device__ __forceinline__ void cold_blocks(int cold_base, ColdA& A, ColdB* B, ColdC* C) {
 #if defined(__HIP_DEVICE_COMPILE__)
     auto ka = __builtin_amdgcn_kernarg_segment_ptr();
     u32x16s a, b = {};
     u32x4s c = {};
-    if (B && C) asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx4 %2, %3, %6\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(ka), "s"(HEAD_COLD_OFFSET), "s"(HEAD_COLD_OFFSET + 64), "s"(HEAD_COLD_OFFSET + 128) : "memory");
-    else if (B) asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(ka), "s"(HEAD_COLD_OFFSET), "s"(HEAD_COLD_OFFSET + 64) : "memory");
-    else if (C) asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(c) : "s"(ka), "s"(HEAD_COLD_OFFSET), "s"(HEAD_COLD_OFFSET + 128) : "memory");
-    else asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(ka), "s"(HEAD_COLD_OFFSET) : "memory");
+    if (B && C) asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx4 %2, %3, %6\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(ka), "s"(cold_base), "s"(cold_base + 64), "s"(cold_base + 128) : "memory");
+    else if (B) asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(ka), "s"(cold_base), "s"(cold_base + 64) : "memory");
+    else if (C) asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(c) : "s"(ka), "s"(cold_base), "s"(cold_base + 128) : "memory");
+    else asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(ka), "s"(cold_base) : "memory");
     A = __builtin_bit_cast(ColdA, a);
     if (B) *B = __builtin_bit_cast(ColdB, b);
     if (C) *C = __builtin_bit_cast(ColdC, c);
@@ -312,8 +313,8 @@ __device__ __forceinline__ void cold_blocks(ColdA& A, ColdB* B, ColdC* C) {
     (void)A; (void)B; (void)C;
 #endif
 }
-#define COLD(T, field) cold_ptr<T>((int)offsetof(HeadCold, field))
-#define COLD_U64(field) ((uint64_t)cold_ptr<void>((int)offsetof(HeadCold, field)))
+#define COLD(T, field) cold_ptr<T>(COLD_BASE, (int)offsetof(HeadCold, field))
+#define COLD_U64(field) ((uint64_t)cold_ptr<void>(COLD_BASE, (int)offsetof(HeadCold, field)))
 
 // One K-step (c) of a 4-output-tile product as two halves, so that a SEQUENCE of products can request the next step's A fragments
 // from LDS before the current step's MFMAs issue (a wave that is alone on its SIMD has nothing else to hide the ds_read latency):
@@ -491,12 +492,12 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
 // The kernel arguments once more, from the kernarg segment (HeadK is the FIRST argument of k_head and of k_inc_encode): the address is
 // made opaque to the compiler, so the scalar loads are issued where the call stands and their results are not values that were live
 // since kernel entry.  The looped kernels call this at the top of every pass over a tile (see head_body).
-__device__ __forceinline__ void refetch_head_args(HeadK& out) {
+__device__ __forceinline__ void refetch_head_args(HeadK& out, int k_off) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(4))) const uint32_t k_u32;
     uint64_t p = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
-    k_u32* src = (k_u32*)p;
+    k_u32* src = (k_u32*)(p + (uint64_t)k_off);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&out);
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(HeadK) / 4); ++i) dst[i] = src[i];
@@ -506,8 +507,10 @@ __device__ __forceinline__ void refetch_head_args(HeadK& out) {
 }
 static_assert(sizeof(HeadK) % 4 == 0, "HeadK is copied dword by dword");
 
-template <int INC, int PREC, int AT, int GEN, int WAVES, bool LOOP = false>
+// KOFF: the offset of the HeadK argument in the launch's kernarg segment (behind the kernel's leading scalar arguments)
+template <int INC, int PREC, int AT, int GEN, int WAVES, bool LOOP = false, int KOFF = 0>
 __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw, const int block) {
+    constexpr int COLD_BASE = KOFF + HEAD_COLD_OFFSET;
     constexpr int IMAGE_BYTES = SSD_POLICY_IMAGE_BYTES(PREC);
     constexpr float XS = PREC == 2 ? HEAD_XSCALE : 1.f, INV = PREC == 2 ? 1.f / (HEAD_WSCALE * HEAD_XSCALE) : 1.f;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -667,7 +670,7 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
         if (q == 0) {
             const size_t er = (size_t)b * n + agent;                   // env-major row
             ColdA ca; ColdC cc;
-            cold_blocks(ca, nullptr, &cc);
+            cold_blocks(COLD_BASE, ca, nullptr, &cc);
             const float o0 = a.orient ? in.o0 : 0.f, o1 = a.orient ? in.o1 : 0.f;     // no orientation given: zeros
             if (ca.pos_copy) {
                 ca.pos_copy[er * 2] = in.p0; ca.pos_copy[er * 2 + 1] = in.p1; ca.orient_copy[er * 2] = o0; ca.orient_copy[er * 2 + 1] = o1;
@@ -803,7 +806,7 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
         if (!INC) {
             const int bb = tile * 16 + lane;
             ColdA ca;
-            cold_blocks(ca, nullptr, nullptr);
+            cold_blocks(COLD_BASE, ca, nullptr, nullptr);
             auto out_actions = ca.out_actions; auto p_act = ca.p_act; auto d_actions = ca.d_actions;
             auto out_i32 = ca.out_actions_i32;
             auto q_out = ca.q_out; auto d_onehot = ca.d_onehot;
@@ -832,7 +835,7 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
             if (first) PSTAMP(8);
             const float* w2o = tail + HT_W2O;                          // [E][4]: 3 advantages + value per extra feature
             ColdA ca; ColdB cb;
-            cold_blocks(ca, &cb, nullptr);
+            cold_blocks(COLD_BASE, ca, &cb, nullptr);
             auto out_actions = ca.out_actions; auto p_inc = cb.p_inc; auto d_actions_inc = cb.d_actions_inc;
             auto q_out = ca.q_out;
             auto recv_out = COLD(uint8_t, recv_out);
@@ -900,7 +903,7 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
             int tile = tile0;
             do {                                                       // the image is resident from the second pass on (seen == every chunk)
                 HeadK al;
-                refetch_head_args(al);
+                refetch_head_args(al, KOFF);
                 int lane = lane0;
 #if defined(__HIP_DEVICE_COMPILE__)
                 asm volatile("" : "+v"(lane));
@@ -933,10 +936,19 @@ constexpr int HEAD_WAVES = SSD_HEAD_WAVES;
 #endif
 constexpr int HEAD_WAVES_LOOP = SSD_HEAD_WAVES_LOOP;   // (round 3: 6, when the looped instantiations filled the register file; 160-168 registers now)
 constexpr int head_waves(bool loop) { return loop ? HEAD_WAVES_LOOP : HEAD_WAVES; }
+// The leading scalar arguments repeat what a compute wave needs for its largest loads (the tile's state and input rows): built
+// with -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave (struct arguments are not preloaded).  The looped
+// instantiations re-read HeadK from the segment at every pass (refetch_head_args) and ignore them.
+constexpr int HEAD_LEAD_BYTES = 4 * 4 + 2 * 8;
 template <int INC, int PREC, int AT, int GEN = 0, bool LOOP = false>
-__global__ __launch_bounds__((head_waves(LOOP) + 1) * 64) void k_head(HeadK a, HeadCold cold_unused) {
+__global__ __launch_bounds__((head_waves(LOOP) + 1) * 64) void k_head(int p_N, int p_n, int p_bpa, int p_pad, float* p_h, float* p_inputs, HeadK a, HeadCold cold_unused) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    head_body<INC, PREC, AT, GEN, head_waves(LOOP), LOOP>(a, lds_raw, (int)blockIdx.x);
+    if constexpr (LOOP) head_body<INC, PREC, AT, GEN, head_waves(LOOP), LOOP, HEAD_LEAD_BYTES>(a, lds_raw, (int)blockIdx.x);
+    else {
+        HeadK al = a;
+        al.N = p_N; al.n = p_n; al.bpa = p_bpa; al.h = p_h; al.inputs = p_inputs;
+        head_body<INC, PREC, AT, GEN, head_waves(LOOP), LOOP, HEAD_LEAD_BYTES>(al, lds_raw, (int)blockIdx.x);
+    }
 }
 
 static int chip_cus() {
@@ -1036,7 +1048,8 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess) return -1;
         gen_attr_done_dev[dev] = true;
     }
-    void* args[2] = {&k, &c};
+    int pad = 0;
+    void* args[8] = {&k.N, &k.n, &k.bpa, &pad, &k.h, &k.inputs, &k, &c};
     const void* fn = gen ? gen_fns[(k.A == 8 ? 2 : 0) + (prec == 1 ? 1 : 0)]
                          : fns[(looped ? 8 : 0) + (k.A == 8 ? 4 : 0) + (prec == 1 ? 2 : 0) + (inc ? 1 : 0)];
     if (hipLaunchKernel(fn, dim3(k.n * bpa), dim3((waves + 1) * 64), args, lds, s) != hipSuccess) return -1;
@@ -1677,7 +1690,10 @@ static int enc_bt(int V, int rows) {
 constexpr int FUSED_WAVES = SSD_FUSED_WAVES;    // k_inc_encode: one block size for both bodies (waves past ENC_WAVES leave an encoder workgroup at once)
 static_assert(FUSED_WAVES >= ENC_WAVES, "the encoder body needs its waves");
 template <int PREC, int AT, int V, bool LOOP, int BT, bool LUT = false>
-__global__ __launch_bounds__(FUSED_WAVES * 64) void k_inc_encode(HeadK a, HeadCold cold_unused, EncK e, int heads, int enc_groups) {
+__global__ __launch_bounds__(FUSED_WAVES * 64) void k_inc_encode(int heads, int enc_groups, int p_N, int p_n, int p_bpa, int p_pad, float* p_h, float* p_inputs,
+                                                                 const uint8_t* p_codes, const int64_t* p_slot_t, HeadK a, HeadCold cold_unused, EncK e) {
+    // (leading scalars: which body a workgroup runs, then what each body's first requests need -- see k_head)
+    constexpr int LEAD = 6 * 4 + 4 * 8;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 #ifndef SSD_ENC_FIRST
 #define SSD_ENC_FIRST 0
@@ -1685,12 +1701,19 @@ __global__ __launch_bounds__(FUSED_WAVES * 64) void k_inc_encode(HeadK a, HeadCo
     const int total = (int)gridDim.x;
     const int b = SSD_ENC_FIRST ? ((int)blockIdx.x + heads) % total : (int)blockIdx.x;      // (which body the first workgroups run)
     if (b < heads) {
-        head_body<1, PREC, AT, 0, FUSED_WAVES - 1, LOOP>(a, lds_raw, b);    // 7 compute waves + the loader
+        if constexpr (LOOP) head_body<1, PREC, AT, 0, FUSED_WAVES - 1, LOOP, LEAD>(a, lds_raw, b);
+        else {
+            HeadK al = a;
+            al.N = p_N; al.n = p_n; al.bpa = p_bpa; al.h = p_h; al.inputs = p_inputs;
+            head_body<1, PREC, AT, 0, FUSED_WAVES - 1, LOOP, LEAD>(al, lds_raw, b);    // 7 compute waves + the loader
+        }
     } else {
         const int i = b - heads, by = i / enc_groups;
         if (FUSED_WAVES > ENC_WAVES && (int)threadIdx.x >= ENC_WAVES * 64) return;
-        if constexpr (LUT) encode_body_lut<V, PREC, BT>(e, lds_raw, i - by * enc_groups, by);
-        else encode_body<V, PREC, false, BT>(e, lds_raw, i - by * enc_groups, by);
+        EncK el = e;
+        el.codes = p_codes; el.slot_t = p_slot_t;
+        if constexpr (LUT) encode_body_lut<V, PREC, BT>(el, lds_raw, i - by * enc_groups, by);
+        else encode_body<V, PREC, false, BT>(el, lds_raw, i - by * enc_groups, by);
     }
 }
 
@@ -1759,7 +1782,8 @@ static int launch_inc_encode_bt(HeadK& k, HeadCold& c, EncK& e, hipStream_t s) {
         done[dev] = true;
     }
     int heads = k.n * k.bpa, groups = (e.rows + BT * 16 - 1) / (BT * 16);
-    void* args[5] = {&k, &c, &e, &heads, &groups};
+    int pad = 0;
+    void* args[13] = {&heads, &groups, &k.N, &k.n, &k.bpa, &pad, &k.h, &k.inputs, &e.codes, &e.slot_t, &k, &c, &e};
     if (hipLaunchKernel(fn, dim3(heads + groups * Geo<V>::NB), dim3(FUSED_WAVES * 64), args, lds, s) != hipSuccess) return -1;
     return 0;
 }
