@@ -403,14 +403,30 @@ struct TileIn {
 // the image's first chunks included (measured: 5 300 of the prologue's 12 000 cycles).
 template <typename T>
 __device__ __forceinline__ T ld32(const T* base, uint32_t idx) { return *reinterpret_cast<const T*>(reinterpret_cast<const uint8_t*>(base) + (size_t)(idx * (uint32_t)sizeof(T))); }
+// The tile's largest loads -- the agent-major state row and (unless the encoder left band partials) the input row: they need
+// nothing but the kernel's leading scalar arguments (k_head), so the kernels without a back edge request them before anything else.
 template <int INC>
-__device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, int lane, TileIn<INC>& in) {
-    const int m = lane & 15, q = lane >> 4, N = a.N, n = a.n;
+__device__ __forceinline__ void load_tile_rows(const HeadK& a, int tile, int agent, int lane, TileIn<INC>& in) {
+    const int m = lane & 15, q = lane >> 4, N = a.N;
     const int b = tile * 16 + m, bc = b < N ? b : N - 1;
     const uint32_t arow = (uint32_t)agent * (uint32_t)N + (uint32_t)bc;
     const uint32_t ro = arow * 64u + 4u * (uint32_t)q;                 // this lane's first float of the agent-major row
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) in.hp[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.h) + (size_t)((ro + 16u * ct) * 4u));
+#pragma unroll
+    for (int ct = 0; ct < (INC ? 4 : 2); ++ct) in.x[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)((ro + 16u * ct) * 4u));
+}
+// ROWS_DONE: load_tile_rows already requested the state row and (feat_part == nullptr or INC) the input row
+template <int INC, bool ROWS_DONE = false>
+__device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, int lane, TileIn<INC>& in) {
+    const int m = lane & 15, q = lane >> 4, N = a.N, n = a.n;
+    const int b = tile * 16 + m, bc = b < N ? b : N - 1;
+    const uint32_t arow = (uint32_t)agent * (uint32_t)N + (uint32_t)bc;
+    const uint32_t ro = arow * 64u + 4u * (uint32_t)q;                 // this lane's first float of the agent-major row
+    if (!ROWS_DONE) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) in.hp[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.h) + (size_t)((ro + 16u * ct) * 4u));
+    }
     if (!INC) {
         if (a.feat_part) {          // the encoder left per-band partial sums: lin_b + sum over the bands, band order (wave-uniform branch)
             const uint32_t rows = (uint32_t)n * (uint32_t)N;
@@ -427,7 +443,7 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
                 for (int bd = 0; bd < 6; ++bd) { const float on = bd < a.feat_bands ? 1.f : 0.f; s += part[bd] * on; }
                 in.x[ct] = s;
             }
-        } else {
+        } else if (!ROWS_DONE) {
             in.x[0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)(ro * 4u));
             in.x[1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)((ro + 16u) * 4u));
         }
@@ -456,8 +472,10 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
         const f32x2v oo = ld32(reinterpret_cast<const f32x2v*>(orient), er);
         in.o0 = oo.x; in.o1 = oo.y;                                    // (raw: an arithmetic use here would be a wait for every load of the tile)
     } else {
+        if (!ROWS_DONE) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) in.x[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)((ro + 16u * ct) * 4u));
+            for (int ct = 0; ct < 4; ++ct) in.x[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)((ro + 16u * ct) * 4u));
+        }
         in.act = (int)ld32(reinterpret_cast<const int32_t*>(a.actions), 2u * ((uint32_t)bc * (uint32_t)n + (uint32_t)agent));
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -519,12 +537,17 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
     bool first = true;
     // LDS: the image (as in global memory) | per-wave scratch | the loader's progress word
     volatile lds_u32* landed = (volatile lds_u32*)(lds_raw + IMAGE_BYTES + WAVES * SCRATCH * 4);      // generic -> LDS address space
+    TileIn<INC> in_rows;                                               // !LOOP: the tile's row loads, requested in the prologue
     {
         const HeadK& a = a_entry;
         const int lane = tid & 63;
         (void)lane;
         PSTAMP(0);
         PSTAMP_REAL(14);
+        if (!LOOP && wave < WAVES) {   // (see load_tile_rows; the loader wave has no tile)
+            const int bia0 = block - (block / a.bpa) * a.bpa, tile00 = wave * a.bpa + bia0;
+            if (tile00 < ((a.N + 15) >> 4)) load_tile_rows<INC>(a, tile00, block / a.bpa, lane, in_rows);
+        }
         // Every kernel argument the input phase reads, requested in ONE batch with the first one (by-value arguments are fetched from
         // the kernarg segment where they are first used: three dependent scalar-memory trips, ~ 1 K cycles each while the segment
         // is cold, stand between the wave's start and its first tile load otherwise).
@@ -554,13 +577,18 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
     const int N = a.N, n = a.n;
     const int tiles = (N + 15) >> 4;
     TileIn<INC> in;
+    if constexpr (!LOOP) in = in_rows;
     if (!INC) PSTAMP_DRAINED(8);                                       // (diagnostic builds: kernel arguments fetched)
     if (!INC) PSTAMP(9);
     // the device-side counters first: scalar loads through pointers, in flight under the tile's loads instead of behind them
     float eps = *a.eps;
     int64_t step64 = *a.step;
     long slot_t = a.t_index ? (long)*a.t_index : 0;
-    if (tile < tiles) load_tile<INC>(a, tile, agent, lane, in);        // queued behind the first chunks
+    if (tile < tiles) {                                                // queued behind the first chunks
+        if constexpr (LOOP) load_tile<INC, false>(a, tile, agent, lane, in);
+        else if (!INC && a.feat_part) { load_tile<INC, false>(a, tile, agent, lane, in); }     // (band partials instead of the input row: Harvest)
+        else load_tile<INC, true>(a, tile, agent, lane, in);
+    }
     if (!INC) PSTAMP(10);
     uint32_t step = 0;                                                 // (both assigned once the loads above are pinned, see below)
     bool file = false;
