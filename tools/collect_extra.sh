@@ -8,7 +8,8 @@ set -x
 python3 -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1 || exit 1
 python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 || exit 1
 python3 tools/pstamps.py > $OUT/pstamps.txt 2> $OUT/pstamps.err || exit 1
-python3 tools/stamps.py --fmt code --dest storage > $OUT/env_stamps.txt 2> $OUT/env_stamps.err || exit 1
+python3 tools/stamps.py --fmt code --dest storage --light > $OUT/env_stamps.txt 2> $OUT/env_stamps.err || exit 1
+python3 tools/stamps.py --fmt f32 --light > $OUT/env_stamps_f32.txt 2>> $OUT/env_stamps.err || exit 1
 python3 tools/gru_prof.py > $OUT/gru_prof.txt 2>&1 || exit 1
 python3 tools/bmm_prof.py > $OUT/bmm_prof.txt 2>&1 || exit 1
 python3 tools/train_prof.py > $OUT/train_prof.txt 2>&1 || exit 1
