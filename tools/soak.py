@@ -72,20 +72,14 @@ if a.nan_check:      # check after EVERY learner.train: the first step whose gra
                 mac = ctx.mac
                 sh = mac.unroll_shared(sb)
                 B, T, n = sb.batch_size, sb.max_seq_length, mac.n_agents
-                feat = mac.agent.rgb_preprocess(sh["obs"].reshape(B * T * n, 3, 15, 15))
-                print("   feat finite", bool(th.isfinite(feat).all()), "max", float(feat.abs().max()), " tail max", float(sh["tail"].abs().max()))
-                gi, wh, bh = mac.unroll_pre(sb, sh)
-                print("   gi finite", bool(th.isfinite(gi).all()), "max", float(gi.abs().max()), " wh max", float(wh.abs().max()))
+                parts, wh, bh = mac.unroll_pre(sb, sh)              # [gi_env, gi_inc] (each [n, T * B, 192]), weight / bias parts
+                for nm, gi in zip(("gi_env", "gi_inc"), parts):
+                    print("   %s finite" % nm, bool(th.isfinite(gi).all()), "max", float(gi[th.isfinite(gi)].abs().max()))
+                print("   wh max", max(float(w.abs().max()) for w in wh), " bh max", max(float(x.abs().max()) for x in bh))
                 from homophily_marl_amd import ops
-                hs = ops.gru_sequence(gi, wh, bh)
-                print("   hs finite", bool(th.isfinite(hs).all()), "max", float(hs[th.isfinite(hs)].abs().max()))
-                bad = (~th.isfinite(hs)).nonzero()
-                print("   first non-finite hs index (g, t, b, f):", bad[0].tolist() if bad.numel() else None, " count", bad.shape[0])
-                h = gi.new_zeros(gi.shape[1], gi.shape[2], 64)
-                for t in range(T):          # the same recurrence with torch ops
-                    h = ops.gru_gates(gi[t].cpu(), th.baddbmm(bh.cpu(), h.cpu(), wh.cpu()), h.cpu())
-                print("   torch (CPU) recurrence finite", bool(th.isfinite(h).all()), "max |h_T|", float(h.abs().max()),
-                      " max |kernel - torch| at T", float((hs[:, -1].cpu() - h).abs().max()))
+                for nm, hs in zip(("h_env", "h_inc"), ops.gru_sequence_parts(parts, T, B, wh, bh)):
+                    bad = (~th.isfinite(hs)).nonzero()
+                    print("   %s finite" % nm, bad.numel() == 0, " first non-finite index:", bad[0].tolist() if bad.numel() else None, " count", bad.shape[0])
                 L = ctx.learner
                 tgt_ok = all(bool(th.isfinite(v).all()) for v in L.target_mac.agent.state_dict().values())
                 print("   target net finite", tgt_ok, " optimiser state finite",
