@@ -22,6 +22,8 @@
 #include "ssd_policy_common.h"
 
 namespace ssd {
+#define SSD_GLOBAL __attribute__((address_space(1)))    // a pointer type that carries the global address space
+
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
@@ -280,7 +282,6 @@ constexpr int HEAD_COLD_OFFSET = (int)((sizeof(HeadK) + alignof(HeadCold) - 1) /
 // The cold pointers are GLOBAL pointers by type: assembled from scalar loads the compiler knows nothing about their address space
 // and a plain `T*` becomes a FLAT access -- which counts in lgkmcnt as well as in vmcnt, so that the next wait for an LDS read or
 // a scalar load (every K-step has one) would also wait for every by-product store in flight.
-#define SSD_GLOBAL __attribute__((address_space(1)))
 // (cold_base: the offset of the launch's HeadCold argument in its kernarg segment = the kernel's leading scalars + HEAD_COLD_OFFSET)
 template <typename T>
 __device__ __forceinline__ T SSD_GLOBAL* cold_ptr(int cold_base, int field_offset) {
@@ -402,7 +403,20 @@ struct TileIn {
 // and nothing in here branches: a branch the compiler makes out of a predicated load waits for EVERY outstanding load of the wave,
 // the image's first chunks included (measured: 5 300 of the prologue's 12 000 cycles).
 template <typename T>
-__device__ __forceinline__ T ld32(const T* base, uint32_t idx) { return *reinterpret_cast<const T*>(reinterpret_cast<const uint8_t*>(base) + (size_t)(idx * (uint32_t)sizeof(T))); }
+__device__ __forceinline__ T ld32(const T* base, uint32_t idx) {
+    // (a GLOBAL access by type: the looped kernels rebuild HeadK from dwords of the kernarg segment, which leaves the compiler with
+    // generic pointers -- and FLAT loads, which count in lgkmcnt as well: every wait for an LDS read would wait for them too)
+    typedef const T SSD_GLOBAL gT;
+    return *(gT*)((const uint8_t SSD_GLOBAL*)(const void SSD_GLOBAL*)base + (size_t)(idx * (uint32_t)sizeof(T)));
+}
+__device__ __forceinline__ void stg128(void* base, size_t byte_off, f32x4 v) {
+    typedef f32x4 SSD_GLOBAL gv;
+    *(gv*)((uint8_t SSD_GLOBAL*)(void SSD_GLOBAL*)base + byte_off) = v;
+}
+__device__ __forceinline__ f32x4 ldg128(const void* base, size_t byte_off) {
+    typedef const f32x4 SSD_GLOBAL gv;
+    return *(gv*)((const uint8_t SSD_GLOBAL*)(const void SSD_GLOBAL*)base + byte_off);
+}
 // The tile's largest loads -- the agent-major state row and (unless the encoder left band partials) the input row: they need
 // nothing but the kernel's leading scalar arguments (k_head), so the kernels without a back edge request them before anything else.
 template <int INC>
@@ -412,9 +426,9 @@ __device__ __forceinline__ void load_tile_rows(const HeadK& a, int tile, int age
     const uint32_t arow = (uint32_t)agent * (uint32_t)N + (uint32_t)bc;
     const uint32_t ro = arow * 64u + 4u * (uint32_t)q;                 // this lane's first float of the agent-major row
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) in.hp[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.h) + (size_t)((ro + 16u * ct) * 4u));
+    for (int ct = 0; ct < 4; ++ct) in.hp[ct] = ldg128(a.h, (size_t)((ro + 16u * ct) * 4u));
 #pragma unroll
-    for (int ct = 0; ct < (INC ? 4 : 2); ++ct) in.x[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)((ro + 16u * ct) * 4u));
+    for (int ct = 0; ct < (INC ? 4 : 2); ++ct) in.x[ct] = ldg128(a.inputs, (size_t)((ro + 16u * ct) * 4u));
 }
 // ROWS_DONE: load_tile_rows already requested the state row and (feat_part == nullptr or INC) the input row
 template <int INC, bool ROWS_DONE = false>
@@ -425,7 +439,7 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
     const uint32_t ro = arow * 64u + 4u * (uint32_t)q;                 // this lane's first float of the agent-major row
     if (!ROWS_DONE) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) in.hp[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.h) + (size_t)((ro + 16u * ct) * 4u));
+        for (int ct = 0; ct < 4; ++ct) in.hp[ct] = ldg128(a.h, (size_t)((ro + 16u * ct) * 4u));
     }
     if (!INC) {
         if (a.feat_part) {          // the encoder left per-band partial sums: lin_b + sum over the bands, band order (wave-uniform branch)
@@ -436,16 +450,16 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
 #pragma unroll
                 for (int bd = 0; bd < 6; ++bd) {   // branch-free: bands past the last re-read the last one and are masked out
                     const int bdc = bd < a.feat_bands ? bd : a.feat_bands - 1;
-                    part[bd] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.feat_part) + (size_t)((((uint32_t)bdc * rows + arow) * 32u + 16u * ct + 4u * q) * 4u));
+                    part[bd] = ldg128(a.feat_part, (size_t)((((uint32_t)bdc * rows + arow) * 32u + 16u * ct + 4u * q) * 4u));
                 }
-                f32x4 s = *reinterpret_cast<const f32x4*>(a.lin_b + 16 * ct + 4 * q);
+                f32x4 s = ldg128(a.lin_b, (size_t)((16 * ct + 4 * q) * 4));
 #pragma unroll
                 for (int bd = 0; bd < 6; ++bd) { const float on = bd < a.feat_bands ? 1.f : 0.f; s += part[bd] * on; }
                 in.x[ct] = s;
             }
         } else if (!ROWS_DONE) {
-            in.x[0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)(ro * 4u));
-            in.x[1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)((ro + 16u) * 4u));
+            in.x[0] = ldg128(a.inputs, (size_t)(ro * 4u));
+            in.x[1] = ldg128(a.inputs, (size_t)((ro + 16u) * 4u));
         }
         const uint32_t er = (uint32_t)bc * (uint32_t)n + (uint32_t)agent;     // env-major row
         in.pa = (int)ld32(reinterpret_cast<const int32_t*>(a.prev_actions), 2u * er);   // low word of the int64 (little endian; -1 .. A - 1)
@@ -474,7 +488,7 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
     } else {
         if (!ROWS_DONE) {
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) in.x[ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint8_t*>(a.inputs) + (size_t)((ro + 16u * ct) * 4u));
+            for (int ct = 0; ct < 4; ++ct) in.x[ct] = ldg128(a.inputs, (size_t)((ro + 16u * ct) * 4u));
         }
         in.act = (int)ld32(reinterpret_cast<const int32_t*>(a.actions), 2u * ((uint32_t)bc * (uint32_t)n + (uint32_t)agent));
 #pragma unroll
@@ -581,9 +595,9 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
     if (!INC) PSTAMP_DRAINED(8);                                       // (diagnostic builds: kernel arguments fetched)
     if (!INC) PSTAMP(9);
     // the device-side counters first: scalar loads through pointers, in flight under the tile's loads instead of behind them
-    float eps = *a.eps;
-    int64_t step64 = *a.step;
-    long slot_t = a.t_index ? (long)*a.t_index : 0;
+    float eps = *(const float SSD_GLOBAL*)a.eps;
+    int64_t step64 = *(const int64_t SSD_GLOBAL*)a.step;
+    long slot_t = a.t_index ? (long)*(const int64_t SSD_GLOBAL*)a.t_index : 0;
     if (tile < tiles) {                                                // queued behind the first chunks
         if constexpr (LOOP) load_tile<INC, false>(a, tile, agent, lane, in);
         else if (!INC && a.feat_part) { load_tile<INC, false>(a, tile, agent, lane, in); }     // (band partials instead of the input row: Harvest)
@@ -694,7 +708,7 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
         float* in_row = a.inputs + ((size_t)agent * N + b) * 64;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-            if (ct >= 2 || a.feat_part) *reinterpret_cast<f32x4*>(in_row + 16 * ct + 4 * q) = xk[ct];
+            if (ct >= 2 || a.feat_part) stg128(in_row, (size_t)((16 * ct + 4 * q) * 4), xk[ct]);
         if (q == 0) {
             const size_t er = (size_t)b * n + agent;                   // env-major row
             ColdA ca; ColdC cc;
@@ -812,7 +826,7 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
                 const float ng = tanh_fast(fmaf(g[8 + ft][r], INV, bin[r]) + rg * fmaf(g[12 + ft][r], INV, bhn[r]));
                 hn[ft][r] = (1.f - zg) * ng + zg * hp[ft][r];
             }
-            if (valid) *reinterpret_cast<f32x4*>(h_row + 16 * ft + 4 * q) = hn[ft];
+            if (valid) stg128(h_row, (size_t)((16 * ft + 4 * q) * 4), hn[ft]);
         }
         if (first) PSTAMP(5);
         // ---- fc2 (advantages + value, padded to 16 outputs) ---------------------------------------------------------------
