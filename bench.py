@@ -221,12 +221,18 @@ def self_launch(n_ranks, argv):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SSD_SELF_LAUNCHED="1")
     print("[bench] self-launch: %s" % " ".join(cmd), file=sys.stderr, flush=True)
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
-    lines = [l for l in p.stdout.read().decode(errors="replace").splitlines() if l.strip()]
+    js = []
+    for raw in p.stdout:                                   # relayed as the ranks print: everything but JSON lines goes to stderr at once
+        l = raw.decode(errors="replace").rstrip("\n")
+        if not l.strip():
+            continue
+        if l.lstrip().startswith("{"):
+            js.append(l)
+        else:
+            print(l, file=sys.stderr, flush=True)
     rc = p.wait()
-    js = [l for l in lines if l.lstrip().startswith("{")]
-    for l in lines:
-        if l not in js[-1:]:
-            print(l, file=sys.stderr)
+    for l in js[:-1]:                                      # (only the last JSON line is the job's result)
+        print(l, file=sys.stderr)
     if rc == 0 and not js:
         print("[bench] the ranks exited 0 without a JSON line", file=sys.stderr)
         rc = 1
