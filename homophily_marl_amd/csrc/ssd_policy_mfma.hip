@@ -419,7 +419,10 @@ __device__ __forceinline__ f32x4 ldg128(const void* base, size_t byte_off) {
 }
 // The tile's largest loads -- the agent-major state row and (unless the encoder left band partials) the input row: they need
 // nothing but the kernel's leading scalar arguments (k_head), so the kernels without a back edge request them before anything else.
-template <int INC>
+// SMALL (the standalone env head): also the tail's scalars -- previous action / reward, the receiver-major incentive bytes, the
+// position -- whose pointers are leading arguments of k_head too: every load the input assembly waits for is then in flight
+// before the first trip to the kernarg segment returns.
+template <int INC, bool SMALL = false>
 __device__ __forceinline__ void load_tile_rows(const HeadK& a, int tile, int agent, int lane, TileIn<INC>& in) {
     const int m = lane & 15, q = lane >> 4, N = a.N;
     const int b = tile * 16 + m, bc = b < N ? b : N - 1;
@@ -429,9 +432,18 @@ __device__ __forceinline__ void load_tile_rows(const HeadK& a, int tile, int age
     for (int ct = 0; ct < 4; ++ct) in.hp[ct] = ldg128(a.h, (size_t)((ro + 16u * ct) * 4u));
 #pragma unroll
     for (int ct = 0; ct < (INC ? 4 : 2); ++ct) in.x[ct] = ldg128(a.inputs, (size_t)((ro + 16u * ct) * 4u));
+    if constexpr (SMALL && !INC) {
+        const uint32_t er = (uint32_t)bc * (uint32_t)a.n + (uint32_t)agent;   // env-major row
+        in.pa = (int)ld32(reinterpret_cast<const int32_t*>(a.prev_actions), 2u * er);
+        in.pr = ld32(a.prev_reward, er);
+        in.rv = a.recv ? ld32(reinterpret_cast<const uint32_t*>(a.recv), arow * 4u + (uint32_t)q) : 0u;
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
+        const f32x2v pp = ld32(reinterpret_cast<const f32x2v*>(a.pos), er);
+        in.p0 = pp.x; in.p1 = pp.y;
+    }
 }
 // ROWS_DONE: load_tile_rows already requested the state row and (feat_part == nullptr or INC) the input row
-template <int INC, bool ROWS_DONE = false>
+template <int INC, bool ROWS_DONE = false, bool SMALL_DONE = false>
 __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, int lane, TileIn<INC>& in) {
     const int m = lane & 15, q = lane >> 4, N = a.N, n = a.n;
     const int b = tile * 16 + m, bc = b < N ? b : N - 1;
@@ -462,12 +474,14 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
             in.x[1] = ldg128(a.inputs, (size_t)((ro + 16u) * 4u));
         }
         const uint32_t er = (uint32_t)bc * (uint32_t)n + (uint32_t)agent;     // env-major row
-        in.pa = (int)ld32(reinterpret_cast<const int32_t*>(a.prev_actions), 2u * er);   // low word of the int64 (little endian; -1 .. A - 1)
-        in.pr = ld32(a.prev_reward, er);
+        if (!SMALL_DONE) {
+            in.pa = (int)ld32(reinterpret_cast<const int32_t*>(a.prev_actions), 2u * er);   // low word of the int64 (little endian; -1 .. A - 1)
+            in.pr = ld32(a.prev_reward, er);
+        }
         // received incentives: prev_inc[bc, g, agent] for every giver g (values 0 / 1 / 2: the low word); givers past n re-read giver
         // n - 1 and count nothing
         if (a.recv) {                                                  // (wave-uniform) the row's 16 giver bytes: dword q for lane quarter q
-            in.rv = ld32(reinterpret_cast<const uint32_t*>(a.recv), arow * 4u + (uint32_t)q);
+            if (!SMALL_DONE) in.rv = ld32(reinterpret_cast<const uint32_t*>(a.recv), arow * 4u + (uint32_t)q);
             in.inc[0] = in.inc[1] = in.inc[2] = 0;
         } else {
             in.rv = 0u;
@@ -480,8 +494,10 @@ __device__ __forceinline__ void load_tile(const HeadK& a, int tile, int agent, i
             }
         }
         typedef float f32x2v __attribute__((ext_vector_type(2)));
-        const f32x2v pp = ld32(reinterpret_cast<const f32x2v*>(a.pos), er);      // one 8-byte load per pair
-        in.p0 = pp.x; in.p1 = pp.y;
+        if (!SMALL_DONE) {
+            const f32x2v pp = ld32(reinterpret_cast<const f32x2v*>(a.pos), er);      // one 8-byte load per pair
+            in.p0 = pp.x; in.p1 = pp.y;
+        }
         const float* orient = a.orient ? a.orient : a.pos;             // no orientation given: read something valid; file_inputs writes zeros
         const f32x2v oo = ld32(reinterpret_cast<const f32x2v*>(orient), er);
         in.o0 = oo.x; in.o1 = oo.y;                                    // (raw: an arithmetic use here would be a wait for every load of the tile)
@@ -540,7 +556,7 @@ __device__ __forceinline__ void refetch_head_args(HeadK& out, int k_off) {
 static_assert(sizeof(HeadK) % 4 == 0, "HeadK is copied dword by dword");
 
 // KOFF: the offset of the HeadK argument in the launch's kernarg segment (behind the kernel's leading scalar arguments)
-template <int INC, int PREC, int AT, int GEN, int WAVES, bool LOOP = false, int KOFF = 0>
+template <int INC, int PREC, int AT, int GEN, int WAVES, bool LOOP = false, int KOFF = 0, bool PRE_SMALL = false>
 __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw, const int block) {
     constexpr int COLD_BASE = KOFF + HEAD_COLD_OFFSET;
     constexpr int IMAGE_BYTES = SSD_POLICY_IMAGE_BYTES(PREC);
@@ -560,7 +576,7 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
         PSTAMP_REAL(14);
         if (!LOOP && wave < WAVES) {   // (see load_tile_rows; the loader wave has no tile)
             const int bia0 = block - (block / a.bpa) * a.bpa, tile00 = wave * a.bpa + bia0;
-            if (tile00 < ((a.N + 15) >> 4)) load_tile_rows<INC>(a, tile00, block / a.bpa, lane, in_rows);
+            if (tile00 < ((a.N + 15) >> 4)) load_tile_rows<INC, PRE_SMALL>(a, tile00, block / a.bpa, lane, in_rows);
         }
         // Every kernel argument the input phase reads, requested in ONE batch with the first one (by-value arguments are fetched from
         // the kernarg segment where they are first used: three dependent scalar-memory trips, ~ 1 K cycles each while the segment
@@ -600,8 +616,8 @@ __device__ __forceinline__ void head_body(const HeadK& a_entry, uint8_t* lds_raw
     long slot_t = a.t_index ? (long)*(const int64_t SSD_GLOBAL*)a.t_index : 0;
     if (tile < tiles) {                                                // queued behind the first chunks
         if constexpr (LOOP) load_tile<INC, false>(a, tile, agent, lane, in);
-        else if (!INC && a.feat_part) { load_tile<INC, false>(a, tile, agent, lane, in); }     // (band partials instead of the input row: Harvest)
-        else load_tile<INC, true>(a, tile, agent, lane, in);
+        else if (!INC && a.feat_part) { load_tile<INC, false, PRE_SMALL>(a, tile, agent, lane, in); }     // (band partials instead of the input row: Harvest)
+        else load_tile<INC, true, PRE_SMALL>(a, tile, agent, lane, in);
     }
     if (!INC) PSTAMP(10);
     uint32_t step = 0;                                                 // (both assigned once the loads above are pinned, see below)
@@ -981,15 +997,17 @@ constexpr int head_waves(bool loop) { return loop ? HEAD_WAVES_LOOP : HEAD_WAVES
 // The leading scalar arguments repeat what a compute wave needs for its largest loads (the tile's state and input rows): built
 // with -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave (struct arguments are not preloaded).  The looped
 // instantiations re-read HeadK from the segment at every pass (refetch_head_args) and ignore them.
-constexpr int HEAD_LEAD_BYTES = 4 * 4 + 2 * 8;
+constexpr int HEAD_LEAD_BYTES = 2 * 4 + 6 * 8;     // (N | n << 24, bpa, six pointers: 14 dwords, what gfx950 preloads)
 template <int INC, int PREC, int AT, int GEN = 0, bool LOOP = false>
-__global__ __launch_bounds__((head_waves(LOOP) + 1) * 64) void k_head(int p_N, int p_n, int p_bpa, int p_pad, float* p_h, float* p_inputs, HeadK a, HeadCold cold_unused) {
+__global__ __launch_bounds__((head_waves(LOOP) + 1) * 64) void k_head(uint32_t p_Nn, int p_bpa, float* p_h, float* p_inputs, const int64_t* p_prev_actions,
+                                                                      const float* p_prev_reward, const uint8_t* p_recv, const float* p_pos, HeadK a, HeadCold cold_unused) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     if constexpr (LOOP) head_body<INC, PREC, AT, GEN, head_waves(LOOP), LOOP, HEAD_LEAD_BYTES>(a, lds_raw, (int)blockIdx.x);
     else {
         HeadK al = a;
-        al.N = p_N; al.n = p_n; al.bpa = p_bpa; al.h = p_h; al.inputs = p_inputs;
-        head_body<INC, PREC, AT, GEN, head_waves(LOOP), LOOP, HEAD_LEAD_BYTES>(al, lds_raw, (int)blockIdx.x);
+        al.N = (int)(p_Nn & 0xFFFFFFu); al.n = (int)(p_Nn >> 24); al.bpa = p_bpa; al.h = p_h; al.inputs = p_inputs;
+        if constexpr (!INC) { al.prev_actions = p_prev_actions; al.prev_reward = p_prev_reward; al.recv = p_recv; al.pos = p_pos; }
+        head_body<INC, PREC, AT, GEN, head_waves(LOOP), LOOP, HEAD_LEAD_BYTES, !INC>(al, lds_raw, (int)blockIdx.x);
     }
 }
 
@@ -1090,8 +1108,9 @@ int launch_policy_head(const ssd_policy_head* p, int inc, hipStream_t s) {
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess) return -1;
         gen_attr_done_dev[dev] = true;
     }
-    int pad = 0;
-    void* args[8] = {&k.N, &k.n, &k.bpa, &pad, &k.h, &k.inputs, &k, &c};
+    if (k.N >= (1 << 24) || k.n >= 256) return -1;
+    uint32_t nn = (uint32_t)k.N | ((uint32_t)k.n << 24);
+    void* args[10] = {&nn, &k.bpa, &k.h, &k.inputs, &k.prev_actions, &k.prev_reward, &k.recv, &k.pos, &k, &c};
     const void* fn = gen ? gen_fns[(k.A == 8 ? 2 : 0) + (prec == 1 ? 1 : 0)]
                          : fns[(looped ? 8 : 0) + (k.A == 8 ? 4 : 0) + (prec == 1 ? 2 : 0) + (inc ? 1 : 0)];
     if (hipLaunchKernel(fn, dim3(k.n * bpa), dim3((waves + 1) * 64), args, lds, s) != hipSuccess) return -1;
