@@ -919,12 +919,14 @@ __global__ __launch_bounds__(kBlock) void k_env(EnvHdr* p_hdr, uint2* p_agents, 
     // Speed only (never correctness): the 4 waves that share a SIMD get distinct static priorities from their hardware
     // wave slot, so they drift apart and their 16-byte store bursts are spread over the kernel instead of hitting the
     // per-CU store path all at once at the end (profiles/: stores and compute otherwise do not overlap at all).
+#ifndef SSD_NO_SETPRIO
     if (MODE == MODE_STEP_OBS || MODE == MODE_OBS) {
         const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 3u;   // HW_REG_HW_ID.WAVE_ID[1:0]
         if (slot == 0) __builtin_amdgcn_s_setprio(3);
         else if (slot == 1) __builtin_amdgcn_s_setprio(2);
         else if (slot == 2) __builtin_amdgcn_s_setprio(1);
     }
+#endif
 
     Env E;
     E.S = S; E.h = h; E.lane = lane; E.n = NT ? NT : h->n; E.W = h->W; E.HW = h->HW; E.GS = p_GS;
