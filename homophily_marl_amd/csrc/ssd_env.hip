@@ -409,7 +409,7 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
             k += popc64(bal);
         }
     }
-    { const int env = E.env; STAMP_TO(E.stamps, 14); }
+    { const int env = E.env; (void)env; STAMP_TO(E.stamps, 14); }
     // waste: at most one spawn, first free site in shuffled order whose draw succeeds (cleanup.py:177-186)
     if (waste_on) {
         uint16_t* scratch = (uint16_t*)E.pm;                  // tape mode: rank of each site in the shuffled list
@@ -450,7 +450,7 @@ __device__ __forceinline__ int spawn_cleanup(Env& E, const Rng& R, const uint8_t
             if (b) J = base + first_lane(b);
         }
         k += J >= 0 ? J + 1 : nfree;
-        { const int env = E.env; STAMP_TO(E.stamps, 15); }
+        { const int env = E.env; (void)env; STAMP_TO(E.stamps, 15); }
         if (J >= 0) {
             // the (J+1)-th smallest (key, site) among the free sites
             uint32_t sel = ~0u;
