@@ -65,6 +65,33 @@ def _compare_state(tag, dev, orc):
         assert (sa[k] == sb[k]).all(), (tag, k, np.argwhere(sa[k] != sb[k])[:4].tolist())
 
 
+@pytest.mark.parametrize("env_name,n,mapname,view", [("cleanup", 4, "default5", 7), ("cleanup", 7, "default10", 7), ("cleanup", 5, "default5", 7),
+                                                     ("cleanup", 10, "default10", 7), ("harvest", 6, "default10", 7)])
+def test_counter_mode_other_team_sizes_and_the_class_code_request(env_name, n, mapname, view):
+    """The step kernel has instantiations per team size (3 / 5 / 10 at compile time, anything else at run time) and per observation
+    request (class-code windows and f32 planes have their own, everything else takes the all-formats kernel): team sizes that take
+    the run-time instantiation, and the fused step + class-code observation the rollout issues, against the oracle every step."""
+    from oracle.oracle_py import OracleEnv
+    HipEnv, _ = _hip()
+    N, T = 130, 24
+    kw = dict(map=mapname, num_agents=n, n_env=N, view_size=view, episode_limit=T, rng_mode=abi.RNG_COUNTER, seed=0xBEEF + n, env_id_base=77)
+    dev, orc = HipEnv(env_name, **kw), OracleEnv(env_name, **kw)
+    rng = np.random.default_rng(n)
+    avail = [a for a in range(dev.n_actions) if a not in (5, 6)]
+    _compare_step("reset", dev.reset(), orc.reset(), keys=("n_draws",))
+    for t in range(T):
+        acts = rng.choice(avail, size=(N, n)).astype(np.int32)
+        fmt = (abi.OBS_CODE, abi.OBS_F32, abi.OBS_U8)[t % 3]
+        a = dev.step_observe(acts, fmt=fmt)
+        b = orc.step(acts)
+        _compare_step(t, a, b)
+        ob = orc.observe(fmt)
+        for k in ("obs", "pos", "orient"):
+            assert (a[k] == ob[k]).all(), (t, fmt, k)
+        _compare_state(t, dev, orc)
+    dev.close(); orc.close()
+
+
 @pytest.mark.parametrize("name", list(CONFIGS))
 @pytest.mark.parametrize("opts", [None, dict(ALL, random_spawn_rotation=None, obs_color="full"),
                                   dict(ALL, random_spawn_point=True, random_spawn_rotation=None)], ids=["default", "allact_full", "randspawn"])
