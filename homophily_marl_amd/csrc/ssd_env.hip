@@ -897,8 +897,13 @@ __device__ __forceinline__ T cold_kernarg(int offset) {
 // as SCALAR kernel arguments in front of the struct: built with -mllvm -amdgpu-kernarg-preload-count=14 they arrive in SGPRs with
 // the wave (gfx950 kernarg preload; struct arguments are not preloaded), so the state loads are requested before the first
 // scalar-memory trip to the kernarg segment has returned.  Without the flag they are ordinary arguments.
+#ifdef SSD_ENV_WPE      // experiment knob: tell the register allocator / scheduler how many waves per SIMD the launch really has
+#define SSD_ENV_OCC __attribute__((amdgpu_waves_per_eu(SSD_ENV_WPE, SSD_ENV_WPE)))
+#else
+#define SSD_ENV_OCC
+#endif
 template <int MODE, int NT, bool TAPE, int OV = OV_ANY>
-__global__ __launch_bounds__(kBlock) void k_env(EnvHdr* p_hdr, uint2* p_agents, uint8_t* p_grid, const int32_t* p_actions, const DevSpec* p_spec,
+__global__ __launch_bounds__(kBlock) SSD_ENV_OCC void k_env(EnvHdr* p_hdr, uint2* p_agents, uint8_t* p_grid, const int32_t* p_actions, const DevSpec* p_spec,
                                                 int p_N, int p_GS, int p_PMS, int p_lds_stride, const EnvArgs A) {
     const DevHead& hd = A.hd;
     const DevSpec* __restrict__ S = p_spec;
